@@ -1,0 +1,571 @@
+// c_api.cpp — extern "C" boundary (include/paraformer_hip.h).  Every entry point converts C++
+// exceptions into a negative pf_status + thread-local message; no exception crosses the ABI.
+#include <cstring>
+#include <mutex>
+
+#include "engine.h"
+#include "recognizer.h"
+
+namespace pf {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+}  // namespace pf
+
+using namespace pf;
+
+struct pf_engine { Engine* e; };
+struct pf_recognizer { Recognizer* r; pf_engine eng; };
+struct pf_stream { Stream* s; std::vector<int32_t> hw_flat; };
+struct pf_decoded { ResultEntity r; };
+
+#define PF_TRY try {
+#define PF_CATCH                                                          \
+  }                                                                       \
+  catch (const pf::Error& ex) { pf::set_last_error(ex.what()); return ex.code; } \
+  catch (const std::bad_alloc&) { pf::set_last_error("out of host memory"); return PF_ERR_DEVICE; } \
+  catch (const std::exception& ex) { pf::set_last_error(ex.what()); return PF_ERR_INVALID_ARG; }
+
+#define NEED(p) PF_CHECK((p) != nullptr, PF_ERR_INVALID_ARG, "null argument: " #p)
+
+extern "C" {
+
+int pf_version(void) { return PF_ABI_VERSION; }
+const char* pf_last_error(void) { return pf::g_last_error.c_str(); }
+
+int pf_engine_create(const pf_engine_config* cfg, pf_engine** out) {
+  PF_TRY
+  NEED(cfg); NEED(out);
+  PF_CHECK(cfg->struct_size == (int32_t)sizeof(pf_engine_config), PF_ERR_INVALID_ARG, "pf_engine_config.struct_size mismatch");
+  *out = nullptr;
+  Engine* e = new Engine(*cfg);
+  *out = new pf_engine{e};
+  return PF_OK;
+  PF_CATCH
+}
+
+void pf_engine_destroy(pf_engine* h) {
+  if (!h) return;
+  try { delete h->e; } catch (...) {}
+  h->e = nullptr;
+  delete h;
+}
+
+static Engine* E(pf_engine* h) {
+  PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null engine");
+  PF_CHECK(h->e != nullptr, PF_ERR_DISPOSED, "OfflineRecognizer");
+  return h->e;
+}
+
+int pf_engine_info(pf_engine* h, int32_t* kind, int32_t* vocab, int32_t* feat_dim, int32_t* has_ts) {
+  PF_TRY
+  Engine* e = E(h);
+  if (kind) *kind = e->model().kind_id();
+  if (vocab) *vocab = e->model().vocab;
+  if (feat_dim) *feat_dim = e->model().feat_dim;
+  if (has_ts) *has_ts = e->model().timestamp_head ? 1 : 0;
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_frontend_num_frames(pf_engine* h, int64_t n, int32_t* t) {
+  PF_TRY
+  NEED(t);
+  *t = E(h)->num_lfr_frames(n);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_frontend(pf_engine* h, const float* samples, int64_t n, float* feats, int64_t cap, int32_t* t_out) {
+  PF_TRY
+  Engine* e = E(h);
+  if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  std::vector<float> f;
+  int t = 0;
+  e->frontend_host(samples, n, f, t);
+  if (t_out) *t_out = t;
+  PF_CHECK((int64_t)f.size() <= cap, PF_ERR_CAPACITY, "feats capacity < " + std::to_string(f.size()));
+  if (!f.empty()) { NEED(feats); std::memcpy(feats, f.data(), f.size() * 4); }
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_fbank(pf_engine* h, const float* samples, int64_t n, float* out, int64_t cap, int32_t* t80_out) {
+  PF_TRY
+  Engine* e = E(h);
+  if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  std::vector<float> f;
+  int t = 0;
+  e->fbank_host(samples, n, f, t);
+  if (t80_out) *t80_out = t;
+  PF_CHECK((int64_t)f.size() <= cap, PF_ERR_CAPACITY, "fbank capacity < " + std::to_string(f.size()));
+  if (!f.empty()) { NEED(out); std::memcpy(out, f.data(), f.size() * 4); }
+  return PF_OK;
+  PF_CATCH
+}
+
+static bool want_logits(const pf_batch_out* o) { return o && o->logits && o->logits_cap > 0; }
+
+int pf_forward_feats(pf_engine* h, const float* speech, int32_t B, int32_t Tmax, const int32_t* hotwords,
+                     int32_t n_hotwords, pf_batch_out* out) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(out);
+  (void)hotwords; (void)n_hotwords;
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->forward_feats_host(speech, B, Tmax, want_logits(out));
+  e->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_model_proj(pf_engine* h, const float* const* speech, const int32_t* lens, int32_t B,
+                  const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(out); NEED(speech); NEED(lens);
+  (void)hotwords; (void)n_hotwords;
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->model_proj_host(speech, lens, B, want_logits(out));
+  e->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_recognize(pf_engine* h, const float* const* samples, const int64_t* n, int32_t B, const int32_t* hotwords,
+                 int32_t n_hotwords, pf_batch_out* out) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(out); NEED(samples); NEED(n);
+  (void)hotwords; (void)n_hotwords;
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->stage_audio(samples, n, B);
+  e->run_staged(want_logits(out));
+  e->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_stage_audio(pf_engine* h, const float* const* samples, const int64_t* n, int32_t B) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(samples); NEED(n);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->stage_audio(samples, n, B);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_run_staged(pf_engine* h) {
+  PF_TRY
+  Engine* e = E(h);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->run_staged(false);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_sync(pf_engine* h) {
+  PF_TRY
+  E(h)->sync();
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_fetch(pf_engine* h, pf_batch_out* out) {
+  PF_TRY
+  Engine* e = E(h);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_profile_enable(pf_engine* h, int32_t on) {
+  PF_TRY
+  E(h)->profile_enable(on != 0);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_profile_reset(pf_engine* h) {
+  PF_TRY
+  E(h)->profile_reset();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_profile_get(pf_engine* h, const char* cls, double* ms, int64_t* launches, double* fpl) {
+  PF_TRY
+  NEED(cls);
+  if (!E(h)->profile_get(cls, ms, launches, fpl)) {
+    if (ms) *ms = 0;
+    if (launches) *launches = 0;
+    if (fpl) *fpl = 0;
+  }
+  return PF_OK;
+  PF_CATCH
+}
+int pf_last_flops(pf_engine* h, double* f) {
+  PF_TRY
+  NEED(f);
+  *f = E(h)->last_flops();
+  return PF_OK;
+  PF_CATCH
+}
+
+// ---- stand-alone ops -------------------------------------------------------
+int pf_op_lfr_cmvn_pad(pf_engine* h, const float* const* fbank, const int32_t* t80, int32_t B, int32_t sentinel,
+                       float* out, int64_t cap, int32_t* tmax) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(fbank); NEED(t80);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_lfr_cmvn_pad(fbank, t80, B, sentinel, out, cap, tmax);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_argmax(pf_engine* h, const float* x, int64_t rows, int32_t V, int64_t* ids) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(x); NEED(ids);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_argmax(x, rows, V, ids);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_gemm(pf_engine* h, const float* A, const float* W, const float* bias, int32_t M, int32_t N, int32_t K,
+               int32_t epi, float* C) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(A); NEED(W); NEED(C);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_gemm(A, W, bias, M, N, K, epi, C);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_layernorm(pf_engine* h, const float* x, const float* g, const float* b, int64_t rows, int32_t D, float* y) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(x); NEED(g); NEED(b); NEED(y);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_layernorm(x, g, b, rows, D, y);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_attention(pf_engine* h, const float* q, const float* k, const float* v, int32_t B, int32_t Lq, int32_t Lk,
+                    int32_t heads, float* out) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(q); NEED(k); NEED(v); NEED(out);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_attention(q, k, v, B, Lq, Lk, heads, out);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_fsmn(pf_engine* h, const float* v, const float* w, const float* mask, int32_t B, int32_t T, int32_t D,
+               int32_t k, float* y) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(v); NEED(w); NEED(y);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_fsmn(v, w, mask, B, T, D, k, y);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_cif(pf_engine* h, const float* H, const float* alphas, int32_t B, int32_t T, int32_t D, float thr,
+              int32_t Lcap, float* E_, int32_t* fire_count, int32_t* token_num, int32_t* L_out) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(H); NEED(alphas); NEED(fire_count); NEED(token_num);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_cif(H, alphas, B, T, D, thr, Lcap, E_, fire_count, token_num, L_out);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_encoder(pf_engine* h, const float* speech, int32_t B, int32_t T, float* Hout) {
+  PF_TRY
+  Engine* e = E(h);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_encoder(speech, B, T, Hout);
+  return PF_OK;
+  PF_CATCH
+}
+
+// ---- recognizer mirror -------------------------------------------------------
+int pf_recognizer_create(const char* model, const char* config, const char* mvn, const char* tokens,
+                         const char* modeleb, const char* hotword, int32_t batch_size, int32_t threads_num,
+                         int32_t device, pf_recognizer** out) {
+  PF_TRY
+  NEED(out);
+  *out = nullptr;
+  auto s = [](const char* p) { return std::string(p ? p : ""); };
+  Recognizer* r = new Recognizer(s(model), s(config), s(mvn), s(tokens), s(modeleb), s(hotword), batch_size,
+                                 threads_num, device);
+  *out = new pf_recognizer{r, {r->engine()}};
+  return PF_OK;
+  PF_CATCH
+}
+
+void pf_recognizer_dispose(pf_recognizer* h) {
+  if (!h || !h->r) return;
+  try { h->r->Dispose(); } catch (...) {}
+  h->eng.e = nullptr;
+}
+
+void pf_recognizer_free(pf_recognizer* h) {
+  if (!h) return;
+  try { delete h->r; } catch (...) {}
+  delete h;
+}
+
+pf_engine* pf_recognizer_engine(pf_recognizer* h) { return (h && h->r && h->eng.e) ? &h->eng : nullptr; }
+
+static Recognizer* R(pf_recognizer* h) {
+  PF_CHECK(h != nullptr && h->r != nullptr, PF_ERR_INVALID_ARG, "null recognizer");
+  return h->r;
+}
+static Stream* S(pf_stream* h) {
+  PF_CHECK(h != nullptr && h->s != nullptr, PF_ERR_INVALID_ARG, "null stream");
+  PF_CHECK(!h->s->disposed, PF_ERR_DISPOSED, "OfflineStream");
+  return h->s;
+}
+
+int pf_recognizer_create_stream(pf_recognizer* h, pf_stream** out) {
+  PF_TRY
+  NEED(out);
+  *out = nullptr;
+  Stream* s = R(h)->CreateOfflineStream();
+  *out = new pf_stream{s, {}};
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_stream_add_samples(pf_stream* h, const float* samples, int64_t n) {
+  PF_TRY
+  Stream* s = S(h);
+  PF_CHECK(!s->owner->disposed(), PF_ERR_DISPOSED, "OfflineRecognizer");
+  s->AddSamples(samples, n);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_stream_set_hotwords(pf_stream* h, const int32_t* ids, const int32_t* lens, int32_t n) {
+  PF_TRY
+  Stream* s = S(h);
+  s->Hotwords.clear();
+  s->hotwords_null = n < 0;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    NEED(lens);
+    PF_CHECK(lens[i] >= 0, PF_ERR_INVALID_ARG, "negative hotword length");
+    if (lens[i] > 0) NEED(ids);
+    s->Hotwords.emplace_back(ids + off, ids + off + lens[i]);
+    off += (size_t)lens[i];
+  }
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_stream_get_hotwords(pf_stream* h, int32_t* ids, int32_t ids_cap, int32_t* lens, int32_t lens_cap, int32_t* n) {
+  PF_TRY
+  Stream* s = S(h);
+  NEED(n);
+  if (s->hotwords_null) { *n = -1; return PF_OK; }
+  *n = (int32_t)s->Hotwords.size();
+  size_t tot = 0;
+  for (auto& w : s->Hotwords) tot += w.size();
+  PF_CHECK((int32_t)s->Hotwords.size() <= lens_cap && (int64_t)tot <= ids_cap, PF_ERR_CAPACITY, "hotword buffers too small");
+  size_t off = 0;
+  for (size_t i = 0; i < s->Hotwords.size(); ++i) {
+    lens[i] = (int32_t)s->Hotwords[i].size();
+    for (int32_t v : s->Hotwords[i]) ids[off++] = v;
+  }
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_stream_num_feature_floats(pf_stream* h, int32_t* n) {
+  PF_TRY
+  NEED(n);
+  *n = S(h)->SpeechLength;
+  return PF_OK;
+  PF_CATCH
+}
+
+void pf_stream_dispose(pf_stream* h) {
+  if (!h) return;
+  if (h->s) {
+    h->s->disposed = true;
+    h->s->Speech.clear();
+    h->s->Speech.shrink_to_fit();
+  }
+  delete h;
+}
+
+int pf_recognizer_get_results(pf_recognizer* h, pf_stream* const* streams, int32_t n) {
+  PF_TRY
+  Recognizer* r = R(h);
+  std::vector<Stream*> ss;
+  for (int i = 0; i < n; ++i) { NEED(streams); ss.push_back(S(streams[i])); }
+  r->GetResults(ss);
+  return PF_OK;
+  PF_CATCH
+}
+
+static const ResultEntity& RES(pf_recognizer* h, int32_t i) {
+  Recognizer* r = R(h);
+  PF_CHECK(i >= 0 && i < (int32_t)r->results.size(), PF_ERR_INVALID_ARG, "result index out of range");
+  return r->results[(size_t)i];
+}
+
+int pf_result_text(pf_recognizer* h, int32_t i, const char** utf8, int32_t* len16) {
+  PF_TRY
+  const ResultEntity& e = RES(h, i);
+  if (utf8) *utf8 = e.Text.c_str();
+  if (len16) *len16 = e.TextLen;
+  return PF_OK;
+  PF_CATCH
+}
+int pf_result_num_tokens(pf_recognizer* h, int32_t i, int32_t* n) {
+  PF_TRY
+  NEED(n);
+  *n = (int32_t)RES(h, i).Tokens.size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_result_token(pf_recognizer* h, int32_t i, int32_t j, const char** utf8) {
+  PF_TRY
+  const ResultEntity& e = RES(h, i);
+  PF_CHECK(j >= 0 && j < (int32_t)e.Tokens.size(), PF_ERR_INVALID_ARG, "token index out of range");
+  NEED(utf8);
+  *utf8 = e.Tokens[(size_t)j].c_str();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_result_num_timestamps(pf_recognizer* h, int32_t i, int32_t* n) {
+  PF_TRY
+  NEED(n);
+  *n = (int32_t)RES(h, i).Timestamps.size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_result_timestamp(pf_recognizer* h, int32_t i, int32_t j, const int32_t** ints, int32_t* n_ints) {
+  PF_TRY
+  const ResultEntity& e = RES(h, i);
+  PF_CHECK(j >= 0 && j < (int32_t)e.Timestamps.size(), PF_ERR_INVALID_ARG, "timestamp index out of range");
+  if (ints) *ints = e.Timestamps[(size_t)j].data();
+  if (n_ints) *n_ints = (int32_t)e.Timestamps[(size_t)j].size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_stream_tokens(pf_stream* h, const int64_t** ids, int32_t* n) {
+  PF_TRY
+  Stream* s = S(h);
+  if (ids) *ids = s->Tokens.data();
+  if (n) *n = (int32_t)s->Tokens.size();
+  return PF_OK;
+  PF_CATCH
+}
+
+// ---- host text stage --------------------------------------------------------
+int pf_host_timestamps(const float* peak, int32_t n, const int64_t* tokens, int32_t n_tokens, int32_t* out_pairs,
+                       int32_t cap_pairs) {
+  PF_TRY
+  NEED(peak);
+  std::vector<int64_t> tk;
+  if (n_tokens > 0) { NEED(tokens); tk.assign(tokens, tokens + n_tokens); }
+  auto ts = time_stamp_lfr6(peak, n, tk);
+  PF_CHECK((int32_t)ts.size() <= cap_pairs, PF_ERR_CAPACITY, "timestamp capacity too small");
+  for (size_t i = 0; i < ts.size(); ++i) { out_pairs[2 * i] = ts[i][0]; out_pairs[2 * i + 1] = ts[i][1]; }
+  return (int)ts.size();
+  PF_CATCH
+}
+
+int pf_host_hotword_ids(const char* const* tokens, int32_t n_tokens, const char* const* lines, int32_t n_lines,
+                        int32_t* ids, int32_t ids_cap, int32_t* lens, int32_t lens_cap, int32_t* n_hotwords) {
+  PF_TRY
+  NEED(n_hotwords);
+  std::vector<std::string> tk, ln;
+  for (int i = 0; i < n_tokens; ++i) tk.emplace_back(tokens[i]);
+  for (int i = 0; i < n_lines; ++i) ln.emplace_back(lines[i]);
+  auto hw = hotword_ids(tk, ln, 1);
+  size_t tot = 0;
+  for (auto& w : hw) tot += w.size();
+  PF_CHECK((int32_t)hw.size() <= lens_cap && (int64_t)tot <= ids_cap, PF_ERR_CAPACITY, "hotword buffers too small");
+  size_t off = 0;
+  for (size_t i = 0; i < hw.size(); ++i) {
+    lens[i] = (int32_t)hw[i].size();
+    for (int32_t v : hw[i]) ids[off++] = v;
+  }
+  *n_hotwords = (int32_t)hw.size();
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_host_decode(const char* const* tokens, int32_t n_tokens, const int64_t* ids, int32_t n_ids,
+                   const int32_t* ts_ints, const int32_t* ts_lens, int32_t n_ts, pf_decoded** out) {
+  PF_TRY
+  NEED(out);
+  *out = nullptr;
+  std::vector<std::string> tk;
+  for (int i = 0; i < n_tokens; ++i) tk.emplace_back(tokens[i]);
+  std::vector<int64_t> idv(ids, ids + n_ids);
+  std::vector<std::vector<int32_t>> ts;
+  size_t off = 0;
+  for (int i = 0; i < n_ts; ++i) {
+    ts.emplace_back(ts_ints + off, ts_ints + off + ts_lens[i]);
+    off += (size_t)ts_lens[i];
+  }
+  pf_decoded* d = new pf_decoded();
+  try {
+    d->r = decode_multi_one(tk, idv, ts);
+  } catch (...) {
+    delete d;
+    throw;
+  }
+  *out = d;
+  return PF_OK;
+  PF_CATCH
+}
+int pf_decoded_text(pf_decoded* d, const char** utf8, int32_t* len16) {
+  PF_TRY
+  NEED(d);
+  if (utf8) *utf8 = d->r.Text.c_str();
+  if (len16) *len16 = d->r.TextLen;
+  return PF_OK;
+  PF_CATCH
+}
+int pf_decoded_num_tokens(pf_decoded* d, int32_t* n) {
+  PF_TRY
+  NEED(d); NEED(n);
+  *n = (int32_t)d->r.Tokens.size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_decoded_token(pf_decoded* d, int32_t j, const char** utf8) {
+  PF_TRY
+  NEED(d); NEED(utf8);
+  PF_CHECK(j >= 0 && j < (int32_t)d->r.Tokens.size(), PF_ERR_INVALID_ARG, "token index out of range");
+  *utf8 = d->r.Tokens[(size_t)j].c_str();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_decoded_num_timestamps(pf_decoded* d, int32_t* n) {
+  PF_TRY
+  NEED(d); NEED(n);
+  *n = (int32_t)d->r.Timestamps.size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_decoded_timestamp(pf_decoded* d, int32_t j, const int32_t** ints, int32_t* n_ints) {
+  PF_TRY
+  NEED(d);
+  PF_CHECK(j >= 0 && j < (int32_t)d->r.Timestamps.size(), PF_ERR_INVALID_ARG, "timestamp index out of range");
+  if (ints) *ints = d->r.Timestamps[(size_t)j].data();
+  if (n_ints) *n_ints = (int32_t)d->r.Timestamps[(size_t)j].size();
+  return PF_OK;
+  PF_CATCH
+}
+void pf_decoded_free(pf_decoded* d) { delete d; }
+
+}  // extern "C"

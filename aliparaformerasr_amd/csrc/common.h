@@ -1,0 +1,37 @@
+// common.h — shared host-side helpers for libparaformer_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/paraformer_hip.h"
+
+namespace pf {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string& msg);
+
+#define PF_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      throw ::pf::Error(PF_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define PF_CHECK(cond, code, msg)                     \
+  do {                                                \
+    if (!(cond)) throw ::pf::Error((code), (msg));    \
+  } while (0)
+
+using half_t = _Float16;
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace pf

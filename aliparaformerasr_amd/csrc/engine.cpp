@@ -1,0 +1,988 @@
+// engine.cpp — see engine.h.  Orchestrates the gfx950 kernels into the graph the reference
+// obtains from InferenceSession.Run (AliParaformerAsr/OfflineProjOfParaformer.cs:68,
+// OfflineProjOfSenseVoiceSmall.cs:156): SAN-M encoder -> CIF predictor -> parallel SAN-M
+// decoder -> log-softmax, followed by the reference's own last-index arg-max
+// (AliParaformerAsr/OfflineRecognizer.cs:139-152).
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "hostutil.h"
+
+namespace pf {
+
+static const size_t kAlign = 256;
+
+// ------------------------------------------------------------------ construction ----------
+Engine::Engine(const pf_engine_config& cfg) {
+  device_ = cfg.device;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    throw Error(PF_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  PF_CHECK(device_ >= 0 && device_ < ndev, PF_ERR_DEVICE, "device ordinal out of range");
+  PF_HIP(hipSetDevice(device_));
+  hipDeviceProp_t prop;
+  PF_HIP(hipGetDeviceProperties(&prop, device_));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    throw Error(PF_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+
+  fc_.fs = cfg.fs > 0 ? cfg.fs : 16000;
+  fc_.n_mels = cfg.n_mels > 0 ? cfg.n_mels : 80;
+  fc_.lfr_m = cfg.lfr_m > 0 ? cfg.lfr_m : 7;
+  fc_.lfr_n = cfg.lfr_n > 0 ? cfg.lfr_n : 6;
+  fc_.snip_edges = cfg.snip_edges != 0;
+  fc_.dither = cfg.dither;
+  fc_.window = cfg.window ? cfg.window : "hamming";
+  PF_CHECK(fc_.dither == 0.f, PF_ERR_UNSUPPORTED,
+           "dither != 0 is not supported by the device fbank (set frontend_conf.dither: 0)");
+  PF_CHECK(fc_.fs == 16000, PF_ERR_UNSUPPORTED, "only fs = 16000 is supported");
+
+  load_weights(cfg);
+  mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
+
+  fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
+  std::vector<float> shift, scale;
+  if (cfg.mvn_path && cfg.mvn_path[0]) {
+    parse_mvn_text(read_text_file(cfg.mvn_path), shift, scale);
+  } else if (cfg.cmvn_shift && cfg.cmvn_scale && cfg.cmvn_dim > 0) {
+    shift.assign(cfg.cmvn_shift, cfg.cmvn_shift + cfg.cmvn_dim);
+    scale.assign(cfg.cmvn_scale, cfg.cmvn_scale + cfg.cmvn_dim);
+  }
+  if (!shift.empty()) {
+    PF_CHECK(shift.size() == scale.size(), PF_ERR_FORMAT, "am.mvn: shift/scale length mismatch");
+    PF_CHECK((int)shift.size() == fc_.lfr_m * fc_.n_mels, PF_ERR_FORMAT,
+             "am.mvn: CMVN dim must equal lfr_m * n_mels");
+    cmvn_dim_ = (int)shift.size();
+    cmvn_shift_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
+    cmvn_scale_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
+    PF_HIP(hipMemcpy(cmvn_shift_, shift.data(), sizeof(float) * cmvn_dim_, hipMemcpyHostToDevice));
+    PF_HIP(hipMemcpy(cmvn_scale_, scale.data(), sizeof(float) * cmvn_dim_, hipMemcpyHostToDevice));
+  }
+}
+
+Engine::~Engine() {
+  hipSetDevice(device_);
+  if (stream_) hipStreamSynchronize(stream_);
+  profile_reset();
+  fbank_tables_destroy(fb_);
+  for (void* p : owned_) hipFree(p);
+  DevBuf* bufs[] = {&ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_};
+  for (DevBuf* b : bufs)
+    if (b->p) hipFree(b->p);
+  if (blob_owned_ && blob_dev_) hipFree(blob_dev_);
+  if (stream_) hipStreamDestroy(stream_);
+}
+
+void* Engine::dalloc(size_t bytes) {
+  void* p = nullptr;
+  PF_HIP(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+  owned_.push_back(p);
+  return p;
+}
+
+void Engine::ensure(DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return;
+  if (b.p) {
+    PF_HIP(hipStreamSynchronize(stream_));
+    PF_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  const size_t want = round_up((int64_t)(bytes + bytes / 8), 1 << 20);
+  PF_HIP(hipMalloc(&b.p, want));
+  PF_HIP(hipMemsetAsync(b.p, 0, want, stream_));
+  b.bytes = want;
+}
+
+void Engine::sync() { PF_HIP(hipStreamSynchronize(stream_)); }
+
+// ------------------------------------------------------------------ weights ---------------
+const Engine::Tensor& Engine::tensor(const std::string& name) const {
+  auto it = tensors_.find(name);
+  if (it == tensors_.end()) throw Error(PF_ERR_FORMAT, "weights: missing tensor '" + name + "'");
+  return it->second;
+}
+
+void Engine::load_weights(const pf_engine_config& cfg) {
+  std::vector<char> file;
+  const char* host = nullptr;
+  int64_t nbytes = 0;
+  std::vector<char> head;          // header bytes when the image lives on the device
+  const char* dev_image = nullptr;
+  if (cfg.weights_path && cfg.weights_path[0]) {
+    read_binary_file(cfg.weights_path, file);
+    host = file.data();
+    nbytes = (int64_t)file.size();
+  } else if (cfg.weights_host) {
+    host = (const char*)cfg.weights_host;
+    nbytes = cfg.weights_bytes;
+  } else if (cfg.weights_device) {
+    dev_image = (const char*)cfg.weights_device;
+    nbytes = cfg.weights_bytes;
+    PF_CHECK(nbytes >= 16, PF_ERR_FORMAT, "weights: image too small");
+    head.resize(16);
+    PF_HIP(hipMemcpy(head.data(), dev_image, 16, hipMemcpyDeviceToHost));
+  } else {
+    throw Error(PF_ERR_INVALID_ARG, "weights: no source given (weights_path / weights_host / weights_device)");
+  }
+  PF_CHECK(nbytes >= 16, PF_ERR_FORMAT, "weights: image too small");
+  const char* h16 = host ? host : head.data();
+  PF_CHECK(std::memcmp(h16, "PFW1", 4) == 0, PF_ERR_FORMAT, "weights: bad magic (expected PFW1 container)");
+  uint64_t hlen = 0;
+  std::memcpy(&hlen, h16 + 8, 8);
+  PF_CHECK((int64_t)(16 + hlen) <= nbytes, PF_ERR_FORMAT, "weights: truncated header");
+  std::string hdr;
+  if (host) hdr.assign(host + 16, hlen);
+  else {
+    hdr.resize(hlen);
+    PF_HIP(hipMemcpy(&hdr[0], dev_image + 16, hlen, hipMemcpyDeviceToHost));
+  }
+  Json j = JsonParser(hdr.data(), hdr.size()).parse();
+  const Json* jc = j.get("config");
+  const Json* jt = j.get("tensors");
+  PF_CHECK(jc && jt && jt->type == Json::Arr, PF_ERR_FORMAT, "weights: header lacks config/tensors");
+  mc_.kind = jc->str_or("kind", mc_.kind);
+  mc_.feat_dim = (int)jc->num_or("feat_dim", mc_.feat_dim);
+  mc_.d_model = (int)jc->num_or("d_model", mc_.d_model);
+  mc_.heads = (int)jc->num_or("heads", mc_.heads);
+  mc_.ffn = (int)jc->num_or("ffn", mc_.ffn);
+  mc_.enc_layers = (int)jc->num_or("enc_layers", mc_.enc_layers);
+  mc_.tp_layers = (int)jc->num_or("tp_layers", mc_.tp_layers);
+  mc_.kernel = (int)jc->num_or("kernel", mc_.kernel);
+  mc_.dec_layers = (int)jc->num_or("dec_layers", mc_.dec_layers);
+  mc_.vocab = (int)jc->num_or("vocab", mc_.vocab);
+  mc_.cif_threshold = (float)jc->num_or("cif_threshold", mc_.cif_threshold);
+  mc_.cif_tail = (float)jc->num_or("cif_tail", mc_.cif_tail);
+  mc_.cif_smooth = (float)jc->num_or("cif_smooth", mc_.cif_smooth);
+  mc_.cif_noise = (float)jc->num_or("cif_noise", mc_.cif_noise);
+  mc_.cif_l_order = (int)jc->num_or("cif_l_order", mc_.cif_l_order);
+  mc_.cif_r_order = (int)jc->num_or("cif_r_order", mc_.cif_r_order);
+  mc_.timestamp_head = jc->bool_or("timestamp_head", false);
+  mc_.seaco = jc->bool_or("seaco", false);
+  mc_.use_itn = jc->bool_or("use_itn", false);
+  PF_CHECK(mc_.d_model == 512 && mc_.heads == 4, PF_ERR_UNSUPPORTED,
+           "kernels are built for d_model = 512, 4 heads of 128");
+  PF_CHECK(mc_.d_model % 8 == 0 && mc_.ffn % 64 == 0 && mc_.feat_dim % 4 == 0, PF_ERR_UNSUPPORTED,
+           "unsupported model dimensions");
+  PF_CHECK(!mc_.timestamp_head && !mc_.seaco, PF_ERR_UNSUPPORTED,
+           "timestamp (BiCIF) head / SeACo bias decoder are not built in this round");
+
+  const int64_t data_off = round_up((int64_t)(16 + hlen), (int64_t)kAlign);
+  const int64_t data_bytes = nbytes - data_off;
+  PF_CHECK(data_bytes >= 0, PF_ERR_FORMAT, "weights: truncated data section");
+  const char* data_dev = nullptr;
+  if (host) {
+    PF_HIP(hipMalloc(&blob_dev_, std::max<int64_t>(data_bytes, 256)));
+    blob_owned_ = true;
+    PF_HIP(hipMemcpy(blob_dev_, host + data_off, data_bytes, hipMemcpyHostToDevice));
+    data_dev = (const char*)blob_dev_;
+  } else {
+    data_dev = dev_image + data_off;
+  }
+  for (const Json& t : jt->arr) {
+    Tensor tt;
+    const std::string name = t.str_or("name", "");
+    PF_CHECK(t.str_or("dtype", "f32") == "f32", PF_ERR_FORMAT, "weights: only f32 tensors are supported");
+    const int64_t off = (int64_t)t.num_or("offset", -1), nb = (int64_t)t.num_or("nbytes", -1);
+    PF_CHECK(off >= 0 && nb >= 0 && off + nb <= data_bytes && off % 16 == 0, PF_ERR_FORMAT,
+             "weights: bad tensor extent for '" + name + "'");
+    tt.dev = (const float*)(data_dev + off);
+    tt.numel = 1;
+    if (const Json* sh = t.get("shape"))
+      for (const Json& d : sh->arr) { tt.shape.push_back((int64_t)d.num); tt.numel *= (int64_t)d.num; }
+    PF_CHECK(tt.numel * 4 == nb, PF_ERR_FORMAT, "weights: shape/nbytes mismatch for '" + name + "'");
+    tensors_[name] = tt;
+  }
+
+  // ---- bind layers, build f16 GEMM operands
+  const int D = mc_.d_model;
+  auto enc_layer = [&](const std::string& p, int d_in) {
+    EncLayer L;
+    L.d_in = d_in;
+    L.norm1 = make_ln(p + ".norm1");
+    L.qkv = make_lin(p + ".attn.qkv", true);
+    L.fsmn_wT = make_fsmn_wT(p + ".attn.fsmn.weight");
+    L.out = make_lin(p + ".attn.out", true);
+    L.norm2 = make_ln(p + ".norm2");
+    L.w1 = make_lin(p + ".ffn.w1", true);
+    L.w2 = make_lin(p + ".ffn.w2", true);
+    PF_CHECK(L.qkv.K == d_in && L.qkv.N == 3 * D, PF_ERR_FORMAT, "weights: qkv shape mismatch in " + p);
+    return L;
+  };
+  for (int i = 0; i < mc_.enc_layers; ++i)
+    enc_.push_back(enc_layer("encoder.layers." + std::to_string(i), i == 0 ? mc_.feat_dim : D));
+  enc_after_ = make_ln("encoder.after_norm");
+  for (int i = 0; i < mc_.tp_layers; ++i) tp_.push_back(enc_layer("encoder.tp_layers." + std::to_string(i), D));
+  if (mc_.tp_layers) tp_norm_ = make_ln("encoder.tp_norm");
+
+  if (mc_.kind == "sensevoicesmall") {
+    ctc_ = make_lin("ctc", true);
+    if (has_tensor("embed.weight")) {
+      const Tensor& t = tensor("embed.weight");
+      embed_host_.resize(t.numel);
+      PF_HIP(hipMemcpy(embed_host_.data(), t.dev, t.numel * 4, hipMemcpyDeviceToHost));
+    }
+    return;
+  }
+
+  // CIF predictor: conv weight [out, in, k] -> GEMM operand [out][j*D + in]
+  {
+    const Tensor& cw = tensor("predictor.conv.weight");
+    const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
+    PF_CHECK(cw.shape.size() == 3 && cw.shape[0] == D && cw.shape[1] == D && cw.shape[2] == taps, PF_ERR_FORMAT,
+             "weights: predictor.conv.weight shape");
+    std::vector<float> hostw(cw.numel), re(cw.numel);
+    PF_HIP(hipMemcpy(hostw.data(), cw.dev, cw.numel * 4, hipMemcpyDeviceToHost));
+    for (int o = 0; o < D; ++o)
+      for (int i = 0; i < D; ++i)
+        for (int jx = 0; jx < taps; ++jx) re[(size_t)o * taps * D + (size_t)jx * D + i] = hostw[((size_t)o * D + i) * taps + jx];
+    float* tmp = nullptr;
+    PF_HIP(hipMalloc(&tmp, re.size() * 4));
+    PF_HIP(hipMemcpy(tmp, re.data(), re.size() * 4, hipMemcpyHostToDevice));
+    cif_conv_.N = D; cif_conv_.K = taps * D; cif_conv_.Kpad = (int)round_up(taps * D, 64);
+    const int npad = (int)round_up(D, 128);
+    cif_conv_.w = (half_t*)dalloc((size_t)npad * cif_conv_.Kpad * 2);
+    PF_HIP(hipMemsetAsync(cif_conv_.w, 0, (size_t)npad * cif_conv_.Kpad * 2, stream_));
+    launch_f32_to_f16(stream_, tmp, D, taps * D, taps * D, cif_conv_.w, cif_conv_.Kpad);
+    PF_HIP(hipStreamSynchronize(stream_));
+    PF_HIP(hipFree(tmp));
+    cif_conv_.bias = tensor("predictor.conv.bias").dev;
+    cif_out_w_ = tensor("predictor.out.weight").dev;
+    cif_out_b_ = tensor("predictor.out.bias").dev;
+  }
+  // decoder
+  const int nd = mc_.dec_layers;
+  if (nd > 0) {
+    dec_kv_all_.N = nd * 2 * D; dec_kv_all_.K = D; dec_kv_all_.Kpad = D;
+    dec_kv_all_.w = (half_t*)dalloc((size_t)round_up(dec_kv_all_.N, 128) * D * 2);
+    PF_HIP(hipMemsetAsync(dec_kv_all_.w, 0, (size_t)round_up(dec_kv_all_.N, 128) * D * 2, stream_));
+    float* kvb = (float*)dalloc((size_t)dec_kv_all_.N * 4);
+    dec_kv_all_.bias = kvb;
+    for (int i = 0; i < nd; ++i) {
+      const std::string p = "decoder.layers." + std::to_string(i);
+      DecLayer L;
+      L.norm1 = make_ln(p + ".norm1");
+      L.w1 = make_lin(p + ".ffn.w1", true);
+      L.ffn_norm = make_ln(p + ".ffn.norm");
+      L.w2 = make_lin(p + ".ffn.w2", false);
+      L.norm2 = make_ln(p + ".norm2");
+      L.fsmn_wT = make_fsmn_wT(p + ".fsmn.weight");
+      L.norm3 = make_ln(p + ".norm3");
+      L.q = make_lin(p + ".src.q", true);
+      L.out = make_lin(p + ".src.out", true);
+      const Tensor& kvw = tensor(p + ".src.kv.weight");
+      const Tensor& kvbias = tensor(p + ".src.kv.bias");
+      PF_CHECK(kvw.numel == (int64_t)2 * D * D && kvbias.numel == 2 * D, PF_ERR_FORMAT, "weights: src.kv shape in " + p);
+      launch_f32_to_f16(stream_, kvw.dev, 2 * D, D, D, dec_kv_all_.w + (size_t)i * 2 * D * D, D);
+      PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
+      dec_.push_back(L);
+    }
+  }
+  dec_final_norm1_ = make_ln("decoder.final.norm1");
+  dec_final_w1_ = make_lin("decoder.final.ffn.w1", true);
+  dec_final_ffn_norm_ = make_ln("decoder.final.ffn.norm");
+  dec_final_w2_ = make_lin("decoder.final.ffn.w2", false);
+  dec_after_ = make_ln("decoder.after_norm");
+  dec_out_ = make_lin("decoder.output", true);
+  PF_CHECK(dec_out_.N == mc_.vocab, PF_ERR_FORMAT, "weights: decoder.output rows != vocab");
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+Lin Engine::make_lin(const std::string& prefix, bool bias) {
+  const Tensor& w = tensor(prefix + ".weight");
+  PF_CHECK(w.shape.size() == 2, PF_ERR_FORMAT, "weights: '" + prefix + ".weight' must be 2-D [out,in]");
+  Lin L;
+  L.N = (int)w.shape[0];
+  L.K = (int)w.shape[1];
+  L.Kpad = (int)round_up(L.K, 64);
+  const size_t npad = (size_t)round_up(L.N, 128);
+  L.w = (half_t*)dalloc(npad * L.Kpad * 2);
+  PF_HIP(hipMemsetAsync(L.w, 0, npad * L.Kpad * 2, stream_));
+  launch_f32_to_f16(stream_, w.dev, L.N, L.K, L.K, L.w, L.Kpad);
+  if (bias) {
+    const Tensor& b = tensor(prefix + ".bias");
+    PF_CHECK(b.numel == L.N, PF_ERR_FORMAT, "weights: bias length mismatch for " + prefix);
+    L.bias = b.dev;
+  }
+  return L;
+}
+
+LNp Engine::make_ln(const std::string& prefix) {
+  LNp p;
+  const Tensor& g = tensor(prefix + ".weight");
+  const Tensor& b = tensor(prefix + ".bias");
+  PF_CHECK(g.numel == b.numel, PF_ERR_FORMAT, "weights: LayerNorm size mismatch for " + prefix);
+  p.g = g.dev; p.b = b.dev; p.D = (int)g.numel;
+  return p;
+}
+
+float* Engine::make_fsmn_wT(const std::string& name) {
+  const Tensor& w = tensor(name);
+  PF_CHECK(w.shape.size() == 2 && w.shape[0] == mc_.d_model && w.shape[1] == mc_.kernel, PF_ERR_FORMAT,
+           "weights: '" + name + "' must be [d_model, kernel]");
+  const int D = mc_.d_model, K = mc_.kernel;
+  std::vector<float> h(w.numel), t(w.numel);
+  PF_HIP(hipMemcpy(h.data(), w.dev, w.numel * 4, hipMemcpyDeviceToHost));
+  for (int c = 0; c < D; ++c)
+    for (int jx = 0; jx < K; ++jx) t[(size_t)jx * D + c] = h[(size_t)c * K + jx];
+  float* d = (float*)dalloc(w.numel * 4);
+  PF_HIP(hipMemcpy(d, t.data(), w.numel * 4, hipMemcpyHostToDevice));
+  return d;
+}
+
+// ------------------------------------------------------------------ profiling -------------
+void Engine::profile_reset() {
+  for (auto& kv : prof_)
+    for (auto& pr : kv.second.ev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  prof_.clear();
+}
+void Engine::prof_begin(const char* cls, double flops) {
+  if (!prof_on_) return;
+  ProfClass& pc = prof_[cls];
+  hipEvent_t a, b;
+  PF_HIP(hipEventCreate(&a));
+  PF_HIP(hipEventCreate(&b));
+  pc.ev.emplace_back(a, b);
+  pc.flops += flops;
+  pc.n += 1;
+  PF_HIP(hipEventRecord(a, stream_));
+}
+void Engine::prof_end(const char* cls) {
+  if (!prof_on_) return;
+  ProfClass& pc = prof_[cls];
+  PF_HIP(hipEventRecord(pc.ev.back().second, stream_));
+}
+bool Engine::profile_get(const std::string& cls, double* ms, int64_t* launches, double* flops_per_launch) {
+  auto it = prof_.find(cls);
+  if (it == prof_.end()) return false;
+  PF_HIP(hipStreamSynchronize(stream_));
+  double total = 0;
+  for (auto& pr : it->second.ev) {
+    float t = 0;
+    PF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    total += t;
+  }
+  if (ms) *ms = total;
+  if (launches) *launches = it->second.n;
+  if (flops_per_launch) *flops_per_launch = it->second.n ? it->second.flops / it->second.n : 0;
+  return true;
+}
+
+void Engine::gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
+                  half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
+                  int scale_cols, float scale, bool bias) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = w.w; g.ldw = w.Kpad; g.bias = bias ? w.bias : nullptr;
+  g.M = M; g.N = w.N; g.K = w.Kpad;
+  g.out_f32 = out32; g.ldc32 = ld32; g.out_f16 = out16; g.ldc16 = ld16;
+  g.resid = resid; g.ldr = ldr; g.add2 = add2; g.ld2 = ld2;
+  g.relu = relu ? 1 : 0; g.scale_cols = scale_cols; g.scale = scale;
+  prof_begin(cls, 2.0 * M * (double)w.N * w.K);
+  launch_gemm(stream_, g);
+  prof_end(cls);
+}
+
+// ------------------------------------------------------------------ front-end -------------
+int Engine::num_fbank_frames(int64_t n) const {
+  if (fc_.snip_edges) return n < 400 ? 0 : (int)(1 + (n - 400) / 160);
+  return (int)((n + 80) / 160);
+}
+int Engine::num_lfr_frames(int64_t n) const {
+  const int t80 = num_fbank_frames(n);
+  if (fc_.lfr_m == 1 && fc_.lfr_n == 1) return t80;
+  return t80 / fc_.lfr_n;
+}
+
+void Engine::stage_audio(const float* const* samples, const int64_t* n, int B) {
+  PF_CHECK(B >= 0, PF_ERR_INVALID_ARG, "negative batch");
+  PF_HIP(hipSetDevice(device_));
+  st_B_ = B;
+  st_n_.assign(n, n + B);
+  st_t80_.resize(B);
+  std::vector<int64_t> meta(3 * (size_t)(B + 1), 0);   // audio_off | n_samples | frame_off
+  int64_t tot = 0, frames = 0;
+  int tmax = 0;
+  for (int b = 0; b < B; ++b) {
+    if (!samples[b] && n[b] > 0) throw Error(PF_ERR_NULL_SAMPLES, "source");
+    PF_CHECK(n[b] >= 0, PF_ERR_INVALID_ARG, "negative sample count");
+    meta[b] = tot;
+    meta[(B + 1) + b] = n[b];
+    meta[2 * (B + 1) + b] = frames;
+    st_t80_[b] = num_fbank_frames(n[b]);
+    tot += round_up(n[b], 4);
+    frames += st_t80_[b];
+    tmax = std::max(tmax, num_lfr_frames(n[b]));
+  }
+  meta[2 * (B + 1) + B] = frames;
+  st_total_frames_ = frames;
+  st_T_ = tmax;
+  ensure(ws_audio_, (size_t)std::max<int64_t>(tot, 1) * 4);
+  ensure(ws_meta_, meta.size() * 8 + (size_t)B * 4 + 64);
+  for (int b = 0; b < B; ++b)
+    if (n[b] > 0)
+      PF_HIP(hipMemcpyAsync((float*)ws_audio_.p + meta[b], samples[b], n[b] * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(ws_meta_.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync((char*)ws_meta_.p + meta.size() * 8, st_t80_.data(), (size_t)B * 4, hipMemcpyHostToDevice,
+                        stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::run_staged(bool want_logits) {
+  PF_HIP(hipSetDevice(device_));
+  const int B = st_B_, T = st_T_;
+  if (B == 0) { last_ = HostBatchOut(); return; }
+  PF_CHECK(T > 0, PF_ERR_INVALID_ARG, "audio too short: no LFR frame");
+  const int W = fc_.lfr_m * fc_.n_mels;
+  PF_CHECK(W == mc_.feat_dim, PF_ERR_INVALID_ARG, "lfr_m * n_mels != model feature dim");
+  const int64_t* meta = (const int64_t*)ws_meta_.p;
+  const int32_t* t80d = (const int32_t*)((const char*)ws_meta_.p + 3 * (size_t)(B + 1) * 8);
+  ensure(ws_fbank_, (size_t)std::max<int64_t>(st_total_frames_, 1) * fc_.n_mels * 4);
+  ensure(ws_speech_, (size_t)B * T * W * 4);
+  prof_begin("fbank", 0);
+  launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + (B + 1), meta + 2 * (B + 1), B,
+               st_total_frames_, fc_.snip_edges ? 1 : 0, (float*)ws_fbank_.p);
+  prof_end("fbank");
+  prof_begin("lfr_cmvn_pad", 0);
+  launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, meta + 2 * (B + 1), t80d, B, T, fc_.lfr_m, fc_.lfr_n,
+                      fc_.n_mels, cmvn_shift_, cmvn_scale_, cmvn_shift_ ? 1 : 0, 1, (float*)ws_speech_.p);
+  prof_end("lfr_cmvn_pad");
+  forward_device((const float*)ws_speech_.p, B, T, want_logits);
+}
+
+void Engine::fbank_host(const float* samples, int64_t n, std::vector<float>& out, int& t80) {
+  if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
+  const float* arr[1] = {samples};
+  const int64_t nn[1] = {n};
+  stage_audio(arr, nn, 1);
+  t80 = st_t80_[0];
+  out.assign((size_t)t80 * fc_.n_mels, 0.f);
+  if (t80 == 0) return;
+  const int64_t* meta = (const int64_t*)ws_meta_.p;
+  ensure(ws_fbank_, (size_t)t80 * fc_.n_mels * 4);
+  launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + 2, meta + 4, 1, t80, fc_.snip_edges ? 1 : 0,
+               (float*)ws_fbank_.p);
+  PF_HIP(hipMemcpyAsync(out.data(), ws_fbank_.p, out.size() * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::frontend_host(const float* samples, int64_t n, std::vector<float>& feats, int& t_lfr) {
+  if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
+  const float* arr[1] = {samples};
+  const int64_t nn[1] = {n};
+  stage_audio(arr, nn, 1);
+  const int t80 = st_t80_[0];
+  const bool lfr = fc_.lfr_m != 1 || fc_.lfr_n != 1;
+  const int m = lfr ? fc_.lfr_m : 1, nn_ = lfr ? fc_.lfr_n : 1;
+  t_lfr = t80 / nn_;
+  const int W = m * fc_.n_mels;
+  feats.assign((size_t)t_lfr * W, 0.f);
+  if (t_lfr == 0) return;
+  const int64_t* meta = (const int64_t*)ws_meta_.p;
+  const int32_t* t80d = (const int32_t*)((const char*)ws_meta_.p + 3 * 2 * 8);
+  ensure(ws_fbank_, (size_t)t80 * fc_.n_mels * 4);
+  ensure(ws_speech_, feats.size() * 4);
+  launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + 2, meta + 4, 1, t80, fc_.snip_edges ? 1 : 0,
+               (float*)ws_fbank_.p);
+  const bool cm = cmvn_shift_ && cmvn_dim_ == W;
+  launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, meta + 4, t80d, 1, t_lfr, m, nn_, fc_.n_mels, cmvn_shift_,
+                      cmvn_scale_, cm ? 1 : 0, 0, (float*)ws_speech_.p);
+  PF_HIP(hipMemcpyAsync(feats.data(), ws_speech_.p, feats.size() * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------ encoder ---------------
+void Engine::build_pe(int T) {
+  if (T <= pe_T_) return;
+  const int F = mc_.feat_dim, half = F / 2;
+  const int Tn = (int)round_up(T, 256);
+  std::vector<float> pe((size_t)Tn * F);
+  // SinusoidalPositionEncoder.encode in float32: inv_timescales = exp(i * -(ln 1e4 / (half-1)))
+  const float inc = (float)(std::log(10000.0) / (double)(half - 1));
+  std::vector<float> inv(half);
+  for (int i = 0; i < half; ++i) inv[i] = std::exp((float)i * (-inc));
+  for (int t = 0; t < Tn; ++t) {
+    const float pos = (float)(t + 1);
+    for (int i = 0; i < half; ++i) {
+      const float st = pos * inv[i];
+      pe[(size_t)t * F + i] = (float)std::sin((double)st);
+      pe[(size_t)t * F + half + i] = (float)std::cos((double)st);
+    }
+  }
+  ensure(ws_pe_, pe.size() * 4);
+  PF_HIP(hipMemcpyAsync(ws_pe_.p, pe.data(), pe.size() * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  pe_T_ = Tn;
+}
+
+void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T) {
+  const int D = mc_.d_model, M = B * T, F = mc_.ffn;
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  const int lda = first ? L.qkv.Kpad : D;
+  if (first) {
+    prof_begin("layernorm", 0);
+    launch_posenc_ln_tab(stream_, speech_dev, B, T, mc_.feat_dim, std::sqrt((float)D), (const float*)ws_pe_.p,
+                         L.norm1.g, L.norm1.b, xn16_, lda);
+    prof_end("layernorm");
+  } else {
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, x_, M, D, L.norm1.g, L.norm1.b, xn16_, D, nullptr, 0);
+    prof_end("layernorm");
+  }
+  gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
+  prof_begin("fsmn", 0);
+  launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
+  prof_end("fsmn");
+  AttnArgs a{};
+  a.q = qkv16_; a.k = qkv16_ + D; a.v = qkv16_ + 2 * D; a.o = ctx16_;
+  a.q_bstride = a.k_bstride = a.v_bstride = (int64_t)T * 3 * D;
+  a.q_rstride = a.k_rstride = a.v_rstride = 3 * D;
+  a.o_bstride = (int64_t)T * D; a.o_rstride = D;
+  a.B = B; a.H = mc_.heads; a.Lq = T; a.Lk = T;
+  prof_begin("attn_self", 4.0 * B * (double)T * T * D);
+  launch_attention(stream_, a);
+  prof_end("attn_self");
+  gemm("gemm_out", L.out, ctx16_, D, M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
+  prof_begin("layernorm", 0);
+  launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
+  prof_end("layernorm");
+  gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f);
+  gemm("gemm_ffn2", L.w2, h16_, F, M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f);
+}
+
+void Engine::encoder(const float* speech_dev, int B, int T) {
+  const int D = mc_.d_model, F = mc_.ffn;
+  const int64_t M = (int64_t)B * T;
+  const int64_t Mp = round_up(M, 128) + 128;
+  PF_CHECK(M < (1ll << 31) / (3 * D), PF_ERR_INVALID_ARG, "batch too large for 32-bit row indexing");
+  build_pe(T);
+  const int k0 = enc_.empty() ? D : enc_[0].qkv.Kpad;
+  // carve the encoder arena
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_x = carve(Mp * D * 4), o_xn = carve(Mp * std::max(k0, D) * 2), o_qkv = carve(Mp * 3 * D * 2);
+  const size_t o_ctx = carve(Mp * D * 2), o_fsm = carve(Mp * D * 4), o_h = carve(Mp * std::max(F, 3 * D) * 2);
+  const size_t o_H32 = carve(Mp * D * 4), o_H16 = carve(Mp * D * 2), o_al = carve((size_t)B * (T + 1) * 4);
+  const size_t o_fc = carve((size_t)B * 4), o_tn = carve((size_t)B * 4), o_ff = carve((size_t)B * (T + 1) * 4);
+  const size_t o_wc = carve((size_t)B * (T + 1) * 4), o_wr = carve((size_t)B * (T + 1) * 4), o_mx = carve(256);
+  ensure(ws_enc_, off);
+  char* base = (char*)ws_enc_.p;
+  x_ = (float*)(base + o_x); xn16_ = (half_t*)(base + o_xn); qkv16_ = (half_t*)(base + o_qkv);
+  ctx16_ = (half_t*)(base + o_ctx); fsm_ = (float*)(base + o_fsm); h16_ = (half_t*)(base + o_h);
+  H32_ = (float*)(base + o_H32); H16_ = (half_t*)(base + o_H16); alphas_ = (float*)(base + o_al);
+  plan_.fire_count = (int32_t*)(base + o_fc); plan_.token_num = (int32_t*)(base + o_tn);
+  plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
+  plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
+
+  for (size_t i = 0; i < enc_.size(); ++i) enc_layer(enc_[i], i == 0, speech_dev, B, T);
+  const bool has_tp = !tp_.empty();
+  prof_begin("layernorm", 0);
+  if (has_tp) {
+    // after_norm output continues as the residual stream of the tp blocks
+    launch_layernorm(stream_, x_, M, D, enc_after_.g, enc_after_.b, nullptr, 0, x_, D);
+  } else {
+    launch_layernorm(stream_, x_, M, D, enc_after_.g, enc_after_.b, H16_, D, H32_, D);
+  }
+  prof_end("layernorm");
+  if (has_tp) {
+    for (size_t i = 0; i < tp_.size(); ++i) enc_layer(tp_[i], false, nullptr, B, T);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, x_, M, D, tp_norm_.g, tp_norm_.b, H16_, D, H32_, D);
+    prof_end("layernorm");
+  }
+}
+
+// ------------------------------------------------------------------ CIF + decoder ---------
+void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
+  const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab;
+  const int M = B * T, T1 = T + 1;
+  const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
+  // conv1d(k=3) as im2col GEMM; reuse the FFN hidden buffer for the [M, 3D] operand and the
+  // FSMN buffer for the fp32 conv output.
+  half_t* col16 = h16_;
+  float* conv32 = fsm_;
+  prof_begin("cif_misc", 0);
+  launch_cif_im2col(stream_, H16_, B, T, D, mc_.cif_l_order, mc_.cif_r_order, col16);
+  prof_end("cif_misc");
+  gemm("gemm_cif", cif_conv_, col16, taps * D, M, conv32, D, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+  prof_begin("cif_misc", 0);
+  launch_cif_alpha(stream_, conv32, B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail,
+                   alphas_);
+  launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
+  prof_end("cif_misc");
+  // the path's only host sync: the decoder length L is data dependent
+  int32_t L = 0;
+  last_.fire_count.resize(B);
+  last_.token_num.resize(B);
+  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  last_.B = B; last_.L = L; last_.V = V; last_.T = T;
+  last_.ids.assign((size_t)B * L, 0);
+  if (L == 0) return;
+
+  const int Md = B * L;
+  const int64_t Mdp = round_up(Md, 128) + 128;
+  const int64_t Mp = round_up(M, 128) + 128;
+  const int nd = (int)dec_.size();
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_kv = carve((size_t)Mp * std::max(nd, 1) * 2 * D * 2), o_x = carve(Mdp * D * 4), o_xn = carve(Mdp * D * 2);
+  const size_t o_h32 = carve(Mdp * F * 4), o_h16 = carve(Mdp * F * 2), o_t = carve(Mdp * D * 4), o_tn = carve(Mdp * D * 4);
+  const size_t o_q = carve(Mdp * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * V * 4), o_ids = carve((size_t)Md * 8);
+  ensure(ws_dec_, off);
+  char* base = (char*)ws_dec_.p;
+  half_t* kv16 = (half_t*)(base + o_kv);
+  float* xd = (float*)(base + o_x); half_t* xdn16 = (half_t*)(base + o_xn);
+  float* hd32 = (float*)(base + o_h32); half_t* hd16 = (half_t*)(base + o_h16);
+  float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
+  half_t* qd16 = (half_t*)(base + o_q); half_t* ctxd16 = (half_t*)(base + o_ctx);
+  logits_ = (float*)(base + o_lg); ids_dev_ = (int64_t*)(base + o_ids);
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  const int ldkv = nd * 2 * D;
+
+  prof_begin("cif_misc", 0);
+  launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
+  prof_end("cif_misc");
+  if (nd > 0)
+    gemm("gemm_dec_kv", dec_kv_all_, H16_, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_dec_ffn1", w1, xdn16, D, Md, hd32, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, hd32, Md, F, fn.g, fn.b, hd16, F, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_dec_ffn2", w2, hd16, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
+  };
+
+  for (int i = 0; i < nd; ++i) {
+    const DecLayer& Lr = dec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    prof_end("layernorm");
+    prof_begin("fsmn", 0);
+    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
+    prof_end("fsmn");
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, xdn16, D, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_dec_q", Lr.q, xdn16, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
+    AttnArgs a{};
+    a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
+    a.k = kv16 + (size_t)i * 2 * D; a.v = kv16 + (size_t)i * 2 * D + D;
+    a.k_bstride = a.v_bstride = (int64_t)T * ldkv; a.k_rstride = a.v_rstride = ldkv;
+    a.o = ctxd16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
+    a.B = B; a.H = mc_.heads; a.Lq = L; a.Lk = T;
+    prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
+    launch_attention(stream_, a);
+    prof_end("attn_cross");
+    gemm("gemm_dec_out", Lr.out, ctxd16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
+  }
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
+  prof_begin("layernorm", 0);
+  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, xdn16, D, nullptr, 0);
+  prof_end("layernorm");
+  gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, V, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  prof_begin("argmax", 0);
+  launch_argmax(stream_, logits_, Md, V, V, want_logits ? 1 : 0, ids_dev_);
+  prof_end("argmax");
+  PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::sensevoice_head(int B, int T, bool want_logits) {
+  const int D = mc_.d_model, V = mc_.vocab;
+  const int M = B * T;
+  const int64_t Mp = round_up(M, 128) + 128;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_lg = carve((size_t)Mp * V * 4), o_ids = carve((size_t)M * 8);
+  ensure(ws_dec_, off);
+  logits_ = (float*)((char*)ws_dec_.p + o_lg);
+  ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids);
+  gemm("gemm_vocab", ctc_, H16_, D, M, logits_, V, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  prof_begin("argmax", 0);
+  launch_argmax(stream_, logits_, M, V, V, want_logits ? 1 : 0, ids_dev_);
+  prof_end("argmax");
+  last_.B = B; last_.L = T; last_.V = V; last_.T = T;
+  last_.ids.assign((size_t)M, 0);
+  last_.token_num.assign(B, T);
+  last_.fire_count.assign(B, T);
+  PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)M * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::forward_device(const float* speech_dev, int B, int T, bool want_logits) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(B > 0 && T > 0, PF_ERR_INVALID_ARG, "forward: empty batch");
+  last_logits_ = want_logits;
+  encoder(speech_dev, B, T);
+  if (mc_.kind == "sensevoicesmall") sensevoice_head(B, T, want_logits);
+  else predictor_and_decoder(B, T, want_logits);
+  // algorithmic FLOPs
+  const double D = mc_.d_model, F = mc_.ffn, Td = T, Ld = last_.L, K = mc_.kernel, V = mc_.vocab;
+  double enc = 2 * Td * mc_.feat_dim * 3 * D + (mc_.enc_layers - 1 + mc_.tp_layers) * 2 * Td * D * 3 * D +
+               (mc_.enc_layers + mc_.tp_layers) * (4 * Td * Td * D + 2 * Td * D * D + 4 * Td * D * F + 2 * Td * D * K);
+  double fl = enc;
+  if (mc_.kind == "sensevoicesmall") fl += 2 * Td * D * V;
+  else {
+    fl += 2 * Td * D * D * 3 + 2 * Td * D;
+    fl += mc_.dec_layers * (4 * Ld * D * F + 2 * Ld * D * K + 2 * Ld * D * D + 4 * Td * D * D + 4 * Ld * Td * D + 2 * Ld * D * D) +
+          4 * Ld * D * F + 2 * Ld * D * V;
+  }
+  last_flops_ = fl * B;
+}
+
+void Engine::forward_feats_host(const float* speech, int B, int T, bool want_logits) {
+  PF_CHECK(speech && B > 0 && T > 0, PF_ERR_INVALID_ARG, "forward_feats: bad arguments");
+  PF_HIP(hipSetDevice(device_));
+  const size_t n = (size_t)B * T * mc_.feat_dim;
+  ensure(ws_speech_, n * 4);
+  PF_HIP(hipMemcpyAsync(ws_speech_.p, speech, n * 4, hipMemcpyHostToDevice, stream_));
+  forward_device((const float*)ws_speech_.p, B, T, want_logits);
+}
+
+void Engine::model_proj_host(const float* const* speech, const int32_t* n_floats, int B, bool want_logits) {
+  PF_CHECK(B > 0, PF_ERR_INVALID_ARG, "model_proj: empty batch");
+  PF_HIP(hipSetDevice(device_));
+  const int W = mc_.feat_dim;
+  int maxf = 0;
+  std::vector<int64_t> offs(B);
+  int64_t tot = 0;
+  for (int b = 0; b < B; ++b) {
+    PF_CHECK(speech[b] || n_floats[b] == 0, PF_ERR_INVALID_ARG, "model_proj: null speech");
+    offs[b] = tot;
+    tot += round_up(n_floats[b], 4);
+    maxf = std::max(maxf, n_floats[b]);
+  }
+  PF_CHECK(maxf > 0 && maxf % W == 0, PF_ERR_INVALID_ARG, "model_proj: feature length not a multiple of 560");
+  const int T = maxf / W;
+  ensure(ws_tmp_, (size_t)tot * 4 + (size_t)B * 12 + 64);
+  float* rag = (float*)ws_tmp_.p;
+  int64_t* offd = (int64_t*)((char*)ws_tmp_.p + round_up(tot * 4, 8));
+  int32_t* nd = (int32_t*)(offd + B);
+  for (int b = 0; b < B; ++b)
+    if (n_floats[b] > 0)
+      PF_HIP(hipMemcpyAsync(rag + offs[b], speech[b], (size_t)n_floats[b] * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(offd, offs.data(), (size_t)B * 8, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(nd, n_floats, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+  ensure(ws_speech_, (size_t)B * maxf * 4);
+  launch_pad_sentinel(stream_, rag, offd, nd, B, maxf, (float*)ws_speech_.p);
+  forward_device((const float*)ws_speech_.p, B, T, want_logits);
+}
+
+void Engine::fetch(pf_batch_out* out) {
+  PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");
+  PF_HIP(hipStreamSynchronize(stream_));
+  const int B = last_.B, L = last_.L, V = last_.V;
+  out->L = L; out->V = V; out->cif_peak_len = 0;
+  if (out->token_ids) {
+    PF_CHECK(out->l_cap >= L, PF_ERR_CAPACITY, "token_ids capacity " + std::to_string(out->l_cap) + " < L = " + std::to_string(L));
+    for (int b = 0; b < B; ++b) {
+      std::memcpy(out->token_ids + (size_t)b * out->l_cap, last_.ids.data() + (size_t)b * L, (size_t)L * 8);
+    }
+  }
+  if (out->token_num) std::memcpy(out->token_num, last_.token_num.data(), (size_t)B * 4);
+  if (out->logits && out->logits_cap > 0) {
+    PF_CHECK(last_logits_, PF_ERR_INVALID_ARG, "logits were not requested for the last forward");
+    const int64_t need = (int64_t)B * L * V;
+    PF_CHECK(out->logits_cap >= need, PF_ERR_CAPACITY, "logits capacity < B*L*V = " + std::to_string(need));
+    if (need > 0) PF_HIP(hipMemcpy(out->logits, logits_, (size_t)need * 4, hipMemcpyDeviceToHost));
+  }
+}
+
+// ------------------------------------------------------------------ stand-alone ops -------
+void Engine::op_lfr_cmvn_pad(const float* const* fbank, const int32_t* t80, int B, int sentinel, float* out,
+                             int64_t cap, int32_t* tmax_out) {
+  PF_HIP(hipSetDevice(device_));
+  const int nm = fc_.n_mels, W = fc_.lfr_m * nm;
+  std::vector<int64_t> foff(B + 1, 0);
+  int tmax = 0;
+  for (int b = 0; b < B; ++b) { foff[b + 1] = foff[b] + t80[b]; tmax = std::max(tmax, t80[b] / fc_.lfr_n); }
+  if (tmax_out) *tmax_out = tmax;
+  const int64_t need = (int64_t)B * tmax * W;
+  PF_CHECK(cap >= need, PF_ERR_CAPACITY, "lfr_cmvn_pad: out capacity < " + std::to_string(need));
+  if (need == 0) return;
+  ensure(ws_fbank_, (size_t)std::max<int64_t>(foff[B], 1) * nm * 4);
+  ensure(ws_meta_, (size_t)(B + 1) * 8 + (size_t)B * 4 + 64);
+  ensure(ws_speech_, (size_t)need * 4);
+  for (int b = 0; b < B; ++b)
+    if (t80[b] > 0)
+      PF_HIP(hipMemcpyAsync((float*)ws_fbank_.p + foff[b] * nm, fbank[b], (size_t)t80[b] * nm * 4,
+                            hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(ws_meta_.p, foff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream_));
+  int32_t* t80d = (int32_t*)((char*)ws_meta_.p + (size_t)(B + 1) * 8);
+  PF_HIP(hipMemcpyAsync(t80d, t80, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+  launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, (const int64_t*)ws_meta_.p, t80d, B, tmax, fc_.lfr_m,
+                      fc_.lfr_n, nm, cmvn_shift_, cmvn_scale_, cmvn_shift_ ? 1 : 0, sentinel, (float*)ws_speech_.p);
+  PF_HIP(hipMemcpyAsync(out, ws_speech_.p, (size_t)need * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_argmax(const float* x, int64_t rows, int V, int64_t* ids) {
+  PF_HIP(hipSetDevice(device_));
+  if (rows == 0) return;
+  ensure(ws_tmp_, (size_t)rows * V * 4 + (size_t)rows * 8 + 256);
+  float* xd = (float*)ws_tmp_.p;
+  int64_t* idd = (int64_t*)((char*)ws_tmp_.p + round_up((int64_t)rows * V * 4, 256));
+  PF_HIP(hipMemcpyAsync(xd, x, (size_t)rows * V * 4, hipMemcpyHostToDevice, stream_));
+  launch_argmax(stream_, xd, rows, V, V, 0, idd);
+  PF_HIP(hipMemcpyAsync(ids, idd, (size_t)rows * 8, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C) {
+  PF_HIP(hipSetDevice(device_));
+  if (M == 0 || N == 0) return;
+  const int Kp = (int)round_up(K, 64);
+  const int64_t Mp = round_up(M, 128), Np = round_up(N, 128);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t oA = carve((size_t)M * K * 4), oW = carve((size_t)N * K * 4), ob = carve((size_t)N * 4);
+  const size_t oA16 = carve((size_t)Mp * Kp * 2), oW16 = carve((size_t)Np * Kp * 2), oC = carve((size_t)M * N * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemcpyAsync(base + oA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
+  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemsetAsync(base + oA16, 0, (size_t)Mp * Kp * 2, stream_));
+  PF_HIP(hipMemsetAsync(base + oW16, 0, (size_t)Np * Kp * 2, stream_));
+  launch_f32_to_f16(stream_, (const float*)(base + oA), M, K, K, (half_t*)(base + oA16), Kp);
+  launch_f32_to_f16(stream_, (const float*)(base + oW), N, K, K, (half_t*)(base + oW16), Kp);
+  GemmArgs g{};
+  g.A = (half_t*)(base + oA16); g.lda = Kp; g.W = (half_t*)(base + oW16); g.ldw = Kp;
+  g.bias = bias ? (const float*)(base + ob) : nullptr;
+  g.M = M; g.N = N; g.K = Kp; g.out_f32 = (float*)(base + oC); g.ldc32 = N; g.relu = epi == 1;
+  prof_begin("gemm_op", 2.0 * M * (double)N * K);
+  launch_gemm(stream_, g);
+  prof_end("gemm_op");
+  PF_HIP(hipMemcpyAsync(C, base + oC, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y) {
+  PF_HIP(hipSetDevice(device_));
+  if (rows == 0) return;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t ox = carve((size_t)rows * D * 4), og = carve((size_t)D * 4), obb = carve((size_t)D * 4), oy = carve((size_t)rows * D * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)rows * D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + obb, b, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+  launch_layernorm(stream_, (const float*)(base + ox), rows, D, (const float*)(base + og), (const float*)(base + obb),
+                   nullptr, 0, (float*)(base + oy), D);
+  PF_HIP(hipMemcpyAsync(y, base + oy, (size_t)rows * D * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_attention(const float* q, const float* k, const float* v, int B, int Lq, int Lk, int H, float* o) {
+  PF_HIP(hipSetDevice(device_));
+  const int Dm = H * 128;
+  const int64_t nq = (int64_t)B * Lq, nk = (int64_t)B * Lk;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
+  const size_t oin = carve((size_t)std::max(nq, nk) * Dm * 4);
+  const size_t oq = carve((size_t)(nq + 128) * Dm * 2), ok = carve((size_t)(nk + 128) * Dm * 2);
+  const size_t ov = carve((size_t)(nk + 128) * Dm * 2), oo = carve((size_t)(nq + 128) * Dm * 2), oo32 = carve((size_t)nq * Dm * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + oq, 0, off - oq, stream_));
+  auto up = [&](const float* src, int64_t rows, size_t dst) {
+    PF_HIP(hipMemcpyAsync(base + oin, src, (size_t)rows * Dm * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + oin), rows, Dm, Dm, (half_t*)(base + dst), Dm);
+    PF_HIP(hipStreamSynchronize(stream_));
+  };
+  up(q, nq, oq); up(k, nk, ok); up(v, nk, ov);
+  AttnArgs a{};
+  a.q = (half_t*)(base + oq); a.k = (half_t*)(base + ok); a.v = (half_t*)(base + ov); a.o = (half_t*)(base + oo);
+  a.q_bstride = (int64_t)Lq * Dm; a.k_bstride = a.v_bstride = (int64_t)Lk * Dm; a.o_bstride = (int64_t)Lq * Dm;
+  a.q_rstride = a.k_rstride = a.v_rstride = a.o_rstride = Dm;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  prof_begin("attn_op", 4.0 * B * (double)Lq * Lk * Dm);
+  launch_attention(stream_, a);
+  prof_end("attn_op");
+  // f16 -> f32 on the host side of the copy
+  std::vector<uint16_t> tmp((size_t)nq * Dm);
+  PF_HIP(hipMemcpyAsync(tmp.data(), base + oo, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < tmp.size(); ++i) {
+    half_t hv;
+    std::memcpy(&hv, &tmp[i], 2);
+    o[i] = (float)hv;
+  }
+  (void)oo32;
+}
+
+void Engine::op_fsmn(const float* v, const float* w, const float* mask, int B, int T, int D, int k, float* y) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(D % 4 == 0, PF_ERR_INVALID_ARG, "fsmn: D must be a multiple of 4");
+  const size_t n = (size_t)B * T * D;
+  if (n == 0) return;
+  std::vector<float> wT((size_t)D * k);
+  for (int c = 0; c < D; ++c)
+    for (int j = 0; j < k; ++j) wT[(size_t)j * D + c] = w[(size_t)c * k + j];
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
+  const size_t ov = carve(n * 4), ow = carve(wT.size() * 4), om = carve((size_t)B * T * 4), oy = carve(n * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemcpyAsync(base + ov, v, n * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ow, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
+  if (mask) PF_HIP(hipMemcpyAsync(base + om, mask, (size_t)B * T * 4, hipMemcpyHostToDevice, stream_));
+  launch_fsmn_f32(stream_, (const float*)(base + ov), (const float*)(base + ow), mask ? (const float*)(base + om) : nullptr,
+                  B, T, D, k, (float*)(base + oy));
+  PF_HIP(hipMemcpyAsync(y, base + oy, n * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_cif(const float* H, const float* alphas, int B, int T, int D, float thr, int Lcap, float* E,
+                    int32_t* fire_count, int32_t* token_num, int32_t* L_out) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(D % 4 == 0 && B > 0 && T > 0, PF_ERR_INVALID_ARG, "cif: bad shape");
+  const int T1 = T + 1;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
+  const size_t oH = carve((size_t)B * T * D * 4), oa = carve((size_t)B * T1 * 4), ofc = carve((size_t)B * 4), otn = carve((size_t)B * 4);
+  const size_t off_ = carve((size_t)B * T1 * 4), owc = carve((size_t)B * T1 * 4), owr = carve((size_t)B * T1 * 4), omx = carve(256);
+  const size_t oE = carve((size_t)B * std::max(Lcap, 1) * D * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  CifPlan p;
+  p.fire_count = (int32_t*)(base + ofc); p.token_num = (int32_t*)(base + otn); p.fire_frame = (int32_t*)(base + off_);
+  p.w_cur = (float*)(base + owc); p.w_rem = (float*)(base + owr); p.max_count = (int32_t*)(base + omx);
+  PF_HIP(hipMemcpyAsync(base + oH, H, (size_t)B * T * D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + oa, alphas, (size_t)B * T1 * 4, hipMemcpyHostToDevice, stream_));
+  launch_cif_scan(stream_, (const float*)(base + oa), B, T1, thr, p);
+  int32_t L = 0;
+  PF_HIP(hipMemcpyAsync(&L, p.max_count, 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(fire_count, p.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(token_num, p.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  if (L_out) *L_out = L;
+  PF_CHECK(L <= Lcap, PF_ERR_CAPACITY, "cif: Lcap " + std::to_string(Lcap) + " < L = " + std::to_string(L));
+  if (Lcap == 0) return;
+  launch_cif_gather(stream_, (const float*)(base + oH), B, T, D, T1, p, Lcap, (float*)(base + oE));
+  PF_HIP(hipMemcpyAsync(E, base + oE, (size_t)B * Lcap * D * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::op_encoder(const float* speech, int B, int T, float* H) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(speech && H && B > 0 && T > 0, PF_ERR_INVALID_ARG, "encoder: bad arguments");
+  const size_t n = (size_t)B * T * mc_.feat_dim;
+  ensure(ws_speech_, n * 4);
+  PF_HIP(hipMemcpyAsync(ws_speech_.p, speech, n * 4, hipMemcpyHostToDevice, stream_));
+  encoder((const float*)ws_speech_.p, B, T);
+  PF_HIP(hipMemcpyAsync(H, H32_, (size_t)B * T * mc_.d_model * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+}  // namespace pf

@@ -1,0 +1,166 @@
+// engine.h — device engine: weights, workspace and the forward pipeline.
+// Replaces OfflineModel (ORT session, AliParaformerAsr/OfflineModel.cs:35-70) and the numeric
+// body of IOfflineProj.ModelProj (AliParaformerAsr/IOfflineProj.cs:38).
+#pragma once
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "json.h"
+#include "kernels.h"
+
+namespace pf {
+
+struct ModelCfg {
+  std::string kind = "paraformer";
+  int feat_dim = 560, d_model = 512, heads = 4, ffn = 2048, enc_layers = 50, tp_layers = 0, kernel = 11;
+  int dec_layers = 16, vocab = 8404;
+  float cif_threshold = 1.0f, cif_tail = 0.45f, cif_smooth = 1.0f, cif_noise = 0.0f;
+  int cif_l_order = 1, cif_r_order = 1;
+  bool timestamp_head = false, seaco = false, use_itn = false;
+  int kind_id() const { return kind == "sensevoicesmall" ? 1 : (kind == "seacoparaformer" ? 2 : 0); }
+};
+
+struct FrontendCfg {
+  int fs = 16000, n_mels = 80, lfr_m = 7, lfr_n = 6;
+  bool snip_edges = false;
+  float dither = 0.f;
+  std::string window = "hamming";
+};
+
+struct Lin {          // y = x W^T + b ; W stored f16 [Npad][Kpad]
+  half_t* w = nullptr;
+  const float* bias = nullptr;
+  int N = 0, K = 0, Kpad = 0;
+};
+struct LNp { const float* g = nullptr; const float* b = nullptr; int D = 0; };
+struct EncLayer { LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512; };
+struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out; float* fsmn_wT = nullptr; };
+
+struct DevBuf {       // grow-only device allocation
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct HostBatchOut { // results of the last forward, host side
+  int B = 0, L = 0, V = 0, T = 0;
+  std::vector<int64_t> ids;        // [B, L]
+  std::vector<int32_t> token_num;  // [B]
+  std::vector<int32_t> fire_count; // [B]
+};
+
+class Engine {
+ public:
+  explicit Engine(const pf_engine_config& cfg);
+  ~Engine();
+
+  // ---- front-end ---------------------------------------------------------
+  int num_lfr_frames(int64_t n_samples) const;
+  int num_fbank_frames(int64_t n_samples) const;
+  void fbank_host(const float* samples, int64_t n, std::vector<float>& out, int& t80);
+  void frontend_host(const float* samples, int64_t n, std::vector<float>& feats, int& t_lfr);
+
+  // ---- forward -----------------------------------------------------------
+  // speech_dev: [B,T,feat] fp32 already on device (padded + sentinel)
+  void forward_device(const float* speech_dev, int B, int T, bool want_logits);
+  void forward_feats_host(const float* speech, int B, int T, bool want_logits);
+  void model_proj_host(const float* const* speech, const int32_t* n_floats, int B, bool want_logits);
+  void stage_audio(const float* const* samples, const int64_t* n, int B);
+  void run_staged(bool want_logits);
+  void fetch(pf_batch_out* out);
+  void sync();
+
+  // ---- stand-alone ops (parity tests) -------------------------------------
+  void op_lfr_cmvn_pad(const float* const* fbank, const int32_t* t80, int B, int sentinel, float* out,
+                       int64_t cap, int32_t* tmax);
+  void op_argmax(const float* x, int64_t rows, int V, int64_t* ids);
+  void op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C);
+  void op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y);
+  void op_attention(const float* q, const float* k, const float* v, int B, int Lq, int Lk, int H, float* o);
+  void op_fsmn(const float* v, const float* w, const float* mask, int B, int T, int D, int k, float* y);
+  void op_cif(const float* H, const float* alphas, int B, int T, int D, float thr, int Lcap, float* E,
+              int32_t* fire_count, int32_t* token_num, int32_t* L_out);
+  void op_encoder(const float* speech, int B, int T, float* H);
+
+  // ---- profiling -----------------------------------------------------------
+  void profile_enable(bool on) { prof_on_ = on; }
+  void profile_reset();
+  bool profile_get(const std::string& cls, double* ms, int64_t* launches, double* flops_per_launch);
+  double last_flops() const { return last_flops_; }
+
+  const ModelCfg& model() const { return mc_; }
+  const FrontendCfg& frontend() const { return fc_; }
+  const std::vector<float>& embed_table() const { return embed_host_; }   // SenseVoice [16,560]
+  std::mutex& mutex() { return mu_; }
+  int device() const { return device_; }
+
+ private:
+  struct Tensor { const float* dev = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
+  struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0; int64_t n = 0; };
+
+  void load_weights(const pf_engine_config& cfg);
+  const Tensor& tensor(const std::string& name) const;
+  bool has_tensor(const std::string& name) const { return tensors_.count(name) != 0; }
+  Lin make_lin(const std::string& prefix, bool bias);
+  LNp make_ln(const std::string& prefix);
+  float* make_fsmn_wT(const std::string& name);
+  void* dalloc(size_t bytes);
+  void ensure(DevBuf& b, size_t bytes);
+  void build_pe(int T);
+  void encoder(const float* speech_dev, int B, int T);
+  void enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T);
+  void predictor_and_decoder(int B, int T, bool want_logits);
+  void sensevoice_head(int B, int T, bool want_logits);
+  void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
+            half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
+            int scale_cols, float scale, bool bias = true);
+  void prof_begin(const char* cls, double flops);
+  void prof_end(const char* cls);
+
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  ModelCfg mc_;
+  FrontendCfg fc_;
+  std::mutex mu_;
+
+  // weights
+  void* blob_dev_ = nullptr;        // device copy of the PFW data section (owned unless external)
+  bool blob_owned_ = false;
+  std::map<std::string, Tensor> tensors_;
+  std::vector<void*> owned_;        // every other device allocation
+  std::vector<EncLayer> enc_, tp_;
+  std::vector<DecLayer> dec_;
+  LNp enc_after_, tp_norm_, dec_final_norm1_, dec_final_ffn_norm_, dec_after_;
+  Lin cif_conv_, dec_kv_all_, dec_final_w1_, dec_final_w2_, dec_out_, ctc_;
+  const float* cif_out_w_ = nullptr;
+  const float* cif_out_b_ = nullptr;
+  std::vector<float> embed_host_;
+
+  // front-end
+  FbankTables* fb_ = nullptr;
+  float* cmvn_shift_ = nullptr;
+  float* cmvn_scale_ = nullptr;
+  int cmvn_dim_ = 0;
+
+  // workspace
+  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_;
+  int pe_T_ = 0;
+  // encoder views (valid after encoder())
+  float* x_ = nullptr; half_t* xn16_ = nullptr; half_t* qkv16_ = nullptr; half_t* ctx16_ = nullptr;
+  float* fsm_ = nullptr; half_t* h16_ = nullptr; float* H32_ = nullptr; half_t* H16_ = nullptr;
+  float* alphas_ = nullptr; CifPlan plan_{};
+  // decoder views
+  float* logits_ = nullptr; int64_t* ids_dev_ = nullptr;
+  // staged audio
+  std::vector<int64_t> st_n_; std::vector<int32_t> st_t80_; int st_B_ = 0, st_T_ = 0;
+  int64_t st_total_frames_ = 0;
+  HostBatchOut last_;
+  bool last_logits_ = false;
+  double last_flops_ = 0;
+
+  bool prof_on_ = false;
+  std::map<std::string, ProfClass> prof_;
+};
+
+}  // namespace pf

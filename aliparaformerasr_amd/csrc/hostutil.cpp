@@ -1,0 +1,239 @@
+// hostutil.cpp — see hostutil.h
+#include "hostutil.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace pf {
+
+bool file_exists(const std::string& path) {
+  if (path.empty()) return false;
+  std::ifstream f(path, std::ios::binary);
+  return f.good();
+}
+
+std::string read_text_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.good()) throw Error(PF_ERR_IO, "cannot open file: " + path);
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+void read_binary_file(const std::string& path, std::vector<char>& out) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f.good()) throw Error(PF_ERR_IO, "cannot open file: " + path);
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  out.resize((size_t)n);
+  if (n > 0 && !f.read(out.data(), n)) throw Error(PF_ERR_IO, "short read: " + path);
+}
+
+std::vector<std::string> split_lines(const std::string& text) {
+  // File.ReadAllLines: splits on \n, \r\n, \r; a trailing newline does not create an empty line
+  std::vector<std::string> lines;
+  size_t i = 0, n = text.size();
+  // skip UTF-8 BOM like StreamReader does
+  if (n >= 3 && (unsigned char)text[0] == 0xEF && (unsigned char)text[1] == 0xBB && (unsigned char)text[2] == 0xBF) i = 3;
+  std::string cur;
+  bool any = false;
+  for (; i < n; ++i) {
+    char c = text[i];
+    if (c == '\n' || c == '\r') {
+      lines.push_back(cur);
+      cur.clear();
+      any = false;
+      if (c == '\r' && i + 1 < n && text[i + 1] == '\n') ++i;
+    } else {
+      cur += c;
+      any = true;
+    }
+  }
+  if (any) lines.push_back(cur);
+  return lines;
+}
+
+std::vector<std::string> read_lines(const std::string& path) { return split_lines(read_text_file(path)); }
+
+static std::string trim(const std::string& s) {
+  size_t a = 0, b = s.size();
+  while (a < b && (s[a] == ' ' || s[a] == '\t' || s[a] == '\r' || s[a] == '\n')) ++a;
+  while (b > a && (s[b - 1] == ' ' || s[b - 1] == '\t' || s[b - 1] == '\r' || s[b - 1] == '\n')) --b;
+  return s.substr(a, b - a);
+}
+
+static bool starts_with(const std::string& s, const char* p) { return s.compare(0, std::strlen(p), p) == 0; }
+
+static void parse_bracket_floats(const std::string& line, std::vector<float>& out) {
+  const size_t a = line.find('['), b = line.rfind(']');
+  if (a == std::string::npos || b == std::string::npos || b <= a)
+    throw Error(PF_ERR_FORMAT, "am.mvn: missing [ ] in <LearnRateCoef> line");
+  const std::string inner = line.substr(a + 1, b - a - 1);
+  out.clear();
+  size_t i = 0;
+  while (i <= inner.size()) {
+    size_t j = inner.find(' ', i);
+    if (j == std::string::npos) j = inner.size();
+    std::string tok = trim(inner.substr(i, j - i));
+    if (!tok.empty()) {
+      char* end = nullptr;
+      const float v = std::strtof(tok.c_str(), &end);
+      if (end == tok.c_str() || *end != '\0') throw Error(PF_ERR_FORMAT, "am.mvn: bad number '" + tok + "'");
+      out.push_back(v);
+    }
+    i = j + 1;
+  }
+}
+
+void parse_mvn_text(const std::string& text, std::vector<float>& shift, std::vector<float>& scale) {
+  shift.clear();
+  scale.clear();
+  int state = 0;
+  for (const std::string& line : split_lines(text)) {
+    if (line.empty()) continue;
+    if (starts_with(line, "<AddShift>")) { state = 1; continue; }
+    if (starts_with(line, "<Rescale>")) { state = 2; continue; }
+    if (starts_with(line, "<LearnRateCoef>") && state == 1) { parse_bracket_floats(line, shift); continue; }
+    if (starts_with(line, "<LearnRateCoef>") && state == 2) { parse_bracket_floats(line, scale); continue; }
+  }
+}
+
+// ------------------------------------------------------------------ config ----------------
+static std::string unquote(std::string v) {
+  v = trim(v);
+  if (v.size() >= 2 && ((v.front() == '"' && v.back() == '"') || (v.front() == '\'' && v.back() == '\'')))
+    v = v.substr(1, v.size() - 2);
+  return v;
+}
+static bool to_bool(const std::string& v, bool d) {
+  std::string s;
+  for (char c : v) s += (char)std::tolower((unsigned char)c);
+  if (s == "true" || s == "yes" || s == "on" || s == "1") return true;
+  if (s == "false" || s == "no" || s == "off" || s == "0") return false;
+  return d;
+}
+
+ConfEntity conf_from_yaml(const std::string& text) {
+  ConfEntity c;
+  std::string section;   // current top-level mapping key
+  for (std::string raw : split_lines(text)) {
+    // strip comments (outside quotes)
+    bool inq = false;
+    char qc = 0;
+    for (size_t i = 0; i < raw.size(); ++i) {
+      if ((raw[i] == '"' || raw[i] == '\'') && (!inq || raw[i] == qc)) { inq = !inq; qc = raw[i]; }
+      if (raw[i] == '#' && !inq && (i == 0 || raw[i - 1] == ' ' || raw[i - 1] == '\t')) { raw = raw.substr(0, i); break; }
+    }
+    if (trim(raw).empty()) continue;
+    size_t indent = 0;
+    while (indent < raw.size() && raw[indent] == ' ') ++indent;
+    const std::string body = trim(raw);
+    const size_t colon = body.find(':');
+    if (colon == std::string::npos) continue;
+    const std::string key = trim(body.substr(0, colon));
+    const std::string val = unquote(body.substr(colon + 1));
+    if (indent == 0) {
+      section = val.empty() ? key : "";
+      if (key == "model" && !val.empty()) c.model = val;
+      else if (key == "use_itn") c.use_itn = to_bool(val, c.use_itn);
+      continue;
+    }
+    if (section == "frontend_conf") {
+      if (key == "fs") c.fs = std::atoi(val.c_str());
+      else if (key == "window") c.window = val;
+      else if (key == "n_mels") c.n_mels = std::atoi(val.c_str());
+      else if (key == "frame_length") c.frame_length = std::atoi(val.c_str());
+      else if (key == "frame_shift") c.frame_shift = std::atoi(val.c_str());
+      else if (key == "dither") c.dither = std::strtof(val.c_str(), nullptr);
+      else if (key == "lfr_m") c.lfr_m = std::atoi(val.c_str());
+      else if (key == "lfr_n") c.lfr_n = std::atoi(val.c_str());
+      else if (key == "snip_edges") c.snip_edges = to_bool(val, c.snip_edges);
+    }
+  }
+  return c;
+}
+
+ConfEntity conf_from_json(const std::string& text) {
+  ConfEntity c;
+  Json j = JsonParser(text.data(), text.size()).parse();
+  c.model = j.str_or("model", c.model);
+  c.use_itn = j.bool_or("use_itn", c.use_itn);
+  if (const Json* f = j.get("frontend_conf")) {
+    c.fs = (int)f->num_or("fs", c.fs);
+    c.window = f->str_or("window", c.window);
+    c.n_mels = (int)f->num_or("n_mels", c.n_mels);
+    c.frame_length = (int)f->num_or("frame_length", c.frame_length);
+    c.frame_shift = (int)f->num_or("frame_shift", c.frame_shift);
+    c.dither = (float)f->num_or("dither", c.dither);
+    c.lfr_m = (int)f->num_or("lfr_m", c.lfr_m);
+    c.lfr_n = (int)f->num_or("lfr_n", c.lfr_n);
+    c.snip_edges = f->bool_or("snip_edges", c.snip_edges);
+  }
+  return c;
+}
+
+static std::string lower(std::string s) {
+  for (char& ch : s) ch = (char)std::tolower((unsigned char)ch);
+  return s;
+}
+static bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = std::strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+ConfEntity load_conf(const std::string& path) {
+  ConfEntity c;
+  if (path.empty()) return c;
+  const std::string lp = lower(path);
+  if (ends_with(lp, ".json")) {
+    if (file_exists(path)) c = conf_from_json(read_text_file(path));
+  } else if (ends_with(lp, ".yaml")) {
+    if (file_exists(path)) c = conf_from_yaml(read_text_file(path));
+  }
+  return c;
+}
+
+// ------------------------------------------------------------------ UTF-8 -----------------
+std::vector<uint32_t> utf8_decode(const std::string& s) {
+  std::vector<uint32_t> out;
+  size_t i = 0, n = s.size();
+  while (i < n) {
+    unsigned char c = (unsigned char)s[i];
+    uint32_t cp;
+    int extra;
+    if (c < 0x80) { cp = c; extra = 0; }
+    else if ((c >> 5) == 0x6) { cp = c & 0x1F; extra = 1; }
+    else if ((c >> 4) == 0xE) { cp = c & 0x0F; extra = 2; }
+    else if ((c >> 3) == 0x1E) { cp = c & 0x07; extra = 3; }
+    else { cp = 0xFFFD; extra = 0; }
+    ++i;
+    for (int k = 0; k < extra && i < n; ++k, ++i) cp = (cp << 6) | ((unsigned char)s[i] & 0x3F);
+    out.push_back(cp);
+  }
+  return out;
+}
+
+std::string utf8_encode(uint32_t cp) {
+  std::string o;
+  if (cp < 0x80) o += (char)cp;
+  else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+  else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+  else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+  return o;
+}
+
+std::string utf8_encode(const std::vector<uint32_t>& cps) {
+  std::string o;
+  for (uint32_t c : cps) o += utf8_encode(c);
+  return o;
+}
+
+int utf16_length(const std::string& utf8) {
+  int n = 0;
+  for (uint32_t cp : utf8_decode(utf8)) n += cp >= 0x10000 ? 2 : 1;
+  return n;
+}
+
+}  // namespace pf

@@ -1,0 +1,312 @@
+// k_frontend.hip — WavFrontend on the device: kaldi fbank, LFR, CMVN, PadSequence.
+//
+// Reference sites replaced:
+//   AliParaformerAsr/WavFrontend.cs:31-37   GetFbank: x*32768 then SpeechFeatures.OnlineFbank
+//                                           (kaldi-native-fbank; algorithm restated from the
+//                                           published kaldi feature-window / mel-computations)
+//   AliParaformerAsr/WavFrontend.cs:73-111  ApplyLfr  (3 ZERO left-context frames, floor count)
+//   AliParaformerAsr/WavFrontend.cs:53-71   ApplyCmvn ((x + shift) * scale, two roundings)
+//   AliParaformerAsr/Utils/PadHelper.cs:23-65 PadSequence (right pad with 0, then every value
+//                                           == 0.0f becomes float32(-23.025850929940457f*32768))
+//
+// fbank: one wavefront per 25 ms frame.  The 400 samples (mirror-reflected at the utterance
+// edges when snip_edges == false) are staged in LDS, DC-removed, pre-emphasised, windowed,
+// zero-padded to 512 and transformed with a 256-point complex Stockham radix-2 FFT in LDS
+// (real-input split afterwards); the 80 triangular mel filters are stored sparse.
+// HBM-bound: 4 B/sample in (each sample is touched by 2.5 frames, served from L2),
+// 320 B/frame out.
+#include "kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace pf {
+
+#define FB_FRAME_LEN 400
+#define FB_SHIFT 160
+#define FB_NFFT 512
+#define FB_MAX_BINS 128
+
+struct FbankTables {
+  int n_mels;
+  float* window;    // [400]
+  float2* tw512;    // [256]  e^{-2 pi i m / 512}
+  int* mel_start;   // [n_mels]
+  int* mel_off;     // [n_mels + 1] offsets into mel_w
+  float* mel_w;     // packed non-zero weights
+};
+
+FbankTables* fbank_tables_create(int n_mels, int fs, const char* window) {
+  PF_CHECK(n_mels > 0 && n_mels <= FB_MAX_BINS, PF_ERR_INVALID_ARG, "fbank: n_mels out of range");
+  std::string wt = window ? window : "hamming";
+  std::vector<float> win(FB_FRAME_LEN);
+  const double a = 2.0 * M_PI / (FB_FRAME_LEN - 1);
+  for (int i = 0; i < FB_FRAME_LEN; ++i) {
+    double w;
+    if (wt == "hamming") w = 0.54 - 0.46 * std::cos(a * i);
+    else if (wt == "hanning") w = 0.5 - 0.5 * std::cos(a * i);
+    else if (wt == "povey") w = std::pow(0.5 - 0.5 * std::cos(a * i), 0.85);
+    else if (wt == "rectangular") w = 1.0;
+    else throw Error(PF_ERR_UNSUPPORTED, "fbank: unsupported window type " + wt);
+    win[i] = (float)w;
+  }
+  std::vector<float2> tw(256);
+  for (int m = 0; m < 256; ++m) {
+    const double ang = -2.0 * M_PI * m / 512.0;
+    tw[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  // kaldi MelBanks (float arithmetic): low 20 Hz, high = Nyquist, bins over FFT bins 0..255
+  auto mel = [](float f) { return 1127.0f * logf(1.0f + f / 700.0f); };
+  const float nyq = 0.5f * fs;
+  const float bin_w = (float)fs / FB_NFFT;
+  const float mel_low = mel(20.0f), mel_high = mel(nyq);
+  const float delta = (mel_high - mel_low) / (float)(n_mels + 1);
+  std::vector<int> start(n_mels), off(n_mels + 1, 0);
+  std::vector<float> wts;
+  for (int b = 0; b < n_mels; ++b) {
+    const float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+    int first = -1;
+    for (int i = 0; i < FB_NFFT / 2; ++i) {
+      const float m = mel(bin_w * i);
+      if (m > left && m < right) {
+        const float w = (m <= center) ? (m - left) / (center - left) : (right - m) / (right - center);
+        if (first < 0) first = i;
+        wts.push_back(w);
+      }
+    }
+    start[b] = first < 0 ? 0 : first;
+    off[b + 1] = (int)wts.size();
+  }
+  if (wts.empty()) wts.push_back(0.f);
+  auto* t = new FbankTables();
+  t->n_mels = n_mels;
+  PF_HIP(hipMalloc(&t->window, sizeof(float) * FB_FRAME_LEN));
+  PF_HIP(hipMalloc(&t->tw512, sizeof(float2) * 256));
+  PF_HIP(hipMalloc(&t->mel_start, sizeof(int) * n_mels));
+  PF_HIP(hipMalloc(&t->mel_off, sizeof(int) * (n_mels + 1)));
+  PF_HIP(hipMalloc(&t->mel_w, sizeof(float) * wts.size()));
+  PF_HIP(hipMemcpy(t->window, win.data(), sizeof(float) * FB_FRAME_LEN, hipMemcpyHostToDevice));
+  PF_HIP(hipMemcpy(t->tw512, tw.data(), sizeof(float2) * 256, hipMemcpyHostToDevice));
+  PF_HIP(hipMemcpy(t->mel_start, start.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice));
+  PF_HIP(hipMemcpy(t->mel_off, off.data(), sizeof(int) * (n_mels + 1), hipMemcpyHostToDevice));
+  PF_HIP(hipMemcpy(t->mel_w, wts.data(), sizeof(float) * wts.size(), hipMemcpyHostToDevice));
+  return t;
+}
+
+void fbank_tables_destroy(FbankTables* t) {
+  if (!t) return;
+  hipFree(t->window); hipFree(t->tw512); hipFree(t->mel_start); hipFree(t->mel_off); hipFree(t->mel_w);
+  delete t;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// 4 frames per 256-thread block, one wavefront each.  LDS per wave: 2 x 256 complex (4 KiB).
+__global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ audio,
+                                                    const int64_t* __restrict__ audio_off,
+                                                    const int64_t* __restrict__ n_samples,
+                                                    const int64_t* __restrict__ frame_off, int B,
+                                                    int64_t total_frames, int snip_edges, int n_mels,
+                                                    const float* __restrict__ window,
+                                                    const float2* __restrict__ tw512,
+                                                    const int* __restrict__ mel_start,
+                                                    const int* __restrict__ mel_off,
+                                                    const float* __restrict__ mel_w,
+                                                    float* __restrict__ out) {
+  __shared__ float2 lds[4][2][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t gf = (int64_t)blockIdx.x * 4 + wv;       // global frame index
+  const bool active = gf < total_frames;
+  float2* bufA = lds[wv][0];
+  float2* bufB = lds[wv][1];
+  float* fr = reinterpret_cast<float*>(bufA);             // 512 floats: the real frame, later z[n]
+
+  int b = 0;
+  int64_t f = 0, n = 0;
+  const float* wav = audio;
+  if (active) {
+    int lo = 0, hi = B;                                   // largest b with frame_off[b] <= gf
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (frame_off[mid] <= gf) lo = mid; else hi = mid;
+    }
+    b = lo;
+    f = gf - frame_off[b];
+    n = n_samples[b];
+    wav = audio + audio_off[b];
+  }
+  const int64_t start = snip_edges ? f * FB_SHIFT : f * FB_SHIFT + FB_SHIFT / 2 - FB_FRAME_LEN / 2;
+
+  // ---- load (x * 32768), reflect at the edges, partial sums for the DC offset
+  float part = 0.f;
+  for (int i = lane; i < FB_NFFT; i += 64) {
+    float v = 0.f;
+    if (active && i < FB_FRAME_LEN) {
+      int64_t sidx = start + i;
+      while (sidx < 0 || sidx >= n) sidx = sidx < 0 ? -sidx - 1 : 2 * n - 1 - sidx;
+      v = wav[sidx] * 32768.0f;
+      part += v;
+    }
+    fr[i] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const float mean = part / (float)FB_FRAME_LEN;
+  __syncthreads();
+  // ---- remove DC, pre-emphasis 0.97 (x[i] -= 0.97 x[i-1]; x[0] -= 0.97 x[0]), window
+  float pre[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int i = lane + 64 * r;
+    float v = 0.f;
+    if (i < FB_FRAME_LEN) {
+      const float cur = fr[i] - mean;
+      const float prev = fr[i > 0 ? i - 1 : 0] - mean;
+      v = __fsub_rn(cur, __fmul_rn(0.97f, prev)) * window[i];
+    }
+    pre[r] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int i = lane + 64 * r;
+    if (i < FB_FRAME_LEN) fr[i] = pre[r];
+  }
+  __syncthreads();
+  // fr viewed as float2[256] is z[n] = x[2n] + i x[2n+1]  (bufA).  256-point Stockham radix-2.
+  float2* src = bufA;
+  float2* dst = bufB;
+#pragma unroll
+  for (int ns = 1; ns < 256; ns <<= 1) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = lane + 64 * r;                 // 0..127
+      const int k = j & (ns - 1);
+      const float2 w = tw512[2 * k * (128 / ns)];  // e^{-2 pi i k / (2 ns)}
+      const float2 a = src[j];
+      const float2 t = cmul(src[j + 128], w);
+      const int j0 = ((j - k) << 1) + k;           // (j / ns) * 2ns + k
+      dst[j0] = make_float2(a.x + t.x, a.y + t.y);
+      dst[j0 + ns] = make_float2(a.x - t.x, a.y - t.y);
+    }
+    __syncthreads();
+    float2* tmp = src; src = dst; dst = tmp;
+  }
+  // src holds Z[k]; real-input split: X[k] = (Z[k] + conj Z[256-k])/2 - i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])/2
+  float* power = reinterpret_cast<float*>(dst);   // 256 floats
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = lane + 64 * r;
+    const float2 zk = src[k];
+    const float2 zc = src[(256 - k) & 255];
+    const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));   // even part
+    const float2 o = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));   // (Z - conj Z')/2
+    const float2 t = cmul(o, tw512[k]);
+    // X = e - i*t = (e.x + t.y, e.y - t.x)
+    const float re = e.x + t.y, im = e.y - t.x;
+    power[k] = re * re + im * im;
+  }
+  __syncthreads();
+  if (!active) return;
+  for (int m = lane; m < n_mels; m += 64) {
+    const int s0 = mel_start[m], o0 = mel_off[m], cnt = mel_off[m + 1] - o0;
+    float acc = 0.f;
+    for (int i = 0; i < cnt; ++i) acc += mel_w[o0 + i] * power[s0 + i];
+    acc = fmaxf(acc, 1.1920929e-07f);
+    out[gf * n_mels + m] = logf(acc);
+  }
+}
+
+void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, const int64_t* audio_off,
+                  const int64_t* n_samples, const int64_t* frame_off, int B, int64_t total_frames,
+                  int snip_edges, float* fbank) {
+  if (total_frames <= 0) return;
+  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total_frames + 3) / 4)), dim3(256), 0, s, audio, audio_off,
+                     n_samples, frame_off, B, total_frames, snip_edges, tb->n_mels, tb->window, tb->tw512,
+                     tb->mel_start, tb->mel_off, tb->mel_w, fbank);
+  PF_HIP(hipGetLastError());
+}
+
+// -------------------------------------------------------------------------------------------
+// LFR + CMVN + right-pad + sentinel, one float4 per thread, written straight into [B,Tmax,W].
+__global__ __launch_bounds__(256) void lfr_cmvn_pad_kernel(const float* __restrict__ fbank,
+                                                           const int64_t* __restrict__ frame_off,
+                                                           const int32_t* __restrict__ t80, int B, int Tmax,
+                                                           int lfr_m, int lfr_n, int n_mels,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ scale, int apply_cmvn,
+                                                           int apply_sentinel, float* __restrict__ out) {
+  const int W = lfr_m * n_mels;
+  const int wq = W >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * Tmax * wq;
+  if (i >= total) return;
+  const int qd = (int)(i % wq);
+  const int64_t bt = i / wq;
+  const int t = (int)(bt % Tmax);
+  const int b = (int)(bt / Tmax);
+  const int T80 = t80[b];
+  const int T = T80 / lfr_n;                      // floor (WavFrontend.cs:76)
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < T) {
+    const int j = qd * 4;
+    const int sub = j / n_mels, col = j - sub * n_mels;
+    int f = t * lfr_n + sub - (lfr_m - 1) / 2;   // left context = ZERO frames (quirk Q1)
+    if (f >= T80) f = T80 - 1;                   // tail branch replicates the last frame
+    if (f >= 0) v = *reinterpret_cast<const float4*>(fbank + (frame_off[b] + f) * n_mels + col);
+    if (apply_cmvn) {
+      const float4 sh = *reinterpret_cast<const float4*>(shift + j);
+      const float4 sc = *reinterpret_cast<const float4*>(scale + j);
+      v.x = __fmul_rn(__fadd_rn(v.x, sh.x), sc.x);
+      v.y = __fmul_rn(__fadd_rn(v.y, sh.y), sc.y);
+      v.z = __fmul_rn(__fadd_rn(v.z, sh.z), sc.z);
+      v.w = __fmul_rn(__fadd_rn(v.w, sh.w), sc.w);
+    }
+  }
+  if (apply_sentinel) {
+    const float S = -23.025850929940457f * 32768.0f;
+    v.x = v.x == 0.f ? S : v.x; v.y = v.y == 0.f ? S : v.y;
+    v.z = v.z == 0.f ? S : v.z; v.w = v.w == 0.f ? S : v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = v;
+}
+
+void launch_lfr_cmvn_pad(hipStream_t s, const float* fbank, const int64_t* frame_off, const int32_t* t80, int B,
+                         int Tmax, int lfr_m, int lfr_n, int n_mels, const float* shift, const float* scale,
+                         int apply_cmvn, int apply_sentinel, float* out) {
+  PF_CHECK(n_mels % 4 == 0, PF_ERR_INVALID_ARG, "lfr: n_mels must be a multiple of 4");
+  const int64_t total = (int64_t)B * Tmax * (lfr_m * n_mels / 4);
+  if (total == 0) return;
+  hipLaunchKernelGGL(lfr_cmvn_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, fbank,
+                     frame_off, t80, B, Tmax, lfr_m, lfr_n, n_mels, shift, scale, apply_cmvn, apply_sentinel, out);
+  PF_HIP(hipGetLastError());
+}
+
+// ragged [n_floats[b]] feature buffers -> [B, row_floats] right-padded with 0, then sentinel.
+__global__ __launch_bounds__(256) void pad_sentinel_kernel(const float* __restrict__ feats,
+                                                           const int64_t* __restrict__ feat_off,
+                                                           const int32_t* __restrict__ n_floats, int B,
+                                                           int row_floats, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * row_floats;
+  if (i >= total) return;
+  const int b = (int)(i / row_floats);
+  const int j = (int)(i - (int64_t)b * row_floats);
+  float v = j < n_floats[b] ? feats[feat_off[b] + j] : 0.f;
+  const float S = -23.025850929940457f * 32768.0f;
+  out[i] = v == 0.f ? S : v;
+}
+
+void launch_pad_sentinel(hipStream_t s, const float* feats, const int64_t* feat_off, const int32_t* n_floats,
+                         int B, int row_floats, float* out) {
+  const int64_t total = (int64_t)B * row_floats;
+  if (total == 0) return;
+  hipLaunchKernelGGL(pad_sentinel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feats,
+                     feat_off, n_floats, B, row_floats, out);
+  PF_HIP(hipGetLastError());
+}
+
+}  // namespace pf

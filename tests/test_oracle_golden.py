@@ -1,0 +1,158 @@
+"""CPU: the oracle against the known-answer vectors hand-derived from the reference source
+(tests/golden/kat.json) — this is what pins the oracle's glue functions."""
+import numpy as np
+import pytest
+
+from oracle import frontend as fe
+from oracle import glue
+from oracle import model as om
+
+
+def test_pad_sentinel(kat):
+    k = kat["pad_sentinel"]
+    assert float(fe.PAD_SENTINEL) == k["value"]
+    out = fe.pad_sequence([np.asarray(x, np.float32) for x in k["inputs"]])
+    np.testing.assert_array_equal(out, np.asarray(k["expected"], np.float32))
+    assert abs(float(fe.PAD_SENTINEL) - (-754511.06)) < 0.1
+
+
+def test_lfr_values_and_counts(kat):
+    k = kat["lfr"]
+    fb = np.repeat(np.arange(1, k["t80"] + 1, dtype=np.float32)[:, None], 80, axis=1)
+    out = fe.apply_lfr(fb)
+    assert out.shape == (2, 560)
+    for i, row in enumerate(k["expected_frame_values"]):
+        got = out[i].reshape(7, 80)
+        for j, v in enumerate(row):
+            assert np.all(got[j] == v)
+    for t80, t in k["frame_counts"].items():
+        fbx = np.ones((int(t80), 80), np.float32)
+        assert fe.apply_lfr(fbx).shape[0] == t
+
+
+def test_cmvn(kat):
+    k = kat["cmvn"]
+    out = fe.apply_cmvn(np.asarray(k["x"], np.float32)[None], k["shift"], k["scale"])
+    np.testing.assert_array_equal(out[0], np.asarray(k["expected"], np.float32))
+
+
+def test_argmax_last(kat, nanlist):
+    for c in kat["argmax"]["cases"]:
+        assert int(om.argmax_last(np.asarray(nanlist(c["x"]), np.float32))) == c["expected"]
+
+
+def test_timestamps(kat):
+    for c in kat["timestamps"]["cases"]:
+        peak = np.zeros(c["len"], np.float32)
+        peak[c["fires"]] = 1.0
+        if c["expected"] == "throws":
+            with pytest.raises(glue.RecognitionFailed):
+                glue.time_stamp_lfr6_onnx(peak, c["tokens"])
+        else:
+            assert glue.time_stamp_lfr6_onnx(peak, c["tokens"]) == c["expected"]
+
+
+def test_decode_multi(kat):
+    for c in kat["decode_multi"]["cases"]:
+        text, tlen, toks, ts = glue.decode_multi_one(c["tokens_table"], c["ids"], c["timestamps"])
+        assert text == c["text"]
+        assert tlen == c["text_len"]
+        assert toks == c["tokens"]
+        assert ts == c["out_timestamps"]
+
+
+def test_sensevoice_ids(kat, sv_embed):
+    k = kat["sensevoice_ids"]
+    for flag, key in ((True, "use_itn_true"), (False, "use_itn_false")):
+        lang, tn, rows = glue.sensevoice_prompt_ids(flag)
+        assert (lang, tn, rows) == (k[key]["language"], k[key]["textnorm"], k[key]["prompt_rows"])
+    sp = np.ones((3, 560), np.float32)
+    out = glue.sensevoice_prepend(sp, sv_embed, True)
+    assert out.shape == (7, 560)
+    np.testing.assert_array_equal(out[0], sv_embed[14])
+    np.testing.assert_array_equal(out[3], sv_embed[15])
+    assert abs(float(sv_embed[0, 0]) - 1.315616) < 1e-6
+
+
+def test_seaco_padlist_and_layout(kat):
+    k = kat["seaco_padlist"]
+    assert glue.pad_list(k["hotwords"]) == k["expected"]
+    hw = np.arange(10 * 3 * 4, dtype=np.float32).reshape(10, 3, 4)
+    be = glue.bias_embed(hw, 2)
+    assert be.shape == (2, 30, 4)
+    for n in range(3):
+        for j in range(10):
+            np.testing.assert_array_equal(be[1, n * 10 + j], hw[j, n])
+
+
+def test_hotword_ids(kat):
+    k = kat["hotword_ids"]
+    assert glue.hotword_ids(k["tokens_table"], k["lines"]) == k["expected"]
+
+
+def test_mvn_roundtrip():
+    sh = np.linspace(-9, -7, 560).astype(np.float32)
+    sc = np.linspace(0.1, 0.3, 560).astype(np.float32)
+    text = fe.format_mvn_text(sh, sc)
+    a, b = fe.parse_mvn_text(text)
+    np.testing.assert_array_equal(a, sh)
+    np.testing.assert_array_equal(b, sc)
+
+
+def test_fbank_frame_counts_and_reference_values():
+    conf = fe.FrontendConf(dither=0.0, snip_edges=False)
+    assert fe.num_frames(480000, False) == 3000
+    assert fe.num_frames(80000, False) == 500
+    assert fe.num_frames(1000, False) == 6
+    assert fe.num_frames(399, True) == 0 and fe.num_frames(400, True) == 1
+    # a pure DC signal has (numerically almost) zero energy after DC removal: every bin sits at
+    # or just above the log(FLT_EPSILON) floor
+    fb = fe.kaldi_fbank(np.full(1600, 0.1, np.float32), conf)
+    assert fb.shape == (10, 80)
+    floor = np.log(np.float32(1.1920929e-07))
+    assert (fb[3:7] >= floor - 1e-3).all() and (fb[3:7] < -10).all()
+    assert np.isclose(fb[3:7], floor, atol=1e-3).mean() > 0.9
+    # a 1 kHz tone peaks in the mel bin whose centre is nearest 1 kHz
+    t = np.arange(16000) / 16000.0
+    fb = fe.kaldi_fbank((0.5 * np.sin(2 * np.pi * 1000 * t)).astype(np.float32), conf)
+    mel = lambda f: 1127.0 * np.log(1 + f / 700.0)
+    centres = mel(20.0) + (np.arange(80) + 1) * (mel(8000.0) - mel(20.0)) / 81
+    assert abs(int(np.argmax(fb[50])) - int(np.argmin(np.abs(centres - mel(1000.0))))) <= 1
+
+
+def test_mel_banks_shape_and_partition():
+    w = fe.mel_banks(80, 16000)
+    assert w.shape == (80, 256)
+    assert (w >= 0).all() and (w <= 1).all()
+    # interior FFT bins are covered by exactly two overlapping triangles summing to 1
+    s = w.sum(axis=0)
+    assert np.allclose(s[3:245], 1.0, atol=1e-4)
+
+
+def test_cif_fire_matches_streaming_definition():
+    """cif_fire restates OnlineRecognizer.cs:147-200; check it against a direct transcription of
+    that C# loop on random data (integrate/frames semantics, threshold 1.0)."""
+    rng = np.random.default_rng(3)
+    B, T, D = 2, 40, 8
+    H = rng.standard_normal((B, T, D)).astype(np.float32)
+    a = rng.uniform(0.05, 0.6, (B, T + 1)).astype(np.float32)
+    E, counts, tnum = om.Oracle.cif_fire(H, a, 1.0)
+    Hn = np.concatenate([H, np.zeros((B, 1, D), np.float32)], axis=1)
+    for b in range(B):
+        integrate = np.float32(0)
+        frames = np.zeros(D, np.float32)
+        out = []
+        for j in range(T + 1):
+            alpha = a[b, j]
+            if np.float32(alpha + integrate) < np.float32(1.0):
+                integrate = np.float32(integrate + alpha)
+                frames = (frames + alpha * Hn[b, j]).astype(np.float32)
+            else:
+                frames = (frames + (np.float32(1.0) - integrate) * Hn[b, j]).astype(np.float32)
+                out.append(frames)
+                integrate = np.float32(integrate + alpha)
+                integrate = np.float32(integrate - np.float32(1.0))
+                frames = (integrate * Hn[b, j]).astype(np.float32)
+        assert counts[b] == len(out)
+        np.testing.assert_allclose(E[b, : counts[b]], np.stack(out), rtol=1e-5, atol=1e-6)
+        assert tnum[b] == int(np.floor(a[b].sum(dtype=np.float32)))
