@@ -49,13 +49,13 @@ def test_lfr_cmvn_pad_bit_exact(eng, kat):
     t80s = [13, 6, 5, 61, 300, 12]
     fbs = [rng.standard_normal((t, 80)).astype(np.float32) for t in t80s]
     fbs[0] = np.repeat(np.arange(1, 14, dtype=np.float32)[:, None], 80, axis=1)
-    fbs[3][10, 5] = 8.0 - 0.0           # plant a value that CMVN maps to exactly 0 -> sentinel
-    fbs[3][10, 5] = -shift[3 * 80 + 5 - 240] if False else fbs[3][10, 5]
+    fbs[3][10, 5] = -shift[85]          # frame 10 = LFR row 2, slot 1: (x + shift) * scale == 0 -> sentinel
     got = eng.op_lfr_cmvn_pad(fbs, sentinel=True)
     feats = [fe.apply_cmvn(fe.apply_lfr(f), shift, scale) if f.shape[0] >= 6 else np.zeros((0, 560), np.float32) for f in fbs]
     exp = fe.pad_sequence(feats).reshape(len(fbs), -1, 560)
     assert got.shape == exp.shape
     np.testing.assert_array_equal(got, exp)
+    assert got[3, 2, 85] == fe.PAD_SENTINEL     # genuine zero replaced too (quirk Q3)
     # without the sentinel the padding stays 0
     got0 = eng.op_lfr_cmvn_pad(fbs, sentinel=False)
     assert (got0[2] == 0).all() and (got[2] == fe.PAD_SENTINEL).all()
