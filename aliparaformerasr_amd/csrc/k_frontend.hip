@@ -16,6 +16,7 @@
 // HBM-bound: 4 B/sample in (each sample is touched by 2.5 frames, served from L2),
 // 320 B/frame out.
 #include "kernels.h"
+#include "exact.h"
 
 #include <cmath>
 #include <cstring>
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
     if (i < FB_FRAME_LEN) {
       const float cur = fr[i] - mean;
       const float prev = fr[i > 0 ? i - 1 : 0] - mean;
-      v = __fsub_rn(cur, __fmul_rn(0.97f, prev)) * window[i];
+      v = sub_rn(cur, mul_rn(0.97f, prev)) * window[i];
     }
     pre[r] = v;
   }
@@ -260,10 +261,10 @@ __global__ __launch_bounds__(256) void lfr_cmvn_pad_kernel(const float* __restri
     if (apply_cmvn) {
       const float4 sh = *reinterpret_cast<const float4*>(shift + j);
       const float4 sc = *reinterpret_cast<const float4*>(scale + j);
-      v.x = __fmul_rn(__fadd_rn(v.x, sh.x), sc.x);
-      v.y = __fmul_rn(__fadd_rn(v.y, sh.y), sc.y);
-      v.z = __fmul_rn(__fadd_rn(v.z, sh.z), sc.z);
-      v.w = __fmul_rn(__fadd_rn(v.w, sh.w), sc.w);
+      v.x = mul_rn(add_rn(v.x, sh.x), sc.x);
+      v.y = mul_rn(add_rn(v.y, sh.y), sc.y);
+      v.z = mul_rn(add_rn(v.z, sh.z), sc.z);
+      v.w = mul_rn(add_rn(v.w, sh.w), sc.w);
     }
   }
   if (apply_sentinel) {

@@ -11,6 +11,7 @@
 //   * FSMN: external ONNX graph (FunASR MultiHeadedAttentionSANM.forward_fsmn and
 //     MultiHeadedAttentionSANMDecoder); kernel_size 11 from EncoderConfEntity.cs:23.
 #include "kernels.h"
+#include "exact.h"
 
 namespace pf {
 
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
   float* wr = plan.w_rem + (int64_t)b * T1;
   for (int t = 0; t < T1; ++t) {
     const float alpha = sa[t];
-    sum = __fadd_rn(sum, alpha);
-    const float completion = __fsub_rn(1.0f, integrate);
-    integrate = __fadd_rn(integrate, alpha);
+    sum = add_rn(sum, alpha);
+    const float completion = sub_rn(1.0f, integrate);
+    integrate = add_rn(integrate, alpha);
     if (integrate >= threshold) {
-      integrate = __fsub_rn(integrate, 1.0f);
+      integrate = sub_rn(integrate, 1.0f);
       wc[t] = completion;
-      wr[t] = __fsub_rn(alpha, completion);
+      wr[t] = sub_rn(alpha, completion);
       ff[count++] = t;
     } else {
       wc[t] = alpha;
@@ -257,16 +258,16 @@ __global__ __launch_bounds__(128) void cif_gather_kernel(const float* __restrict
         if (sfr < T) {
           const float w = wr[sfr];
           const float4 h = *reinterpret_cast<const float4*>(H + ((int64_t)b * T + sfr) * D + c4);
-          acc = make_float4(__fmul_rn(w, h.x), __fmul_rn(w, h.y), __fmul_rn(w, h.z), __fmul_rn(w, h.w));
+          acc = make_float4(mul_rn(w, h.x), mul_rn(w, h.y), mul_rn(w, h.z), mul_rn(w, h.w));
         }
       }
       for (int t = t0; t <= e && t < T; ++t) {
         const float w = wc[t];
         const float4 h = *reinterpret_cast<const float4*>(H + ((int64_t)b * T + t) * D + c4);
-        acc.x = __fadd_rn(acc.x, __fmul_rn(w, h.x));
-        acc.y = __fadd_rn(acc.y, __fmul_rn(w, h.y));
-        acc.z = __fadd_rn(acc.z, __fmul_rn(w, h.z));
-        acc.w = __fadd_rn(acc.w, __fmul_rn(w, h.w));
+        acc.x = add_rn(acc.x, mul_rn(w, h.x));
+        acc.y = add_rn(acc.y, mul_rn(w, h.y));
+        acc.z = add_rn(acc.z, mul_rn(w, h.z));
+        acc.w = add_rn(acc.w, mul_rn(w, h.w));
       }
     }
     *reinterpret_cast<float4*>(out + c4) = acc;

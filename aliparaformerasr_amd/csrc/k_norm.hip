@@ -10,6 +10,7 @@
 // into the first layer's norm1; the multiply and the add are kept as two separately
 // rounded fp32 operations (no FMA contraction) to match a Mul node followed by an Add node.
 #include "kernels.h"
+#include "exact.h"
 
 namespace pf {
 
@@ -37,7 +38,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const float4* per = nullptr;
   if (POSENC) per = reinterpret_cast<const float4*>(pe + (row % T) * (int64_t)D);
   float4 v[NV];
-  float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int qd = lane + 64 * i;
@@ -45,18 +45,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       float4 t = xr[qd];
       if (POSENC) {
         const float4 p = per[qd];
-        t.x = __fadd_rn(__fmul_rn(t.x, xscale), p.x);
-        t.y = __fadd_rn(__fmul_rn(t.y, xscale), p.y);
-        t.z = __fadd_rn(__fmul_rn(t.z, xscale), p.z);
-        t.w = __fadd_rn(__fmul_rn(t.w, xscale), p.w);
+        t.x = add_rn(mul_rn(t.x, xscale), p.x);
+        t.y = add_rn(mul_rn(t.y, xscale), p.y);
+        t.z = add_rn(mul_rn(t.z, xscale), p.z);
+        t.w = add_rn(mul_rn(t.w, xscale), p.w);
       }
       v[i] = t;
-      s += (t.x + t.y) + (t.z + t.w);
     } else {
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float mean = wave_sum(s) / (float)D;
+  // Shifted statistics: d = x - x0 (x0 = first element of the row).  For the sentinel rows
+  // (|x| ~ 1.7e7, spread of a few ulps) x - x0 is exact, so the mean and the deviations keep
+  // full precision where sum(x)/D would not.
+  const float x0 = __shfl(v[0].x, 0, 64);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int qd = lane + 64 * i;
+    if (qd < nq) {
+      v[i].x = sub_rn(v[i].x, x0); v[i].y = sub_rn(v[i].y, x0);
+      v[i].z = sub_rn(v[i].z, x0); v[i].w = sub_rn(v[i].w, x0);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;       // mean of (x - x0)
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {

@@ -69,11 +69,17 @@ def quantizer(mode: str):
 
 
 def layer_norm(x, w, b):
-    # two-pass definition (mean, then mean of squared deviations), fp32
-    mu = x.mean(dim=-1, keepdim=True)
-    d = x - mu
+    """LayerNorm of the float32 input VALUES: two-pass statistics carried in float64, result
+    rounded to float32.  (The sentinel rows of PadHelper.cs:63 reach |x| ~ 1.7e7 with a spread of
+    a few ulps; float32 statistics are ill-conditioned there and what onnxruntime's fused
+    LayerNormalization returns for them is not recoverable from the reference — the oracle
+    defines the mathematically exact value.)"""
+    xd = x.to(torch.float64)
+    mu = xd.mean(dim=-1, keepdim=True)
+    d = xd - mu
     var = (d * d).mean(dim=-1, keepdim=True)
-    return d / torch.sqrt(var + LN_EPS) * w + b
+    y = d / torch.sqrt(var + LN_EPS) * w.to(torch.float64) + b.to(torch.float64)
+    return y.to(torch.float32)
 
 
 def sinusoidal_pe(T: int, depth: int) -> torch.Tensor:
