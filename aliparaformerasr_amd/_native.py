@@ -72,6 +72,7 @@ SIGNATURES = {
     "pf_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
     "pf_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "pf_profile_reset": (C.c_int, [_vp]),
+    "pf_profile_select": (C.c_int, [_vp, C.c_char_p]),
     "pf_profile_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _i64, _P(C.c_double)]),
     "pf_last_flops": (C.c_int, [_vp, _P(C.c_double)]),
     "pf_op_lfr_cmvn_pad": (C.c_int, [_vp, _P(_f), _i32, C.c_int32, C.c_int32, _f, C.c_int64, _i32]),

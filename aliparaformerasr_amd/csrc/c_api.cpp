@@ -194,6 +194,12 @@ int pf_profile_reset(pf_engine* h) {
   return PF_OK;
   PF_CATCH
 }
+int pf_profile_select(pf_engine* h, const char* cls) {
+  PF_TRY
+  E(h)->profile_select(cls ? cls : "");
+  return PF_OK;
+  PF_CATCH
+}
 int pf_profile_get(pf_engine* h, const char* cls, double* ms, int64_t* launches, double* fpl) {
   PF_TRY
   NEED(cls);

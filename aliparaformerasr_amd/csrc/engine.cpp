@@ -342,6 +342,7 @@ void Engine::profile_reset() {
 }
 void Engine::prof_begin(const char* cls, double flops) {
   if (!prof_on_) return;
+  if (!prof_only_.empty() && prof_only_ != cls) return;
   ProfClass& pc = prof_[cls];
   hipEvent_t a, b;
   PF_HIP(hipEventCreate(&a));
@@ -353,6 +354,7 @@ void Engine::prof_begin(const char* cls, double flops) {
 }
 void Engine::prof_end(const char* cls) {
   if (!prof_on_) return;
+  if (!prof_only_.empty() && prof_only_ != cls) return;
   ProfClass& pc = prof_[cls];
   PF_HIP(hipEventRecord(pc.ev.back().second, stream_));
 }

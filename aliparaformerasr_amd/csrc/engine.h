@@ -86,6 +86,7 @@ class Engine {
   // ---- profiling -----------------------------------------------------------
   void profile_enable(bool on) { prof_on_ = on; }
   void profile_reset();
+  void profile_select(const std::string& cls) { prof_only_ = cls; }
   bool profile_get(const std::string& cls, double* ms, int64_t* launches, double* flops_per_launch);
   double last_flops() const { return last_flops_; }
 
@@ -160,6 +161,7 @@ class Engine {
   double last_flops_ = 0;
 
   bool prof_on_ = false;
+  std::string prof_only_;
   std::map<std::string, ProfClass> prof_;
 };
 

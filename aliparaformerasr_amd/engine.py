@@ -192,6 +192,9 @@ class Engine:
     def profile(self, on: bool):
         N.check(self._lib.pf_profile_enable(self._h, 1 if on else 0))
 
+    def profile_select(self, cls: str = ""):
+        N.check(self._lib.pf_profile_select(self._h, cls.encode()))
+
     def profile_reset(self):
         N.check(self._lib.pf_profile_reset(self._h))
 

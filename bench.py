@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the offline Paraformer path on MI355X.
+
+Metric (BASELINE.json): RTFx = audio-seconds / wall-seconds (the inverse of the reference's
+`rtf = elapsed_ms / total_audio_ms`, AliParaformerAsr.Examples/OfflineAliParaformerAsrRecognizer.cs:244-249;
+both are printed) + utterances/s, paraformer-large, batch 32 x 30 s synthetic 16 kHz per GPU.
+
+One "step" = one pass of the whole hot path (fbank -> LFR/CMVN -> SAN-M encoder x50 -> CIF ->
+SAN-M decoder x16 -> vocab GEMM -> last-index arg-max, + the gather of hypotheses when N > 1)
+over one batch per GPU, audio already resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU; utterances are independent, so each rank recognises its own
+shard (weak scaling, no data-path collective); RCCL is used for the one-off weight broadcast
+(rank 0 -> all) and the per-step gather of hypotheses.
+
+The JSON line also carries
+  roofline     — the dominant kernel class (FFN up-projection GEMM) timed live with HIP events
+                 on the engine stream during the timed steps: algorithmic FLOPs / avg duration
+                 against the 2.5 PFLOP/s dense f16 MFMA peak;
+  cpu_baseline — the CPU oracle (a port, NOT onnxruntime: neither ORT nor a model file exists
+                 in the image) timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 32
+SECONDS = 30
+SAMPLES = SECONDS * 16000
+LCAP = 512
+DOMINANT = "gemm_ffn1"
+PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(cfg, weights, cmvn):
+    """Oracle (fp32 port of the same graph) on the host cores, bounded sample."""
+    import torch
+    from oracle import frontend as fe, model as om
+    from aliparaformerasr_amd import weights as W
+    threads = torch.get_num_threads()
+    conf = fe.FrontendConf(dither=0.0)
+    orc = om.Oracle(om.ModelConfig(**cfg), weights, quant="fp32")
+    warm = [W.synth_audio(16000, 999)]
+    sp = fe.pad_sequence([fe.wav_frontend(a, conf, cmvn[0], cmvn[1]) for a in warm]).reshape(1, -1, 560)
+    orc.paraformer(sp)
+    def run(n):
+        audio = [W.synth_audio(SAMPLES, u) for u in range(n)]
+        t0 = time.perf_counter()
+        feats = [fe.wav_frontend(a, conf, cmvn[0], cmvn[1]) for a in audio]
+        speech = fe.pad_sequence(feats).reshape(n, -1, 560)
+        out = orc.paraformer(speech)
+        om.argmax_last(out["logits"])
+        return time.perf_counter() - t0
+    t1 = run(1)                                   # sizes the bounded sample (~15 s of CPU work)
+    n_utts = int(min(8, max(1, round(15.0 / max(t1, 1e-3)))))
+    dt = run(n_utts) if n_utts > 1 else t1
+    return {"value": n_utts * SECONDS / dt, "unit": "audio-sec/wall-sec", "cores": threads, "kind": "port",
+            "sample": "%d x %d s utterances of the same synthetic workload, fp32 torch-CPU oracle "
+                      "(stand-in, not onnxruntime), %.1f s wall" % (n_utts, SECONDS, dt),
+            "rtf": dt / (n_utts * SECONDS)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed step with per-class kernel times")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from aliparaformerasr_amd import weights as W
+    from aliparaformerasr_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    dev = torch.device("cuda", local)
+
+    # ---- weights: rank 0 builds the synthetic paraformer-large image, RCCL-broadcasts it
+    cfg = W.paraformer_large_config()
+    cmvn = W.synth_cmvn()
+    weights = None
+    if rank == 0:
+        weights = W.synth_weights(cfg, 42)
+        blob = np.frombuffer(W.pack_pfw(cfg, weights), dtype=np.uint8)
+        nbytes = torch.tensor([blob.size], dtype=torch.int64, device=dev)
+    else:
+        nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(nbytes, 0)
+    n = int(nbytes.item())
+    if rank == 0:
+        wdev = torch.from_numpy(blob.copy()).to(dev)
+    else:
+        wdev = torch.empty(n, dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.broadcast(wdev, 0)
+    torch.cuda.synchronize()
+    eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local)
+
+    # ---- workload: this rank's shard of the utterance list, staged to HBM before timing
+    B = args.batch
+    audio = [W.synth_audio(SAMPLES, rank * B + u) for u in range(B)]
+    eng.stage_audio(audio)
+    ids_dev = torch.zeros((B, LCAP), dtype=torch.int32, device=dev)
+    gathered = [torch.zeros_like(ids_dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        eng.run_staged()
+        if world > 1:
+            r = eng.fetch()
+            ids = np.zeros((B, LCAP), np.int32)
+            ids[:, : r.L] = r.token_ids[:, :LCAP]
+            ids_dev.copy_(torch.from_numpy(ids))
+            dist.all_gather(gathered, ids_dev)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.profile_reset()
+    eng.profile_select(DOMINANT)
+    eng.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    eng.profile(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    res = eng.fetch()
+    ms_dom, n_dom, fpl_dom = eng.profile_get(DOMINANT)
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        eng.profile_reset()
+        eng.profile_select("")
+        eng.profile(True)
+        eng.run_staged()
+        eng.sync()
+        eng.profile(False)
+        breakdown = {}
+        for cls in ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
+                    "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn1", "gemm_dec_ffn2",
+                    "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax"):
+            ms, cnt, fpl = eng.profile_get(cls)
+            breakdown[cls] = {"ms": round(ms, 4), "launches": cnt,
+                              "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
+
+    if rank == 0:
+        audio_s = world * B * SECONDS * args.steps
+        value = audio_s / dt
+        flops_step = eng.last_flops()
+        ach = fpl_dom / ((ms_dom / max(n_dom, 1)) * 1e-3) / 1e12 if n_dom else 0.0
+        out = {
+            "metric": "RTFx (audio-sec/wall-sec), paraformer-large offline, batch 32x30s per GPU",
+            "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "paraformer-large-zh offline, batch %dx%d s synthetic 16 kHz per GPU "
+                                   "(BASELINE.json configs[1]), seeded synthetic weights" % (B, SECONDS),
+                       "global_batch": world * B, "samples_per_utt": SAMPLES, "T_lfr": 500, "L": int(res.L),
+                       "parallelism": "dp%d (utterance shards, no data-path collective)" % world},
+            "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
+            "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
+            "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
+                         % (DOMINANT, B * 500), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F16_TFLOPS, "traffic": None,
+                         "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
+                         "flops_per_launch": fpl_dom},
+        }
+        if breakdown is not None:
+            out["kernel_breakdown_ms_per_step"] = breakdown
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, cmvn)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

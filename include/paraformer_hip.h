@@ -168,6 +168,8 @@ int pf_fetch(pf_engine* e, pf_batch_out* out);
    profiling is enabled (bench.py roofline leg).  class_name e.g. "gemm_ffn1". */
 int pf_profile_enable(pf_engine* e, int32_t on);
 int pf_profile_reset(pf_engine* e);
+/* Restrict event recording to one class (NULL or "" = all classes). */
+int pf_profile_select(pf_engine* e, const char* class_name);
 int pf_profile_get(pf_engine* e, const char* class_name, double* total_ms, int64_t* launches,
                    double* flops_per_launch);
 
