@@ -112,29 +112,59 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmDev p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 
-  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // ---- epilogue.  The MFMA is issued as D^T = W_tile * X_tile^T, so the 32x32 C/D layout gives
+  // every lane ONE output row m (col = lane&31) and, per register quad g, FOUR consecutive
+  // output columns n = 8g + 4*(lane>>5) + 0..3: bias / residual / FSMN reads and the result
+  // stores are 16-byte (fp32) or 8-byte (f16) vectors straight from registers.
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-    const bool nok = n < p.N;
-    const float bv = (p.bias && nok) ? p.bias[n] : 0.f;
-    const float sc = (n < p.scale_cols) ? p.scale : 1.f;
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (nok && m < p.M) {
-          float v = (acc[i][j][e] + bv) * sc;
-          if (p.add2) v += p.add2[(size_t)m * p.ld2 + n];
-          if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
-          if (p.relu) v = v > 0.f ? v : 0.f;
-          if (p.out_f32) p.out_f32[(size_t)m * p.ldc32 + n] = v;
-          if (p.out_f16) p.out_f16[(size_t)m * p.ldc16 + n] = (half_t)v;
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * lh;
+        if (n >= p.N) continue;
+        float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (n + 3 < p.N) {
+          if (p.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+          }
+          if (n < p.scale_cols) { v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale; }
+          if (p.add2) {
+            const float4 a4 = *reinterpret_cast<const float4*>(p.add2 + (size_t)m * p.ld2 + n);
+            v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+          }
+          if (p.resid) {
+            const float4 r4 = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.out_f16) {
+            h4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = hv;
+          }
+        } else {
+          for (int e = 0; e < 4 && n + e < p.N; ++e) {
+            float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
+            if (n + e < p.scale_cols) x *= p.scale;
+            if (p.add2) x += p.add2[(size_t)m * p.ld2 + n + e];
+            if (p.resid) x += p.resid[(size_t)m * p.ldr + n + e];
+            if (p.relu) x = x > 0.f ? x : 0.f;
+            if (p.out_f32) p.out_f32[(size_t)m * p.ldc32 + n + e] = x;
+            if (p.out_f16) p.out_f16[(size_t)m * p.ldc16 + n + e] = (half_t)x;
+          }
         }
       }
     }
@@ -144,6 +174,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmDev p) {
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
   PF_CHECK(a.K % GEMM_BK == 0 && a.K > 0, PF_ERR_INVALID_ARG, "gemm: K must be a multiple of 64");
   PF_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, PF_ERR_INVALID_ARG, "gemm: lda/ldw must be multiples of 8");
+  PF_CHECK((!a.out_f32 || a.ldc32 % 4 == 0) && (!a.out_f16 || a.ldc16 % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&
+               (!a.add2 || a.ld2 % 4 == 0) && a.scale_cols % 4 == 0,
+           PF_ERR_INVALID_ARG, "gemm: output leading dimensions must be multiples of 4");
   GemmDev d;
   d.A = a.A; d.W = a.W; d.bias = a.bias;
   d.out_f32 = a.out_f32; d.out_f16 = a.out_f16; d.resid = a.resid; d.add2 = a.add2;
