@@ -383,6 +383,7 @@ void Engine::gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M
   g.out_f32 = out32; g.ldc32 = ld32; g.out_f16 = out16; g.ldc16 = ld16;
   g.resid = resid; g.ldr = ldr; g.add2 = add2; g.ld2 = ld2;
   g.relu = relu ? 1 : 0; g.scale_cols = scale_cols; g.scale = scale;
+  g.out_padded = 1;   // every pipeline buffer is carved with round_up(rows,128)+128 rows
   prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   launch_gemm(stream_, g);
   prof_end(cls);
@@ -843,11 +844,11 @@ void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, i
   PF_HIP(hipSetDevice(device_));
   if (M == 0 || N == 0) return;
   const int Kp = (int)round_up(K, 64);
-  const int64_t Mp = round_up(M, 128), Np = round_up(N, 128);
+  const int64_t Mp = round_up(M, 256), Np = round_up(N, 256);
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
   const size_t oA = carve((size_t)M * K * 4), oW = carve((size_t)N * K * 4), ob = carve((size_t)N * 4);
-  const size_t oA16 = carve((size_t)Mp * Kp * 2), oW16 = carve((size_t)Np * Kp * 2), oC = carve((size_t)M * N * 4);
+  const size_t oA16 = carve((size_t)Mp * Kp * 2), oW16 = carve((size_t)Np * Kp * 2), oC = carve((size_t)Mp * N * 4);
   ensure(ws_tmp_, off);
   char* base = (char*)ws_tmp_.p;
   PF_HIP(hipMemcpyAsync(base + oA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
@@ -860,12 +861,27 @@ void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, i
   GemmArgs g{};
   g.A = (half_t*)(base + oA16); g.lda = Kp; g.W = (half_t*)(base + oW16); g.ldw = Kp;
   g.bias = bias ? (const float*)(base + ob) : nullptr;
-  g.M = M; g.N = N; g.K = Kp; g.out_f32 = (float*)(base + oC); g.ldc32 = N; g.relu = epi == 1;
+  g.M = M; g.N = N; g.K = Kp; g.relu = epi == 1;
+  g.out_padded = 1;
+  const bool f16out = epi == 2;
+  if (f16out) { g.out_f16 = (half_t*)(base + oC); g.ldc16 = N; }
+  else { g.out_f32 = (float*)(base + oC); g.ldc32 = N; }
   prof_begin("gemm_op", 2.0 * M * (double)N * K);
   launch_gemm(stream_, g);
   prof_end("gemm_op");
-  PF_HIP(hipMemcpyAsync(C, base + oC, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
+  if (f16out) {
+    std::vector<uint16_t> tmp((size_t)M * N);
+    PF_HIP(hipMemcpyAsync(tmp.data(), base + oC, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
+    PF_HIP(hipStreamSynchronize(stream_));
+    for (size_t i = 0; i < tmp.size(); ++i) {
+      half_t hv;
+      std::memcpy(&hv, &tmp[i], 2);
+      C[i] = (float)hv;
+    }
+  } else {
+    PF_HIP(hipMemcpyAsync(C, base + oC, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
+    PF_HIP(hipStreamSynchronize(stream_));
+  }
 }
 
 void Engine::op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y) {

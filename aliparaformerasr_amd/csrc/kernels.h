@@ -19,7 +19,8 @@ struct GemmArgs {
   const float* resid; int ldr;   // += resid[m,n] (fp32), may alias out_f32
   const float* add2; int ld2;    // += add2[m,n]  (fp32), e.g. the FSMN memory
   int relu;                      // max(v,0) after bias/resid
-  int scale_cols; float scale;   // columns n < scale_cols are multiplied by scale (after bias)
+  int scale_cols; float scale;   // columns n < scale_cols are multiplied by scale (after bias); multiple of 64
+  int out_padded;                // out_f16 has >= round_up(M,256) writable rows (enables whole-tile stores)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 

@@ -228,14 +228,14 @@ class Engine:
         N.check(self._lib.pf_op_argmax(self._h, _fp(a), rows, V, ids.ctypes.data_as(C.POINTER(C.c_int64))))
         return ids.reshape(a.shape[:-1])
 
-    def op_gemm(self, A, W, bias=None, relu=False) -> np.ndarray:
+    def op_gemm(self, A, W, bias=None, relu=False, f16_out=False) -> np.ndarray:
         A, W = _f32(A), _f32(W)
         M, K = A.shape
         Nn = W.shape[0]
         out = np.zeros((M, Nn), np.float32)
         b = _f32(bias) if bias is not None else None
         N.check(self._lib.pf_op_gemm(self._h, _fp(A), _fp(W), _fp(b) if b is not None else None, M, Nn, K,
-                                     1 if relu else 0, _fp(out)))
+                                     2 if f16_out else (1 if relu else 0), _fp(out)))
         return out
 
     def op_layernorm(self, x, gamma, beta) -> np.ndarray:

@@ -185,7 +185,8 @@ int pf_op_lfr_cmvn_pad(pf_engine* e, const float* const* fbank, const int32_t* t
                        int32_t apply_sentinel, float* out, int64_t out_cap, int32_t* tmax_out);
 /* last-index arg-max over the trailing dim: x [rows, V] -> ids [rows]. */
 int pf_op_argmax(pf_engine* e, const float* x, int64_t rows, int32_t V, int64_t* ids_out);
-/* C = A[M,K] * W[N,K]^T + bias, f16 operands / f32 accumulate; epilogue 0 none, 1 relu. */
+/* C = A[M,K] * W[N,K]^T + bias, f16 operands / f32 accumulate; epilogue 0 none, 1 relu,
+   2 = f16 result store (the path the pipeline uses), returned widened to fp32. */
 int pf_op_gemm(pf_engine* e, const float* A, const float* W, const float* bias,
                int32_t M, int32_t N, int32_t K, int32_t epilogue, float* C);
 /* LayerNorm over the last dim (eps 1e-12), fp32. */

@@ -16,8 +16,8 @@ if what in ("gemm", "all"):
         A = rng.standard_normal((M, K)).astype(np.float32)
         Wm = rng.standard_normal((N, K)).astype(np.float32)
         eng.profile_reset(); eng.profile_select("gemm_op"); eng.profile(True)
-        for _ in range(6):
-            eng.op_gemm(A, Wm, None)
+        for _ in range(4):
+            eng.op_gemm(A, Wm, None, f16_out=True)
         eng.profile(False)
         ms, n, fpl = eng.profile_get("gemm_op")
         print("gemm M=%d N=%d K=%d: %.1f us  %.0f TF" % (M, N, K, ms / n * 1e3, fpl / (ms / n * 1e-3) / 1e12), flush=True)
