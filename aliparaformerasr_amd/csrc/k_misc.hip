@@ -19,46 +19,93 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------ encoder FSMN ----------
 // f[b,t,c] = sum_j wT[j][c] * v[b,t+j-left,c] + v[b,t,c]   (zero outside the utterance)
-// one thread = one row x 8 channels; v is f16 (the V slice of the QKV buffer), f is fp32.
+// One thread = 8 channels x FS_ROWS consecutive frames with a register sliding window: each v
+// row is loaded once per FS_ROWS outputs (+ the K-1 halo rows) instead of K times.  v is f16
+// (the V slice of the QKV buffer), f is fp32.  HBM-bound: 2 B/elem in, 4 B/elem out.
+#define FS_ROWS 8
+template <int K>
 __global__ __launch_bounds__(256) void fsmn_enc_kernel(const half_t* __restrict__ v, int ldv,
-                                                       const float* __restrict__ wT, int B, int T, int D, int K,
+                                                       const float* __restrict__ wT, int B, int T, int D,
                                                        float* __restrict__ f) {
+  constexpr int FS_MAXK = K;
   const int cq = D >> 3;
+  const int tb = (T + FS_ROWS - 1) / FS_ROWS;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)B * T * cq;
+  const int64_t total = (int64_t)B * tb * cq;
   if (i >= total) return;
   const int c8 = (int)(i % cq) * 8;
-  const int64_t row = i / cq;
-  const int t = (int)(row % T);
-  const int left = (K - 1) / 2;
-  float acc[8];
-  {
-    const h8 x = *reinterpret_cast<const h8*>(v + row * (int64_t)ldv + c8);
+  const int64_t r = i / cq;
+  const int t0 = (int)(r % tb) * FS_ROWS;
+  const int b = (int)(r / tb);
+  constexpr int left = (K - 1) / 2;
+  const half_t* vb = v + (int64_t)b * T * ldv + c8;
+  float w[FS_MAXK][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = (float)x[e];
+  for (int j = 0; j < FS_MAXK; ++j) {
+    if (j < K) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8);
+      const float4 w1 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8 + 4);
+      w[j][0] = w0.x; w[j][1] = w0.y; w[j][2] = w0.z; w[j][3] = w0.w;
+      w[j][4] = w1.x; w[j][5] = w1.y; w[j][6] = w1.z; w[j][7] = w1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[j][e] = 0.f;
+    }
   }
-  for (int j = 0; j < K; ++j) {
-    const int tt = t + j - left;
+  float acc[FS_ROWS][8];
+#pragma unroll
+  for (int q = 0; q < FS_ROWS; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+  // input row tt = t0 - left + s contributes to output row q = s - j (tap j) for 0 <= q < FS_ROWS
+#pragma unroll
+  for (int s = 0; s < FS_ROWS + FS_MAXK - 1; ++s) {
+    const int tt = t0 - left + s;
+    if (s >= FS_ROWS + K - 1) break;
     if (tt < 0 || tt >= T) continue;
-    const h8 x = *reinterpret_cast<const h8*>(v + (row + (j - left)) * (int64_t)ldv + c8);
-    const float4 w0 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8);
-    const float4 w1 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8 + 4);
-    acc[0] += w0.x * (float)x[0]; acc[1] += w0.y * (float)x[1];
-    acc[2] += w0.z * (float)x[2]; acc[3] += w0.w * (float)x[3];
-    acc[4] += w1.x * (float)x[4]; acc[5] += w1.y * (float)x[5];
-    acc[6] += w1.z * (float)x[6]; acc[7] += w1.w * (float)x[7];
+    const h8 x = *reinterpret_cast<const h8*>(vb + (int64_t)tt * ldv);
+    float xf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xf[e] = (float)x[e];
+#pragma unroll
+    for (int j = 0; j < FS_MAXK; ++j) {
+      const int q = s - j;
+      if (q >= 0 && q < FS_ROWS && j < K) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[q][e] += w[j][e] * xf[e];
+      }
+    }
+    const int q0 = s - left;                      // identity term
+    if (q0 >= 0 && q0 < FS_ROWS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[q0][e] += xf[e];
+    }
   }
-  float4* o = reinterpret_cast<float4*>(f + row * (int64_t)D + c8);
-  o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+  for (int q = 0; q < FS_ROWS; ++q) {
+    if (t0 + q < T) {
+      float4* o = reinterpret_cast<float4*>(f + ((int64_t)b * T + t0 + q) * D + c8);
+      o[0] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+      o[1] = make_float4(acc[q][4], acc[q][5], acc[q][6], acc[q][7]);
+    }
+  }
 }
 
 void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* wT, int B, int T, int D, int k,
                      float* f) {
-  const int64_t total = (int64_t)B * T * (D / 8);
+
+  const int tb = (T + FS_ROWS - 1) / FS_ROWS;
+  const int64_t total = (int64_t)B * tb * (D / 8);
   if (total == 0) return;
-  hipLaunchKernelGGL(fsmn_enc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, ldv, wT, B, T,
-                     D, k, f);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  switch (k) {
+    case 11: hipLaunchKernelGGL(fsmn_enc_kernel<11>, grid, dim3(256), 0, s, v, ldv, wT, B, T, D, f); break;
+    case 9: hipLaunchKernelGGL(fsmn_enc_kernel<9>, grid, dim3(256), 0, s, v, ldv, wT, B, T, D, f); break;
+    case 7: hipLaunchKernelGGL(fsmn_enc_kernel<7>, grid, dim3(256), 0, s, v, ldv, wT, B, T, D, f); break;
+    case 5: hipLaunchKernelGGL(fsmn_enc_kernel<5>, grid, dim3(256), 0, s, v, ldv, wT, B, T, D, f); break;
+    case 3: hipLaunchKernelGGL(fsmn_enc_kernel<3>, grid, dim3(256), 0, s, v, ldv, wT, B, T, D, f); break;
+    default: throw Error(PF_ERR_UNSUPPORTED, "fsmn: unsupported kernel size (3/5/7/9/11)");
+  }
   PF_HIP(hipGetLastError());
 }
 
