@@ -1,0 +1,155 @@
+"""GPU: the reference's own API-contract tests (AliParaformerAsr.Tests/OfflineRecognizerTests .cs:166-353)
+replayed through the drop-in OfflineRecognizer / OfflineStream mirror, plus an end-to-end
+text check against the oracle (front-end -> model -> arg-max -> DecodeMulti)."""
+import numpy as np
+import pytest
+
+from aliparaformerasr_amd import weights as W
+from oracle import frontend as fe
+from oracle import glue
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = 300
+
+
+def _tokens():
+    toks = ["<blank>", "<s>", "</s>", "<unk>"]
+    cjk = [chr(0x4E00 + 37 * i) for i in range(120)]
+    bpe = []
+    for i in range(VOCAB - 4 - len(cjk)):
+        w = "w%d" % i
+        bpe.append(w + "@@" if i % 3 == 0 else ("▁" + w if i % 3 == 1 else w))
+    return toks + cjk + bpe
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("model")
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=VOCAB)
+    w = W.synth_weights(cfg, seed=77)
+    W.save_pfw(str(d / "model.pfw"), cfg, w)
+    shift, scale = W.synth_cmvn()
+    (d / "am.mvn").write_text(fe.format_mvn_text(shift, scale))
+    (d / "asr.yaml").write_text("model: paraformer\nuse_itn: false\nfrontend_conf:\n  fs: 16000\n  window: hamming\n"
+                                "  n_mels: 80\n  dither: 0\n  lfr_m: 7\n  lfr_n: 6\n  snip_edges: false\n")
+    (d / "tokens.txt").write_text("\n".join(_tokens()) + "\n", encoding="utf-8")
+    (d / "hotword.txt").write_text(_tokens()[10] + _tokens()[20] + "\n", encoding="utf-8")
+    return d, cfg, w, (shift, scale)
+
+
+def _make(model_dir, **kw):
+    from aliparaformerasr_amd.offline_recognizer import OfflineRecognizer
+    d = model_dir[0]
+    return OfflineRecognizer(modelFilePath=str(d / "model.pfw"), configFilePath=str(d / "asr.yaml"),
+                             mvnFilePath=str(d / "am.mvn"), tokensFilePath=str(d / "tokens.txt"), **kw)
+
+
+def test_init_with_valid_params(model_dir):                       # :167
+    assert _make(model_dir) is not None
+
+
+def test_init_with_missing_tokens_file(model_dir):                # :185
+    from aliparaformerasr_amd.offline_recognizer import OfflineRecognizer, RecognizerException
+    d = model_dir[0]
+    with pytest.raises(RecognizerException, match="tokens invalid"):
+        OfflineRecognizer(str(d / "model.pfw"), str(d / "asr.yaml"), str(d / "am.mvn"), "")
+
+
+def test_create_stream_add_samples(model_dir):                    # :214 — 1 s of zeros accepted
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    s.AddSamples(np.zeros(16000, np.float32))
+    assert s is not None and s.SpeechLength == 16 * 560
+
+
+def test_get_result_with_valid_stream(model_dir):                 # :232 — silence gives a well-formed entity
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    s.AddSamples(np.zeros(16000, np.float32))
+    res = r.GetResult(s)
+    assert res.Text is not None and res.Tokens is not None and res.Timestamps is not None
+    assert res.TextLen == len(res.Text.encode("utf-16-le")) // 2
+
+
+def test_add_samples_with_valid_samples(model_dir):               # :267 — 1000 x 0.1f must not throw
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    s.AddSamples(np.full(1000, 0.1, np.float32))
+    assert s.SpeechLength == 560                                  # 6 fbank frames -> 1 LFR frame
+
+
+def test_add_samples_with_null_samples(model_dir):                # :286 — ArgumentNullException("source")
+    from aliparaformerasr_amd.offline_recognizer import ArgumentNullException
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    with pytest.raises(ArgumentNullException) as ei:
+        s.AddSamples(None)
+    assert ei.value.ParamName == "source"
+
+
+def test_set_hotwords(model_dir):                                 # :303 / :322
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    assert s.Hotwords == []
+    s.Hotwords = [[5, 6, 7], [9], []]
+    assert s.Hotwords == [[5, 6, 7], [9], []]
+    s.Hotwords = None
+    assert s.Hotwords is None
+
+
+def test_dispose_releases_resources(model_dir):                   # :341
+    from aliparaformerasr_amd.offline_recognizer import ObjectDisposedException
+    r = _make(model_dir)
+    r.Dispose()
+    with pytest.raises(ObjectDisposedException) as ei:
+        r.CreateOfflineStream()
+    assert ei.value.ObjectName == "OfflineRecognizer"
+    r.Dispose()                                                   # idempotent (Dispose(bool) pattern)
+
+
+def test_empty_stream_list_is_noop(model_dir):                    # OfflineRecognizer.cs:120-123
+    assert _make(model_dir).GetResults([]) == []
+
+
+def test_stream_without_samples_fails_like_reference(model_dir):  # PadSequence NRE inside Forward's try
+    from aliparaformerasr_amd.offline_recognizer import RecognizerException
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    with pytest.raises(RecognizerException, match="Offline recognition failed"):
+        r.GetResult(s)
+
+
+def test_end_to_end_text_matches_oracle(model_dir):
+    d, cfg, w, cmvn = model_dir
+    r = _make(model_dir, hotwordFilePath=str(d / "hotword.txt"))
+    audio = [W.synth_audio(n, 40 + u) for u, n in enumerate((40000, 48000, 33000))]
+    streams = []
+    for a in audio:
+        s = r.CreateOfflineStream()
+        s.AddSamples(a)
+        streams.append(s)
+    results = r.GetResults(streams)
+    conf = fe.FrontendConf(dither=0.0)
+    feats = [fe.wav_frontend(a, conf, cmvn[0], cmvn[1]) for a in audio]
+    T = max(f.shape[0] for f in feats)
+    speech = fe.pad_sequence(feats).reshape(len(audio), T, 560)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").paraformer(speech)
+    ids_ref = om.argmax_last(ref["logits"])
+    srt = np.sort(ref["logits"], axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 0.04
+    table = _tokens()
+    for b, (s, res) in enumerate(zip(streams, results)):
+        ids = np.asarray(s.Tokens)
+        assert ids.shape[0] == ids_ref.shape[1]
+        assert (ids[safe[b]] == ids_ref[b][safe[b]]).all()
+        # DecodeMulti over the ids the device produced must equal the oracle's DecodeMulti
+        L = ids.shape[0]
+        text, tlen, toks, ts = glue.decode_multi_one(table, ids.tolist(), [[0, 0]] * L)
+        assert (res.Text, res.TextLen, res.Tokens, res.Timestamps) == (text, tlen, toks, ts)
+        assert s.SpeechLength == 0                                  # RemoveChunk after > 2 tokens
+    # a second GetResults on a consumed stream fails like the reference (Speech == null)
+    from aliparaformerasr_amd.offline_recognizer import RecognizerException
+    with pytest.raises(RecognizerException):
+        r.GetResults(streams[:1])
