@@ -100,24 +100,20 @@ def main():
     dev = torch.device("cuda", local)
 
     # ---- weights: rank 0 builds the synthetic paraformer-large image, RCCL-broadcasts it
+    from aliparaformerasr_amd import shard as sh
     cfg = W.paraformer_large_config()
     cmvn = W.synth_cmvn()
     weights = None
+    blob = b""
     if rank == 0:
         weights = W.synth_weights(cfg, 42)
-        blob = np.frombuffer(W.pack_pfw(cfg, weights), dtype=np.uint8)
-        nbytes = torch.tensor([blob.size], dtype=torch.int64, device=dev)
-    else:
-        nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+        blob = W.pack_pfw(cfg, weights)
     if world > 1:
-        dist.broadcast(nbytes, 0)
-    n = int(nbytes.item())
-    if rank == 0:
-        wdev = torch.from_numpy(blob.copy()).to(dev)
+        wdev = sh.broadcast_bytes(blob, dist, dev)            # RCCL broadcast rank 0 -> all
     else:
-        wdev = torch.empty(n, dtype=torch.uint8, device=dev)
-    if world > 1:
-        dist.broadcast(wdev, 0)
+        wdev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    del blob
+    n = wdev.numel()
     torch.cuda.synchronize()
     eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local)
 
@@ -125,17 +121,13 @@ def main():
     B = args.batch
     audio = [W.synth_audio(SAMPLES, rank * B + u) for u in range(B)]
     eng.stage_audio(audio)
-    ids_dev = torch.zeros((B, LCAP), dtype=torch.int32, device=dev)
-    gathered = [torch.zeros_like(ids_dev) for _ in range(world)] if world > 1 else None
+    gathered = {}
 
     def step():
         eng.run_staged()
-        if world > 1:
+        if world > 1:                                         # gather of hypotheses over RCCL
             r = eng.fetch()
-            ids = np.zeros((B, LCAP), np.int32)
-            ids[:, : r.L] = r.token_ids[:, :LCAP]
-            ids_dev.copy_(torch.from_numpy(ids))
-            dist.all_gather(gathered, ids_dev)
+            gathered["ids"] = sh.gather_hypotheses(r.token_ids, world * B, LCAP, dist, dev)
 
     for _ in range(args.warmup):
         step()
