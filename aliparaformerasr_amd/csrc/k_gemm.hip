@@ -591,13 +591,22 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp2(GemmDev p) {
   // 16 MFMAs with the step's LPS LDS-DMA pieces slotted between them (one piece per MFMA pair):
   // the address unit then sees an even stream instead of 8 waves bursting 6 loads each at a
   // phase boundary, and the issuing wave hides the DMA issue latency behind its own MFMAs.
-  auto mfma_burst_dma = [&]() {
+  // `mid` runs after 12 of the 16 MFMAs (all DMA pieces already issued): the counted wait and the
+  // phase barrier sit INSIDE the burst, so when the partner group is released there are still 4
+  // MFMAs queued on this SIMD and the matrix pipe does not drain at the phase boundary.  Legal
+  // because everything the barrier guards (this wave's LDS reads of the stage, its DMA wait) is
+  // settled before the burst's tail.
+  auto mfma_burst_dma = [&](auto&& mid) {
     __builtin_amdgcn_s_setprio(1);
     int piece = 0;
 #pragma unroll
     for (int s = 0; s < KSUB; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+        if (s * 2 + i == (KSUB * 2) - 2) {
+          issue_advance();
+          mid();
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
@@ -608,7 +617,6 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp2(GemmDev p) {
         }
       }
     __builtin_amdgcn_s_setprio(0);
-    issue_advance();
   };
   auto mfma_burst = [&]() {
     __builtin_amdgcn_s_setprio(1);
@@ -787,19 +795,17 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp2(GemmDev p) {
       stamp(k, 1);
       __builtin_amdgcn_s_barrier();
       stamp(k, 2);
-      if (INTERLEAVE) mfma_burst_dma(); else mfma_burst();
-      stamp(k, 3);
-      if (sA) pass_store();
-      // younger than DMA(k+1) [issued in COMPUTE(k-1)]: store(k-1), DMA(k+2), store(k)
-      {
+      auto midA = [&]() {
+        if (sA) pass_store();
+        // younger than DMA(k+1) [issued in COMPUTE(k-1)]: store(k-1), DMA(k+2), store(k)
         const int ns = sA + sA_prev;
         if (ns == 2) wait_vmcnt<LPS * (S - 2) + 2>();
         else if (ns == 1) wait_vmcnt<LPS * (S - 2) + 1>();
         else wait_vmcnt<LPS * (S - 2)>();
         sA_prev = sA;
-      }
-      stamp(k, 4);
-      __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      };
+      if (INTERLEAVE) mfma_burst_dma(midA); else { mfma_burst(); midA(); }
       stamp(k, 5);
       if (--kt == 0) { kt = nk; epilogue(); }
       stamp(k, 6);
@@ -829,10 +835,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp2(GemmDev p) {
       stamp(k, 2);
       __builtin_amdgcn_s_barrier();
       stamp(k, 3);
-      if (INTERLEAVE) mfma_burst_dma(); else { issue_next(); mfma_burst(); }   // DMA of step k+S (clamped)
-      if (sB) pass_store();
-      stamp(k, 4);
-      if (k + 1 < T) __builtin_amdgcn_s_barrier();
+      auto midB = [&]() {
+        if (sB) pass_store();
+        if (k + 1 < T) __builtin_amdgcn_s_barrier();
+      };
+      if (INTERLEAVE) mfma_burst_dma(midB); else { issue_next(); mfma_burst(); midB(); }   // DMA of step k+S (clamped)
       stamp(k, 5);
       if (--kt == 0) { kt = nk; epilogue(); }
       stamp(k, 6);

@@ -188,7 +188,7 @@ def main():
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp2 (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
                          % (DOMINANT, B * 500), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": None,
                          "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
