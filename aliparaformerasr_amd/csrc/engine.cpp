@@ -168,8 +168,12 @@ void Engine::load_weights(const pf_engine_config& cfg) {
            "kernels are built for d_model = 512, 4 heads of 128");
   PF_CHECK(mc_.d_model % 8 == 0 && mc_.ffn % 64 == 0 && mc_.feat_dim % 4 == 0, PF_ERR_UNSUPPORTED,
            "unsupported model dimensions");
-  PF_CHECK(!mc_.timestamp_head && !mc_.seaco, PF_ERR_UNSUPPORTED,
-           "timestamp (BiCIF) head / SeACo bias decoder are not built in this round");
+  mc_.cif_smooth2 = (float)jc->num_or("cif_smooth2", mc_.cif_smooth2);
+  mc_.cif_noise2 = (float)jc->num_or("cif_noise2", mc_.cif_noise2);
+  mc_.upsample = (int)jc->num_or("upsample", mc_.upsample);
+  PF_CHECK(!mc_.seaco && mc_.kind != "seacoparaformer", PF_ERR_UNSUPPORTED,
+           "the SeACo bias decoder is not built in this round");
+  PF_CHECK(!mc_.timestamp_head || mc_.upsample == 3, PF_ERR_UNSUPPORTED, "timestamp head: only upsample = 3");
 
   const int64_t data_off = round_up((int64_t)(16 + hlen), (int64_t)kAlign);
   const int64_t data_bytes = nbytes - data_off;
@@ -253,6 +257,61 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     cif_conv_.bias = tensor("predictor.conv.bias").dev;
     cif_out_w_ = tensor("predictor.out.weight").dev;
     cif_out_b_ = tensor("predictor.out.bias").dev;
+  }
+  // BiCIF timestamp head: ConvTranspose1d weight [in, out, j] -> GEMM operand [(j, out)][in];
+  // W_ih of both directions stacked [8D, D] with b_ih + b_hh folded into one bias; W_hh f16 [2][4D][D].
+  if (mc_.timestamp_head) {
+    const int up = mc_.upsample;
+    const Tensor& uw = tensor("predictor.upsample.weight");
+    const Tensor& ub = tensor("predictor.upsample.bias");
+    PF_CHECK(uw.shape.size() == 3 && uw.shape[0] == D && uw.shape[1] == D && uw.shape[2] == up && ub.numel == D,
+             PF_ERR_FORMAT, "weights: predictor.upsample shape");
+    std::vector<float> hw(uw.numel), re(uw.numel), hb(D), rb((size_t)up * D);
+    PF_HIP(hipMemcpy(hw.data(), uw.dev, uw.numel * 4, hipMemcpyDeviceToHost));
+    PF_HIP(hipMemcpy(hb.data(), ub.dev, (size_t)D * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < D; ++i)
+      for (int o = 0; o < D; ++o)
+        for (int jx = 0; jx < up; ++jx) re[((size_t)jx * D + o) * D + i] = hw[((size_t)i * D + o) * up + jx];
+    for (int jx = 0; jx < up; ++jx) std::memcpy(&rb[(size_t)jx * D], hb.data(), (size_t)D * 4);
+    float* tmp = nullptr;
+    PF_HIP(hipMalloc(&tmp, std::max(re.size(), (size_t)8 * D * D) * 4));
+    PF_HIP(hipMemcpy(tmp, re.data(), re.size() * 4, hipMemcpyHostToDevice));
+    ts_up_.N = up * D; ts_up_.K = D; ts_up_.Kpad = D;
+    ts_up_.w = (half_t*)dalloc((size_t)round_up(up * D, 128) * D * 2);
+    PF_HIP(hipMemsetAsync(ts_up_.w, 0, (size_t)round_up(up * D, 128) * D * 2, stream_));
+    launch_f32_to_f16(stream_, tmp, up * D, D, D, ts_up_.w, D);
+    float* ubias = (float*)dalloc(rb.size() * 4);
+    PF_HIP(hipMemcpyAsync(ubias, rb.data(), rb.size() * 4, hipMemcpyHostToDevice, stream_));
+    ts_up_.bias = ubias;
+    PF_HIP(hipStreamSynchronize(stream_));
+
+    ts_ih_.N = 8 * D; ts_ih_.K = D; ts_ih_.Kpad = D;
+    ts_ih_.w = (half_t*)dalloc((size_t)8 * D * D * 2);
+    ts_whh_ = (half_t*)dalloc((size_t)8 * D * D * 2);
+    std::vector<float> bsum((size_t)8 * D), b1((size_t)4 * D), b2((size_t)4 * D);
+    const char* sfx[2] = {"", "_reverse"};
+    for (int d = 0; d < 2; ++d) {
+      const Tensor& wih = tensor(std::string("predictor.blstm.weight_ih") + sfx[d]);
+      const Tensor& whh = tensor(std::string("predictor.blstm.weight_hh") + sfx[d]);
+      const Tensor& bih = tensor(std::string("predictor.blstm.bias_ih") + sfx[d]);
+      const Tensor& bhh = tensor(std::string("predictor.blstm.bias_hh") + sfx[d]);
+      PF_CHECK(wih.numel == (int64_t)4 * D * D && whh.numel == (int64_t)4 * D * D && bih.numel == 4 * D && bhh.numel == 4 * D,
+               PF_ERR_FORMAT, "weights: predictor.blstm shapes");
+      launch_f32_to_f16(stream_, wih.dev, 4 * D, D, D, ts_ih_.w + (size_t)d * 4 * D * D, D);
+      launch_f32_to_f16(stream_, whh.dev, 4 * D, D, D, ts_whh_ + (size_t)d * 4 * D * D, D);
+      PF_HIP(hipMemcpy(b1.data(), bih.dev, (size_t)4 * D * 4, hipMemcpyDeviceToHost));
+      PF_HIP(hipMemcpy(b2.data(), bhh.dev, (size_t)4 * D * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 4 * D; ++i) bsum[(size_t)d * 4 * D + i] = b1[i] + b2[i];
+    }
+    float* gb = (float*)dalloc(bsum.size() * 4);
+    PF_HIP(hipMemcpyAsync(gb, bsum.data(), bsum.size() * 4, hipMemcpyHostToDevice, stream_));
+    ts_ih_.bias = gb;
+    const Tensor& ow = tensor("predictor.out2.weight");
+    PF_CHECK(ow.numel == 2 * D, PF_ERR_FORMAT, "weights: predictor.out2.weight shape");
+    ts_out_w_ = ow.dev;
+    ts_out_b_ = tensor("predictor.out2.bias").dev;
+    PF_HIP(hipStreamSynchronize(stream_));
+    PF_HIP(hipFree(tmp));
   }
   // decoder
   const int nd = mc_.dec_layers;
@@ -616,6 +675,9 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
                    alphas_);
   launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
   prof_end("cif_misc");
+  last_.peak_len = 0;
+  last_.cif_peak.clear();
+  if (mc_.timestamp_head) timestamp_head(B, T);
   // the path's only host sync: the decoder length L is data dependent
   int32_t L = 0;
   last_.fire_count.resize(B);
@@ -700,6 +762,45 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
 }
 
+// BiCIF timestamp head (k_bicif.hip): us_cif_peak [B, 3T]; needs token_num (device) only.
+void Engine::timestamp_head(int B, int T) {
+  const int D = mc_.d_model, up = mc_.upsample;
+  const int M = B * T, T3 = up * T;
+  const int64_t M3 = (int64_t)B * T3;
+  const int64_t Mp = round_up(M, 128) + 128, M3p = round_up(M3, 128) + 128;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_up = carve((size_t)std::max<int64_t>(Mp * up, M3p) * D * 2), o_xg = carve((size_t)M3p * 8 * D * 4);
+  const size_t o_ho = carve((size_t)M3 * 2 * D * 4), o_hs = carve((size_t)4 * B * D * 2), o_cs = carve((size_t)2 * B * D * 4);
+  const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4);
+  ensure(ws_ts_, off);
+  char* base = (char*)ws_ts_.p;
+  half_t* up16 = (half_t*)(base + o_up);
+  float* xg = (float*)(base + o_xg);
+  float* hout = (float*)(base + o_ho);
+  half_t* hs = (half_t*)(base + o_hs);
+  float* cs = (float*)(base + o_cs);
+  float* al = (float*)(base + o_al);
+  us_peak_ = (float*)(base + o_pk);
+  // [M, 3D] row-major IS [3M, D]: output row m of the transposed conv holds frames 3t, 3t+1, 3t+2
+  gemm("gemm_ts", ts_up_, H16_, D, M, nullptr, 0, up16, up * D, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  gemm("gemm_ts", ts_ih_, up16, D, (int)M3, xg, 8 * D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  prof_begin("lstm", 2.0 * 2 * M3 * 4.0 * D * D);
+  PF_HIP(hipMemsetAsync(hs, 0, (size_t)4 * B * D * 2, stream_));
+  PF_HIP(hipMemsetAsync(cs, 0, (size_t)2 * B * D * 4, stream_));
+  LstmArgs a{};
+  a.whh = ts_whh_; a.xg = xg; a.hstate = hs; a.cstate = cs; a.hout = hout; a.B = B; a.T3 = T3; a.D = D;
+  for (int s = 0; s < T3; ++s) { a.step = s; launch_lstm_step(stream_, a); }
+  prof_end("lstm");
+  prof_begin("ts_misc", 0);
+  launch_us_alpha(stream_, hout, M3, 2 * D, ts_out_w_, ts_out_b_, mc_.cif_smooth2, mc_.cif_noise2, al);
+  launch_us_peak(stream_, al, plan_.token_num, B, T3, mc_.cif_threshold - 1e-4f, us_peak_);
+  prof_end("ts_misc");
+  last_.peak_len = T3;
+  last_.cif_peak.resize((size_t)M3);
+  PF_HIP(hipMemcpyAsync(last_.cif_peak.data(), us_peak_, (size_t)M3 * 4, hipMemcpyDeviceToHost, stream_));
+}
+
 void Engine::sensevoice_head(int B, int T, bool want_logits) {
   const int D = mc_.d_model, V = mc_.vocab;
   const int M = B * T;
@@ -736,6 +837,7 @@ void Engine::forward_device(const float* speech_dev, int B, int T, bool want_log
   if (mc_.kind == "sensevoicesmall") fl += 2 * Td * D * V;
   else {
     fl += 2 * Td * D * D * 3 + 2 * Td * D;
+    if (mc_.timestamp_head) fl += 2 * Td * D * 3 * D + 2 * (2 * 3 * Td * D * 8 * D);
     fl += mc_.dec_layers * (4 * Ld * D * F + 2 * Ld * D * K + 2 * Ld * D * D + 4 * Td * D * D + 4 * Ld * Td * D + 2 * Ld * D * D) +
           4 * Ld * D * F + 2 * Ld * D * V;
   }
@@ -784,7 +886,11 @@ void Engine::fetch(pf_batch_out* out) {
   PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");
   PF_HIP(hipStreamSynchronize(stream_));
   const int B = last_.B, L = last_.L, V = last_.V;
-  out->L = L; out->V = V; out->cif_peak_len = 0;
+  out->L = L; out->V = V; out->cif_peak_len = last_.peak_len;
+  if (out->cif_peak && out->cif_peak_cap > 0 && last_.peak_len > 0) {
+    PF_CHECK(out->cif_peak_cap >= (int64_t)last_.cif_peak.size(), PF_ERR_CAPACITY, "cif_peak capacity < B*3T");
+    std::memcpy(out->cif_peak, last_.cif_peak.data(), last_.cif_peak.size() * 4);
+  }
   if (out->token_ids) {
     PF_CHECK(out->l_cap >= L, PF_ERR_CAPACITY, "token_ids capacity " + std::to_string(out->l_cap) + " < L = " + std::to_string(L));
     for (int b = 0; b < B; ++b) {

@@ -19,6 +19,8 @@ struct ModelCfg {
   float cif_threshold = 1.0f, cif_tail = 0.45f, cif_smooth = 1.0f, cif_noise = 0.0f;
   int cif_l_order = 1, cif_r_order = 1;
   bool timestamp_head = false, seaco = false, use_itn = false;
+  float cif_smooth2 = 0.25f, cif_noise2 = 0.01f;
+  int upsample = 3;
   int kind_id() const { return kind == "sensevoicesmall" ? 1 : (kind == "seacoparaformer" ? 2 : 0); }
 };
 
@@ -48,6 +50,8 @@ struct HostBatchOut { // results of the last forward, host side
   std::vector<int64_t> ids;        // [B, L]
   std::vector<int32_t> token_num;  // [B]
   std::vector<int32_t> fire_count; // [B]
+  std::vector<float> cif_peak;     // [B, peak_len] us_cif_peak (timestamp models), else empty
+  int peak_len = 0;
 };
 
 class Engine {
@@ -113,6 +117,7 @@ class Engine {
   void enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T);
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
+  void timestamp_head(int B, int T);
   void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
             half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
             int scale_cols, float scale, bool bias = true);
@@ -136,6 +141,10 @@ class Engine {
   Lin cif_conv_, dec_kv_all_, dec_final_w1_, dec_final_w2_, dec_out_, ctc_;
   const float* cif_out_w_ = nullptr;
   const float* cif_out_b_ = nullptr;
+  Lin ts_up_, ts_ih_;               // BiCIF: ConvTranspose1d as [3D, D], W_ih of both directions [8D, D]
+  half_t* ts_whh_ = nullptr;        // [2][4D][D]
+  const float* ts_out_w_ = nullptr;
+  const float* ts_out_b_ = nullptr;
   std::vector<float> embed_host_;
 
   // front-end
@@ -145,12 +154,13 @@ class Engine {
   int cmvn_dim_ = 0;
 
   // workspace
-  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_;
+  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_, ws_ts_;
   int pe_T_ = 0;
   // encoder views (valid after encoder())
   float* x_ = nullptr; half_t* xn16_ = nullptr; half_t* qkv16_ = nullptr; half_t* ctx16_ = nullptr;
   float* fsm_ = nullptr; half_t* h16_ = nullptr; float* H32_ = nullptr; half_t* H16_ = nullptr;
   float* alphas_ = nullptr; CifPlan plan_{};
+  float* us_peak_ = nullptr;
   // decoder views
   float* logits_ = nullptr; int64_t* ids_dev_ = nullptr;
   // staged audio

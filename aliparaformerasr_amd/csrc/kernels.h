@@ -85,6 +85,19 @@ struct CifPlan {           // device arrays sized for B utterances
 void launch_cif_scan(hipStream_t s, const float* alphas, int B, int T1, float threshold, CifPlan plan);
 void launch_cif_gather(hipStream_t s, const float* H, int B, int T, int D, int T1, CifPlan plan, int L,
                        float* E);
+// ---------------------------------------------------- BiCIF timestamp head ----
+struct LstmArgs {
+  const half_t* whh;   // [2 dir][4D][D] f16, PyTorch gate order i,f,g,o
+  const float* xg;     // [B*T3][2 dir * 4D] input-side gate pre-activations (+ both biases)
+  half_t* hstate;      // [2 dir][2 ping-pong][B][D]
+  float* cstate;       // [2 dir][B][D]
+  float* hout;         // [B*T3][2D]  forward | reverse hidden states
+  int B, T3, D, step;  // step s handles t = s (forward) and t = T3-1-s (reverse)
+};
+void launch_lstm_step(hipStream_t s, const LstmArgs& a);
+void launch_us_alpha(hipStream_t s, const float* hout, int64_t rows, int W, const float* w, const float* b0,
+                     float smooth, float noise, float* out);
+void launch_us_peak(hipStream_t s, float* alphas, const int32_t* token_num, int B, int T3, float thr, float* peak);
 // last-index arg-max (+ optional in-place log_softmax) over rows of width V
 void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int do_logsoftmax, int64_t* ids);
 

@@ -301,11 +301,20 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     std::vector<int64_t> ids((size_t)B * std::max(L, 1));
     out.token_ids = ids.data();
     out.l_cap = std::max(L, 1);
+    const int P = out.cif_peak_len;                                    // 3*Tmax for timestamp models (:172-183)
+    std::vector<float> peak((size_t)B * std::max(P, 1));
+    if (P > 0) { out.cif_peak = peak.data(); out.cif_peak_cap = (int64_t)peak.size(); }
     e->fetch(&out);
     for (int b = 0; b < B; ++b) {
       Stream* s = streams[b];
       s->Tokens.assign(ids.begin() + (size_t)b * out.l_cap, ids.begin() + (size_t)b * out.l_cap + L);   // :187
-      for (int l = 0; l < L; ++l) s->Timestamps.push_back({0, 0});                                      // :151,:188
+      if (P > 0) {
+        // :172-183: the peak row and ALL L arg-max ids go to time_stamp_lfr6_onnx
+        std::vector<std::vector<int32_t>> ts = time_stamp_lfr6(peak.data() + (size_t)b * P, P, s->Tokens);
+        for (auto& t2 : ts) s->Timestamps.push_back(t2);
+      } else {
+        for (int l = 0; l < L; ++l) s->Timestamps.push_back({0, 0});                                    // :151,:188
+      }
       s->RemoveChunk();                                                                                  // :189
     }
   } catch (const Error& ex) {

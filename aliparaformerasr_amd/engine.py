@@ -17,12 +17,13 @@ def _f32(a) -> np.ndarray:
 
 
 class BatchResult:
-    def __init__(self, token_ids, token_num, L, V, logits=None):
+    def __init__(self, token_ids, token_num, L, V, logits=None, cif_peak=None):
         self.token_ids = token_ids      # [B, L] int64
         self.token_num = token_num      # [B] int32
         self.L = L
         self.V = V
         self.logits = logits            # [B, L, V] float32 log-probs or None
+        self.cif_peak = cif_peak        # [B, 3*Tmax] float32 us_cif_peak (timestamp models) or None
 
 
 class Engine:
@@ -109,7 +110,12 @@ class Engine:
         out = N.PfBatchOut()
         out.struct_size = C.sizeof(N.PfBatchOut)
         N.check(call(out))                       # first pass: learn L, V (no buffers)
-        L, V = out.L, out.V
+        L, V, P = out.L, out.V, out.cif_peak_len
+        peak = None
+        if P > 0:
+            peak = np.zeros((B, P), np.float32)
+            out.cif_peak = _fp(peak)
+            out.cif_peak_cap = peak.size
         ids = np.zeros((B, max(L, 1)), np.int64)
         tn = np.zeros(B, np.int32)
         out.token_ids = ids.ctypes.data_as(C.POINTER(C.c_int64))
@@ -121,7 +127,7 @@ class Engine:
             out.logits = _fp(logits)
             out.logits_cap = logits.size
         N.check(self._lib.pf_fetch(self._h, C.byref(out)))
-        return BatchResult(ids[:, :L].copy(), tn, L, V, logits)
+        return BatchResult(ids[:, :L].copy(), tn, L, V, logits, peak)
 
     def forward_feats(self, speech, want_logits=False) -> BatchResult:
         sp = _f32(speech)

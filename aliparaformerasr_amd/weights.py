@@ -35,6 +35,8 @@ DEFAULT_CONFIG = dict(
     tp_layers=0, kernel=11, dec_layers=16, vocab=8404, cif_threshold=1.0, cif_tail=0.45,
     cif_l_order=1, cif_r_order=1, cif_smooth=1.0, cif_noise=0.0, timestamp_head=False,
     seaco=False, use_itn=False,
+    # BiCIF timestamp head (CifPredictorV3): ConvTranspose1d x3 upsample -> BiLSTM -> Linear(1024,1)
+    cif_smooth2=0.25, cif_noise2=0.01, upsample=3,
 )
 
 
@@ -116,6 +118,17 @@ def synth_weights(cfg: dict, seed: int = 42) -> dict:
                                  / np.float32(np.sqrt(D))).astype(np.float32)
     # calibrated on the seed-42 paraformer-large geometry so that sum(alpha) ~ 150 for 30 s (5 tokens/s)
     w["predictor.out.bias"] = np.asarray([-1.35], np.float32)
+    if cfg.get("timestamp_head"):
+        up = cfg["upsample"]
+        w["predictor.upsample.weight"] = (rng.standard_normal((D, D, up), dtype=np.float32) / np.float32(np.sqrt(D))).astype(np.float32)
+        w["predictor.upsample.bias"] = (0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+        for sfx in ("", "_reverse"):
+            for nm in ("weight_ih", "weight_hh"):
+                w["predictor.blstm.%s%s" % (nm, sfx)] = (rng.standard_normal((4 * D, D), dtype=np.float32) / np.float32(np.sqrt(D))).astype(np.float32)
+            for nm in ("bias_ih", "bias_hh"):
+                w["predictor.blstm.%s%s" % (nm, sfx)] = (0.1 * rng.standard_normal(4 * D, dtype=np.float32)).astype(np.float32)
+        w["predictor.out2.weight"] = (rng.standard_normal((1, 2 * D), dtype=np.float32) * np.float32(4.0 / np.sqrt(2 * D))).astype(np.float32)
+        w["predictor.out2.bias"] = np.asarray([0.3], np.float32)
     # decoder
     for i in range(cfg["dec_layers"]):
         p = f"decoder.layers.{i}"

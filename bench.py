@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed step with per-class kernel times")
+    ap.add_argument("--timestamp-head", action="store_true",
+                    help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
     args = ap.parse_args()
 
     import torch
@@ -101,7 +103,7 @@ def main():
 
     # ---- weights: rank 0 builds the synthetic paraformer-large image, RCCL-broadcasts it
     from aliparaformerasr_amd import shard as sh
-    cfg = W.paraformer_large_config()
+    cfg = W.paraformer_large_config(timestamp_head=bool(args.timestamp_head))
     cmvn = W.synth_cmvn()
     weights = None
     blob = b""
@@ -166,7 +168,7 @@ def main():
         breakdown = {}
         for cls in ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
                     "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn1", "gemm_dec_ffn2",
-                    "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax"):
+                    "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc"):
             ms, cnt, fpl = eng.profile_get(cls)
             breakdown[cls] = {"ms": round(ms, 4), "launches": cnt,
                               "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
@@ -181,14 +183,16 @@ def main():
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "paraformer-large-zh offline, batch %dx%d s synthetic 16 kHz per GPU "
-                                   "(BASELINE.json configs[1]), seeded synthetic weights" % (B, SECONDS),
+            "config": {"workload": "paraformer-large-zh offline%s, batch %dx%d s synthetic 16 kHz per GPU "
+                                   "(BASELINE.json configs[%d]), seeded synthetic weights"
+                                   % (" + BiCIF timestamp head" if args.timestamp_head else "", B, SECONDS,
+                                      4 if args.timestamp_head else 1),
                        "global_batch": world * B, "samples_per_utt": SAMPLES, "T_lfr": 500, "L": int(res.L),
                        "parallelism": "dp%d (utterance shards, no data-path collective)" % world},
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp2 (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp3 (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
                          % (DOMINANT, B * 500), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS, "traffic": None,
                          "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,

@@ -52,6 +52,9 @@ class ModelConfig:
     timestamp_head: bool = False      # BiCIF upsample head (us_alphas/us_cif_peak)
     seaco: bool = False
     use_itn: bool = False
+    cif_smooth2: float = 0.25
+    cif_noise2: float = 0.01
+    upsample: int = 3
 
     def to_dict(self):
         return dict(self.__dict__)
@@ -231,6 +234,55 @@ class Oracle:
                 E[b, : counts[b]] = np.stack(frames_all[b])
         return E, np.asarray(counts, np.int32), np.asarray(tnum, np.int32)
 
+    # -- BiCIF timestamp head ----------------------------------------------
+    def us_alphas_peak(self, H, token_num):
+        """CifPredictorV3.get_upsample_timestmap (FunASR export; external to /root/reference, consumed by
+        AliParaformerAsr/OfflineRecognizer.cs:172-183 as output [3] `us_cif_peak`):
+          ConvTranspose1d(D, D, k=3, stride=3) -> BiLSTM(D) -> Linear(2D, 1) -> sigmoid ->
+          relu(a * smooth2 - noise2) (mask all ones) -> renormalise each row to token_num ->
+          cif_wo_hidden(alphas, threshold - 1e-4): running integrate, recorded BEFORE the reset.
+        H [B,T,D] torch, token_num [B] ints.  Returns us_alphas, us_cif_peak  [B, 3T] float32."""
+        c = self.cfg
+        q = self.q
+        B, T, D = H.shape
+        up = c.upsample
+        Wt = q(self.w["predictor.upsample.weight"])                 # [in, out, k]
+        # out[b, 3t+j, o] = sum_c H[b,t,c] * W[c,o,j] + bias[o]
+        y = torch.einsum("btc,coj->btjo", q(H), Wt).reshape(B, T * up, D) + self.w["predictor.upsample.bias"]
+        yq = q(y)                                                   # engine keeps it as a 16-bit GEMM operand
+        outs = []
+        for sfx, rev in (("", False), ("_reverse", True)):
+            Wih = q(self.w["predictor.blstm.weight_ih" + sfx]); Whh = q(self.w["predictor.blstm.weight_hh" + sfx])
+            bias = self.w["predictor.blstm.bias_ih" + sfx] + self.w["predictor.blstm.bias_hh" + sfx]
+            xg = torch.matmul(yq, Wih.t()) + bias                  # [B, 3T, 4D]
+            h = torch.zeros(B, D); cst = torch.zeros(B, D)
+            hs = [None] * (T * up)
+            order = range(T * up - 1, -1, -1) if rev else range(T * up)
+            for t in order:
+                g = xg[:, t] + torch.matmul(q(h), Whh.t())
+                i_, f_, g_, o_ = torch.split(g, D, dim=-1)
+                cst = torch.sigmoid(f_) * cst + torch.sigmoid(i_) * torch.tanh(g_)
+                h = torch.sigmoid(o_) * torch.tanh(cst)
+                hs[t] = h
+            outs.append(torch.stack(hs, dim=1))
+        hcat = torch.cat(outs, dim=-1)                              # [B, 3T, 2D]
+        z = torch.matmul(hcat, self.w["predictor.out2.weight"].t()).squeeze(-1) + self.w["predictor.out2.bias"]
+        a2 = torch.relu(torch.sigmoid(z) * c.cif_smooth2 - c.cif_noise2)
+        a2 = a2.numpy().astype(F32)
+        tn = np.asarray(token_num, dtype=F32)
+        ssum = a2.sum(axis=1, dtype=F32)
+        a2 = (a2 * (tn / ssum)[:, None].astype(F32)).astype(F32)
+        thr = F32(F32(c.cif_threshold) - F32(1e-4))
+        peak = np.zeros_like(a2)
+        for b in range(B):
+            integ = F32(0.0)
+            for t in range(a2.shape[1]):
+                integ = F32(integ + a2[b, t])
+                peak[b, t] = integ
+                if integ >= thr:
+                    integ = F32(integ - thr)
+        return a2, peak
+
     # -- decoder -----------------------------------------------------------
     def ffn_dec(self, x, p):
         h = torch.relu(self.lin(x, p + ".ffn.w1"))
@@ -272,8 +324,11 @@ class Oracle:
         a = self.cif_alphas(H)
         E, counts, tnum = self.cif_fire(H.numpy(), a.numpy(), self.cfg.cif_threshold)
         logits = self.decoder(E, H, tnum)
-        return {"logits": logits.numpy(), "token_num": tnum, "fire_count": counts,
-                "alphas": a.numpy(), "H": H.numpy(), "E": E}
+        out = {"logits": logits.numpy(), "token_num": tnum, "fire_count": counts,
+               "alphas": a.numpy(), "H": H.numpy(), "E": E}
+        if self.cfg.timestamp_head:
+            out["us_alphas"], out["us_cif_peak"] = self.us_alphas_peak(H, tnum)
+        return out
 
     def sensevoice(self, speech):
         """SenseVoice-small (speech already carries the 4 prompt frames):

@@ -156,3 +156,28 @@ def test_cif_fire_matches_streaming_definition():
         assert counts[b] == len(out)
         np.testing.assert_allclose(E[b, : counts[b]], np.stack(out), rtol=1e-5, atol=1e-6)
         assert tnum[b] == int(np.floor(a[b].sum(dtype=np.float32)))
+
+
+def test_bicif_head_properties():
+    """BiCIF timestamp head restatement (no reference vectors exist for it — parity unpinned):
+    size-independent properties the export guarantees: rows of us_alphas sum to token_num, the running
+    integrate stays below 2*threshold, and the number of fires equals token_num (+-1 for the tail)."""
+    import numpy as np
+    from aliparaformerasr_amd import weights as W
+    from oracle import frontend as fe, model as om, glue
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=32, timestamp_head=True)
+    w = W.synth_weights(cfg, 9)
+    w["predictor.out.bias"] = np.asarray([0.0], np.float32)
+    cmvn = W.synth_cmvn()
+    feats = [fe.wav_frontend(W.synth_audio(n, u), fe.FrontendConf(dither=0.0), *cmvn) for u, n in enumerate((24000, 16000))]
+    sp = fe.pad_sequence(feats).reshape(2, -1, 560)
+    r = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").paraformer(sp)
+    T = sp.shape[1]
+    assert r["us_alphas"].shape == (2, 3 * T) and r["us_cif_peak"].shape == (2, 3 * T)
+    assert np.allclose(r["us_alphas"].sum(1), r["token_num"], rtol=1e-5)
+    assert r["us_cif_peak"].max() < 2.0
+    fires = (r["us_cif_peak"] > 1 - 1e-4).sum(1)
+    assert np.all(np.abs(fires - r["token_num"]) <= 1)
+    ids = om.argmax_last(r["logits"])
+    ts = glue.time_stamp_lfr6_onnx(r["us_cif_peak"][0], ids[0])
+    assert all(len(t) == 2 and t[1] >= t[0] for t in ts)
