@@ -38,6 +38,14 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   const int bb = min(bt * 32 + r, a.B - 1);
   const half_t* hrow = hprev + (size_t)bb * D;
 
+  // the cell's own inputs (this thread's unit / utterance) are fetched first: their HBM latency then
+  // overlaps the W_hh / h loads and the MFMAs instead of following the LDS reduction
+  const int bq = min(bt * 32 + r, a.B - 1);
+  const int uq = ub * 8 + 2 * wave + kg;
+  const float* xgp = a.xg + ((size_t)bq * a.T3 + t) * (size_t)(8 * D) + (size_t)dir * 4 * D + uq;
+  float* cp = a.cstate + ((size_t)dir * a.B + bq) * D + uq;
+  const float xi = xgp[0], xf = xgp[D], xc = xgp[2 * D], xo = xgp[3 * D], cprev = *cp;
+
   const int kspan = D / 4;               // K slice of this wave
   f16v acc;
 #pragma unroll
@@ -64,11 +72,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
 
   const int b = bt * 32 + r;
   if (b >= a.B) return;
-  const int u = ub * 8 + 2 * wave + kg;
-  const float* xg = a.xg + ((size_t)b * a.T3 + t) * (size_t)(8 * D) + (size_t)dir * 4 * D + u;
-  const float gi = g[0] + xg[0], gf = g[1] + xg[D], gg = g[2] + xg[2 * D], go = g[3] + xg[3 * D];
-  float* cp = a.cstate + ((size_t)dir * a.B + b) * D + u;
-  const float c = sigmoidf_(gf) * (*cp) + sigmoidf_(gi) * tanhf(gg);
+  const int u = uq;
+  const float gi = g[0] + xi, gf = g[1] + xf, gg = g[2] + xc, go = g[3] + xo;
+  const float c = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
   const float h = sigmoidf_(go) * tanhf(c);
   *cp = c;
   hnext[(size_t)b * D + u] = (half_t)h;

@@ -79,6 +79,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
+// compile-time ablation bits for tools/gemm_abl.sh (timing experiments only; 0 in every shipped build):
+// 1 no steady-state DMA, 2 no fragment reads, 4 no MFMA, 8 no f16 output stores, 16 no direct (fp32) epilogue, 32 no transpose passes
+#ifndef PF_ABL
+#define PF_ABL 0
+#endif
+constexpr int ABL = PF_ABL;
 constexpr int GEMM_BM = 256, GEMM_BN = 128, GEMM_BK = 64, GEMM_S = 3;
 constexpr int GEMM_SCRATCH = 8 * 2048;                                   // 2 KiB per wave
 constexpr int GEMM_LDS = GEMM_S * (GEMM_BM + GEMM_BN) * GEMM_BK * 2 + GEMM_SCRATCH;   // 160 KiB
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   };
   set_issue_tile();
   auto issue_piece = [&](int i) __attribute__((always_inline)) {
+    if constexpr (ABL & 1) return;
     if (i < A_PW) glds16(is_a + a_vo[i < A_PW ? i : 0], is_lds + NW * i * 1024);
     else glds16(is_w + w_vo[i >= A_PW ? i - A_PW : 0], is_lds + A_BYTES + NW * (i - A_PW) * 1024);
   };
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   h8 af[KSUB][2], bf[KSUB][2];
   const char* rd = smem;
   auto load_frags = [&]() __attribute__((always_inline)) {
+    if constexpr (!(ABL & 2))
 #pragma unroll
     for (int s = 0; s < KSUB; ++s)
 #pragma unroll
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 
   // one deferred pass: rows 8*idx .. 8*idx+7 of this wave's 64x64 block (already packed in hq)
   auto pass = [&](int idx) __attribute__((always_inline)) {
+    if constexpr (ABL & 32) return;
     auto body = [&](auto IC, auto QC) __attribute__((always_inline)) {
       constexpr int i = decltype(IC)::value, q = decltype(QC)::value;
       if (((lane & 31) >> 3) == q) {
@@ -248,13 +257,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
       default: body(ic<1>{}, ic<3>{}); break;
     }
   };
-  auto pass_store = [&]() __attribute__((always_inline)) { *reinterpret_cast<h8*>(rowp) = rowv; };     // padded rows: always issued
+  auto pass_store = [&]() __attribute__((always_inline)) { if constexpr (!(ABL & 8)) *reinterpret_cast<h8*>(rowp) = rowv; };     // padded rows: always issued
   auto flush = [&]() __attribute__((always_inline)) {
     while (pend > 0) { pass(8 - pend); --pend; pass_store(); }
   };
 
   // direct epilogue (fp32 results, residual / FSMN add, or a wave tile that straddles N)
   auto direct_epilogue = [&](int tile) __attribute__((always_inline)) {
+    if constexpr (ABL & 16) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * BM + wm * 64, n0 = tn * BN + wn * 64;
     const bool interior = (m0 + 64 <= p.M) && (n0 + 64 <= p.N);
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
           issue_advance();
           mid();
         }
+        if constexpr (!(ABL & 4))
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
