@@ -41,6 +41,17 @@ SAMPLES = SECONDS * 16000
 LCAP = 512
 DOMINANT = "gemm_ffn1"
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
+PMC_FILE = os.path.join(ROOT, "profiles", "round1_c_gemm_ffn1_pmc.json")
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2
+    on gfx950 + WRITE_SIZE, separate passes; see the file's notes).  bench.py cannot run a profiler itself."""
+    try:
+        with open(PMC_FILE) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(cfg, weights, cmvn):
@@ -194,7 +205,9 @@ def main():
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
             "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp3 (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
                          % (DOMINANT, B * 500), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F16_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_F16_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_unit": "bytes/launch (PMC, profiles/round1_c_gemm_ffn1_pmc.json)",
+                         "algorithmic_bytes_per_launch": B * 500 * 512 * 2 + 2048 * 512 * 2 + B * 500 * 2048 * 2,
                          "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
                          "flops_per_launch": fpl_dom},
         }
