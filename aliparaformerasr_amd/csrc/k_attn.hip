@@ -29,10 +29,15 @@ typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
 #define ATT_DK 128
+// compile-time ablation bits for tools/attn_abl.sh (timing experiments only; 0 in every shipped build):
+// 1 no exp (P = t), 2 no PV MFMAs/V reads, 4 no QK, 8 no steady-state DMA, 16 no O rescale / max tracking
+#ifndef ATT_ABL
+#define ATT_ABL 0
+#endif
 #define ATT_BQ 128
 #define ATT_BK 64
 #define ATT_TILE_BYTES (ATT_BK * ATT_DK * 2)      // 16 KiB
-#define ATT_STAGE_BYTES (2 * ATT_TILE_BYTES)      // K + V
+#define ATT_LDS_BYTES (4 * ATT_TILE_BYTES)        // K0 K1 V0 V1
 
 struct AttnDev {
   const half_t* q; const half_t* k; const half_t* v; half_t* o;
@@ -41,18 +46,36 @@ struct AttnDev {
   int H, Lq, Lk;
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int V>
+struct att_ic { static constexpr int value = V; };
+
 __device__ __forceinline__ void att_glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// Software pipeline (per wave, tile kt):   S(kt+1) = K(kt+1) Q^T  is ISSUED first (the matrix pipe
+// works through it in the background), then the softmax arithmetic of S(kt) runs on the vector
+// ALU, then O^T += V(kt)^T P(kt)^T.  K and V are double buffered separately (K(kt+2) and V(kt+1)
+// are in flight during iteration kt), one workgroup barrier per tile.
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, lc = lane & 31;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * ATT_BQ + wave * 32;
+  // XCD-aware block order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; remap
+  // so that the query tiles of one (batch, head) — which stream the same K/V — are consecutive on ONE
+  // XCD and share its L2 (otherwise every K/V byte is fetched from HBM once per query tile)
+  const int nqt = gridDim.x, total = gridDim.x * gridDim.y;
+  int lid = blockIdx.x + nqt * blockIdx.y;
+  {
+    const int q8 = total >> 3, r8 = total & 7, xcd = lid & 7, idx = lid >> 3;
+    lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int bh = lid / nqt, qt = lid - bh * nqt;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qt * ATT_BQ + wave * 32;
 
   const half_t* qb = p.q + b * p.q_bs + h * ATT_DK;
   const half_t* kb_ = p.k + b * p.k_bs + h * ATT_DK;
@@ -71,67 +94,118 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
 
   // ---- staging: wave-instruction i of this wave covers tile rows (wave*4+i)*4 .. +3
   const int srow = lane >> 4, schunk = lane & 15;
-  int64_t k_src[4], v_src[4];
+  unsigned k_src[4], v_src[4];                     // byte offsets inside a 64-key tile
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 4 + srow;
-    k_src[i] = (int64_t)row * p.k_rs + ((schunk ^ (row & 15)) << 3);
-    v_src[i] = (int64_t)row * p.v_rs + ((schunk ^ ((row & 3) << 2)) << 3);
+    k_src[i] = (unsigned)(row * p.k_rs + ((schunk ^ (row & 15)) << 3)) * 2u;
+    v_src[i] = (unsigned)(row * p.v_rs + ((schunk ^ ((row & 3) << 2)) << 3)) * 2u;
   }
-  auto stage = [&](int buf, int kt) {
-    char* kl = smem + buf * ATT_STAGE_BYTES;
-    char* vl = kl + ATT_TILE_BYTES;
-    const half_t* kg = kb_ + (int64_t)kt * ATT_BK * p.k_rs;
-    const half_t* vg = vb + (int64_t)kt * ATT_BK * p.v_rs;
+  auto stage_k = [&](int buf, int kt) __attribute__((always_inline)) {
+    char* kl = smem + buf * ATT_TILE_BYTES;
+    const char* kg = reinterpret_cast<const char*>(kb_ + (int64_t)kt * ATT_BK * p.k_rs);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      att_glds16(kg + k_src[i], kl + (wave * 4 + i) * 1024);
-      att_glds16(vg + v_src[i], vl + (wave * 4 + i) * 1024);
-    }
+    for (int i = 0; i < 4; ++i) att_glds16(kg + k_src[i], kl + (wave * 4 + i) * 1024);
+  };
+  auto stage_v = [&](int buf, int kt) __attribute__((always_inline)) {
+    char* vl = smem + (2 + buf) * ATT_TILE_BYTES;
+    const char* vg = reinterpret_cast<const char*>(vb + (int64_t)kt * ATT_BK * p.v_rs);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) att_glds16(vg + v_src[i], vl + (wave * 4 + i) * 1024);
   };
 
-  // ---- per-lane read offsets
-  // K (A operand of S^T): key row kb*32 + lc, chunk (2*ds + lh) ^ (row & 15)
-  int k_off[2], k_swz[2];
+  // ---- per-lane LDS read addresses, hoisted (buffer / key-block / row-group parts are immediates)
+  // K (A operand of S^T): key row kb*32 + lc, 16-byte chunk (2*ds + lh) ^ (row & 15)
+  typedef const __attribute__((address_space(3))) char* lds_cptr;
+  const lds_cptr smem3 = (lds_cptr)smem;
+  unsigned k_rd[8];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int row = kb * 32 + lc;
-    k_off[kb] = row * 256; k_swz[kb] = row & 15;
-  }
+  for (int ds = 0; ds < 8; ++ds) k_rd[ds] = lc * 256 + (((2 * ds + lh) ^ (lc & 15)) << 4);
   // V tr-read: key row = kb*32 + 16*s2 + 8*jj + 4*lh + (i>>2), element col = db*32 + 16*g + 4*(i&3)
   const int vi = lane & 15, vg_ = (lane >> 4) & 1;
-  const int v_row_base = 4 * lh + (vi >> 2);            // + kb*32 + 16*s2 + 8*jj
-  const int v_col_base = 16 * vg_ + 4 * (vi & 3);       // + db*32   (halfs)
-  const int v_rswz = (v_row_base & 3) << 2;             // (row & 3) << 2: row offsets added are multiples of 4
+  const int v_row_base = 4 * lh + (vi >> 2);
+  const int v_col_base = 16 * vg_ + 4 * (vi & 3);
+  const int v_rswz = (v_row_base & 3) << 2;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned vaddr[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    vaddr[db] = lds0 + v_row_base * 256 + ((((v_col_base >> 3) + ((4 * db) ^ v_rswz))) << 4) + ((v_col_base & 7) << 1);
 
   f16x o_acc[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o_acc[d][e] = 0.f;
+  // running max (log2 domain) and sum; the max is only raised when some lane's tile max exceeds it by
+  // more than 2^8 (P then stays <= 256, exact in f16/fp32), which skips most O^T rescales
   float m_run = -INFINITY, l_run = 0.f;
   const float LOG2E = 1.4426950408889634f;
-
+  const f16x zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int nkt = (p.Lk + ATT_BK - 1) / ATT_BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-    const char* kl = smem + (kt & 1) * ATT_STAGE_BYTES;
-    const char* vl = kl + ATT_TILE_BYTES;
 
-    // ---- S^T = K Q^T
-    f16x s_acc[2];
+  // S^T = K Q^T for the K tile in buffer KB (compile-time): 8 fragments in flight per 8-MFMA chain
+  auto qk = [&](auto KB, f16x(&s)[2]) __attribute__((always_inline)) {
+    constexpr int kbase = decltype(KB)::value * ATT_TILE_BYTES;
+    typedef const __attribute__((address_space(3))) h8* lds_h8;
+    h8 kf0[8], kf1[8];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int ds = 0; ds < 8; ++ds) kf0[ds] = *(lds_h8)(smem3 + k_rd[ds] + kbase);
+    __builtin_amdgcn_sched_barrier(0);
+    // chain 0; the fragments of chain 1 are requested one MFMA behind, into the registers chain 0 frees
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s_acc[kb][e] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 8; ++ds) {
-        const h8 kf = *reinterpret_cast<const h8*>(kl + k_off[kb] + (((2 * ds + lh) ^ k_swz[kb]) << 4));
-        s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ds], s_acc[kb], 0, 0, 0);
-      }
+    for (int ds = 0; ds < 8; ++ds) {
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[ds], qf[ds], ds == 0 ? zero16 : s[0], 0, 0, 0);
+      kf1[ds] = *(lds_h8)(smem3 + k_rd[ds] + kbase + 32 * 256);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds)
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[ds], qf[ds], ds == 0 ? zero16 : s[1], 0, 0, 0);
+  };
+
+#define ATT_TR(dst, db, off) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr[db]), "n"(off))
+#define ATT_ISSUE(dst, db, VB)                                                                                   \
+  ATT_TR(dst[0], db, VB + 0);    ATT_TR(dst[1], db, VB + 2048);  ATT_TR(dst[2], db, VB + 4096);  ATT_TR(dst[3], db, VB + 6144); \
+  ATT_TR(dst[4], db, VB + 8192); ATT_TR(dst[5], db, VB + 10240); ATT_TR(dst[6], db, VB + 12288); ATT_TR(dst[7], db, VB + 14336);
+#define ATT_WAIT(cur, n)                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                 \
+               : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]),        \
+                 "+v"(cur[6]), "+v"(cur[7]));
+#define ATT_PV(cur, db)                                                                                    \
+  {                                                                                                        \
+    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                         \
+      const h4 lo_ = __builtin_bit_cast(h4, cur[2 * f]), hi_ = __builtin_bit_cast(h4, cur[2 * f + 1]);      \
+      const h8 vf = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                              \
+      o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[f >> 1][f & 1], o_acc[db], 0, 0, 0);        \
+    }                                                                                                      \
+  }
+
+  f16x s_cur[2], s_nxt[2];
+
+  // one tile: BUF = kt & 1 (compile time).  K(kt+1) sits in K buffer BUF^1, V(kt) in V buffer BUF.
+  auto tile = [&](int kt, auto BUFC) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(BUFC)::value;
+    constexpr int VB = (2 + BUF) * ATT_TILE_BYTES;
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));          // vmcnt(0): K(kt+1), V(kt) pieces of this wave landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // ... everybody's; K buffer BUF and V buffer BUF^1 are free
+    asm volatile("" ::: "memory");
+    if (!(ATT_ABL & 8)) {
+      if (kt + 2 < nkt) stage_k(BUF, kt + 2);
+      if (kt + 1 < nkt) stage_v(BUF ^ 1, kt + 1);
+    }
+
+    // ---- issue S(kt+1): the MFMAs execute under the softmax arithmetic below
+    if (!(ATT_ABL & 4)) { if (kt + 1 < nkt) qk(att_ic<BUF ^ 1>{}, s_nxt); }
+
+    // first V^T fragments (d block 0)
+    fp4 va[8], vb2[8];
+#if !(ATT_ABL & 2)
+    ATT_ISSUE(va, 0, VB)
+#endif
+
     // ---- mask the tile tail (keys >= Lk)
     if ((kt + 1) * ATT_BK > p.Lk) {
 #pragma unroll
@@ -139,66 +213,94 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = kt * ATT_BK + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (key >= p.Lk) s_acc[kb][e] = -INFINITY;
+          if (key >= p.Lk) s_cur[kb][e] = -INFINITY;
         }
     }
-    // ---- online softmax (lane = one query; its 32 keys here, the other 32 in lane^32)
-    float mloc = s_acc[0][0];
+    // ---- online softmax (lane = one query; its 32 keys here, the other 32 in lane^32).  P is taken
+    // against the running max m_run, which is the same in both half-waves of a query and is only
+    // raised (slow path, wave-uniform) when some lane's tile max exceeds it by more than 2^8; the
+    // two half-wave partial sums are combined once, after the last tile.
+    float mloc = s_cur[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s_acc[kb][e]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = exp2f((m_run - m_new) * LOG2E);
-    const float mb = m_new * LOG2E;
-    float psum = 0.f;
+      for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s_cur[kb][e]);
+    mloc *= LOG2E;
+    if (!(ATT_ABL & 16) && __any(mloc > m_run + 8.0f)) {
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[d][e] *= alpha;
+    }
+    f2 psum2 = {0.f, 0.f};
+    const f2 l2 = {LOG2E, LOG2E}, nm2 = {-m_run, -m_run};
     h8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = exp2f(s_acc[kb][e] * LOG2E - mb);
-        psum += pv;
-        pf[kb][e >> 3][e & 7] = (half_t)pv;
+      for (int e = 0; e < 16; e += 2) {
+        f2 t = {s_cur[kb][e], s_cur[kb][e + 1]};
+        t = t * l2 + nm2;
+#if ATT_ABL & 1
+        f2 pv = t;
+#else
+        f2 pv = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+#endif
+        psum2 += pv;
+        pf[kb][e >> 3][e & 7] = (half_t)pv.x;
+        pf[kb][e >> 3][(e & 7) + 1] = (half_t)pv.y;
       }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[d][e] *= alpha;
+    l_run += psum2.x + psum2.y;
 
-    // ---- O^T += V^T P^T
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          h8 vf;
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int row = v_row_base + kb * 32 + 16 * s2 + 8 * jj;
-            const int colh = v_col_base + db * 32;                 // halfs
-            const int chunk = (colh >> 3) ^ v_rswz;
-            const int addr = row * 256 + (chunk << 4) + ((colh & 7) << 1);
-            const fp4 t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                (__attribute__((address_space(3))) fp4*)(vl + addr));
-            vf[4 * jj + 0] = (half_t)t[0]; vf[4 * jj + 1] = (half_t)t[1];
-            vf[4 * jj + 2] = (half_t)t[2]; vf[4 * jj + 3] = (half_t)t[3];
-          }
-          o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s2], o_acc[db], 0, 0, 0);
-        }
-      }
-    }
+    // ---- O^T += V^T P^T : fragments of d block db+1 are requested before the MFMAs of block db
+#if !(ATT_ABL & 2)
+    ATT_ISSUE(vb2, 1, VB)
+    ATT_WAIT(va, 8)
+    ATT_PV(va, 0)
+    ATT_ISSUE(va, 2, VB)
+    ATT_WAIT(vb2, 8)
+    ATT_PV(vb2, 1)
+    ATT_ISSUE(vb2, 3, VB)
+    ATT_WAIT(va, 8)
+    ATT_PV(va, 2)
+    ATT_WAIT(vb2, 0)
+    ATT_PV(vb2, 3)
+#else
+    o_acc[0][0] += (float)pf[0][0][0] + (float)pf[1][1][7] + (float)pf[0][1][3] + (float)pf[1][0][5];
+#endif
+    s_cur[0] = s_nxt[0];
+    s_cur[1] = s_nxt[1];
+  };
+
+  // ---- prologue: K(0), V(0), K(1) in flight; S(0)
+  stage_k(0, 0);
+  stage_v(0, 0);
+  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (nkt > 1) stage_k(1, 1);
+  qk(att_ic<0>{}, s_cur);
+
+  for (int kt = 0; kt < nkt; kt += 2) {
+    tile(kt, att_ic<0>{});
+    if (kt + 1 < nkt) tile(kt + 1, att_ic<1>{});
   }
+#undef ATT_TR
+#undef ATT_PV
+#undef ATT_ISSUE
+#undef ATT_WAIT
 
   // ---- normalise and store: lane = query q0+lc, d = db*32 + (e&3) + 8*(e>>2) + 4*lh
   const int qrow = q0 + lc;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qrow < p.Lq) {
-    const float inv = 1.0f / l_run;
+    const float inv = 1.0f / l_tot;
     half_t* op = ob + (int64_t)qrow * p.o_rs + 4 * lh;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -225,11 +327,11 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   PF_HIP(hipGetDevice(&dev));
   if (!attr_set[dev & 63]) {
     PF_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               2 * ATT_STAGE_BYTES));
+                               ATT_LDS_BYTES));
     attr_set[dev & 63] = true;
   }
   dim3 grid((a.Lq + ATT_BQ - 1) / ATT_BQ, a.B * a.H);
-  hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 2 * ATT_STAGE_BYTES, s, d);
+  hipLaunchKernelGGL(attn_kernel, grid, dim3(256), ATT_LDS_BYTES, s, d);
   PF_HIP(hipGetLastError());
 }
 
