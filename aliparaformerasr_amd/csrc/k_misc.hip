@@ -22,7 +22,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // One thread = 8 channels x FS_ROWS consecutive frames with a register sliding window: each v
 // row is loaded once per FS_ROWS outputs (+ the K-1 halo rows) instead of K times.  v is f16
 // (the V slice of the QKV buffer), f is fp32.  HBM-bound: 2 B/elem in, 4 B/elem out.
+#ifndef FS_ROWS
 #define FS_ROWS 8
+#endif
 template <int K>
 __global__ __launch_bounds__(256) void fsmn_enc_kernel(const half_t* __restrict__ v, int ldv,
                                                        const float* __restrict__ wT, int B, int T, int D,
@@ -112,10 +114,14 @@ void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* wT, i
 // ------------------------------------------------------------------ fp32 FSMN -------------
 // y = (dwconv(v*m) + v*m) * m ; m from token_num (l < token_num[b]) or a float mask or none.
 // accumulate != 0: out += y (decoder residual), else out = y.
+// KT > 0: compile-time tap count — all K rows are requested before the first FMA (the runtime-K loop
+// below serialises one L2 round trip per tap, which is what bounds the small decoder launches).
+template <int KT>
 __global__ __launch_bounds__(256) void fsmn_f32_kernel(const float* __restrict__ v, const float* __restrict__ wT,
                                                        const float* __restrict__ mask,
                                                        const int32_t* __restrict__ token_num, int B, int T,
-                                                       int D, int K, int accumulate, float* __restrict__ out) {
+                                                       int D, int Krt, int accumulate, float* __restrict__ out) {
+  const int K = KT > 0 ? KT : Krt;
   const int cq = D >> 2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * T * cq;
@@ -136,14 +142,36 @@ __global__ __launch_bounds__(256) void fsmn_f32_kernel(const float* __restrict__
     const float4 x = *reinterpret_cast<const float4*>(v + row * (int64_t)D + c4);
     acc = make_float4(x.x * mt, x.y * mt, x.z * mt, x.w * mt);
   }
-  for (int j = 0; j < K; ++j) {
-    const int tt = t + j - left;
-    if (tt < 0 || tt >= T) continue;
-    const float mm = m_at(tt);
-    const float4 x = *reinterpret_cast<const float4*>(v + (row + (j - left)) * (int64_t)D + c4);
-    const float4 w = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c4);
-    acc.x += w.x * (x.x * mm); acc.y += w.y * (x.y * mm);
-    acc.z += w.z * (x.z * mm); acc.w += w.w * (x.w * mm);
+  if constexpr (KT > 0) {
+    float4 xs[KT > 0 ? KT : 1], ws[KT > 0 ? KT : 1];
+    float mm[KT > 0 ? KT : 1];
+    bool ok[KT > 0 ? KT : 1];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      const int tt = t + j - left;
+      ok[j] = tt >= 0 && tt < T;
+      const int ttc = ok[j] ? tt : t;
+      xs[j] = *reinterpret_cast<const float4*>(v + (row + (ttc - t)) * (int64_t)D + c4);
+      ws[j] = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c4);
+      mm[j] = m_at(ttc);
+    }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      if (ok[j]) {
+        acc.x += ws[j].x * (xs[j].x * mm[j]); acc.y += ws[j].y * (xs[j].y * mm[j]);
+        acc.z += ws[j].z * (xs[j].z * mm[j]); acc.w += ws[j].w * (xs[j].w * mm[j]);
+      }
+    }
+  } else {
+    for (int j = 0; j < K; ++j) {
+      const int tt = t + j - left;
+      if (tt < 0 || tt >= T) continue;
+      const float mm = m_at(tt);
+      const float4 x = *reinterpret_cast<const float4*>(v + (row + (j - left)) * (int64_t)D + c4);
+      const float4 w = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c4);
+      acc.x += w.x * (x.x * mm); acc.y += w.y * (x.y * mm);
+      acc.z += w.z * (x.z * mm); acc.w += w.w * (x.w * mm);
+    }
   }
   acc.x *= mt; acc.y *= mt; acc.z *= mt; acc.w *= mt;
   float4* o = reinterpret_cast<float4*>(out + row * (int64_t)D + c4);
@@ -154,12 +182,68 @@ __global__ __launch_bounds__(256) void fsmn_f32_kernel(const float* __restrict__
   *o = acc;
 }
 
+// decoder FSMN with the encoder kernel's register sliding window: one thread = 4 channels x FS_ROWS
+// consecutive positions; x[b,l,:] += (sum_j w_j * tn[l+j-left]*m + tn[l]*m) * m_l, m = (l < token_num[b]).
+// (The one-position-per-thread form above re-reads every row K times through L1: 21 us for 11 MB.)
+template <int K>
+__global__ __launch_bounds__(256) void fsmn_dec_kernel(const float* __restrict__ tn, const float* __restrict__ wT,
+                                                       const int32_t* __restrict__ token_num, int B, int L, int D,
+                                                       float* __restrict__ x) {
+  const int cq = D >> 2;
+  const int tb = (L + FS_ROWS - 1) / FS_ROWS;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * tb * cq;
+  if (i >= total) return;
+  const int c4 = (int)(i % cq) * 4;
+  const int64_t r = i / cq;
+  const int t0 = (int)(r % tb) * FS_ROWS;
+  const int b = (int)(r / tb);
+  constexpr int left = (K - 1) / 2;
+  const int nvalid = token_num[b];
+  const float* vb = tn + (int64_t)b * L * D + c4;
+  float4 w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c4);
+  float4 acc[FS_ROWS];
+#pragma unroll
+  for (int q = 0; q < FS_ROWS; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < FS_ROWS + K - 1; ++s) {
+    const int tt = t0 - left + s;
+    if (tt < 0 || tt >= L || tt >= nvalid) continue;      // masked rows contribute exact zeros
+    const float4 xv = *reinterpret_cast<const float4*>(vb + (int64_t)tt * D);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int q = s - j;
+      if (q >= 0 && q < FS_ROWS) {
+        acc[q].x += w[j].x * xv.x; acc[q].y += w[j].y * xv.y; acc[q].z += w[j].z * xv.z; acc[q].w += w[j].w * xv.w;
+      }
+    }
+    const int q0 = s - left;
+    if (q0 >= 0 && q0 < FS_ROWS) { acc[q0].x += xv.x; acc[q0].y += xv.y; acc[q0].z += xv.z; acc[q0].w += xv.w; }
+  }
+#pragma unroll
+  for (int q = 0; q < FS_ROWS; ++q) {
+    const int l = t0 + q;
+    if (l < L && l < nvalid) {                              // masked outputs add zero: x unchanged
+      float4* o = reinterpret_cast<float4*>(x + ((int64_t)b * L + l) * D + c4);
+      const float4 pv = *o;
+      *o = make_float4(pv.x + acc[q].x, pv.y + acc[q].y, pv.z + acc[q].z, pv.w + acc[q].w);
+    }
+  }
+}
+
 void launch_fsmn_dec(hipStream_t s, const float* tn, const float* wT, const int32_t* token_num, int B, int L,
                      int D, int k, float* x) {
   const int64_t total = (int64_t)B * L * (D / 4);
   if (total == 0) return;
-  hipLaunchKernelGGL(fsmn_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tn, wT,
-                     (const float*)nullptr, token_num, B, L, D, k, 1, x);
+  if (k == 11) {
+    const int64_t tot = (int64_t)B * ((L + FS_ROWS - 1) / FS_ROWS) * (D / 4);
+    hipLaunchKernelGGL(fsmn_dec_kernel<11>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tn, wT, token_num,
+                       B, L, D, x);
+  } else
+    hipLaunchKernelGGL(fsmn_f32_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tn, wT,
+                       (const float*)nullptr, token_num, B, L, D, k, 1, x);
   PF_HIP(hipGetLastError());
 }
 
@@ -167,7 +251,7 @@ void launch_fsmn_f32(hipStream_t s, const float* v, const float* wT, const float
                      int k, float* y) {
   const int64_t total = (int64_t)B * T * (D / 4);
   if (total == 0) return;
-  hipLaunchKernelGGL(fsmn_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, wT, mask,
+  hipLaunchKernelGGL(fsmn_f32_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, wT, mask,
                      (const int32_t*)nullptr, B, T, D, k, 0, y);
   PF_HIP(hipGetLastError());
 }
