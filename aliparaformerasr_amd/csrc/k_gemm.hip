@@ -89,6 +89,9 @@ constexpr int GEMM_BM = 256, GEMM_BN = 128, GEMM_BK = 64, GEMM_S = 3;
 constexpr int GEMM_SCRATCH = 8 * 2048;                                   // 2 KiB per wave
 constexpr int GEMM_LDS = GEMM_S * (GEMM_BM + GEMM_BN) * GEMM_BK * 2 + GEMM_SCRATCH;   // 160 KiB
 
+// KIND 1: f16-only results (deferred packed epilogue; direct epilogue only for wave tiles straddling N)
+// KIND 2: fp32 results / residual / FSMN add (LDS row-segment epilogue; direct epilogue for edge tiles)
+template <int KIND>
 __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   constexpr int BK = GEMM_BK, S = GEMM_S, BM = GEMM_BM, BN = GEMM_BN;
   constexpr int WN = 2, NW = 8;
@@ -191,13 +194,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 
   // ---- deferred f16 epilogue state
   char* const scr = smem + S * STAGE + wave * 2048;            // [0,1152) transpose rows, [1152,1408) bias line
-  const bool fast_kind = p.out_f16 && !p.out_f32 && !p.resid && !p.add2 && p.out_padded && (p.ldc16 & 7) == 0;
+  const bool fast_kind = KIND == 1;   // launch_gemm checked: f16 only, no residual/add, padded rows, ldc16 % 8 == 0
   const float lo = p.relu ? 0.f : -INFINITY;
   char* const wp = scr + (lane & 7) * 144 + lh * 8;
   const char* const rp = scr + (lane >> 3) * 144 + (lane & 7) * 16;
   int pend = 0;                                      // passes of the finished tile still to emit
   half_t* op = nullptr;                              // its output pointer (row lane>>3, col (lane&7)*8)
-  float sc_pend = 1.f;
   h8 rowv;
   half_t* rowp = nullptr;
   {                                                  // zero the bias line (bias == null -> stays zero)
@@ -319,6 +321,62 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     }
   };
 
+  // fp32 epilogue through the wave's LDS scratch (interior wave tiles of fp32 results): the D^T
+  // fragment gives a lane one output ROW, so direct 16-byte accesses touch 32 different rows per
+  // instruction (32 bytes used of every 128-byte line; ~4x the address-unit cycles of a full-line
+  // access, and the CU's address unit is what the residual-carrying GEMMs wait on).  Instead 4 rows
+  // at a time are written to the scratch by their 8 owner lanes and read back row-contiguous
+  // (16 lanes x 16 B = one 256-byte row segment), so residual / FSMN-add loads and the stores are
+  // whole lines.
+  auto lds_epilogue32 = [&](int tile) __attribute__((always_inline)) {
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM + wm * 64, n0 = tn * BN + wn * 64;
+    const int lc = lane & 31;
+    const int rr = lane >> 4, cc = lane & 15;              // reader: row in chunk, 4-column group
+    const int n = n0 + cc * 4;
+    char* const wq = scr + (lc & 3) * 272 + lh * 16;
+    const char* const rq = scr + rr * 272 + cc * 16;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    const float sc = (n < p.scale_cols) ? p.scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int m = m0 + i * 32 + c * 4 + rr;
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.resid) r4 = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+        if (p.add2) a4 = *reinterpret_cast<const float4*>(p.add2 + (size_t)m * p.ld2 + n);
+        if ((lc >> 2) == c) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              *reinterpret_cast<float4a*>(wq + (j * 32 + 8 * g) * 4) =
+                  make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        float4 v = *reinterpret_cast<const float4a*>(rq);
+        asm volatile("" ::: "memory");
+        v.x = (v.x + b4.x) * sc; v.y = (v.y + b4.y) * sc; v.z = (v.z + b4.z) * sc; v.w = (v.w + b4.w) * sc;
+        v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+        if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc32 + n) = v;
+        if (p.out_f16)
+          *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+        if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 chunks of loads in flight (VGPRs)
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+
   // tile end: pack the finished tile (fast path) or run the direct epilogue, then re-arm the
   // accumulators for the next tile and prefetch the bias of the tile after it
   const bool fast0 = fast_kind;
@@ -345,6 +403,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
                              (half_t)fmaxf(acc[i][j][4 * g + 2] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 3] * sc, lo)};
       op = p.out_f16 + (size_t)(m0 + (lane >> 3)) * p.ldc16 + n0 + (lane & 7) * 8;
       pend = 8;
+    } else if (KIND == 2 && m0 + 64 <= p.M && n0 + 64 <= p.N) {
+      lds_epilogue32(tile);
     } else {
       direct_epilogue(tile);
     }
@@ -472,12 +532,15 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     cus[dev] = prop.multiProcessorCount;
   }
   if (!attr[dev]) {
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
     attr[dev] = true;
   }
   int grid = cus[dev];
   if (grid > total) grid = total;
-  hipLaunchKernelGGL(gemm_f16_pp3, dim3(grid), dim3(512), GEMM_LDS, s, d);
+  const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && (a.ldc16 & 7) == 0;
+  if (f16_only) hipLaunchKernelGGL(gemm_f16_pp3<1>, dim3(grid), dim3(512), GEMM_LDS, s, d);
+  else hipLaunchKernelGGL(gemm_f16_pp3<2>, dim3(grid), dim3(512), GEMM_LDS, s, d);
   PF_HIP(hipGetLastError());
 }
 
