@@ -40,6 +40,7 @@
 //  * fp32 results (+ residual, + FSMN add): direct 16-byte vector I/O at tile end.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace pf {
@@ -85,15 +86,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define PF_ABL 0
 #endif
 constexpr int ABL = PF_ABL;
-constexpr int GEMM_BM = 256, GEMM_BN = 128, GEMM_BK = 64, GEMM_S = 3;
+constexpr int GEMM_BN = 128, GEMM_BK = 64, GEMM_S = 3;   // tile rows: 128 * MI (MI = 32-row MFMA blocks per wave)
 constexpr int GEMM_SCRATCH = 8 * 2048;                                   // 2 KiB per wave
-constexpr int GEMM_LDS = GEMM_S * (GEMM_BM + GEMM_BN) * GEMM_BK * 2 + GEMM_SCRATCH;   // 160 KiB
+constexpr int gemm_lds_bytes(int mi) { return GEMM_S * (128 * mi + GEMM_BN) * GEMM_BK * 2 + GEMM_SCRATCH; }   // MI=2: 160 KiB
 
 // KIND 1: f16-only results (deferred packed epilogue; direct epilogue only for wave tiles straddling N)
 // KIND 2: fp32 results / residual / FSMN add (LDS row-segment epilogue; direct epilogue for edge tiles)
-template <int KIND>
+// MI: 32-row MFMA blocks per wave (2 -> 256-row tiles; 1 -> 128-row tiles for GEMMs whose 256-row
+//     tile count would leave most CUs idle, i.e. the decoder's M = B*L rows)
+template <int KIND, int MI>
 __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
-  constexpr int BK = GEMM_BK, S = GEMM_S, BM = GEMM_BM, BN = GEMM_BN;
+  constexpr int BK = GEMM_BK, S = GEMM_S, BM = 128 * MI, BN = GEMM_BN, WM = 32 * MI;
   constexpr int WN = 2, NW = 8;
   constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPI = 64 / CPR;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -163,18 +166,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   };
 
   // ---- fragment read offsets inside a stage (bytes), hoisted
-  unsigned fa[KSUB][2], fb[KSUB][2];
+  unsigned fa[KSUB][MI], fb[KSUB][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + (lane & 31);
+    const int ra = wm * WM + i * 32 + (lane & 31);
     const int rb = wn * 64 + i * 32 + (lane & 31);
 #pragma unroll
     for (int s = 0; s < KSUB; ++s) {
-      fa[s][i] = (unsigned)(ra * ROWB + (((2 * s + lh) ^ swz(ra)) << 4));
+      if (i < MI) fa[s][i < MI ? i : 0] = (unsigned)(ra * ROWB + (((2 * s + lh) ^ swz(ra)) << 4));
       fb[s][i] = (unsigned)(A_BYTES + rb * ROWB + (((2 * s + lh) ^ swz(rb)) << 4));
     }
   }
-  h8 af[KSUB][2], bf[KSUB][2];
+  h8 af[KSUB][MI], bf[KSUB][2];
   const char* rd = smem;
   auto load_frags = [&]() __attribute__((always_inline)) {
     if constexpr (!(ABL & 2))
@@ -182,15 +185,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     for (int s = 0; s < KSUB; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[s][i] = *(const h8*)(rd + fa[s][i]);
+        if (i < MI) af[s][i < MI ? i : 0] = *(const h8*)(rd + fa[s][i < MI ? i : 0]);
         bf[s][i] = *(const h8*)(rd + fb[s][i]);
       }
     rd = (rd + STAGE == smem + S * STAGE) ? smem : rd + STAGE;
   };
 
   // ---- accumulators + packed copy of the previous tile
-  f16x acc[2][2];
-  h4 hq[2][2][4];                                      // finished tile, packed f16, awaiting its passes
+  f16x acc[MI][2];
+  h4 hq[MI][2][4];                                      // finished tile, packed f16, awaiting its passes
 
   // ---- deferred f16 epilogue state
   char* const scr = smem + S * STAGE + wave * 2048;            // [0,1152) transpose rows, [1152,1408) bias line
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (with_bias) b4 = *reinterpret_cast<const float4a*>(bl + j * 32 + 8 * g);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
           acc[i][j][4 * g + 0] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w;
         }
       }
@@ -248,31 +251,32 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
       asm volatile("" ::: "memory");
       rowp = op + (size_t)((i * 4 + q) * 8) * p.ldc16;
     };
+    constexpr int I1 = MI - 1;                       // MI == 1: cases 4..7 are never reached
     switch (idx) {
       case 0: body(ic<0>{}, ic<0>{}); break;
       case 1: body(ic<0>{}, ic<1>{}); break;
       case 2: body(ic<0>{}, ic<2>{}); break;
       case 3: body(ic<0>{}, ic<3>{}); break;
-      case 4: body(ic<1>{}, ic<0>{}); break;
-      case 5: body(ic<1>{}, ic<1>{}); break;
-      case 6: body(ic<1>{}, ic<2>{}); break;
-      default: body(ic<1>{}, ic<3>{}); break;
+      case 4: body(ic<I1>{}, ic<0>{}); break;
+      case 5: body(ic<I1>{}, ic<1>{}); break;
+      case 6: body(ic<I1>{}, ic<2>{}); break;
+      default: body(ic<I1>{}, ic<3>{}); break;
     }
   };
   auto pass_store = [&]() __attribute__((always_inline)) { if constexpr (!(ABL & 8)) *reinterpret_cast<h8*>(rowp) = rowv; };     // padded rows: always issued
   auto flush = [&]() __attribute__((always_inline)) {
-    while (pend > 0) { pass(8 - pend); --pend; pass_store(); }
+    while (pend > 0) { pass(4 * MI - pend); --pend; pass_store(); }
   };
 
   // direct epilogue (fp32 results, residual / FSMN add, or a wave tile that straddles N)
   auto direct_epilogue = [&](int tile) __attribute__((always_inline)) {
     if constexpr (ABL & 16) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM + wm * 64, n0 = tn * BN + wn * 64;
-    const bool interior = (m0 + 64 <= p.M) && (n0 + 64 <= p.N);
+    const int m0 = tm * BM + wm * WM, n0 = tn * BN + wn * 64;
+    const bool interior = (m0 + WM <= p.M) && (n0 + 64 <= p.N);
     const int nb = n0 + 4 * lh;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = m0 + i * 32 + (lane & 31);
       const float* r_ptr = p.resid ? p.resid + (size_t)m * p.ldr + nb : nullptr;
       const float* a_ptr = p.add2 ? p.add2 + (size_t)m * p.ld2 + nb : nullptr;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   // whole lines.
   auto lds_epilogue32 = [&](int tile) __attribute__((always_inline)) {
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM + wm * 64, n0 = tn * BN + wn * 64;
+    const int m0 = tm * BM + wm * WM, n0 = tn * BN + wn * 64;
     const int lc = lane & 31;
     const int rr = lane >> 4, cc = lane & 15;              // reader: row in chunk, 4-column group
     const int n = n0 + cc * 4;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + n);
     const float sc = (n < p.scale_cols) ? p.scale : 1.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int m = m0 + i * 32 + c * 4 + rr;
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -390,11 +394,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     const int tile = ep_tile;
     ep_tile += G;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BM + wm * 64, n0 = tn * BN + wn * 64;
+    const int m0 = tm * BM + wm * WM, n0 = tn * BN + wn * 64;
     if (wave_fast(tile)) {
       const float sc = (n0 < p.scale_cols) ? p.scale : 1.f;     // scale_cols is a multiple of 64
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -402,8 +406,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
             hq[i][j][g] = h4{(half_t)fmaxf(acc[i][j][4 * g + 0] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 1] * sc, lo),
                              (half_t)fmaxf(acc[i][j][4 * g + 2] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 3] * sc, lo)};
       op = p.out_f16 + (size_t)(m0 + (lane >> 3)) * p.ldc16 + n0 + (lane & 7) * 8;
-      pend = 8;
-    } else if (KIND == 2 && m0 + 64 <= p.M && n0 + 64 <= p.N) {
+      pend = 4 * MI;
+    } else if (KIND == 2 && m0 + WM <= p.M && n0 + 64 <= p.N) {
       lds_epilogue32(tile);
     } else {
       direct_epilogue(tile);
@@ -421,8 +425,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 #pragma unroll
     for (int s = 0; s < KSUB; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (s * 2 + i == KSUB * 2 - 2) {
+      for (int i = 0; i < MI; ++i) {
+        if (s * MI + i == KSUB * MI - 2) {
           issue_advance();
           mid();
         }
@@ -430,11 +434,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
-        if (piece < LPS) {
-          __builtin_amdgcn_sched_barrier(0);
-          issue_piece(piece++);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        // all LPS pieces go out in the KSUB*MI - 2 iterations before `mid` (which advances the cursor)
+        constexpr int PPI = (LPS + KSUB * MI - 3) / (KSUB * MI - 2);
+#pragma unroll
+        for (int pp = 0; pp < PPI; ++pp)
+          if (piece < LPS) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(piece++);
+            __builtin_amdgcn_sched_barrier(0);
+          }
       }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     for (int t = 0; t < n_my; ++t) {
       for (int kt = 0; kt < nk; ++kt, ++k) {
         const int sA = pend > 0 ? 1 : 0;
-        if (sA) { pass(8 - pend); --pend; }
+        if (sA) { pass(4 * MI - pend); --pend; }
         load_frags();
         __builtin_amdgcn_s_barrier();
         burst([&]() __attribute__((always_inline)) {
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     for (int t = 0; t < n_my; ++t) {
       for (int kt = 0; kt < nk; ++kt, ++k) {
         const int sB = pend > 0 ? 1 : 0;
-        if (sB) { pass(8 - pend); --pend; }
+        if (sB) { pass(4 * MI - pend); --pend; }
         load_frags();
         {
           // younger than DMA(k+1) [issued in COMPUTE(k-2)]: store(k-2), DMA(k+2), store(k-1)
@@ -517,12 +525,9 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   d.M = a.M; d.N = a.N; d.K = a.K;
   d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
   d.out_padded = a.out_padded;
-  d.tiles_m = cdiv(d.M, GEMM_BM);
-  d.tiles_n = cdiv(d.N, GEMM_BN);
-  const int total = d.tiles_m * d.tiles_n;
-  if (total == 0) return;
+  // 128-row tiles when 256-row tiles would leave CUs idle (decoder GEMMs with N = 512: 84 tiles); measured
+  // A/B in one session: x = 0.9 -> 14.85 ms/step, x = 0 -> 15.15, x >= 1.5 (also the encoder N = 512 GEMMs) -> 15.9
   static int cus[64] = {0};
-  static bool attr[64] = {false};
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
   dev &= 63;
@@ -531,16 +536,32 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     PF_HIP(hipGetDeviceProperties(&prop, dev));
     cus[dev] = prop.multiProcessorCount;
   }
+  static float mi_x = -1.f;                          // PF_GEMM_MI_X: tuning knob for tools/ (tiles < x * CUs -> 128-row tiles)
+  if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.9f; }
+  const int mi = ((float)(cdiv(d.M, 256) * cdiv(d.N, GEMM_BN)) < mi_x * cus[dev]) ? 1 : 2;
+  d.tiles_m = cdiv(d.M, 128 * mi);
+  d.tiles_n = cdiv(d.N, GEMM_BN);
+  const int total = d.tiles_m * d.tiles_n;
+  if (total == 0) return;
+  static bool attr[64] = {false};
   if (!attr[dev]) {
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
     attr[dev] = true;
   }
   int grid = cus[dev];
   if (grid > total) grid = total;
   const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && (a.ldc16 & 7) == 0;
-  if (f16_only) hipLaunchKernelGGL(gemm_f16_pp3<1>, dim3(grid), dim3(512), GEMM_LDS, s, d);
-  else hipLaunchKernelGGL(gemm_f16_pp3<2>, dim3(grid), dim3(512), GEMM_LDS, s, d);
+  const int lds = gemm_lds_bytes(mi);
+  if (f16_only) {
+    if (mi == 2) hipLaunchKernelGGL((gemm_f16_pp3<1, 2>), dim3(grid), dim3(512), lds, s, d);
+    else hipLaunchKernelGGL((gemm_f16_pp3<1, 1>), dim3(grid), dim3(512), lds, s, d);
+  } else {
+    if (mi == 2) hipLaunchKernelGGL((gemm_f16_pp3<2, 2>), dim3(grid), dim3(512), lds, s, d);
+    else hipLaunchKernelGGL((gemm_f16_pp3<2, 1>), dim3(grid), dim3(512), lds, s, d);
+  }
   PF_HIP(hipGetLastError());
 }
 

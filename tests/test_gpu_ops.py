@@ -109,6 +109,25 @@ def test_gemm_asymmetric_and_shapes(eng):
     np.testing.assert_allclose(eng.op_gemm(eye, Wm), h16(eye) @ h16(Wm).T, atol=1e-6)
 
 
+def test_gemm_f16_output_and_tile_variants(eng):
+    """The f16-result kernel kind (bias-initialised accumulators, packed deferred full-line epilogue) and the
+    fp32 kind (LDS row-segment epilogue), each in its 128-row (few tiles) and 256-row (many tiles) variant,
+    incl. M and N that are not multiples of the tile."""
+    rng = np.random.default_rng(14)
+    for (M, N, K) in ((150, 1536, 576), (1000, 2048, 512), (333, 512, 2048), (257, 128, 64), (8200, 2048, 512), (8200, 576, 512)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        ref = h16(A).astype(np.float64) @ h16(Wm).astype(np.float64).T + bias
+        got16 = eng.op_gemm(A, Wm, bias, f16_out=True)
+        # one f16 rounding of the result on top of the fp32 accumulation
+        np.testing.assert_allclose(got16, ref, rtol=1.5e-3, atol=1.5e-3)
+        got32 = eng.op_gemm(A, Wm, bias)
+        np.testing.assert_allclose(got32, ref, rtol=1e-4, atol=2e-4 * np.sqrt(K / 512))
+        again = eng.op_gemm(A, Wm, bias, f16_out=True)
+        assert np.array_equal(got16, again)
+
+
 def _mha_ref(q, k, v, heads):
     return om.mha(torch.from_numpy(h16(q)), torch.from_numpy(h16(k)), torch.from_numpy(h16(v)), heads).numpy()
 
