@@ -163,7 +163,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   mc_.cif_r_order = (int)jc->num_or("cif_r_order", mc_.cif_r_order);
   mc_.timestamp_head = jc->bool_or("timestamp_head", false);
   mc_.seaco = jc->bool_or("seaco", false);
-  mc_.use_itn = jc->bool_or("use_itn", false);
+  mc_.use_itn = jc->bool_or("use_itn", false) || cfg.use_itn != 0;
   PF_CHECK(mc_.d_model == 512 && mc_.heads == 4, PF_ERR_UNSUPPORTED,
            "kernels are built for d_model = 512, 4 heads of 128");
   PF_CHECK(mc_.d_model % 8 == 0 && mc_.ffn % 64 == 0 && mc_.feat_dim % 4 == 0, PF_ERR_UNSUPPORTED,
@@ -229,6 +229,17 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       const Tensor& t = tensor("embed.weight");
       embed_host_.resize(t.numel);
       PF_HIP(hipMemcpy(embed_host_.data(), t.dev, t.numel * 4, hipMemcpyDeviceToHost));
+      // device copy of the 4 query rows [language, 1, 2, textnorm] with the EFFECTIVE ids of the
+      // reference (quirk Q7, OfflineProjOfSenseVoiceSmall.cs:57-74): language = 14 if use_itn else 15,
+      // textnorm = 15 — used by the audio-in entry points (pf_recognize / pf_run_staged)
+      const int W = mc_.feat_dim;
+      if (t.numel >= (int64_t)16 * W) {
+        const int order[4] = {mc_.use_itn ? 14 : 15, 1, 2, 15};
+        sv_prompt_ = (float*)dalloc((size_t)4 * W * 4);
+        for (int r = 0; r < 4; ++r)
+          PF_HIP(hipMemcpy(sv_prompt_ + (size_t)r * W, embed_host_.data() + (size_t)order[r] * W, (size_t)W * 4,
+                           hipMemcpyHostToDevice));
+      }
     }
     return;
   }
@@ -503,16 +514,17 @@ void Engine::run_staged(bool want_logits) {
   const int64_t* meta = (const int64_t*)ws_meta_.p;
   const int32_t* t80d = (const int32_t*)((const char*)ws_meta_.p + 3 * (size_t)(B + 1) * 8);
   ensure(ws_fbank_, (size_t)std::max<int64_t>(st_total_frames_, 1) * fc_.n_mels * 4);
-  ensure(ws_speech_, (size_t)B * T * W * 4);
+  const int P = sv_prompt_ ? 4 : 0;                 // SenseVoice: query rows prepended on the device
+  ensure(ws_speech_, (size_t)B * (T + P) * W * 4);
   prof_begin("fbank", 0);
   launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + (B + 1), meta + 2 * (B + 1), B,
                st_total_frames_, fc_.snip_edges ? 1 : 0, (float*)ws_fbank_.p);
   prof_end("fbank");
   prof_begin("lfr_cmvn_pad", 0);
   launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, meta + 2 * (B + 1), t80d, B, T, fc_.lfr_m, fc_.lfr_n,
-                      fc_.n_mels, cmvn_shift_, cmvn_scale_, cmvn_shift_ ? 1 : 0, 1, (float*)ws_speech_.p);
+                      fc_.n_mels, cmvn_shift_, cmvn_scale_, cmvn_shift_ ? 1 : 0, 1, (float*)ws_speech_.p, sv_prompt_, P);
   prof_end("lfr_cmvn_pad");
-  forward_device((const float*)ws_speech_.p, B, T, want_logits);
+  forward_device((const float*)ws_speech_.p, B, T + P, want_logits);
 }
 
 void Engine::fbank_host(const float* samples, int64_t n, std::vector<float>& out, int& t80) {
@@ -698,7 +710,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
   const size_t o_kv = carve((size_t)Mp * std::max(nd, 1) * 2 * D * 2), o_x = carve(Mdp * D * 4), o_xn = carve(Mdp * D * 2);
   const size_t o_h32 = carve(Mdp * F * 4), o_h16 = carve(Mdp * F * 2), o_t = carve(Mdp * D * 4), o_tn = carve(Mdp * D * 4);
-  const size_t o_q = carve(Mdp * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * V * 4), o_ids = carve((size_t)Md * 8);
+  const size_t o_q = carve(Mdp * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * round_up(V, 4) * 4), o_ids = carve((size_t)Md * 8);
   ensure(ws_dec_, off);
   char* base = (char*)ws_dec_.p;
   half_t* kv16 = (half_t*)(base + o_kv);
@@ -755,9 +767,10 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   prof_begin("layernorm", 0);
   launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, xdn16, D, nullptr, 0);
   prof_end("layernorm");
-  gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, V, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
+  gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
-  launch_argmax(stream_, logits_, Md, V, V, want_logits ? 1 : 0, ids_dev_);
+  launch_argmax(stream_, logits_, Md, V, logits_ld_, want_logits ? 1 : 0, ids_dev_);
   prof_end("argmax");
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
 }
@@ -807,13 +820,14 @@ void Engine::sensevoice_head(int B, int T, bool want_logits) {
   const int64_t Mp = round_up(M, 128) + 128;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o_lg = carve((size_t)Mp * V * 4), o_ids = carve((size_t)M * 8);
+  const size_t o_lg = carve((size_t)Mp * round_up(V, 4) * 4), o_ids = carve((size_t)M * 8);
   ensure(ws_dec_, off);
   logits_ = (float*)((char*)ws_dec_.p + o_lg);
   ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids);
-  gemm("gemm_vocab", ctc_, H16_, D, M, logits_, V, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  logits_ld_ = (int)round_up(V, 4);
+  gemm("gemm_vocab", ctc_, H16_, D, M, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
-  launch_argmax(stream_, logits_, M, V, V, want_logits ? 1 : 0, ids_dev_);
+  launch_argmax(stream_, logits_, M, V, logits_ld_, want_logits ? 1 : 0, ids_dev_);
   prof_end("argmax");
   last_.B = B; last_.L = T; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)M, 0);
@@ -902,7 +916,9 @@ void Engine::fetch(pf_batch_out* out) {
     PF_CHECK(last_logits_, PF_ERR_INVALID_ARG, "logits were not requested for the last forward");
     const int64_t need = (int64_t)B * L * V;
     PF_CHECK(out->logits_cap >= need, PF_ERR_CAPACITY, "logits capacity < B*L*V = " + std::to_string(need));
-    if (need > 0) PF_HIP(hipMemcpy(out->logits, logits_, (size_t)need * 4, hipMemcpyDeviceToHost));
+    if (need > 0)
+      PF_HIP(hipMemcpy2D(out->logits, (size_t)V * 4, logits_, (size_t)logits_ld_ * 4, (size_t)V * 4, (size_t)B * L,
+                         hipMemcpyDeviceToHost));
   }
 }
 

@@ -146,6 +146,7 @@ class Engine {
   const float* ts_out_w_ = nullptr;
   const float* ts_out_b_ = nullptr;
   std::vector<float> embed_host_;
+  float* sv_prompt_ = nullptr;      // SenseVoice: device [4, feat_dim] query rows (effective ids)
 
   // front-end
   FbankTables* fb_ = nullptr;
@@ -162,7 +163,7 @@ class Engine {
   float* alphas_ = nullptr; CifPlan plan_{};
   float* us_peak_ = nullptr;
   // decoder views
-  float* logits_ = nullptr; int64_t* ids_dev_ = nullptr;
+  float* logits_ = nullptr; int64_t* ids_dev_ = nullptr; int logits_ld_ = 0;
   // staged audio
   std::vector<int64_t> st_n_; std::vector<int32_t> st_t80_; int st_B_ = 0, st_T_ = 0;
   int64_t st_total_frames_ = 0;

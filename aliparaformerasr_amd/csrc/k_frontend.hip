@@ -232,27 +232,33 @@ void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, cons
 }
 
 // -------------------------------------------------------------------------------------------
-// LFR + CMVN + right-pad + sentinel, one float4 per thread, written straight into [B,Tmax,W].
+// LFR + CMVN + right-pad + sentinel, one float4 per thread, written straight into [B,P+Tmax,W].
+// P > 0: the P rows of `prompt` [P,W] are prepended to every utterance (SenseVoice query rows,
+// OfflineProjOfSenseVoiceSmall.cs:78-106 prepends them to Speech before PadSequence, so the sentinel
+// replacement covers them too).
 __global__ __launch_bounds__(256) void lfr_cmvn_pad_kernel(const float* __restrict__ fbank,
                                                            const int64_t* __restrict__ frame_off,
                                                            const int32_t* __restrict__ t80, int B, int Tmax,
                                                            int lfr_m, int lfr_n, int n_mels,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ scale, int apply_cmvn,
-                                                           int apply_sentinel, float* __restrict__ out) {
+                                                           int apply_sentinel, const float* __restrict__ prompt,
+                                                           int P, float* __restrict__ out) {
   const int W = lfr_m * n_mels;
   const int wq = W >> 2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)B * Tmax * wq;
+  const int64_t total = (int64_t)B * (P + Tmax) * wq;
   if (i >= total) return;
   const int qd = (int)(i % wq);
   const int64_t bt = i / wq;
-  const int t = (int)(bt % Tmax);
-  const int b = (int)(bt / Tmax);
+  const int t = (int)(bt % (P + Tmax)) - P;
+  const int b = (int)(bt / (P + Tmax));
   const int T80 = t80[b];
   const int T = T80 / lfr_n;                      // floor (WavFrontend.cs:76)
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (t < T) {
+  if (t < 0) {
+    v = *reinterpret_cast<const float4*>(prompt + (int64_t)(t + P) * W + qd * 4);
+  } else if (t < T) {
     const int j = qd * 4;
     const int sub = j / n_mels, col = j - sub * n_mels;
     int f = t * lfr_n + sub - (lfr_m - 1) / 2;   // left context = ZERO frames (quirk Q1)
@@ -277,12 +283,13 @@ __global__ __launch_bounds__(256) void lfr_cmvn_pad_kernel(const float* __restri
 
 void launch_lfr_cmvn_pad(hipStream_t s, const float* fbank, const int64_t* frame_off, const int32_t* t80, int B,
                          int Tmax, int lfr_m, int lfr_n, int n_mels, const float* shift, const float* scale,
-                         int apply_cmvn, int apply_sentinel, float* out) {
+                         int apply_cmvn, int apply_sentinel, float* out, const float* prompt, int P) {
   PF_CHECK(n_mels % 4 == 0, PF_ERR_INVALID_ARG, "lfr: n_mels must be a multiple of 4");
-  const int64_t total = (int64_t)B * Tmax * (lfr_m * n_mels / 4);
+  const int64_t total = (int64_t)B * (P + Tmax) * (lfr_m * n_mels / 4);
   if (total == 0) return;
   hipLaunchKernelGGL(lfr_cmvn_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, fbank,
-                     frame_off, t80, B, Tmax, lfr_m, lfr_n, n_mels, shift, scale, apply_cmvn, apply_sentinel, out);
+                     frame_off, t80, B, Tmax, lfr_m, lfr_n, n_mels, shift, scale, apply_cmvn, apply_sentinel, prompt, P,
+                     out);
   PF_HIP(hipGetLastError());
 }
 

@@ -235,34 +235,36 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
       }
   };
 
-  // one deferred pass: rows 8*idx .. 8*idx+7 of this wave's 64x64 block (already packed in hq)
-  auto pass = [&](int idx) __attribute__((always_inline)) {
+  // one deferred pass: rows 8*idx .. 8*idx+7 of this wave's block (already packed in hq), split in
+  // two halves that are slotted between the MFMAs of the wave's own COMPUTE phase (the matrix pipe is
+  // busy 32 cycles per MFMA, the wave issues for 4): first the 16 owner lanes write the 8 rows to the
+  // scratch, a few MFMAs later every lane reads one 16-byte row piece back; the store follows in `mid`.
+  // (Doing this in the LOAD phase put ~400 cycles in front of the fragment reads of every phase.)
+  auto pass_write = [&](int idx) __attribute__((always_inline)) {
     if constexpr (ABL & 32) return;
-    auto body = [&](auto IC, auto QC) __attribute__((always_inline)) {
-      constexpr int i = decltype(IC)::value, q = decltype(QC)::value;
-      if (((lane & 31) >> 3) == q) {
+    const int q = idx & 3;
+    const bool mine = ((lane & 31) >> 3) == q;
+    auto body = [&](auto IC) __attribute__((always_inline)) {
+      constexpr int i = decltype(IC)::value;
+      if (mine) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int g = 0; g < 4; ++g) *reinterpret_cast<h4a*>(wp + (j * 32 + 8 * g) * 2) = hq[i][j][g];
       }
-      asm volatile("" ::: "memory");
-      rowv = *reinterpret_cast<const h8a*>(rp);
-      asm volatile("" ::: "memory");
-      rowp = op + (size_t)((i * 4 + q) * 8) * p.ldc16;
     };
-    constexpr int I1 = MI - 1;                       // MI == 1: cases 4..7 are never reached
-    switch (idx) {
-      case 0: body(ic<0>{}, ic<0>{}); break;
-      case 1: body(ic<0>{}, ic<1>{}); break;
-      case 2: body(ic<0>{}, ic<2>{}); break;
-      case 3: body(ic<0>{}, ic<3>{}); break;
-      case 4: body(ic<I1>{}, ic<0>{}); break;
-      case 5: body(ic<I1>{}, ic<1>{}); break;
-      case 6: body(ic<I1>{}, ic<2>{}); break;
-      default: body(ic<I1>{}, ic<3>{}); break;
-    }
+    if (MI == 1 || idx < 4) body(ic<0>{});
+    else body(ic<MI - 1>{});
+    asm volatile("" ::: "memory");
   };
+  auto pass_read = [&](int idx) __attribute__((always_inline)) {
+    if constexpr (ABL & 32) return;
+    asm volatile("" ::: "memory");
+    rowv = *reinterpret_cast<const h8a*>(rp);
+    asm volatile("" ::: "memory");
+    rowp = op + (size_t)(idx * 8) * p.ldc16;
+  };
+  auto pass = [&](int idx) __attribute__((always_inline)) { pass_write(idx); pass_read(idx); };
   auto pass_store = [&]() __attribute__((always_inline)) { if constexpr (!(ABL & 8)) *reinterpret_cast<h8*>(rowp) = rowv; };     // padded rows: always issued
   auto flush = [&]() __attribute__((always_inline)) {
     while (pend > 0) { pass(4 * MI - pend); --pend; pass_store(); }
@@ -419,13 +421,23 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 
   // 16 MFMAs with the step's DMA pieces slotted between them; `mid` (counted wait + phase barrier)
   // runs after 12 MFMAs so the matrix pipe does not drain at the phase boundary
-  auto burst = [&](auto&& mid) __attribute__((always_inline)) {
+  auto burst = [&](int pass_idx, auto&& mid) __attribute__((always_inline)) {      // pass_idx < 0: no pass this step
     __builtin_amdgcn_s_setprio(1);
     int piece = 0;
 #pragma unroll
     for (int s = 0; s < KSUB; ++s)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        if (s * MI + i == (MI == 2 ? 1 : 0) && pass_idx >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          pass_write(pass_idx);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s * MI + i == (MI == 2 ? 3 : 1) && pass_idx >= 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          pass_read(pass_idx);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (s * MI + i == KSUB * MI - 2) {
           issue_advance();
           mid();
@@ -463,10 +475,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     for (int t = 0; t < n_my; ++t) {
       for (int kt = 0; kt < nk; ++kt, ++k) {
         const int sA = pend > 0 ? 1 : 0;
-        if (sA) { pass(4 * MI - pend); --pend; }
+        const int pidx = sA ? 4 * MI - pend : -1;
+        pend -= sA;
         load_frags();
         __builtin_amdgcn_s_barrier();
-        burst([&]() __attribute__((always_inline)) {
+        burst(pidx, [&]() __attribute__((always_inline)) {
           if (sA) pass_store();
           // younger than DMA(k+1) [issued in COMPUTE(k-1)]: store(k-1), DMA(k+2), store(k)
           const int ns = sA + s_prev;
@@ -489,7 +502,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     for (int t = 0; t < n_my; ++t) {
       for (int kt = 0; kt < nk; ++kt, ++k) {
         const int sB = pend > 0 ? 1 : 0;
-        if (sB) { pass(4 * MI - pend); --pend; }
+        const int pidx = sB ? 4 * MI - pend : -1;
+        pend -= sB;
         load_frags();
         {
           // younger than DMA(k+1) [issued in COMPUTE(k-2)]: store(k-2), DMA(k+2), store(k-1)
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
           s_prev2 = s_prev; s_prev = sB;
         }
         __builtin_amdgcn_s_barrier();
-        burst([&]() __attribute__((always_inline)) {
+        burst(pidx, [&]() __attribute__((always_inline)) {
           if (sB) pass_store();
           if (k + 1 < T) __builtin_amdgcn_s_barrier();
         });

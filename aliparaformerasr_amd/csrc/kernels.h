@@ -35,7 +35,7 @@ void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, cons
 // LFR (m,n) + CMVN + right pad + sentinel: fbank rows (per-utt offsets) -> [B,Tmax,m*80]
 void launch_lfr_cmvn_pad(hipStream_t s, const float* fbank, const int64_t* frame_off, const int32_t* t80,
                          int B, int Tmax, int lfr_m, int lfr_n, int n_mels, const float* shift,
-                         const float* scale, int apply_cmvn, int apply_sentinel, float* out);
+                         const float* scale, int apply_cmvn, int apply_sentinel, float* out, const float* prompt = nullptr, int P = 0);
 // ragged features -> padded + sentinel (PadSequence)
 void launch_pad_sentinel(hipStream_t s, const float* feats, const int64_t* feat_off, const int32_t* n_floats,
                          int B, int row_floats, float* out);

@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed step with per-class kernel times")
+    ap.add_argument("--model", choices=("paraformer", "sensevoice"), default="paraformer",
+                    help="sensevoice = BASELINE.json configs[2] (sensevoice-small, 64 x 10 s, use_itn on); not the headline config")
+    ap.add_argument("--seconds", type=int, default=0, help="utterance length (default 30; 10 for --model sensevoice)")
     ap.add_argument("--timestamp-head", action="store_true",
                     help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
     args = ap.parse_args()
@@ -114,7 +117,15 @@ def main():
 
     # ---- weights: rank 0 builds the synthetic paraformer-large image, RCCL-broadcasts it
     from aliparaformerasr_amd import shard as sh
-    cfg = W.paraformer_large_config(timestamp_head=bool(args.timestamp_head))
+    sv = args.model == "sensevoice"
+    seconds = args.seconds or (10 if sv else SECONDS)
+    samples = seconds * 16000
+    if sv:
+        cfg = W.sensevoice_small_config(use_itn=True)
+        if args.batch == BATCH_PER_GPU:
+            args.batch = 64
+    else:
+        cfg = W.paraformer_large_config(timestamp_head=bool(args.timestamp_head))
     cmvn = W.synth_cmvn()
     weights = None
     blob = b""
@@ -132,7 +143,7 @@ def main():
 
     # ---- workload: this rank's shard of the utterance list, staged to HBM before timing
     B = args.batch
-    audio = [W.synth_audio(SAMPLES, rank * B + u) for u in range(B)]
+    audio = [W.synth_audio(samples, rank * B + u) for u in range(B)]
     eng.stage_audio(audio)
     gathered = {}
 
@@ -185,35 +196,38 @@ def main():
                               "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
 
     if rank == 0:
-        audio_s = world * B * SECONDS * args.steps
+        audio_s = world * B * seconds * args.steps
         value = audio_s / dt
         flops_step = eng.last_flops()
         ach = fpl_dom / ((ms_dom / max(n_dom, 1)) * 1e-3) / 1e12 if n_dom else 0.0
         out = {
-            "metric": "RTFx (audio-sec/wall-sec), paraformer-large offline, batch 32x30s per GPU",
+            "metric": "RTFx (audio-sec/wall-sec), %s offline, batch %dx%ds per GPU"
+                      % ("sensevoice-small" if sv else "paraformer-large", B, seconds),
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "paraformer-large-zh offline%s, batch %dx%d s synthetic 16 kHz per GPU "
+            "config": {"workload": "%s offline%s, batch %dx%d s synthetic 16 kHz per GPU "
                                    "(BASELINE.json configs[%d]), seeded synthetic weights"
-                                   % (" + BiCIF timestamp head" if args.timestamp_head else "", B, SECONDS,
-                                      4 if args.timestamp_head else 1),
-                       "global_batch": world * B, "samples_per_utt": SAMPLES, "T_lfr": 500, "L": int(res.L),
+                                   % ("sensevoice-small (use_itn on)" if sv else "paraformer-large-zh",
+                                      " + BiCIF timestamp head" if args.timestamp_head else "", B, seconds,
+                                      2 if sv else (4 if args.timestamp_head else 1)),
+                       "global_batch": world * B, "samples_per_utt": samples, "T_lfr": eng.num_frames(samples), "L": int(res.L),
                        "parallelism": "dp%d (utterance shards, no data-path collective)" % world},
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
             "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp3 (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
-                         % (DOMINANT, B * 500), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F16_TFLOPS, "traffic": pmc_traffic(),
+                         % (DOMINANT, B * int(res.L if sv else eng.num_frames(samples))), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F16_TFLOPS,
+                         "traffic": pmc_traffic() if (not sv and B == BATCH_PER_GPU and seconds == SECONDS) else None,
                          "traffic_unit": "bytes/launch (PMC, profiles/round1_c_gemm_ffn1_pmc.json)",
-                         "algorithmic_bytes_per_launch": B * 500 * 512 * 2 + 2048 * 512 * 2 + B * 500 * 2048 * 2,
+                         "algorithmic_bytes_per_launch": int(fpl_dom / (2 * 512 * 2048)) * (512 + 2048) * 2 + 2048 * 512 * 2,
                          "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
                          "flops_per_launch": fpl_dom},
         }
         if breakdown is not None:
             out["kernel_breakdown_ms_per_step"] = breakdown
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not sv and seconds == SECONDS:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, cmvn)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))

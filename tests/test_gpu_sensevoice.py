@@ -11,7 +11,7 @@ from oracle import glue
 from oracle import model as om
 
 pytestmark = pytest.mark.gpu
-VOCAB = 400
+VOCAB = 403          # deliberately not a multiple of 4 (sensevoice-small: 25055)
 
 
 def _cfg():
@@ -41,6 +41,29 @@ def test_sensevoice_forward_feats_vs_oracle(sv_embed):
     safe = (srt[..., -1] - srt[..., -2]) > 0.04
     np.testing.assert_array_equal(res.token_ids[safe], ids_ref[safe])
     eng.close()
+
+
+def test_sensevoice_audio_in_prepends_prompt_on_device(sv_embed):
+    """pf_recognize (audio in, device front-end) must produce exactly what the feature-in entry point
+    produces for host-prepended query rows: same T + 4 length, bit-identical log-probs and ids, for both
+    use_itn settings (effective language id 14 / 15, quirk Q7)."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = _cfg()
+    w = W.synth_weights(cfg, seed=9)
+    w["embed.weight"] = sv_embed.astype(np.float32)
+    cmvn = W.synth_cmvn()
+    audio = [W.synth_audio(n, 90 + u) for u, n in enumerate((32000, 21000, 27000))]
+    for itn in (True, False):
+        eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, use_itn=itn)
+        feats = [glue.sensevoice_prepend(eng.frontend(a), sv_embed, use_itn=itn) for a in audio]
+        T = max(f.shape[0] for f in feats)
+        speech = fe.pad_sequence(feats).reshape(len(audio), T, 560)
+        a = eng.recognize(audio, want_logits=True)
+        b = eng.forward_feats(speech, want_logits=True)
+        assert a.L == b.L == T
+        assert np.array_equal(a.token_ids, b.token_ids)
+        assert np.array_equal(a.logits, b.logits)
+        eng.close()
 
 
 def test_sensevoice_recognizer_prompt_rows(tmp_path, sv_embed):
