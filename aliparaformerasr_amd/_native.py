@@ -67,6 +67,7 @@ SIGNATURES = {
     "pf_model_proj": (C.c_int, [_vp, _P(_f), _i32, C.c_int32, _i32, C.c_int32, _P(PfBatchOut)]),
     "pf_recognize": (C.c_int, [_vp, _P(_f), _i64, C.c_int32, _i32, C.c_int32, _P(PfBatchOut)]),
     "pf_stage_audio": (C.c_int, [_vp, _P(_f), _i64, C.c_int32]),
+    "pf_engine_set_hotwords": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32]),
     "pf_run_staged": (C.c_int, [_vp]),
     "pf_sync": (C.c_int, [_vp]),
     "pf_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),

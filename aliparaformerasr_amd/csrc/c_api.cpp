@@ -112,8 +112,8 @@ int pf_forward_feats(pf_engine* h, const float* speech, int32_t B, int32_t Tmax,
   PF_TRY
   Engine* e = E(h);
   NEED(out);
-  (void)hotwords; (void)n_hotwords;
   std::lock_guard<std::mutex> lk(e->mutex());
+  if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
   e->forward_feats_host(speech, B, Tmax, want_logits(out));
   e->fetch(out);
   return PF_OK;
@@ -125,8 +125,8 @@ int pf_model_proj(pf_engine* h, const float* const* speech, const int32_t* lens,
   PF_TRY
   Engine* e = E(h);
   NEED(out); NEED(speech); NEED(lens);
-  (void)hotwords; (void)n_hotwords;
   std::lock_guard<std::mutex> lk(e->mutex());
+  if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
   e->model_proj_host(speech, lens, B, want_logits(out));
   e->fetch(out);
   return PF_OK;
@@ -138,11 +138,21 @@ int pf_recognize(pf_engine* h, const float* const* samples, const int64_t* n, in
   PF_TRY
   Engine* e = E(h);
   NEED(out); NEED(samples); NEED(n);
-  (void)hotwords; (void)n_hotwords;
   std::lock_guard<std::mutex> lk(e->mutex());
+  if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
   e->stage_audio(samples, n, B);
   e->run_staged(want_logits(out));
   e->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_engine_set_hotwords(pf_engine* h, const int32_t* hotwords, int32_t n_hotwords) {
+  PF_TRY
+  Engine* e = E(h);
+  PF_CHECK(n_hotwords >= 0 && (n_hotwords == 0 || hotwords), PF_ERR_INVALID_ARG, "set_hotwords: bad arguments");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  if (e->model().seaco) e->set_hotwords(hotwords, n_hotwords);
   return PF_OK;
   PF_CATCH
 }

@@ -171,8 +171,14 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   mc_.cif_smooth2 = (float)jc->num_or("cif_smooth2", mc_.cif_smooth2);
   mc_.cif_noise2 = (float)jc->num_or("cif_noise2", mc_.cif_noise2);
   mc_.upsample = (int)jc->num_or("upsample", mc_.upsample);
-  PF_CHECK(!mc_.seaco && mc_.kind != "seacoparaformer", PF_ERR_UNSUPPORTED,
-           "the SeACo bias decoder is not built in this round");
+  mc_.seaco_layers = (int)jc->num_or("seaco_layers", mc_.seaco_layers);
+  mc_.seaco_ffn = (int)jc->num_or("seaco_ffn", mc_.seaco_ffn);
+  mc_.seaco_kernel = (int)jc->num_or("seaco_kernel", mc_.seaco_kernel);
+  mc_.seaco_lstm_layers = (int)jc->num_or("seaco_lstm_layers", mc_.seaco_lstm_layers);
+  mc_.seaco_nobias = (int)jc->num_or("seaco_nobias", mc_.seaco_nobias);
+  if (mc_.kind == "seacoparaformer") mc_.seaco = true;
+  PF_CHECK(!mc_.seaco || (mc_.seaco_ffn % 64 == 0 && mc_.seaco_lstm_layers >= 1), PF_ERR_UNSUPPORTED,
+           "seaco: unsupported dimensions");
   PF_CHECK(!mc_.timestamp_head || mc_.upsample == 3, PF_ERR_UNSUPPORTED, "timestamp head: only upsample = 3");
 
   const int64_t data_off = round_up((int64_t)(16 + hlen), (int64_t)kAlign);
@@ -359,6 +365,70 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   dec_after_ = make_ln("decoder.after_norm");
   dec_out_ = make_lin("decoder.output", true);
   PF_CHECK(dec_out_.N == mc_.vocab, PF_ERR_FORMAT, "weights: decoder.output rows != vocab");
+  // SeACo: hotword embedder (Embedding + LSTM stack) and the bias decoder
+  if (mc_.seaco) {
+    const int ns = mc_.seaco_layers;
+    const Tensor& ew = tensor("seaco.embed.weight");
+    PF_CHECK(ew.shape.size() == 2 && ew.shape[1] == D, PF_ERR_FORMAT, "weights: seaco.embed.weight shape");
+    seaco_embed_w_ = ew.dev;
+    std::vector<float> b1((size_t)4 * D), b2((size_t)4 * D);
+    for (int l = 0; l < mc_.seaco_lstm_layers; ++l) {
+      const std::string p = "seaco.lstm.l" + std::to_string(l);
+      const Tensor& wih = tensor(p + ".weight_ih");
+      const Tensor& whh = tensor(p + ".weight_hh");
+      const Tensor& bih = tensor(p + ".bias_ih");
+      const Tensor& bhh = tensor(p + ".bias_hh");
+      PF_CHECK(wih.numel == (int64_t)4 * D * D && whh.numel == (int64_t)4 * D * D && bih.numel == 4 * D && bhh.numel == 4 * D,
+               PF_ERR_FORMAT, "weights: seaco.lstm shapes");
+      LstmLayer L;
+      L.ih.N = 4 * D; L.ih.K = D; L.ih.Kpad = D;
+      L.ih.w = (half_t*)dalloc((size_t)4 * D * D * 2);
+      L.whh = (half_t*)dalloc((size_t)4 * D * D * 2);
+      launch_f32_to_f16(stream_, wih.dev, 4 * D, D, D, L.ih.w, D);
+      launch_f32_to_f16(stream_, whh.dev, 4 * D, D, D, L.whh, D);
+      PF_HIP(hipMemcpy(b1.data(), bih.dev, (size_t)4 * D * 4, hipMemcpyDeviceToHost));
+      PF_HIP(hipMemcpy(b2.data(), bhh.dev, (size_t)4 * D * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 4 * D; ++i) b1[i] += b2[i];
+      float* gb = (float*)dalloc((size_t)4 * D * 4);
+      PF_HIP(hipMemcpy(gb, b1.data(), (size_t)4 * D * 4, hipMemcpyHostToDevice));
+      L.ih.bias = gb;
+      seaco_lstm_.push_back(L);
+    }
+    if (ns > 0) {
+      seaco_kv_all_.N = ns * 2 * D; seaco_kv_all_.K = D; seaco_kv_all_.Kpad = D;
+      seaco_kv_all_.w = (half_t*)dalloc((size_t)round_up(seaco_kv_all_.N, 128) * D * 2);
+      PF_HIP(hipMemsetAsync(seaco_kv_all_.w, 0, (size_t)round_up(seaco_kv_all_.N, 128) * D * 2, stream_));
+      float* kvb = (float*)dalloc((size_t)seaco_kv_all_.N * 4);
+      seaco_kv_all_.bias = kvb;
+      for (int i = 0; i < ns; ++i) {
+        const std::string p = "seaco.decoder.layers." + std::to_string(i);
+        DecLayer L;
+        L.norm1 = make_ln(p + ".norm1");
+        L.w1 = make_lin(p + ".ffn.w1", true);
+        L.ffn_norm = make_ln(p + ".ffn.norm");
+        L.w2 = make_lin(p + ".ffn.w2", false);
+        L.norm2 = make_ln(p + ".norm2");
+        L.fsmn_wT = make_fsmn_wT(p + ".fsmn.weight", mc_.seaco_kernel);
+        L.norm3 = make_ln(p + ".norm3");
+        L.q = make_lin(p + ".src.q", true);
+        L.out = make_lin(p + ".src.out", true);
+        const Tensor& kvw = tensor(p + ".src.kv.weight");
+        const Tensor& kvbias = tensor(p + ".src.kv.bias");
+        PF_CHECK(kvw.numel == (int64_t)2 * D * D && kvbias.numel == 2 * D, PF_ERR_FORMAT, "weights: src.kv shape in " + p);
+        PF_CHECK(L.w1.N == mc_.seaco_ffn, PF_ERR_FORMAT, "weights: seaco ffn width != seaco_ffn");
+        launch_f32_to_f16(stream_, kvw.dev, 2 * D, D, D, seaco_kv_all_.w + (size_t)i * 2 * D * D, D);
+        PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
+        sdec_.push_back(L);
+      }
+    }
+    seaco_final_norm1_ = make_ln("seaco.decoder.final.norm1");
+    seaco_final_w1_ = make_lin("seaco.decoder.final.ffn.w1", true);
+    seaco_final_ffn_norm_ = make_ln("seaco.decoder.final.ffn.norm");
+    seaco_final_w2_ = make_lin("seaco.decoder.final.ffn.w2", false);
+    seaco_after_ = make_ln("seaco.decoder.after_norm");
+    seaco_out_ = make_lin("seaco.output", true);
+    PF_CHECK(seaco_out_.N == mc_.vocab, PF_ERR_FORMAT, "weights: seaco.output rows != vocab");
+  }
   PF_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -390,11 +460,11 @@ LNp Engine::make_ln(const std::string& prefix) {
   return p;
 }
 
-float* Engine::make_fsmn_wT(const std::string& name) {
+float* Engine::make_fsmn_wT(const std::string& name, int Kopt) {
   const Tensor& w = tensor(name);
-  PF_CHECK(w.shape.size() == 2 && w.shape[0] == mc_.d_model && w.shape[1] == mc_.kernel, PF_ERR_FORMAT,
+  const int D = mc_.d_model, K = Kopt > 0 ? Kopt : mc_.kernel;
+  PF_CHECK(w.shape.size() == 2 && w.shape[0] == D && w.shape[1] == K, PF_ERR_FORMAT,
            "weights: '" + name + "' must be [d_model, kernel]");
-  const int D = mc_.d_model, K = mc_.kernel;
   std::vector<float> h(w.numel), t(w.numel);
   PF_HIP(hipMemcpy(h.data(), w.dev, w.numel * 4, hipMemcpyDeviceToHost));
   for (int c = 0; c < D; ++c)
@@ -725,6 +795,15 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   prof_begin("cif_misc", 0);
   launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
   prof_end("cif_misc");
+  const bool bias_branch = mc_.seaco && n_hotwords_ > 0;
+  float* e0 = nullptr;                                 // SeACo: the bias decoder also starts from the CIF embeds
+  float* hid32 = nullptr;
+  if (bias_branch) {
+    ensure(ws_seaco_in_, (size_t)2 * Mdp * D * 4);
+    e0 = (float*)ws_seaco_in_.p;
+    hid32 = e0 + (size_t)Mdp * D;
+    PF_HIP(hipMemcpyAsync(e0, xd, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  }
   if (nd > 0)
     gemm("gemm_dec_kv", dec_kv_all_, H16_, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
 
@@ -765,14 +844,132 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
   prof_begin("layernorm", 0);
-  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, xdn16, D, nullptr, 0);
+  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, xdn16, D, hid32, hid32 ? D : 0);
   prof_end("layernorm");
   logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
   gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
   launch_argmax(stream_, logits_, Md, V, logits_ld_, want_logits ? 1 : 0, ids_dev_);
   prof_end("argmax");
+  if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::set_hotwords(const int32_t* hw, int n) {
+  PF_CHECK(n >= 0 && (n == 0 || hw), PF_ERR_INVALID_ARG, "set_hotwords: bad arguments");
+  hotwords_.assign(hw, hw + (size_t)n * 10);
+  n_hotwords_ = n;
+}
+
+// SeACo bias branch (export_forward of the FunASR SeACo export; reference call site
+// OfflineProjOfSeacoParaformer.cs:48-135).  hotwords [N,10] -> Embedding -> LSTM stack -> hw_embed; bias_embed
+// row n*10+j = hw_embed[j,n] is the same for every utterance (OfflineProjOfSeacoParaformer.cs:83-111 tiles it
+// over B), so its K/V projections are computed once and every (utterance, head) attends the same rows.  The
+// bias decoder runs once on 2*B*L rows: [CIF embeds ; ASR decoder hidden].
+void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool want_logits) {
+  const int D = mc_.d_model, V = mc_.vocab, Fs = mc_.seaco_ffn, ns = (int)sdec_.size();
+  const int N = n_hotwords_, J = 10, NJ = N * J;
+  const int Md = B * L, R = 2 * Md;
+  const int64_t NJp = round_up(NJ, 128) + 128, Rp = round_up(R, 128) + 128, Mdp = round_up(Md, 128) + 128;
+  const int ldV = (int)round_up(V, 4);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_ids = carve((size_t)NJ * 4), o_e32 = carve((size_t)NJp * D * 4), o_in16 = carve((size_t)NJp * D * 2);
+  const size_t o_xg = carve((size_t)NJp * 4 * D * 4), o_ho = carve((size_t)NJp * D * 4), o_hs = carve((size_t)2 * N * D * 2);
+  const size_t o_cs = carve((size_t)N * D * 4), o_kv = carve((size_t)NJp * std::max(ns, 1) * 2 * D * 2);
+  const size_t o_x = carve((size_t)Rp * D * 4), o_xn = carve((size_t)Rp * D * 2), o_h32 = carve((size_t)Rp * Fs * 4);
+  const size_t o_h16 = carve((size_t)Rp * Fs * 2), o_t = carve((size_t)Rp * D * 4), o_tn = carve((size_t)Rp * D * 4);
+  const size_t o_q = carve((size_t)Rp * D * 2), o_ctx = carve((size_t)Rp * D * 2), o_hid = carve((size_t)Rp * D * 4);
+  const size_t o_m16 = carve((size_t)Mdp * D * 2), o_dha = carve((size_t)Mdp * ldV * 4), o_did = carve((size_t)Md * 8);
+  const size_t o_tn2 = carve((size_t)2 * B * 4);
+  ensure(ws_seaco_, off);
+  char* base = (char*)ws_seaco_.p;
+  int32_t* ids = (int32_t*)(base + o_ids);
+  float* e32 = (float*)(base + o_e32); half_t* in16 = (half_t*)(base + o_in16);
+  float* xg = (float*)(base + o_xg); float* hout = (float*)(base + o_ho);
+  half_t* hs = (half_t*)(base + o_hs); float* cs = (float*)(base + o_cs);
+  half_t* kv16 = (half_t*)(base + o_kv);
+  float* xs = (float*)(base + o_x); half_t* xn16 = (half_t*)(base + o_xn);
+  float* h32 = (float*)(base + o_h32); half_t* h16 = (half_t*)(base + o_h16);
+  float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
+  half_t* q16 = (half_t*)(base + o_q); half_t* ctx16 = (half_t*)(base + o_ctx);
+  float* hid = (float*)(base + o_hid); half_t* m16 = (half_t*)(base + o_m16);
+  float* dha = (float*)(base + o_dha); int64_t* dha_ids = (int64_t*)(base + o_did);
+  int32_t* tn2 = (int32_t*)(base + o_tn2);
+
+  // ---- hotword embedder: Embedding -> LSTM stack (all J outputs kept), batch-major rows n*J + j
+  prof_begin("seaco_embed", 0);
+  PF_HIP(hipMemcpyAsync(ids, hotwords_.data(), (size_t)NJ * 4, hipMemcpyHostToDevice, stream_));
+  launch_embed_gather(stream_, seaco_embed_w_, ids, NJ, D, (int)tensor("seaco.embed.weight").shape[0], e32, in16);
+  prof_end("seaco_embed");
+  for (size_t l = 0; l < seaco_lstm_.size(); ++l) {
+    gemm("gemm_seaco", seaco_lstm_[l].ih, in16, D, NJ, xg, 4 * D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+    prof_begin("seaco_embed", 0);
+    PF_HIP(hipMemsetAsync(hs, 0, (size_t)2 * N * D * 2, stream_));
+    PF_HIP(hipMemsetAsync(cs, 0, (size_t)N * D * 4, stream_));
+    LstmArgs a{};
+    a.whh = seaco_lstm_[l].whh; a.xg = xg; a.hstate = hs; a.cstate = cs; a.hout = hout; a.B = N; a.T3 = J; a.D = D; a.ndir = 1;
+    for (int st = 0; st < J; ++st) { a.step = st; launch_lstm_step(stream_, a); }
+    launch_f32_to_f16(stream_, hout, NJ, D, D, in16, D);
+    prof_end("seaco_embed");
+  }
+  const int ldkv = ns * 2 * D;
+  if (ns > 0)
+    gemm("gemm_seaco", seaco_kv_all_, in16, D, NJ, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+
+  // ---- bias decoder on [CIF embeds ; decoder hidden]
+  PF_HIP(hipMemcpyAsync(xs, e0, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(xs + (size_t)Md * D, hid32, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(tn2, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(tn2 + B, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, xs, R, D, n1.g, n1.b, xn16, D, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_seaco", w1, xn16, D, R, h32, Fs, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, h32, R, Fs, fn.g, fn.b, h16, Fs, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_seaco", w2, h16, Fs, R, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
+  };
+  for (int i = 0; i < ns; ++i) {
+    const DecLayer& Lr = sdec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, t32, R, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    prof_end("layernorm");
+    prof_begin("fsmn", 0);
+    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, tn2, 2 * B, L, D, mc_.seaco_kernel, xs);
+    prof_end("fsmn");
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, xs, R, D, Lr.norm3.g, Lr.norm3.b, xn16, D, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_seaco", Lr.q, xn16, D, R, nullptr, 0, q16, D, nullptr, 0, nullptr, 0, false, D, qscale);
+    AttnArgs a{};
+    a.q = q16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
+    a.k = kv16 + (size_t)i * 2 * D; a.v = kv16 + (size_t)i * 2 * D + D;
+    a.k_bstride = a.v_bstride = 0; a.k_rstride = a.v_rstride = ldkv;      // one bias_embed for every utterance
+    a.o = ctx16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
+    a.B = 2 * B; a.H = mc_.heads; a.Lq = L; a.Lk = NJ;
+    prof_begin("attn_seaco", 4.0 * 2 * B * (double)L * NJ * D);
+    launch_attention(stream_, a);
+    prof_end("attn_seaco");
+    gemm("gemm_seaco", Lr.out, ctx16, D, R, xs, D, nullptr, 0, xs, D, nullptr, 0, false, 0, 1.f);
+  }
+  ffn_dec(seaco_final_norm1_, seaco_final_w1_, seaco_final_ffn_norm_, seaco_final_w2_);
+  prof_begin("layernorm", 0);
+  launch_layernorm(stream_, t32, R, D, seaco_after_.g, seaco_after_.b, nullptr, 0, hid, D);
+  prof_end("layernorm");
+  // ---- merged = cif_attended + dec_attended -> hotword_output_layer -> NO-BIAS merge with the ASR rows
+  prof_begin("seaco_merge", 0);
+  launch_add_to_f16(stream_, hid, hid + (size_t)Md * D, Md, D, m16);
+  prof_end("seaco_merge");
+  gemm("gemm_seaco", seaco_out_, m16, D, Md, dha, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  prof_begin("seaco_merge", 0);
+  launch_argmax(stream_, dha, Md, V, ldV, want_logits ? 1 : 0, dha_ids);
+  launch_seaco_merge(stream_, dha, ldV, dha_ids, Md, V, mc_.seaco_nobias, want_logits ? 1 : 0, logits_, logits_ld_, ids_dev_);
+  prof_end("seaco_merge");
 }
 
 // BiCIF timestamp head (k_bicif.hip): us_cif_peak [B, 3T]; needs token_num (device) only.
@@ -802,7 +999,7 @@ void Engine::timestamp_head(int B, int T) {
   PF_HIP(hipMemsetAsync(hs, 0, (size_t)4 * B * D * 2, stream_));
   PF_HIP(hipMemsetAsync(cs, 0, (size_t)2 * B * D * 4, stream_));
   LstmArgs a{};
-  a.whh = ts_whh_; a.xg = xg; a.hstate = hs; a.cstate = cs; a.hout = hout; a.B = B; a.T3 = T3; a.D = D;
+  a.whh = ts_whh_; a.xg = xg; a.hstate = hs; a.cstate = cs; a.hout = hout; a.B = B; a.T3 = T3; a.D = D; a.ndir = 2;
   for (int s = 0; s < T3; ++s) { a.step = s; launch_lstm_step(stream_, a); }
   prof_end("lstm");
   prof_begin("ts_misc", 0);

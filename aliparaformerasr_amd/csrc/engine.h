@@ -21,6 +21,7 @@ struct ModelCfg {
   bool timestamp_head = false, seaco = false, use_itn = false;
   float cif_smooth2 = 0.25f, cif_noise2 = 0.01f;
   int upsample = 3;
+  int seaco_layers = 4, seaco_ffn = 1024, seaco_kernel = 21, seaco_lstm_layers = 2, seaco_nobias = 8377;
   int kind_id() const { return kind == "sensevoicesmall" ? 1 : (kind == "seacoparaformer" ? 2 : 0); }
 };
 
@@ -74,6 +75,9 @@ class Engine {
   void run_staged(bool want_logits);
   void fetch(pf_batch_out* out);
   void sync();
+  // SeACo: hotword ids [n, 10] (PadList output, EmbedSeacoModel.cs:70-123) used by the following forwards;
+  // n = 0 -> bias_embed [B,0,512]: the bias branch is skipped and the ASR log-probs are returned
+  void set_hotwords(const int32_t* hw, int n);
 
   // ---- stand-alone ops (parity tests) -------------------------------------
   void op_lfr_cmvn_pad(const float* const* fbank, const int32_t* t80, int B, int sentinel, float* out,
@@ -109,7 +113,7 @@ class Engine {
   bool has_tensor(const std::string& name) const { return tensors_.count(name) != 0; }
   Lin make_lin(const std::string& prefix, bool bias);
   LNp make_ln(const std::string& prefix);
-  float* make_fsmn_wT(const std::string& name);
+  float* make_fsmn_wT(const std::string& name, int K = 0);
   void* dalloc(size_t bytes);
   void ensure(DevBuf& b, size_t bytes);
   void build_pe(int T);
@@ -118,6 +122,7 @@ class Engine {
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
   void timestamp_head(int B, int T);
+  void seaco_head(int B, int L, const float* e0, const float* hid32, bool want_logits);
   void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
             half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
             int scale_cols, float scale, bool bias = true);
@@ -141,6 +146,14 @@ class Engine {
   Lin cif_conv_, dec_kv_all_, dec_final_w1_, dec_final_w2_, dec_out_, ctc_;
   const float* cif_out_w_ = nullptr;
   const float* cif_out_b_ = nullptr;
+  struct LstmLayer { Lin ih; half_t* whh = nullptr; };
+  std::vector<DecLayer> sdec_;      // SeACo bias decoder
+  std::vector<LstmLayer> seaco_lstm_;
+  Lin seaco_kv_all_, seaco_final_w1_, seaco_final_w2_, seaco_out_;
+  LNp seaco_final_norm1_, seaco_final_ffn_norm_, seaco_after_;
+  const float* seaco_embed_w_ = nullptr;
+  std::vector<int32_t> hotwords_;   // [n_hotwords_, 10]
+  int n_hotwords_ = 0;
   Lin ts_up_, ts_ih_;               // BiCIF: ConvTranspose1d as [3D, D], W_ih of both directions [8D, D]
   half_t* ts_whh_ = nullptr;        // [2][4D][D]
   const float* ts_out_w_ = nullptr;
@@ -155,7 +168,7 @@ class Engine {
   int cmvn_dim_ = 0;
 
   // workspace
-  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_, ws_ts_;
+  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
   int pe_T_ = 0;
   // encoder views (valid after encoder())
   float* x_ = nullptr; half_t* xn16_ = nullptr; half_t* qkv16_ = nullptr; half_t* ctx16_ = nullptr;

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   // overlaps the W_hh / h loads and the MFMAs instead of following the LDS reduction
   const int bq = min(bt * 32 + r, a.B - 1);
   const int uq = ub * 8 + 2 * wave + kg;
-  const float* xgp = a.xg + ((size_t)bq * a.T3 + t) * (size_t)(8 * D) + (size_t)dir * 4 * D + uq;
+  const float* xgp = a.xg + ((size_t)bq * a.T3 + t) * (size_t)(a.ndir * 4 * D) + (size_t)dir * 4 * D + uq;
   float* cp = a.cstate + ((size_t)dir * a.B + bq) * D + uq;
   const float xi = xgp[0], xf = xgp[D], xc = xgp[2 * D], xo = xgp[3 * D], cprev = *cp;
 
@@ -78,12 +78,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   const float h = sigmoidf_(go) * tanhf(c);
   *cp = c;
   hnext[(size_t)b * D + u] = (half_t)h;
-  a.hout[((size_t)b * a.T3 + t) * (size_t)(2 * D) + (size_t)dir * D + u] = h;
+  a.hout[((size_t)b * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + u] = h;
 }
 
 void launch_lstm_step(hipStream_t s, const LstmArgs& a) {
   PF_CHECK(a.D % 512 == 0, PF_ERR_UNSUPPORTED, "lstm: hidden size must be a multiple of 512");
-  hipLaunchKernelGGL(lstm_step_kernel, dim3(a.D / 8, 2, cdiv(a.B, 32)), dim3(256), 0, s, a);
+  PF_CHECK(a.ndir == 1 || a.ndir == 2, PF_ERR_INVALID_ARG, "lstm: ndir must be 1 or 2");
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(a.D / 8, a.ndir, cdiv(a.B, 32)), dim3(256), 0, s, a);
   PF_HIP(hipGetLastError());
 }
 

@@ -237,9 +237,12 @@ void launch_fsmn_dec(hipStream_t s, const float* tn, const float* wT, const int3
                      int D, int k, float* x) {
   const int64_t total = (int64_t)B * L * (D / 4);
   if (total == 0) return;
+  const int64_t tot = (int64_t)B * ((L + FS_ROWS - 1) / FS_ROWS) * (D / 4);
   if (k == 11) {
-    const int64_t tot = (int64_t)B * ((L + FS_ROWS - 1) / FS_ROWS) * (D / 4);
     hipLaunchKernelGGL(fsmn_dec_kernel<11>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tn, wT, token_num,
+                       B, L, D, x);
+  } else if (k == 21) {                               // SeACo bias decoder
+    hipLaunchKernelGGL(fsmn_dec_kernel<21>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, tn, wT, token_num,
                        B, L, D, x);
   } else
     hipLaunchKernelGGL(fsmn_f32_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tn, wT,
@@ -409,6 +412,88 @@ void launch_cif_gather(hipStream_t s, const float* H, int B, int T, int D, int T
                        float* E) {
   if (B == 0 || L == 0) return;
   hipLaunchKernelGGL(cif_gather_kernel, dim3(B * L), dim3(128), 0, s, H, B, T, D, T1, plan, L, E);
+  PF_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ SeACo -----------------
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                           int rows, int D, int vocab, float* __restrict__ out32,
+                                                           half_t* __restrict__ out16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int dq = D >> 2;
+  if (i >= (int64_t)rows * dq) return;
+  const int r = (int)(i / dq), c4 = (int)(i - (int64_t)r * dq) * 4;
+  int id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float4 v = *reinterpret_cast<const float4*>(table + (int64_t)id * D + c4);
+  *reinterpret_cast<float4*>(out32 + (int64_t)r * D + c4) = v;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<h4*>(out16 + (int64_t)r * D + c4) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+}
+
+void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, int rows, int D, int vocab,
+                         float* out32, half_t* out16) {
+  if (rows == 0) return;
+  const int64_t total = (int64_t)rows * (D / 4);
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, table, ids, rows, D,
+                     vocab, out32, out16);
+  PF_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void add_to_f16_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         int64_t n4, half_t* __restrict__ out16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  reinterpret_cast<h4*>(out16)[i] = h4{(half_t)(x.x + y.x), (half_t)(x.y + y.y), (half_t)(x.z + y.z), (half_t)(x.w + y.w)};
+}
+
+void launch_add_to_f16(hipStream_t s, const float* a, const float* b, int64_t rows, int D, half_t* out16) {
+  const int64_t n4 = rows * (D / 4);
+  if (n4 == 0) return;
+  hipLaunchKernelGGL(add_to_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, b, n4, out16);
+  PF_HIP(hipGetLastError());
+}
+
+// NO-BIAS decision + merge (_merge_res of the SeACo export with seaco_weight = 1): the graph's ArgMax keeps
+// the FIRST maximal index, so "argmax == nobias" <=> x[nobias] > every earlier entry and >= every later one.
+__global__ __launch_bounds__(256) void seaco_merge_kernel(const float* __restrict__ dha, int ld_dha,
+                                                          const int64_t* __restrict__ dha_ids, int V, int nobias,
+                                                          int copy_logits, float* __restrict__ logits, int ld_logits,
+                                                          int64_t* __restrict__ ids) {
+  __shared__ int s_bad[4];
+  const int64_t row = blockIdx.x;
+  const float* xr = dha + row * (int64_t)ld_dha;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int bad = 0;
+  if (nobias >= 0 && nobias < V) {
+    const float ref = xr[nobias];
+    for (int k = tid; k < V; k += 256) {
+      const float v = xr[k];
+      if (k < nobias ? (v >= ref) : (k > nobias && v > ref)) bad = 1;
+    }
+    if (ref != ref) bad = 1;
+  } else {
+    bad = 1;
+  }
+  bad = __any(bad) ? 1 : 0;
+  if (lane == 0) s_bad[wv] = bad;
+  __syncthreads();
+  const int replace = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
+  if (!replace) return;
+  if (tid == 0) ids[row] = dha_ids[row];
+  if (copy_logits) {
+    float* lr = logits + row * (int64_t)ld_logits;
+    for (int k = tid; k < V; k += 256) lr[k] = xr[k];
+  }
+}
+
+void launch_seaco_merge(hipStream_t s, const float* dha, int ld_dha, const int64_t* dha_ids, int64_t rows, int V,
+                        int nobias, int copy_logits, float* logits, int ld_logits, int64_t* ids) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(seaco_merge_kernel, dim3((unsigned)rows), dim3(256), 0, s, dha, ld_dha, dha_ids, V, nobias,
+                     copy_logits, logits, ld_logits, ids);
   PF_HIP(hipGetLastError());
 }
 

@@ -93,11 +93,22 @@ struct LstmArgs {
   float* cstate;       // [2 dir][B][D]
   float* hout;         // [B*T3][2D]  forward | reverse hidden states
   int B, T3, D, step;  // step s handles t = s (forward) and t = T3-1-s (reverse)
+  int ndir;            // 2 = bidirectional (BiCIF head), 1 = forward only (SeACo hotword embedder)
 };
 void launch_lstm_step(hipStream_t s, const LstmArgs& a);
 void launch_us_alpha(hipStream_t s, const float* hout, int64_t rows, int W, const float* w, const float* b0,
                      float smooth, float noise, float* out);
 void launch_us_peak(hipStream_t s, float* alphas, const int32_t* token_num, int B, int T3, float thr, float* peak);
+// ------------------------------------------------------------------ SeACo ----
+// rows[r, :] = table[ids[r], :]  (fp32) and its f16 copy
+void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, int rows, int D, int vocab,
+                         float* out32, half_t* out16);
+// out16[r, :] = f16(a[r, :] + b[r, :])
+void launch_add_to_f16(hipStream_t s, const float* a, const float* b, int64_t rows, int D, half_t* out16);
+// per row: keep = (first-index arg-max of dha[row, 0:V] == nobias); if !keep: ids[row] = dha_ids[row] and
+// (copy_logits) logits[row, 0:V] = dha[row, 0:V]
+void launch_seaco_merge(hipStream_t s, const float* dha, int ld_dha, const int64_t* dha_ids, int64_t rows, int V,
+                        int nobias, int copy_logits, float* logits, int ld_logits, int64_t* ids);
 // last-index arg-max (+ optional in-place log_softmax) over rows of width V
 void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int do_logsoftmax, int64_t* ids);
 

@@ -292,6 +292,21 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
       lens.push_back((int32_t)s->Speech.size());
     }
     const int B = (int)streams.size();
+    if (mc.seaco) {
+      // OfflineProjOfSeacoParaformer.cs:52-60: hotwords = SelectMany over the streams' Hotwords (a null list
+      // throws inside ModelProj -> "Offline recognition failed"); empty -> the constructor's default list
+      // (hotword file + [sos_eos_id] terminator, OfflineRecognizer.cs:72-90).  PadList(…, 0, 10) (EmbedSeacoModel.cs).
+      std::vector<std::vector<int32_t>> hw;
+      for (Stream* s : streams) {
+        if (s->hotwords_null) throw Error(PF_ERR_RECOGNITION, "Value cannot be null (Hotwords)");
+        for (auto& w : s->Hotwords) hw.push_back(w);
+      }
+      if (hw.empty()) hw = hotwords_;
+      std::vector<int32_t> pad;
+      for (auto& w : hw)
+        for (int j = 0; j < 10; ++j) pad.push_back(j < (int)w.size() ? w[j] : 0);
+      e->set_hotwords(pad.data(), (int)hw.size());
+    }
     e->model_proj_host(ptrs.data(), lens.data(), B, false);
     pf_batch_out out;
     std::memset(&out, 0, sizeof(out));

@@ -129,9 +129,18 @@ class Engine:
         N.check(self._lib.pf_fetch(self._h, C.byref(out)))
         return BatchResult(ids[:, :L].copy(), tn, L, V, logits, peak)
 
-    def forward_feats(self, speech, want_logits=False) -> BatchResult:
+    @staticmethod
+    def _hw(hotwords):
+        """SeACo hotword ids [N,10] int32 (PadList output) -> (pointer, N); None -> (NULL, 0)."""
+        if hotwords is None:
+            return None, 0, None
+        a = np.ascontiguousarray(hotwords, dtype=np.int32).reshape(-1, 10)
+        return a.ctypes.data_as(C.POINTER(C.c_int32)), a.shape[0], a
+
+    def forward_feats(self, speech, want_logits=False, hotwords=None) -> BatchResult:
         sp = _f32(speech)
         B, T, _ = sp.shape
+        hp, hn, _keep = self._hw(hotwords)
         if want_logits:
             # logits must be requested at forward time: pass a 1-float dummy capacity marker
             dummy = np.zeros(1, np.float32)
@@ -139,15 +148,16 @@ class Engine:
             def call(out):
                 out.logits = _fp(dummy)
                 out.logits_cap = 1
-                rc = self._lib.pf_forward_feats(self._h, _fp(sp), B, T, None, 0, C.byref(out))
+                rc = self._lib.pf_forward_feats(self._h, _fp(sp), B, T, hp, hn, C.byref(out))
                 # capacity error on the dummy buffer is expected; L and V are filled in
                 return 0 if rc == N.PF_ERR_CAPACITY else rc
         else:
             def call(out):
-                return self._lib.pf_forward_feats(self._h, _fp(sp), B, T, None, 0, C.byref(out))
+                return self._lib.pf_forward_feats(self._h, _fp(sp), B, T, hp, hn, C.byref(out))
         return self._collect(call, B, want_logits)
 
-    def model_proj(self, speeches, want_logits=False) -> BatchResult:
+    def model_proj(self, speeches, want_logits=False, hotwords=None) -> BatchResult:
+        hp, hn, _keep = self._hw(hotwords)
         arrs = [_f32(s).reshape(-1) for s in speeches]
         B = len(arrs)
         ptrs = (C.POINTER(C.c_float) * B)(*[_fp(a) for a in arrs])
@@ -158,11 +168,12 @@ class Engine:
             if want_logits:
                 out.logits = _fp(dummy)
                 out.logits_cap = 1
-            rc = self._lib.pf_model_proj(self._h, ptrs, lens, B, None, 0, C.byref(out))
+            rc = self._lib.pf_model_proj(self._h, ptrs, lens, B, hp, hn, C.byref(out))
             return 0 if (want_logits and rc == N.PF_ERR_CAPACITY) else rc
         return self._collect(call, B, want_logits)
 
-    def recognize(self, samples_list, want_logits=False) -> BatchResult:
+    def recognize(self, samples_list, want_logits=False, hotwords=None) -> BatchResult:
+        hp, hn, _keep = self._hw(hotwords)
         arrs = [_f32(s) for s in samples_list]
         B = len(arrs)
         ptrs = (C.POINTER(C.c_float) * B)(*[_fp(a) for a in arrs])
@@ -173,7 +184,7 @@ class Engine:
             if want_logits:
                 out.logits = _fp(dummy)
                 out.logits_cap = 1
-            rc = self._lib.pf_recognize(self._h, ptrs, ns, B, None, 0, C.byref(out))
+            rc = self._lib.pf_recognize(self._h, ptrs, ns, B, hp, hn, C.byref(out))
             return 0 if (want_logits and rc == N.PF_ERR_CAPACITY) else rc
         return self._collect(call, B, want_logits)
 
@@ -185,6 +196,11 @@ class Engine:
         ns = (C.c_int64 * B)(*[a.shape[0] for a in arrs])
         N.check(self._lib.pf_stage_audio(self._h, ptrs, ns, B))
         self._staged_B = B
+
+    def set_hotwords(self, hotwords):
+        """SeACo hotword ids [N,10] for the following run_staged() calls."""
+        hp, hn, _keep = self._hw(hotwords)
+        N.check(self._lib.pf_engine_set_hotwords(self._h, hp, hn))
 
     def run_staged(self):
         N.check(self._lib.pf_run_staged(self._h))

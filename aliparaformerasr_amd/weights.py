@@ -37,6 +37,9 @@ DEFAULT_CONFIG = dict(
     seaco=False, use_itn=False,
     # BiCIF timestamp head (CifPredictorV3): ConvTranspose1d x3 upsample -> BiLSTM -> Linear(1024,1)
     cif_smooth2=0.25, cif_noise2=0.01, upsample=3,
+    # SeACo (kind "seacoparaformer", seaco=True): hotword embedder Embedding + LSTM(512) x seaco_lstm_layers,
+    # bias decoder = SAN-M decoder without input/output layer attending bias_embed, hotword_output_layer
+    seaco_layers=4, seaco_ffn=1024, seaco_kernel=21, seaco_lstm_layers=2, seaco_nobias=8377,
 )
 
 
@@ -51,6 +54,12 @@ def make_config(**kw) -> dict:
 
 def paraformer_large_config(**kw) -> dict:
     return make_config(**kw)
+
+
+def seaco_paraformer_config(**kw) -> dict:
+    base = dict(kind="seacoparaformer", seaco=True, timestamp_head=True)
+    base.update(kw)
+    return make_config(**base)
 
 
 def sensevoice_small_config(**kw) -> dict:
@@ -149,6 +158,33 @@ def synth_weights(cfg: dict, seed: int = 42) -> dict:
     w.update(_linear(rng, D, F, bias=False, prefix=p + ".ffn.w2"))
     w.update(_ln(rng, D, "decoder.after_norm"))
     w.update(_linear(rng, V, D, prefix="decoder.output"))
+    if cfg.get("seaco"):
+        Fs, Ks = cfg["seaco_ffn"], cfg["seaco_kernel"]
+        w["seaco.embed.weight"] = (0.5 * rng.standard_normal((V, D), dtype=np.float32)).astype(np.float32)
+        for l in range(cfg["seaco_lstm_layers"]):
+            for nm in ("weight_ih", "weight_hh"):
+                w["seaco.lstm.l%d.%s" % (l, nm)] = (rng.standard_normal((4 * D, D), dtype=np.float32) / np.float32(np.sqrt(D))).astype(np.float32)
+            for nm in ("bias_ih", "bias_hh"):
+                w["seaco.lstm.l%d.%s" % (l, nm)] = (0.1 * rng.standard_normal(4 * D, dtype=np.float32)).astype(np.float32)
+        for i in range(cfg["seaco_layers"]):
+            p = f"seaco.decoder.layers.{i}"
+            w.update(_ln(rng, D, p + ".norm1"))
+            w.update(_linear(rng, Fs, D, prefix=p + ".ffn.w1"))
+            w.update(_ln(rng, Fs, p + ".ffn.norm"))
+            w.update(_linear(rng, D, Fs, bias=False, prefix=p + ".ffn.w2"))
+            w.update(_ln(rng, D, p + ".norm2"))
+            w[p + ".fsmn.weight"] = (0.1 * rng.standard_normal((D, Ks), dtype=np.float32)).astype(np.float32)
+            w.update(_ln(rng, D, p + ".norm3"))
+            w.update(_linear(rng, D, D, prefix=p + ".src.q"))
+            w.update(_linear(rng, 2 * D, D, prefix=p + ".src.kv"))
+            w.update(_linear(rng, D, D, prefix=p + ".src.out"))
+        p = "seaco.decoder.final"
+        w.update(_ln(rng, D, p + ".norm1"))
+        w.update(_linear(rng, Fs, D, prefix=p + ".ffn.w1"))
+        w.update(_ln(rng, Fs, p + ".ffn.norm"))
+        w.update(_linear(rng, D, Fs, bias=False, prefix=p + ".ffn.w2"))
+        w.update(_ln(rng, D, "seaco.decoder.after_norm"))
+        w.update(_linear(rng, V, D, prefix="seaco.output"))
     return w
 
 

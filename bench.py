@@ -90,8 +90,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed step with per-class kernel times")
-    ap.add_argument("--model", choices=("paraformer", "sensevoice"), default="paraformer",
-                    help="sensevoice = BASELINE.json configs[2] (sensevoice-small, 64 x 10 s, use_itn on); not the headline config")
+    ap.add_argument("--model", choices=("paraformer", "sensevoice", "seaco"), default="paraformer",
+                    help="sensevoice = BASELINE.json configs[2] (sensevoice-small, 64 x 10 s, use_itn on); seaco = configs[4] "
+                         "(SeACo bias decoder + 20 hotwords + BiCIF timestamps); neither is the headline config")
     ap.add_argument("--seconds", type=int, default=0, help="utterance length (default 30; 10 for --model sensevoice)")
     ap.add_argument("--timestamp-head", action="store_true",
                     help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
@@ -124,6 +125,9 @@ def main():
         cfg = W.sensevoice_small_config(use_itn=True)
         if args.batch == BATCH_PER_GPU:
             args.batch = 64
+    elif args.model == "seaco":
+        cfg = W.seaco_paraformer_config()
+        args.timestamp_head = True
     else:
         cfg = W.paraformer_large_config(timestamp_head=bool(args.timestamp_head))
     cmvn = W.synth_cmvn()
@@ -145,6 +149,10 @@ def main():
     B = args.batch
     audio = [W.synth_audio(samples, rank * B + u) for u in range(B)]
     eng.stage_audio(audio)
+    if args.model == "seaco":                                 # N = 20 hotwords of 2-4 ids + the [1] terminator
+        hrng = np.random.default_rng(99)
+        hws = [list(hrng.integers(3, 8000, size=int(hrng.integers(2, 5)))) for _ in range(20)] + [[1]]
+        eng.set_hotwords(np.asarray([h[:10] + [0] * (10 - len(h)) for h in hws], np.int32))
     gathered = {}
 
     def step():
@@ -190,7 +198,8 @@ def main():
         breakdown = {}
         for cls in ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
                     "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn1", "gemm_dec_ffn2",
-                    "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc"):
+                    "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc",
+                    "seaco_embed", "gemm_seaco", "attn_seaco", "seaco_merge"):
             ms, cnt, fpl = eng.profile_get(cls)
             breakdown[cls] = {"ms": round(ms, 4), "launches": cnt,
                               "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
@@ -208,7 +217,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "%s offline%s, batch %dx%d s synthetic 16 kHz per GPU "
                                    "(BASELINE.json configs[%d]), seeded synthetic weights"
-                                   % ("sensevoice-small (use_itn on)" if sv else "paraformer-large-zh",
+                                   % ("sensevoice-small (use_itn on)" if sv else ("SeACo-paraformer, 21 hotwords" if args.model == "seaco" else "paraformer-large-zh"),
                                       " + BiCIF timestamp head" if args.timestamp_head else "", B, seconds,
                                       2 if sv else (4 if args.timestamp_head else 1)),
                        "global_batch": world * B, "samples_per_utt": samples, "T_lfr": eng.num_frames(samples), "L": int(res.L),

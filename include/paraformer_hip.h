@@ -159,6 +159,9 @@ int pf_recognize(pf_engine* e, const float* const* samples, const int64_t* n_sam
    resident in HBM: stage (H2D) -> run (device only, async on the engine stream) ->
    fetch (D2H of ids). */
 int pf_stage_audio(pf_engine* e, const float* const* samples, const int64_t* n_samples, int32_t B);
+/* SeACo: hotword ids [n_hotwords, 10] (PadList output, EmbedSeacoModel.cs:70-123) used by the following
+   pf_run_staged calls (the other forward entry points take them per call); ignored by other model kinds. */
+int pf_engine_set_hotwords(pf_engine* e, const int32_t* hotwords, int32_t n_hotwords);
 int pf_run_staged(pf_engine* e);      /* enqueues the whole pipeline, returns after the CIF
                                          length read-back (the path's only host sync)          */
 int pf_sync(pf_engine* e);            /* waits for the engine stream                           */

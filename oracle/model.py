@@ -55,6 +55,11 @@ class ModelConfig:
     cif_smooth2: float = 0.25
     cif_noise2: float = 0.01
     upsample: int = 3
+    seaco_layers: int = 4
+    seaco_ffn: int = 1024
+    seaco_kernel: int = 21
+    seaco_lstm_layers: int = 2
+    seaco_nobias: int = 8377
 
     def to_dict(self):
         return dict(self.__dict__)
@@ -289,32 +294,93 @@ class Oracle:
         h = self.ln(h, p + ".ffn.norm")
         return self.lin(h, p + ".ffn.w2", bias=False)
 
-    def decoder(self, E, H, token_num):
-        """E [B,L,512] acoustic embeds, H [B,T,512] memory, token_num [B] -> logits [B,L,V]
-        (log_softmax applied, as the ONNX graph does)."""
+    def _sanm_decoder(self, x, memory, token_num, prefix, n_layers, kernel):
+        """ParaformerSANMDecoder body shared by the ASR decoder (memory = encoder output) and the SeACo bias
+        decoder (wo_input_layer, memory = bias_embed): n_layers x [FFNdec -> FSMN(k) -> cross-attention],
+        then decoders3 (FFNdec, no residual) and after_norm.  Returns the hidden [B,L,D]."""
         c = self.cfg
         q = self.q
-        x = torch.as_tensor(E, dtype=torch.float32)
-        H = torch.as_tensor(H, dtype=torch.float32)
+        x = torch.as_tensor(x, dtype=torch.float32)
+        memory = torch.as_tensor(memory, dtype=torch.float32)
         B, L, D = x.shape
         tn = torch.as_tensor(np.asarray(token_num), dtype=torch.int64)
         mask = (torch.arange(L)[None, :] < tn[:, None]).to(torch.float32).unsqueeze(-1)  # [B,L,1]
         dk = D // c.heads
-        for i in range(c.dec_layers):
-            p = f"decoder.layers.{i}"
+        for i in range(n_layers):
+            p = f"{prefix}.layers.{i}"
             t = self.ffn_dec(self.ln(x, p + ".norm1"), p)
             tn2 = self.ln(t, p + ".norm2")
-            x = x + fsmn(tn2, self.w[p + ".fsmn.weight"], c.kernel, mask)
+            x = x + fsmn(tn2, self.w[p + ".fsmn.weight"], kernel, mask)
             xn = self.ln(x, p + ".norm3")
             qq = self.lin(xn, p + ".src.q")
-            kv = self.lin(H, p + ".src.kv")
+            kv = self.lin(memory, p + ".src.kv")
             k, v = torch.split(kv, D, dim=-1)
             ctx = mha(q(qq * (dk ** -0.5)), q(k), q(v), c.heads)
             x = x + self.lin(ctx, p + ".src.out")
-        x = self.ffn_dec(self.ln(x, "decoder.final.norm1"), "decoder.final")
-        x = self.ln(x, "decoder.after_norm")
-        logits = self.lin(x, "decoder.output")
-        return torch.log_softmax(logits, dim=-1)
+        x = self.ffn_dec(self.ln(x, prefix + ".final.norm1"), prefix + ".final")
+        return self.ln(x, prefix + ".after_norm")
+
+    def decoder(self, E, H, token_num, return_hidden=False):
+        """E [B,L,512] acoustic embeds, H [B,T,512] memory, token_num [B] -> logits [B,L,V]
+        (log_softmax applied, as the ONNX graph does)."""
+        hid = self._sanm_decoder(E, H, token_num, "decoder", self.cfg.dec_layers, self.cfg.kernel)
+        logp = torch.log_softmax(self.lin(hid, "decoder.output"), dim=-1)
+        return (logp, hid) if return_hidden else logp
+
+    # -- SeACo ---------------------------------------------------------------
+    def seaco_embed(self, hotwords):
+        """model_eb (ContextualEmbedderExport of the FunASR export, external to /root/reference; call site
+        AliParaformerAsr/EmbedSeacoModel.cs:70-123): hotword int [N,10] -> Embedding -> LSTM (time-major,
+        no length masking: pad id 0 is embedded like any token) -> ALL 10 outputs, hw_embed [10, N, D]."""
+        c = self.cfg
+        q = self.q
+        ids = torch.as_tensor(np.asarray(hotwords, dtype=np.int64))
+        x = self.w["seaco.embed.weight"][ids]                      # [N,10,D]
+        N, J, D = x.shape
+        for l in range(c.seaco_lstm_layers):
+            Wih = q(self.w["seaco.lstm.l%d.weight_ih" % l]); Whh = q(self.w["seaco.lstm.l%d.weight_hh" % l])
+            bias = self.w["seaco.lstm.l%d.bias_ih" % l] + self.w["seaco.lstm.l%d.bias_hh" % l]
+            xg = torch.matmul(q(x), Wih.t()) + bias
+            h = torch.zeros(N, D); cst = torch.zeros(N, D)
+            outs = []
+            for t in range(J):
+                g = xg[:, t] + torch.matmul(q(h), Whh.t())
+                i_, f_, g_, o_ = torch.split(g, D, dim=-1)
+                cst = torch.sigmoid(f_) * cst + torch.sigmoid(i_) * torch.tanh(g_)
+                h = torch.sigmoid(o_) * torch.tanh(cst)
+                outs.append(h)
+            x = torch.stack(outs, dim=1)                            # [N,10,D]
+        return x.transpose(0, 1).contiguous()                       # [10,N,D]
+
+    def seaco(self, speech, hotwords):
+        """SeACo-paraformer graph (export_forward of the FunASR SeACo export; reference call site
+        AliParaformerAsr/OfflineProjOfSeacoParaformer.cs:48-135).  hotwords: int [N,10] (PadList output).
+        ASR branch as paraformer(); bias branch: the bias decoder is run on the CIF embeds AND on the ASR
+        decoder hidden, both attending bias_embed; merged -> hotword_output_layer -> log_softmax (dha);
+        where argmax(dha) == NO_BIAS the ASR log-probs are kept, elsewhere the dha log-probs replace them
+        (seaco_weight = 1)."""
+        c = self.cfg
+        H = self.encoder(speech)
+        a = self.cif_alphas(H)
+        E, counts, tnum = self.cif_fire(H.numpy(), a.numpy(), c.cif_threshold)
+        logp, hid = self.decoder(E, H, tnum, return_hidden=True)
+        out = {"token_num": tnum, "fire_count": counts, "asr_logits": logp.numpy()}
+        hw = np.asarray(hotwords)
+        if hw.shape[0] > 0:
+            B = H.shape[0]
+            hw_embed = self.seaco_embed(hw)                         # [10,N,D]
+            J, N, D = hw_embed.shape
+            bias = hw_embed.transpose(0, 1).reshape(1, N * J, D).expand(B, N * J, D)   # row n*10+j (EmbedSeacoModel / :83-111)
+            cif_att = self._sanm_decoder(E, bias, tnum, "seaco.decoder", c.seaco_layers, c.seaco_kernel)
+            dec_att = self._sanm_decoder(hid, bias, tnum, "seaco.decoder", c.seaco_layers, c.seaco_kernel)
+            dha = torch.log_softmax(self.lin(cif_att + dec_att, "seaco.output"), dim=-1)
+            nobias = (torch.argmax(dha, dim=-1) == c.seaco_nobias).unsqueeze(-1)
+            logp = torch.where(nobias, logp, dha)
+            out["dha_logits"] = dha.numpy()
+        out["logits"] = logp.numpy()
+        if c.timestamp_head:
+            out["us_alphas"], out["us_cif_peak"] = self.us_alphas_peak(H, tnum)
+        return out
 
     # -- full graphs ---------------------------------------------------------
     def paraformer(self, speech):
