@@ -20,9 +20,11 @@ What it restates (reference = manyeyes/AliParaformerAsr, paths relative to
   (``AliParaformerAsr/AliParaformerAsr.csproj:49-50``).  Neither package nor any
   model file is present, and the reference's tests hold no numeric vectors, so
   for this part the oracle restates the *published* algorithms (kaldi fbank,
-  FunASR SANMEncoder / CifPredictorV2 / ParaformerSANMDecoder export code).
+  FunASR SANMEncoder / CifPredictorV2 / ParaformerSANMDecoder export code, the
+  CifPredictorV3 BiCIF timestamp head, the SeACo hotword embedder / bias decoder /
+  NO-BIAS merge).
 
 PARITY UNPINNED for the model arithmetic (encoder / predictor / decoder /
-fbank): there is no runnable reference and no golden vector for it.  The glue
+BiCIF head / SeACo branch / fbank): there is no runnable reference and no golden vector for it.  The glue
 functions are pinned.
 """

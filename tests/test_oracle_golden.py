@@ -181,3 +181,31 @@ def test_bicif_head_properties():
     ids = om.argmax_last(r["logits"])
     ts = glue.time_stamp_lfr6_onnx(r["us_cif_peak"][0], ids[0])
     assert all(len(t) == 2 and t[1] >= t[0] for t in ts)
+
+
+def test_seaco_oracle_merge_properties():
+    """SeACo restatement (parity unpinned): rows whose hotword distribution peaks at NO-BIAS keep the ASR
+    log-probs bit-for-bit, all other rows carry the hotword log-probs; without hotwords the ASR branch is
+    returned; bias_embed row order follows the pinned KAT (row n*10+j = hw_embed[j,n])."""
+    import numpy as np
+    from aliparaformerasr_amd import weights as W
+    from oracle import frontend as fe, model as om, glue
+    cfg = W.seaco_paraformer_config(enc_layers=1, dec_layers=1, vocab=64, seaco_layers=1, seaco_nobias=60, timestamp_head=False)
+    w = W.synth_weights(cfg, 13)
+    w["predictor.out.bias"] = np.asarray([0.0], np.float32)
+    w["seaco.output.bias"][60] += 4.0           # calibrated: ~2/3 of the 16 positions pick NO-BIAS
+    cmvn = W.synth_cmvn()
+    sp = fe.pad_sequence([fe.wav_frontend(W.synth_audio(48000, 3), fe.FrontendConf(dither=0.0), *cmvn)]).reshape(1, -1, 560)
+    orc = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32")
+    hw = np.asarray(glue.pad_list([[4, 5], [7, 8, 9], [1]]), np.int64)
+    r = orc.seaco(sp, hw)
+    nob = np.argmax(r["dha_logits"], -1) == 60
+    assert nob.any() and (~nob).any()
+    assert np.array_equal(r["logits"][nob], r["asr_logits"][nob])
+    assert np.array_equal(r["logits"][~nob], r["dha_logits"][~nob])
+    r0 = orc.seaco(sp, np.zeros((0, 10), np.int64))
+    assert np.array_equal(r0["logits"], r0["asr_logits"])
+    emb = orc.seaco_embed(hw).numpy()
+    assert emb.shape == (10, 3, 512)
+    be = glue.bias_embed(emb, 2)
+    assert be.shape == (2, 30, 512) and np.array_equal(be[1, 1 * 10 + 4], emb[4, 1])
