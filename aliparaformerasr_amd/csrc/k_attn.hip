@@ -104,14 +104,35 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
   auto stage_k = [&](int buf, int kt) __attribute__((always_inline)) {
     char* kl = smem + buf * ATT_TILE_BYTES;
     const char* kg = reinterpret_cast<const char*>(kb_ + (int64_t)kt * ATT_BK * p.k_rs);
+    if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) att_glds16(kg + k_src[i], kl + (wave * 4 + i) * 1024);
+      for (int i = 0; i < 4; ++i) att_glds16(kg + k_src[i], kl + (wave * 4 + i) * 1024);
+    } else {
+      // tail tile: rows >= Lk are re-reads of row Lk-1.  They are masked out of the softmax anyway, but
+      // what lies behind the last key in memory is not ours (another utterance, or stale workspace bytes
+      // of another dtype, i.e. possibly NaN/Inf bit patterns) and 0 * NaN would poison the P V product.
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + srow;
+        const int rc = min(kt * ATT_BK + row, p.Lk - 1) - kt * ATT_BK;
+        att_glds16(kg + (int64_t)rc * p.k_rs * 2 + ((schunk ^ (row & 15)) << 4), kl + (wave * 4 + i) * 1024);
+      }
+    }
   };
   auto stage_v = [&](int buf, int kt) __attribute__((always_inline)) {
     char* vl = smem + (2 + buf) * ATT_TILE_BYTES;
     const char* vg = reinterpret_cast<const char*>(vb + (int64_t)kt * ATT_BK * p.v_rs);
+    if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) att_glds16(vg + v_src[i], vl + (wave * 4 + i) * 1024);
+      for (int i = 0; i < 4; ++i) att_glds16(vg + v_src[i], vl + (wave * 4 + i) * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + srow;
+        const int rc = min(kt * ATT_BK + row, p.Lk - 1) - kt * ATT_BK;
+        att_glds16(vg + (int64_t)rc * p.v_rs * 2 + ((schunk ^ ((row & 3) << 2)) << 4), vl + (wave * 4 + i) * 1024);
+      }
+    }
   };
 
   // ---- per-lane LDS read addresses, hoisted (buffer / key-block / row-group parts are immediates)

@@ -25,70 +25,70 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #ifndef FS_ROWS
 #define FS_ROWS 8
 #endif
+// FS_CH channels per thread (8 -> one 16-byte f16 load per row, 4 -> 8-byte loads but half the registers
+// and twice the threads in flight; selected at build time, see tools/fsmn_rows.sh)
+#ifndef FS_CH
+#define FS_CH 4
+#endif
 template <int K>
 __global__ __launch_bounds__(256) void fsmn_enc_kernel(const half_t* __restrict__ v, int ldv,
                                                        const float* __restrict__ wT, int B, int T, int D,
                                                        float* __restrict__ f) {
-  constexpr int FS_MAXK = K;
-  const int cq = D >> 3;
+  constexpr int C = FS_CH;
+  typedef _Float16 hC __attribute__((ext_vector_type(C)));
+  const int cq = D / C;
   const int tb = (T + FS_ROWS - 1) / FS_ROWS;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * tb * cq;
   if (i >= total) return;
-  const int c8 = (int)(i % cq) * 8;
+  const int c0 = (int)(i % cq) * C;
   const int64_t r = i / cq;
   const int t0 = (int)(r % tb) * FS_ROWS;
   const int b = (int)(r / tb);
   constexpr int left = (K - 1) / 2;
-  const half_t* vb = v + (int64_t)b * T * ldv + c8;
-  float w[FS_MAXK][8];
+  const half_t* vb = v + (int64_t)b * T * ldv + c0;
+  float w[K][C];
 #pragma unroll
-  for (int j = 0; j < FS_MAXK; ++j) {
-    if (j < K) {
-      const float4 w0 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8);
-      const float4 w1 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c8 + 4);
-      w[j][0] = w0.x; w[j][1] = w0.y; w[j][2] = w0.z; w[j][3] = w0.w;
-      w[j][4] = w1.x; w[j][5] = w1.y; w[j][6] = w1.z; w[j][7] = w1.w;
-    } else {
+  for (int j = 0; j < K; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) w[j][e] = 0.f;
+    for (int e = 0; e < C; e += 4) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c0 + e);
+      w[j][e] = w0.x; w[j][e + 1] = w0.y; w[j][e + 2] = w0.z; w[j][e + 3] = w0.w;
     }
-  }
-  float acc[FS_ROWS][8];
+  float acc[FS_ROWS][C];
 #pragma unroll
   for (int q = 0; q < FS_ROWS; ++q)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+    for (int e = 0; e < C; ++e) acc[q][e] = 0.f;
   // input row tt = t0 - left + s contributes to output row q = s - j (tap j) for 0 <= q < FS_ROWS
 #pragma unroll
-  for (int s = 0; s < FS_ROWS + FS_MAXK - 1; ++s) {
+  for (int s = 0; s < FS_ROWS + K - 1; ++s) {
     const int tt = t0 - left + s;
-    if (s >= FS_ROWS + K - 1) break;
     if (tt < 0 || tt >= T) continue;
-    const h8 x = *reinterpret_cast<const h8*>(vb + (int64_t)tt * ldv);
-    float xf[8];
+    const hC x = *reinterpret_cast<const hC*>(vb + (int64_t)tt * ldv);
+    float xf[C];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xf[e] = (float)x[e];
+    for (int e = 0; e < C; ++e) xf[e] = (float)x[e];
 #pragma unroll
-    for (int j = 0; j < FS_MAXK; ++j) {
+    for (int j = 0; j < K; ++j) {
       const int q = s - j;
-      if (q >= 0 && q < FS_ROWS && j < K) {
+      if (q >= 0 && q < FS_ROWS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[q][e] += w[j][e] * xf[e];
+        for (int e = 0; e < C; ++e) acc[q][e] += w[j][e] * xf[e];
       }
     }
     const int q0 = s - left;                      // identity term
     if (q0 >= 0 && q0 < FS_ROWS) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[q0][e] += xf[e];
+      for (int e = 0; e < C; ++e) acc[q0][e] += xf[e];
     }
   }
 #pragma unroll
   for (int q = 0; q < FS_ROWS; ++q) {
     if (t0 + q < T) {
-      float4* o = reinterpret_cast<float4*>(f + ((int64_t)b * T + t0 + q) * D + c8);
-      o[0] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
-      o[1] = make_float4(acc[q][4], acc[q][5], acc[q][6], acc[q][7]);
+      float4* o = reinterpret_cast<float4*>(f + ((int64_t)b * T + t0 + q) * D + c0);
+#pragma unroll
+      for (int e = 0; e < C; e += 4) o[e / 4] = make_float4(acc[q][e], acc[q][e + 1], acc[q][e + 2], acc[q][e + 3]);
     }
   }
 }
@@ -97,7 +97,7 @@ void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* wT, i
                      float* f) {
 
   const int tb = (T + FS_ROWS - 1) / FS_ROWS;
-  const int64_t total = (int64_t)B * tb * (D / 8);
+  const int64_t total = (int64_t)B * tb * (D / FS_CH);
   if (total == 0) return;
   const dim3 grid((unsigned)((total + 255) / 256));
   switch (k) {

@@ -303,6 +303,8 @@ class Oracle:
         x = torch.as_tensor(x, dtype=torch.float32)
         memory = torch.as_tensor(memory, dtype=torch.float32)
         B, L, D = x.shape
+        if L == 0:                                   # no CIF fire at all: nothing to decode
+            return x
         tn = torch.as_tensor(np.asarray(token_num), dtype=torch.int64)
         mask = (torch.arange(L)[None, :] < tn[:, None]).to(torch.float32).unsqueeze(-1)  # [B,L,1]
         dk = D // c.heads

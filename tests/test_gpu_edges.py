@@ -1,0 +1,114 @@
+"""GPU: edge cases of the offline path — shapes the headline benchmark never visits."""
+import numpy as np
+import pytest
+
+from aliparaformerasr_amd import weights as W
+from oracle import frontend as fe
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+
+
+def _speech(audio, cmvn):
+    conf = fe.FrontendConf(dither=0.0)
+    feats = [fe.wav_frontend(a, conf, cmvn[0], cmvn[1]) for a in audio]
+    T = max(f.shape[0] for f in feats)
+    return fe.pad_sequence(feats).reshape(len(audio), T, 560)
+
+
+def _cmp(res, ref, tol=TOL):
+    assert res.logits.shape == ref["logits"].shape
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    err = np.abs(res.logits - ref["logits"]).max() if ref["logits"].size else 0.0
+    assert err < tol, err
+
+
+@pytest.fixture(scope="module")
+def small():
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=200)
+    w = W.synth_weights(cfg, seed=31)
+    w["predictor.out.bias"] = np.asarray([-0.4], np.float32)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    orc = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16")
+    yield eng, orc, cfg, w, cmvn
+    eng.close()
+
+
+def test_very_ragged_batch_with_all_pad_row(small):
+    """0.5 s next to 6 s: most rows of the short utterance are PadSequence sentinel rows (LayerNorm on
+    |x| ~ 1.7e7); an utterance shorter than one LFR frame contributes only sentinel rows."""
+    eng, orc, cfg, w, cmvn = small
+    audio = [W.synth_audio(n, 500 + u) for u, n in enumerate((96000, 8000, 700, 51000))]
+    speech = _speech(audio, cmvn)
+    assert speech.shape[1] == 100 and fe.wav_frontend(audio[2], fe.FrontendConf(dither=0.0), *cmvn).shape[0] == 0
+    ref = orc.paraformer(speech)
+    res = eng.recognize(audio, want_logits=True)
+    _cmp(res, ref)
+
+
+def test_single_frame_and_tiny_inputs(small):
+    eng, orc, cfg, w, cmvn = small
+    for n in (960, 1100, 3000):                       # T = 1, 1, 3 LFR frames
+        a = [W.synth_audio(n, 600 + n)]
+        speech = _speech(a, cmvn)
+        ref = orc.paraformer(speech)
+        res = eng.recognize(a, want_logits=True)
+        assert res.L == ref["logits"].shape[1]
+        _cmp(res, ref)
+
+
+def test_audio_shorter_than_one_lfr_frame_is_an_error(small):
+    from aliparaformerasr_amd._native import PfError
+    eng = small[0]
+    with pytest.raises(PfError):
+        eng.recognize([W.synth_audio(500, 1)])
+
+
+def test_long_utterance_many_key_tiles(small):
+    """60 s: T = 1000 -> 8 query tiles x 16 key tiles per head; decoder L ~ 180."""
+    eng, orc, cfg, w, cmvn = small
+    a = [W.synth_audio(960000, 77)]
+    speech = _speech(a, cmvn)
+    assert speech.shape[1] == 1000
+    ref = orc.paraformer(speech)
+    res = eng.recognize(a, want_logits=True)
+    _cmp(res, ref, 3e-2)
+
+
+def test_no_fire_gives_empty_hypotheses():
+    """alphas ~ 0 everywhere: sum = tail threshold 0.45 < 1 -> token_num = 0, L = 0, no decoder launch."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=64)
+    w = W.synth_weights(cfg, seed=8)
+    w["predictor.out.bias"] = np.asarray([-30.0], np.float32)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    res = eng.recognize([W.synth_audio(16000, 1), W.synth_audio(12000, 2)])
+    assert res.L == 0 and res.token_ids.shape == (2, 0) and list(res.token_num) == [0, 0]
+    eng.close()
+
+
+def test_timestamp_head_batch_larger_than_one_lstm_tile():
+    """B = 40 > 32: the BiLSTM step kernel runs two utterance tiles; peaks against the oracle."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=64, timestamp_head=True)
+    w = W.synth_weights(cfg, seed=12)
+    w["predictor.out.bias"] = np.asarray([0.0], np.float32)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    audio = [W.synth_audio(9600, 800 + u) for u in range(40)]
+    speech = _speech(audio, cmvn)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").paraformer(speech)
+    res = eng.recognize(audio)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    d = np.abs(res.cif_peak - ref["us_cif_peak"])
+    d = np.minimum(d, np.abs(d - 0.9999))
+    assert np.quantile(d, 0.99) < 2e-2
+    for b in (0, 31, 32, 39):
+        f_dev = np.nonzero(res.cif_peak[b] > 1 - 1e-4)[0]
+        f_ref = np.nonzero(ref["us_cif_peak"][b] > 1 - 1e-4)[0]
+        assert len(f_dev) == len(f_ref) and np.all(np.abs(f_dev - f_ref) <= 1)
+    eng.close()
