@@ -55,10 +55,10 @@ __device__ __forceinline__ void att_glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// Software pipeline (per wave, tile kt):   S(kt+1) = K(kt+1) Q^T  is ISSUED first (the matrix pipe
-// works through it in the background), then the softmax arithmetic of S(kt) runs on the vector
-// ALU, then O^T += V(kt)^T P(kt)^T.  K and V are double buffered separately (K(kt+2) and V(kt+1)
-// are in flight during iteration kt), one workgroup barrier per tile.
+// Per wave and tile kt: S(kt) = K(kt) Q^T, softmax arithmetic, O^T += V(kt)^T P(kt)^T.  K and V are
+// double buffered (tile kt+1 is in flight during tile kt), one workgroup barrier per tile.  (Issuing
+// S(kt+1) ahead of the softmax of S(kt) was tried: +32 VGPRs, no gain — the two workgroups per CU already
+// interleave their phases.)
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -113,9 +113,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
       // of another dtype, i.e. possibly NaN/Inf bit patterns) and 0 * NaN would poison the P V product.
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 4 + srow;
-        const int rc = min(kt * ATT_BK + row, p.Lk - 1) - kt * ATT_BK;
-        att_glds16(kg + (int64_t)rc * p.k_rs * 2 + ((schunk ^ (row & 15)) << 4), kl + (wave * 4 + i) * 1024);
+        const int over = kt * ATT_BK + (wave * 4 + i) * 4 + srow - (p.Lk - 1);     // rows to step back
+        att_glds16(kg + (k_src[i] - (unsigned)((over > 0 ? over : 0) * p.k_rs * 2)), kl + (wave * 4 + i) * 1024);
       }
     }
   };
@@ -128,9 +127,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 4 + srow;
-        const int rc = min(kt * ATT_BK + row, p.Lk - 1) - kt * ATT_BK;
-        att_glds16(vg + (int64_t)rc * p.v_rs * 2 + ((schunk ^ ((row & 3) << 2)) << 4), vl + (wave * 4 + i) * 1024);
+        const int over = kt * ATT_BK + (wave * 4 + i) * 4 + srow - (p.Lk - 1);
+        att_glds16(vg + (v_src[i] - (unsigned)((over > 0 ? over : 0) * p.v_rs * 2)), vl + (wave * 4 + i) * 1024);
       }
     }
   };
@@ -203,23 +201,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
     }                                                                                                      \
   }
 
-  f16x s_cur[2], s_nxt[2];
+  f16x s_cur[2];
 
-  // one tile: BUF = kt & 1 (compile time).  K(kt+1) sits in K buffer BUF^1, V(kt) in V buffer BUF.
+  // one tile: BUF = kt & 1 (compile time): K(kt) and V(kt) sit in the K / V buffers BUF.
   auto tile = [&](int kt, auto BUFC) __attribute__((always_inline)) {
     constexpr int BUF = decltype(BUFC)::value;
     constexpr int VB = (2 + BUF) * ATT_TILE_BYTES;
-    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));          // vmcnt(0): K(kt+1), V(kt) pieces of this wave landed
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));          // vmcnt(0): K(kt), V(kt) pieces of this wave landed
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // ... everybody's; K buffer BUF and V buffer BUF^1 are free
+    __builtin_amdgcn_s_barrier();                                   // ... everybody's; the buffers BUF^1 are free
     asm volatile("" ::: "memory");
     if (!(ATT_ABL & 8)) {
-      if (kt + 2 < nkt) stage_k(BUF, kt + 2);
-      if (kt + 1 < nkt) stage_v(BUF ^ 1, kt + 1);
+      if (kt + 1 < nkt) { stage_k(BUF ^ 1, kt + 1); stage_v(BUF ^ 1, kt + 1); }
     }
-
-    // ---- issue S(kt+1): the MFMAs execute under the softmax arithmetic below
-    if (!(ATT_ABL & 4)) { if (kt + 1 < nkt) qk(att_ic<BUF ^ 1>{}, s_nxt); }
+    if (!(ATT_ABL & 4)) qk(att_ic<BUF>{}, s_cur);
 
     // first V^T fragments (d block 0)
     fp4 va[8], vb2[8];
@@ -294,19 +289,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
 #else
     o_acc[0][0] += (float)pf[0][0][0] + (float)pf[1][1][7] + (float)pf[0][1][3] + (float)pf[1][0][5];
 #endif
-    s_cur[0] = s_nxt[0];
-    s_cur[1] = s_nxt[1];
   };
 
-  // ---- prologue: K(0), V(0), K(1) in flight; S(0)
   stage_k(0, 0);
   stage_v(0, 0);
-  __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (nkt > 1) stage_k(1, 1);
-  qk(att_ic<0>{}, s_cur);
 
   for (int kt = 0; kt < nkt; kt += 2) {
     tile(kt, att_ic<0>{});
