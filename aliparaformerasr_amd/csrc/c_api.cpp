@@ -584,4 +584,54 @@ int pf_decoded_timestamp(pf_decoded* d, int32_t j, const int32_t** ints, int32_t
 }
 void pf_decoded_free(pf_decoded* d) { delete d; }
 
+
+int pf_host_wav_read(const char* path, float* out, int64_t cap, int64_t* n_out, int32_t* sample_rate, int32_t* channels,
+                     double* duration_ms) {
+  PF_TRY
+  NEED(path); NEED(n_out);
+  double dur = 0;
+  int sr = 0, ch = 0;
+  std::vector<float> v;
+  if (!file_exists(path)) {
+    v.assign(1, 0.f);                                   // GetFileSample: new float[1]
+  } else {
+    WavData w = decode_wav_file(path);
+    sr = w.sample_rate; ch = w.channels; dur = w.duration_ms;
+    v = w.sample_rate != 16000 ? resample_linear(w.samples, w.sample_rate, 16000, w.channels) : std::move(w.samples);
+  }
+  *n_out = (int64_t)v.size();
+  if (sample_rate) *sample_rate = sr;
+  if (channels) *channels = ch;
+  if (duration_ms) *duration_ms = dur;
+  if (out) {
+    PF_CHECK(cap >= (int64_t)v.size(), PF_ERR_CAPACITY, "wav_read: output capacity too small");
+    std::memcpy(out, v.data(), v.size() * 4);
+  }
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_host_resample(const float* src, int64_t n, int32_t sr_in, int32_t sr_out, int32_t channels, float* out, int64_t cap,
+                     int64_t* n_out) {
+  PF_TRY
+  NEED(n_out);
+  PF_CHECK(n >= 0 && (n == 0 || src), PF_ERR_INVALID_ARG, "resample: bad arguments");
+  std::vector<float> in(src, src + n);
+  std::vector<float> v = resample_linear(in, sr_in, sr_out, channels);
+  *n_out = (int64_t)v.size();
+  if (out) {
+    PF_CHECK(cap >= (int64_t)v.size(), PF_ERR_CAPACITY, "resample: output capacity too small");
+    std::memcpy(out, v.data(), v.size() * 4);
+  }
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_host_is_audio(const char* path, int32_t* is_audio) {
+  PF_TRY
+  NEED(path); NEED(is_audio);
+  *is_audio = is_wav_header(path) ? 1 : 0;
+  return PF_OK;
+  PF_CATCH
+}
 }  // extern "C"

@@ -1,6 +1,9 @@
 // hostutil.cpp — see hostutil.h
 #include "hostutil.h"
 
+#include <cmath>
+#include <cstring>
+
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -234,6 +237,97 @@ int utf16_length(const std::string& utf8) {
   int n = 0;
   for (uint32_t cp : utf8_decode(utf8)) n += cp >= 0x10000 ? 2 : 1;
   return n;
+}
+
+// ------------------------------------------------------------------ Examples harness -----
+bool is_wav_header(const std::string& path) {
+  std::vector<char> b;
+  if (!file_exists(path)) return false;
+  read_binary_file(path, b);
+  if (b.size() < 16) return false;
+  return std::memcmp(b.data(), "RIFF", 4) == 0 && std::memcmp(b.data() + 8, "WAVE", 4) == 0;
+}
+
+static uint32_t rd32(const char* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+static uint16_t rd16(const char* p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+
+WavData decode_wav_file(const std::string& path) {
+  std::vector<char> b;
+  read_binary_file(path, b);
+  PF_CHECK(b.size() >= 12 && std::memcmp(b.data(), "RIFF", 4) == 0 && std::memcmp(b.data() + 8, "WAVE", 4) == 0,
+           PF_ERR_FORMAT, "not a RIFF/WAVE file: " + path);
+  size_t pos = 12;
+  int fmt_tag = 0, bits = 0, block_align = 0;
+  WavData w;
+  const char* data = nullptr;
+  size_t data_bytes = 0;
+  while (pos + 8 <= b.size()) {
+    const uint32_t sz = rd32(b.data() + pos + 4);
+    const char* body = b.data() + pos + 8;
+    const size_t avail = b.size() - (pos + 8);
+    if (std::memcmp(b.data() + pos, "fmt ", 4) == 0 && sz >= 16 && avail >= 16) {
+      fmt_tag = rd16(body); w.channels = rd16(body + 2); w.sample_rate = (int)rd32(body + 4);
+      block_align = rd16(body + 12); bits = rd16(body + 14);
+      if (fmt_tag == 0xFFFE && sz >= 26 && avail >= 26) fmt_tag = rd16(body + 24);   // WAVE_FORMAT_EXTENSIBLE sub-format
+    } else if (std::memcmp(b.data() + pos, "data", 4) == 0) {
+      data = body; data_bytes = std::min<size_t>(sz, avail);
+      break;
+    }
+    pos += 8 + (size_t)sz + (sz & 1);
+  }
+  PF_CHECK(data && w.channels > 0 && w.sample_rate > 0 && block_align > 0, PF_ERR_FORMAT, "wav: missing fmt/data chunk: " + path);
+  const int bps = bits / 8;
+  PF_CHECK((fmt_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) || (fmt_tag == 3 && bits == 32),
+           PF_ERR_UNSUPPORTED, "wav: unsupported sample format");
+  const size_t n = data_bytes / bps;
+  w.samples.resize(n);
+  const unsigned char* d = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned char* q = d + i * bps;
+    float v;
+    if (fmt_tag == 3) { std::memcpy(&v, q, 4); }
+    else if (bits == 16) { int16_t x; std::memcpy(&x, q, 2); v = x / 32768.0f; }
+    else if (bits == 24) { int32_t x = (int32_t)((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)(int8_t)q[2] << 16)); v = x / 8388608.0f; }
+    else if (bits == 32) { int32_t x; std::memcpy(&x, q, 4); v = x / 2147483648.0f; }
+    else { v = q[0] / 128.0f - 1.0f; }
+    w.samples[i] = v;
+  }
+  w.duration_ms = (double)(data_bytes / block_align) * 1000.0 / w.sample_rate;
+  return w;
+}
+
+std::vector<float> resample_linear(const std::vector<float>& src, int sr_in, int sr_out, int channels) {
+  PF_CHECK(sr_in > 0 && sr_out > 0, PF_ERR_INVALID_ARG, "resample: sample rates must be positive");
+  PF_CHECK(channels == 1 || channels == 2, PF_ERR_INVALID_ARG, "resample: only 1 or 2 channels");
+  if (src.empty()) return {};
+  std::vector<float> mono_buf;
+  const std::vector<float>* mono = &src;
+  if (channels == 2) {
+    mono_buf.resize(src.size() / 2);
+    for (size_t i = 0; i < mono_buf.size(); ++i) mono_buf[i] = (src[2 * i] + src[2 * i + 1]) * 0.5f;
+    mono = &mono_buf;
+  }
+  const std::vector<float>& m = *mono;
+  const double ratio = (double)sr_in / sr_out;
+  const int n_out = (int)std::nearbyint((double)m.size() / ratio);       // Math.Round: half to even
+  std::vector<float> out((size_t)std::max(n_out, 0));
+  const int last = (int)m.size() - 1;
+  for (int i = 0; i < n_out; ++i) {
+    const double pos = i * ratio;
+    const int idx = (int)pos;
+    const double fr = pos - idx;
+    if (idx >= last) { out[i] = m[last < 0 ? 0 : last]; continue; }
+    out[i] = (float)((1 - fr) * m[idx] + fr * m[idx + 1]);
+  }
+  return out;
+}
+
+std::vector<float> get_file_sample(const std::string& path, double* duration_ms) {
+  if (!file_exists(path)) return std::vector<float>(1, 0.f);
+  WavData w = decode_wav_file(path);
+  if (duration_ms) *duration_ms = w.duration_ms;
+  if (w.sample_rate != 16000) return resample_linear(w.samples, w.sample_rate, 16000, w.channels);
+  return w.samples;
 }
 
 }  // namespace pf

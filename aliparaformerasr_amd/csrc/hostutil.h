@@ -38,6 +38,20 @@ ConfEntity load_conf(const std::string& path);
 ConfEntity conf_from_yaml(const std::string& text);
 ConfEntity conf_from_json(const std::string& text);
 
+// ---- Examples harness (AliParaformerAsr.Examples/Utils/AudioHelper.cs) -------------------------------
+// IsAudioByHeader restricted to what this build decodes: RIFF....WAVE in the first 16 bytes (:286-340)
+bool is_wav_header(const std::string& path);
+// AudioFileReader semantics for RIFF/WAVE (NAudio converts every PCM width to IEEE float): interleaved
+// samples, PCM8 -> b/128-1, PCM16 -> /32768, PCM24 -> /8388608, PCM32 -> /2147483648, float32 as is.
+struct WavData { std::vector<float> samples; int sample_rate = 0, channels = 0; double duration_ms = 0; };
+WavData decode_wav_file(const std::string& path);
+// Resample(sourceData, sourceSampleRate, targetSampleRate, sourceChannels) (:223-279): stereo -> mono
+// average first, then linear interpolation in double precision; target length = Round(n / ratio) (banker's)
+std::vector<float> resample_linear(const std::vector<float>& src, int sr_in, int sr_out, int channels);
+// GetFileSample (:12-32): missing file -> float[1]{0}; resampled (and down-mixed) ONLY when the rate is not
+// 16 kHz — a 16 kHz stereo file is handed over interleaved, exactly as upstream does.
+std::vector<float> get_file_sample(const std::string& path, double* duration_ms);
+
 // UTF-8 <-> code points
 std::vector<uint32_t> utf8_decode(const std::string& s);
 std::string utf8_encode(uint32_t cp);

@@ -275,6 +275,18 @@ int pf_decoded_num_timestamps(pf_decoded* d, int32_t* n);
 int pf_decoded_timestamp(pf_decoded* d, int32_t j, const int32_t** ints, int32_t* n_ints);
 void pf_decoded_free(pf_decoded* d);
 
+/* ---- Examples harness helpers (AliParaformerAsr.Examples/Utils/AudioHelper.cs) ---------------------------
+   pf_host_wav_read  = GetFileSample (:12-32) for RIFF/WAVE files: decode to float (NAudio AudioFileReader
+   conversions), resample + down-mix to 16 kHz mono ONLY when the file's rate is not 16 kHz (upstream quirk: a
+   16 kHz stereo file is returned interleaved); a missing file yields one zero sample.  Call with out == NULL to
+   learn *n_out.  pf_host_resample = Resample(source, srIn, srOut, channels) (:223-279).
+   pf_host_is_audio = IsAudioByHeader (:286-340) restricted to RIFF/WAVE. */
+int pf_host_wav_read(const char* path, float* out, int64_t cap, int64_t* n_out, int32_t* sample_rate,
+                     int32_t* channels, double* duration_ms);
+int pf_host_resample(const float* src, int64_t n, int32_t sr_in, int32_t sr_out, int32_t channels, float* out,
+                     int64_t cap, int64_t* n_out);
+int pf_host_is_audio(const char* path, int32_t* is_audio);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,58 @@
+"""GPU: the Examples-harness mirror end to end (wav files -> text lines), `-method one` and `-method batch`."""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+from aliparaformerasr_amd import weights as W
+from oracle import frontend as fe
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_wav(path, x, sr, ch=1):
+    pcm = np.clip(np.round(np.asarray(x) * 32768.0), -32768, 32767).astype("<i2")
+    payload = pcm.tobytes()
+    align = 2 * ch
+    path.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " +
+                     struct.pack("<IHHIIHH", 16, 1, ch, sr, sr * align, align, 16) + b"data" + struct.pack("<I", len(payload)) + payload)
+
+
+def test_cli_one_and_batch(tmp_path):
+    from aliparaformerasr_amd import examples as ex
+    from aliparaformerasr_amd.offline_recognizer import OfflineRecognizer
+    d = tmp_path / "toy-model"
+    d.mkdir()
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=1, vocab=150, timestamp_head=True)
+    w = W.synth_weights(cfg, 44)
+    w["predictor.out.bias"] = np.asarray([0.0], np.float32)
+    W.save_pfw(str(d / "model.pfw"), cfg, w)
+    cmvn = W.synth_cmvn()
+    (d / "am.mvn").write_text(fe.format_mvn_text(*cmvn))
+    toks = ["<blank>", "<s>", "</s>"] + [chr(0x4E00 + 5 * i) for i in range(146)] + ["<unk>"]
+    (d / "tokens.txt").write_text("\n".join(toks) + "\n", encoding="utf-8")
+    (d / "asr.yaml").write_text("model: paraformer\nfrontend_conf:\n  dither: 0.0\n")
+    _write_wav(d / "a.wav", W.synth_audio(32000, 1), 16000)
+    x44 = W.synth_audio(66150, 2)
+    _write_wav(d / "b.wav", np.stack([x44, x44 * 0.5], 1).reshape(-1), 44100, ch=2)     # resampled + down-mixed
+    (d / "notes.wav").write_bytes(b"this is not a wav file, skipped by IsAudioByHeader")
+    outs = {}
+    for method in ("one", "batch"):
+        buf = io.StringIO()
+        res = ex.offline_recognizer(method, "toy-model", "int8", 2, None, str(tmp_path), out=buf)
+        text = buf.getvalue()
+        assert len(res) == 2 and "init_models_elapsed_milliseconds:" in text and text.rstrip().endswith("end!")
+        assert "rtf:" in text and "total_duration_milliseconds:3500" in text        # 2.0 s + 1.5 s
+        assert text.count('{"text": "') == 2 and "notes.wav" not in text
+        outs[method] = [(r.Text, r.Tokens, r.Timestamps) for r in res]
+    # direct use of the recognizer on the same samples gives the same entities
+    rec = OfflineRecognizer(str(d / "model.pfw"), str(d / "asr.yaml"), str(d / "am.mvn"), str(d / "tokens.txt"))
+    for i, name in enumerate(("a.wav", "b.wav")):
+        s, _dur = ex.get_file_sample(str(d / name))
+        st = rec.CreateOfflineStream()
+        st.AddSamples(s)
+        r = rec.GetResult(st)
+        assert (r.Text, r.Tokens, r.Timestamps) == outs["one"][i]
+        assert len(r.Timestamps) == len(r.Tokens) > 0
+    rec.Dispose()

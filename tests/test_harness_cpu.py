@@ -1,0 +1,129 @@
+"""CPU: Examples-harness helpers — native wav decode / resampler
+(pf_host_wav_read, pf_host_resample) against the oracle restatement of
+AliParaformerAsr.Examples/Utils/AudioHelper.cs and hand-evaluated answers."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from aliparaformerasr_amd import _native as N
+from oracle import audio as oa
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return N.load()
+
+
+def _wav(path, sr, ch, bits, data, tag=1):
+    if bits == 16:
+        payload = np.asarray(data, "<i2").tobytes()
+    elif bits == 8:
+        payload = np.asarray(data, np.uint8).tobytes()
+    elif bits == 24:
+        payload = b"".join(struct.pack("<i", int(v))[:3] for v in data)
+    elif tag == 3:
+        payload = np.asarray(data, "<f4").tobytes()
+    else:
+        payload = np.asarray(data, "<i4").tobytes()
+    align = ch * bits // 8
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, tag, ch, sr, sr * align, align, bits)
+    blob = hdr + b"LIST" + struct.pack("<I", 4) + b"abcd" + b"data" + struct.pack("<I", len(payload)) + payload
+    path.write_bytes(blob)
+    return blob
+
+
+def _read(lib, path):
+    n = C.c_int64(); sr = C.c_int32(); ch = C.c_int32(); dur = C.c_double()
+    N.check(lib.pf_host_wav_read(str(path).encode(), None, 0, n, sr, ch, dur))
+    out = np.zeros(max(n.value, 1), np.float32)
+    N.check(lib.pf_host_wav_read(str(path).encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, n, sr, ch, dur))
+    return out[: n.value], sr.value, ch.value, dur.value
+
+
+def _resample(lib, x, sr_in, sr_out, ch):
+    x = np.ascontiguousarray(x, np.float32)
+    n = C.c_int64()
+    N.check(lib.pf_host_resample(x.ctypes.data_as(C.POINTER(C.c_float)), x.size, sr_in, sr_out, ch, None, 0, n))
+    out = np.zeros(max(n.value, 1), np.float32)
+    N.check(lib.pf_host_resample(x.ctypes.data_as(C.POINTER(C.c_float)), x.size, sr_in, sr_out, ch, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, n))
+    return out[: n.value]
+
+
+def test_resample_known_answers(lib):
+    # 32 kHz -> 16 kHz of a ramp: ratio 2, every second sample
+    assert list(_resample(lib, [0, 1, 2, 3, 4, 5], 32000, 16000, 1)) == [0, 2, 4]
+    # 8 kHz -> 16 kHz: ratio 0.5, midpoints interpolated, last positions clamp to the final sample (:266-270)
+    assert list(_resample(lib, [0, 1, 2], 8000, 16000, 1)) == [0, 0.5, 1, 1.5, 2, 2]
+    # stereo -> mono average first (:245-255), odd trailing value ignored
+    assert list(_resample(lib, [1, 3, 2, 4, 9], 16000, 16000, 2)) == [2, 3]
+    # Math.Round half-to-even on the target length: 5 samples at ratio 2 -> Round(2.5) = 2
+    assert _resample(lib, [0, 1, 2, 3, 4], 32000, 16000, 1).size == 2
+    assert _resample(lib, [], 8000, 16000, 1).size == 0
+
+
+def test_resample_matches_oracle_bit_exact(lib):
+    rng = np.random.default_rng(3)
+    for sr_in, ch, n in ((44100, 1, 4411), (48000, 2, 9601), (8000, 1, 803), (22050, 2, 3000), (11025, 1, 1)):
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        got = _resample(lib, x, sr_in, 16000, ch)
+        ref = oa.resample(x, sr_in, 16000, ch)
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_wav_decode_formats(lib, tmp_path):
+    rng = np.random.default_rng(4)
+    cases = [
+        ("p16.wav", 16000, 1, 16, 1, rng.integers(-32768, 32767, 400)),
+        ("p16s.wav", 16000, 2, 16, 1, rng.integers(-32768, 32767, 800)),   # 16 kHz stereo stays interleaved (upstream quirk)
+        ("p24.wav", 44100, 1, 24, 1, rng.integers(-(1 << 23), (1 << 23) - 1, 4410)),
+        ("p32.wav", 8000, 2, 32, 1, rng.integers(-(1 << 31), (1 << 31) - 1, 1600)),
+        ("p8.wav", 22050, 1, 8, 1, rng.integers(0, 255, 2205)),
+        ("f32.wav", 48000, 2, 32, 3, rng.uniform(-1, 1, 9600)),
+    ]
+    for name, sr, ch, bits, tag, data in cases:
+        blob = _wav(tmp_path / name, sr, ch, bits, data, tag)
+        got, gsr, gch, gdur = _read(lib, tmp_path / name)
+        ref, rdur = oa.get_file_sample(blob)
+        assert (gsr, gch) == (sr, ch)
+        assert abs(gdur - rdur) < 1e-9
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    # hand-evaluated PCM16 values
+    _wav(tmp_path / "k.wav", 16000, 1, 16, [0, 16384, -32768, 32767])
+    got, *_ = _read(lib, tmp_path / "k.wav")
+    assert list(got) == [0.0, 0.5, -1.0, np.float32(32767 / 32768)]
+    # missing file -> one zero sample (GetFileSample returns new float[1])
+    got, sr, ch, dur = _read(lib, tmp_path / "missing.wav")
+    assert list(got) == [0.0] and dur == 0.0
+
+
+def test_is_audio_by_header(lib, tmp_path):
+    _wav(tmp_path / "a.wav", 16000, 1, 16, [1, 2, 3, 4, 5, 6, 7, 8])
+    (tmp_path / "b.txt").write_bytes(b"hello, this is not audio at all")
+    (tmp_path / "c.wav").write_bytes(b"RIFF")
+    for name, exp in (("a.wav", 1), ("b.txt", 0), ("c.wav", 0), ("nope.wav", 0)):
+        v = C.c_int32(-1)
+        N.check(lib.pf_host_is_audio(str(tmp_path / name).encode(), v))
+        assert v.value == exp
+
+
+def test_cli_argument_parsing_and_file_selection(tmp_path):
+    from aliparaformerasr_amd import examples as ex
+    cfg = ex.parse_args(["-type", "offline", "-method", "batch", "-base", "/b", "-model", "m", "-threads", "4", "-files", "a.wav", '"b c.wav"', "-accuracy", "fp32"])
+    assert cfg == dict(modelBasePath="/b", recognizerType="offline", methodType="batch", modelName="m", modelAccuracy="fp32",
+                       threads=4, files=["a.wav", "b c.wav"])
+    with pytest.raises(ValueError, match="Unknown parameters"):
+        ex.parse_args(["-type", "offline", "-bogus"])
+    with pytest.raises(ValueError, match="recognizer type"):
+        ex.parse_args(["-method", "one"])
+    d = tmp_path / "m"
+    d.mkdir()
+    for f in ("model.pfw", "model.int8.pfw", "model_eb.int8.pfw", "asr.json", "asr.yaml", "am.mvn", "tokens.txt", "hotword.txt", "readme.md"):
+        (d / f).write_text("x")
+    sel = ex.select_model_files(str(tmp_path), "m", "int8")
+    assert sel["modelFilePath"].endswith("model.int8.pfw") and sel["modelebFilePath"].endswith("model_eb.int8.pfw")
+    assert sel["configFilePath"].endswith("asr.yaml") and sel["mvnFilePath"].endswith("am.mvn")
+    assert sel["tokensFilePath"].endswith("tokens.txt") and sel["hotwordFilePath"].endswith("hotword.txt")
+    assert ex.select_model_files(str(tmp_path), "m", "fp16")["modelFilePath"].endswith("model.pfw")
+    assert ex.select_model_files(str(tmp_path), "absent", "int8") is None
