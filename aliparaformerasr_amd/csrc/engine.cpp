@@ -67,6 +67,7 @@ Engine::Engine(const pf_engine_config& cfg) {
 Engine::~Engine() {
   hipSetDevice(device_);
   if (stream_) hipStreamSynchronize(stream_);
+  if (lstm_graph_exec_) hipGraphExecDestroy(lstm_graph_exec_);
   profile_reset();
   fbank_tables_destroy(fb_);
   for (void* p : owned_) hipFree(p);
@@ -1000,7 +1001,19 @@ void Engine::timestamp_head(int B, int T) {
   PF_HIP(hipMemsetAsync(cs, 0, (size_t)2 * B * D * 4, stream_));
   LstmArgs a{};
   a.whh = ts_whh_; a.xg = xg; a.hstate = hs; a.cstate = cs; a.hout = hout; a.B = B; a.T3 = T3; a.D = D; a.ndir = 2;
-  for (int s = 0; s < T3; ++s) { a.step = s; launch_lstm_step(stream_, a); }
+  // the 3T dependent launches are a launch-bound inner loop: captured once per (shape, workspace) into a
+  // hipGraph and replayed (the state memsets above stay outside; every node's arguments are frozen)
+  if (!lstm_graph_exec_ || lstm_graph_key_.xg != xg || lstm_graph_key_.B != B || lstm_graph_key_.T3 != T3) {
+    if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
+    hipGraph_t g = nullptr;
+    PF_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    for (int s = 0; s < T3; ++s) { a.step = s; launch_lstm_step(stream_, a); }
+    PF_HIP(hipStreamEndCapture(stream_, &g));
+    PF_HIP(hipGraphInstantiate(&lstm_graph_exec_, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    lstm_graph_key_.xg = xg; lstm_graph_key_.B = B; lstm_graph_key_.T3 = T3;
+  }
+  PF_HIP(hipGraphLaunch(lstm_graph_exec_, stream_));
   prof_end("lstm");
   prof_begin("ts_misc", 0);
   launch_us_alpha(stream_, hout, M3, 2 * D, ts_out_w_, ts_out_b_, mc_.cif_smooth2, mc_.cif_noise2, al);

@@ -175,6 +175,8 @@ class Engine {
   float* fsm_ = nullptr; half_t* h16_ = nullptr; float* H32_ = nullptr; half_t* H16_ = nullptr;
   float* alphas_ = nullptr; CifPlan plan_{};
   float* us_peak_ = nullptr;
+  struct { const float* xg = nullptr; int B = 0, T3 = 0; } lstm_graph_key_;
+  hipGraphExec_t lstm_graph_exec_ = nullptr;
   // decoder views
   float* logits_ = nullptr; int64_t* ids_dev_ = nullptr; int logits_ld_ = 0;
   // staged audio
