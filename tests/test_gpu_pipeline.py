@@ -113,3 +113,51 @@ def test_determinism_and_batch_independence():
         Lp = part.L
         np.testing.assert_allclose(part.logits[:, :min(L, Lp)], a.logits[sl, :min(L, Lp)], atol=2e-3)
     eng.close()
+
+
+def test_full_depth_sensevoice_small():
+    """sensevoice-small geometry (50 + 20 blocks, CTC over 25055 tokens), audio in, query rows prepended on the
+    device: error accumulation through 70 layers vs the oracle with the same / without 16-bit rounding points."""
+    from oracle import glue
+    cfg = W.sensevoice_small_config(use_itn=True)
+    eng, w, cmvn = _make(cfg, 42)
+    audio = [W.synth_audio(n, 30 + u) for u, n in enumerate((48000, 40000))]
+    conf = fe.FrontendConf(dither=0.0)
+    feats = [glue.sensevoice_prepend(fe.wav_frontend(a, conf, *cmvn), w["embed.weight"], use_itn=True) for a in audio]
+    T = max(f.shape[0] for f in feats)
+    speech = fe.pad_sequence(feats).reshape(len(audio), T, 560)
+    res = eng.recognize(audio, want_logits=True)
+    mc = om.ModelConfig(**cfg)
+    for quant, tol in (("fp16", TOL_Q), ("fp32", TOL_F)):
+        ref = om.Oracle(mc, w, quant=quant).sensevoice(speech)
+        assert res.logits.shape == ref["logits"].shape == (2, T, 25055)
+        err = np.abs(res.logits - ref["logits"])
+        assert err.max() < tol, (quant, err.max())
+        srt = np.sort(ref["logits"], axis=-1)
+        safe = (srt[..., -1] - srt[..., -2]) > 2 * tol
+        np.testing.assert_array_equal(res.token_ids[safe], om.argmax_last(ref["logits"])[safe])
+    eng.close()
+
+
+def test_full_depth_seaco_with_timestamps():
+    """configs[4] geometry: paraformer-large + BiCIF head + SeACo bias decoder (4 layers, FFN 1024, k = 21) and the
+    hotword embedder, one 5 s utterance, 6 hotwords."""
+    from oracle import glue
+    cfg = W.seaco_paraformer_config()
+    eng, w, cmvn = _make(cfg, 42)
+    audio = [W.synth_audio(80000, 3)]
+    speech = _speech(audio, cmvn)
+    hw = np.asarray(glue.pad_list([[11, 12], [100, 200, 300], [4000, 4001, 4002, 4003], [7, 8], [9], [1]]), np.int32)
+    res = eng.recognize(audio, want_logits=True, hotwords=hw)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").seaco(speech, hw)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    dha = ref["dha_logits"]
+    nb = cfg["seaco_nobias"]
+    other = np.where(np.arange(dha.shape[-1])[None, None, :] == nb, -np.inf, dha).max(-1)
+    clear = np.abs(dha[..., nb] - other) > 0.05                # the NO-BIAS decision is not a near-tie
+    err = np.abs(res.logits - ref["logits"]).max(-1)
+    assert err[clear].max() < 3e-2, err[clear].max()
+    d = np.abs(res.cif_peak - ref["us_cif_peak"])
+    d = np.minimum(d, np.abs(d - 0.9999))
+    assert np.quantile(d, 0.99) < 2e-2
+    eng.close()
