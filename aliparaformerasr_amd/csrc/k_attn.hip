@@ -236,12 +236,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
     // against the running max m_run, which is the same in both half-waves of a query and is only
     // raised (slow path, wave-uniform) when some lane's tile max exceeds it by more than 2^8; the
     // two half-wave partial sums are combined once, after the last tile.
-    float mloc = s_cur[0][0];
+    // four independent max chains (one dependent chain of 32 costs ~8 cycles of latency per link)
+    float mx[4] = {s_cur[0][0], s_cur[0][1], s_cur[1][0], s_cur[1][1]};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mloc = fmaxf(mloc, s_cur[kb][e]);
-    mloc *= LOG2E;
+    for (int e = 2; e < 16; e += 2) {
+      mx[0] = fmaxf(mx[0], s_cur[0][e]); mx[1] = fmaxf(mx[1], s_cur[0][e + 1]);
+      mx[2] = fmaxf(mx[2], s_cur[1][e]); mx[3] = fmaxf(mx[3], s_cur[1][e + 1]);
+    }
+    float mloc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])) * LOG2E;
     if (!(ATT_ABL & 16) && __any(mloc > m_run + 8.0f)) {
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float m_new = fmaxf(m_run, mloc);
@@ -253,13 +255,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) o_acc[d][e] *= alpha;
     }
-    f2 psum2 = {0.f, 0.f};
+    f2 psum4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};       // independent partial sums
     const f2 l2 = {LOG2E, LOG2E}, nm2 = {-m_run, -m_run};
     h8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
+        f2& psum2 = psum4[(kb * 8 + e / 2) & 3];
         f2 t = {s_cur[kb][e], s_cur[kb][e + 1]};
         t = t * l2 + nm2;
 #if ATT_ABL & 1
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
         pf[kb][e >> 3][e & 7] = (half_t)pv.x;
         pf[kb][e >> 3][(e & 7) + 1] = (half_t)pv.y;
       }
-    l_run += psum2.x + psum2.y;
+    const f2 ps = (psum4[0] + psum4[1]) + (psum4[2] + psum4[3]);
+    l_run += ps.x + ps.y;
 
     // ---- O^T += V^T P^T : fragments of d block db+1 are requested before the MFMAs of block db
 #if !(ATT_ABL & 2)
