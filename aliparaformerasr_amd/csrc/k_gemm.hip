@@ -32,12 +32,14 @@
 //    (read from a 256-byte LDS line that is itself fetched a tile ahead by LDS-DMA), so at tile
 //    end the conversion is only [q-scale] [ReLU] cvt_pk into 32 packed registers and the
 //    accumulators are free again at once.  The packed tile is then transposed through a
-//    2 KiB/wave LDS scratch 8 rows at a time, one pass per following LOAD phase (under the
+//    2 KiB/wave LDS scratch 8 rows at a time, one pass per following k-step (slotted into the wave's own burst, under the
 //    partner group's MFMAs), and stored as whole 128-byte lines after that step's own MFMAs.
 //    Output rows are padded (GemmArgs::out_padded) so no store is ever predicated off and the
 //    store count enters the vmcnt immediates exactly (vmcnt is in-order on gfx9).
 //    (Double-buffered accumulators were tried instead: 128 + 64 fragment VGPRs spill.)
-//  * fp32 results (+ residual, + FSMN add): direct 16-byte vector I/O at tile end.
+//  * fp32 results (+ residual, + FSMN add): at tile end, 4 rows at a time through the same scratch so that
+//    residual loads and stores are whole row segments (lds_epilogue32); edge tiles use direct 16-byte I/O.
+//  * Two kernel kinds (f16-only / fp32) x two tile heights (256 / 128 rows, MI = 2 / 1) are instantiated.
 #include "kernels.h"
 
 #include <cstdlib>
