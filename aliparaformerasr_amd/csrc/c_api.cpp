@@ -115,6 +115,7 @@ int pf_forward_feats(pf_engine* h, const float* speech, int32_t B, int32_t Tmax,
   std::lock_guard<std::mutex> lk(e->mutex());
   if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
   e->forward_feats_host(speech, B, Tmax, want_logits(out));
+  e->publish_thread_result();
   e->fetch(out);
   return PF_OK;
   PF_CATCH
@@ -128,6 +129,7 @@ int pf_model_proj(pf_engine* h, const float* const* speech, const int32_t* lens,
   std::lock_guard<std::mutex> lk(e->mutex());
   if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
   e->model_proj_host(speech, lens, B, want_logits(out));
+  e->publish_thread_result();
   e->fetch(out);
   return PF_OK;
   PF_CATCH
@@ -142,6 +144,7 @@ int pf_recognize(pf_engine* h, const float* const* samples, const int64_t* n, in
   if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
   e->stage_audio(samples, n, B);
   e->run_staged(want_logits(out));
+  e->publish_thread_result();
   e->fetch(out);
   return PF_OK;
   PF_CATCH
@@ -171,6 +174,7 @@ int pf_run_staged(pf_engine* h) {
   PF_TRY
   Engine* e = E(h);
   std::lock_guard<std::mutex> lk(e->mutex());
+  e->drop_thread_result();               // pf_fetch after this call reads the engine's staged result
   e->run_staged(false);
   return PF_OK;
   PF_CATCH

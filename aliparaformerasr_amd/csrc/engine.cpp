@@ -1106,29 +1106,51 @@ void Engine::model_proj_host(const float* const* speech, const int32_t* n_floats
   forward_device((const float*)ws_speech_.p, B, T, want_logits);
 }
 
+void Engine::publish_thread_result() {
+  PF_HIP(hipStreamSynchronize(stream_));
+  HostBatchOut& sl = slots_[std::this_thread::get_id()];
+  sl = last_;
+  sl.has_logits = last_logits_;
+  sl.logits.clear();
+  const int64_t need = (int64_t)last_.B * last_.L * last_.V;
+  if (last_logits_ && need > 0) {
+    sl.logits.resize((size_t)need);
+    PF_HIP(hipMemcpy2D(sl.logits.data(), (size_t)last_.V * 4, logits_, (size_t)logits_ld_ * 4, (size_t)last_.V * 4,
+                       (size_t)last_.B * last_.L, hipMemcpyDeviceToHost));
+  }
+}
+
+void Engine::drop_thread_result() { slots_.erase(std::this_thread::get_id()); }
+
 void Engine::fetch(pf_batch_out* out) {
   PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");
   PF_HIP(hipStreamSynchronize(stream_));
-  const int B = last_.B, L = last_.L, V = last_.V;
-  out->L = L; out->V = V; out->cif_peak_len = last_.peak_len;
-  if (out->cif_peak && out->cif_peak_cap > 0 && last_.peak_len > 0) {
-    PF_CHECK(out->cif_peak_cap >= (int64_t)last_.cif_peak.size(), PF_ERR_CAPACITY, "cif_peak capacity < B*3T");
-    std::memcpy(out->cif_peak, last_.cif_peak.data(), last_.cif_peak.size() * 4);
+  auto it = slots_.find(std::this_thread::get_id());
+  const bool slot = it != slots_.end();
+  const HostBatchOut& r = slot ? it->second : last_;
+  const int B = r.B, L = r.L, V = r.V;
+  out->L = L; out->V = V; out->cif_peak_len = r.peak_len;
+  if (out->cif_peak && out->cif_peak_cap > 0 && r.peak_len > 0) {
+    PF_CHECK(out->cif_peak_cap >= (int64_t)r.cif_peak.size(), PF_ERR_CAPACITY, "cif_peak capacity < B*3T");
+    std::memcpy(out->cif_peak, r.cif_peak.data(), r.cif_peak.size() * 4);
   }
   if (out->token_ids) {
     PF_CHECK(out->l_cap >= L, PF_ERR_CAPACITY, "token_ids capacity " + std::to_string(out->l_cap) + " < L = " + std::to_string(L));
     for (int b = 0; b < B; ++b) {
-      std::memcpy(out->token_ids + (size_t)b * out->l_cap, last_.ids.data() + (size_t)b * L, (size_t)L * 8);
+      std::memcpy(out->token_ids + (size_t)b * out->l_cap, r.ids.data() + (size_t)b * L, (size_t)L * 8);
     }
   }
-  if (out->token_num) std::memcpy(out->token_num, last_.token_num.data(), (size_t)B * 4);
+  if (out->token_num) std::memcpy(out->token_num, r.token_num.data(), (size_t)B * 4);
   if (out->logits && out->logits_cap > 0) {
-    PF_CHECK(last_logits_, PF_ERR_INVALID_ARG, "logits were not requested for the last forward");
+    PF_CHECK(slot ? r.has_logits : last_logits_, PF_ERR_INVALID_ARG, "logits were not requested for the last forward");
     const int64_t need = (int64_t)B * L * V;
     PF_CHECK(out->logits_cap >= need, PF_ERR_CAPACITY, "logits capacity < B*L*V = " + std::to_string(need));
-    if (need > 0)
-      PF_HIP(hipMemcpy2D(out->logits, (size_t)V * 4, logits_, (size_t)logits_ld_ * 4, (size_t)V * 4, (size_t)B * L,
-                         hipMemcpyDeviceToHost));
+    if (need > 0) {
+      if (slot) std::memcpy(out->logits, r.logits.data(), (size_t)need * 4);
+      else
+        PF_HIP(hipMemcpy2D(out->logits, (size_t)V * 4, logits_, (size_t)logits_ld_ * 4, (size_t)V * 4, (size_t)B * L,
+                           hipMemcpyDeviceToHost));
+    }
   }
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,8 @@ struct HostBatchOut { // results of the last forward, host side
   std::vector<int32_t> fire_count; // [B]
   std::vector<float> cif_peak;     // [B, peak_len] us_cif_peak (timestamp models), else empty
   int peak_len = 0;
+  std::vector<float> logits;       // [B, L, V] host copy (per-thread result slots only)
+  bool has_logits = false;
 };
 
 class Engine {
@@ -74,6 +77,12 @@ class Engine {
   void stage_audio(const float* const* samples, const int64_t* n, int B);
   void run_staged(bool want_logits);
   void fetch(pf_batch_out* out);
+  // Results are kept per CALLING THREAD: a forward entry point (pf_forward_feats / pf_model_proj / pf_recognize)
+  // publishes its outcome into the caller's slot, and pf_fetch from the same thread reads that slot, so the
+  // two-call protocol (learn L, then fetch into right-sized buffers) is safe with concurrent callers on one
+  // engine.  The staged API (pf_stage_audio / pf_run_staged) is engine state and single-caller by contract.
+  void publish_thread_result();
+  void drop_thread_result();
   void sync();
   // SeACo: hotword ids [n, 10] (PadList output, EmbedSeacoModel.cs:70-123) used by the following forwards;
   // n = 0 -> bias_embed [B,0,512]: the bias branch is skipped and the ASR log-probs are returned
@@ -183,6 +192,7 @@ class Engine {
   std::vector<int64_t> st_n_; std::vector<int32_t> st_t80_; int st_B_ = 0, st_T_ = 0;
   int64_t st_total_frames_ = 0;
   HostBatchOut last_;
+  std::map<std::thread::id, HostBatchOut> slots_;
   bool last_logits_ = false;
   double last_flops_ = 0;
 

@@ -307,6 +307,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
         for (int j = 0; j < 10; ++j) pad.push_back(j < (int)w.size() ? w[j] : 0);
       e->set_hotwords(pad.data(), (int)hw.size());
     }
+    e->drop_thread_result();              // this call's result is read back under the same lock, not from a slot
     e->model_proj_host(ptrs.data(), lens.data(), B, false);
     pf_batch_out out;
     std::memset(&out, 0, sizeof(out));

@@ -165,6 +165,11 @@ int pf_engine_set_hotwords(pf_engine* e, const int32_t* hotwords, int32_t n_hotw
 int pf_run_staged(pf_engine* e);      /* enqueues the whole pipeline, returns after the CIF
                                          length read-back (the path's only host sync)          */
 int pf_sync(pf_engine* e);            /* waits for the engine stream                           */
+/* Copies the results of the calling THREAD's last pf_forward_feats / pf_model_proj / pf_recognize (kept per
+   thread, so the two-call protocol — first call learns L and V, pf_fetch fills right-sized buffers — is safe
+   with concurrent callers on one engine; calls themselves are serialised by an internal mutex, like the
+   reference's static lock, OfflineStream.cs:19).  After pf_run_staged it returns the staged result (the
+   staged API is engine state: one caller at a time). */
 int pf_fetch(pf_engine* e, pf_batch_out* out);
 
 /* Per-kernel-class device time, measured with HIP events on the engine stream while

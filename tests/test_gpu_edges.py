@@ -112,3 +112,30 @@ def test_timestamp_head_batch_larger_than_one_lstm_tile():
         f_ref = np.nonzero(ref["us_cif_peak"][b] > 1 - 1e-4)[0]
         assert len(f_dev) == len(f_ref) and np.all(np.abs(f_dev - f_ref) <= 1)
     eng.close()
+
+
+def test_concurrent_callers_on_one_engine_are_serialised(small):
+    """The reference serialises AddSamples with a static lock and allows concurrent GetResults
+    (OfflineStream.cs:19; SURVEY 8b 'Threading'): calls on one handle from several threads must be safe and
+    give the single-threaded answers."""
+    import threading
+    eng = small[0]
+    audios = [[W.synth_audio(20000 + 3000 * k, 900 + k), W.synth_audio(9000 + 500 * k, 950 + k)] for k in range(4)]
+    expect = [eng.recognize(a, want_logits=True) for a in audios]
+    got = [None] * 4
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = eng.recognize(audios[k], want_logits=True)
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in range(4):
+        assert np.array_equal(got[k].token_ids, expect[k].token_ids)
+        assert np.array_equal(got[k].logits, expect[k].logits)
