@@ -209,3 +209,48 @@ def test_seaco_oracle_merge_properties():
     assert emb.shape == (10, 3, 512)
     be = glue.bias_embed(emb, 2)
     assert be.shape == (2, 30, 512) and np.array_equal(be[1, 1 * 10 + 4], emb[4, 1])
+
+
+def test_oracle_lstm_and_transposed_conv_match_torch_modules():
+    """The BiCIF head and the SeACo embedder are FunASR modules built from torch.nn.LSTM / ConvTranspose1d; the
+    oracle spells their arithmetic out by hand (so that the 16-bit rounding points can be injected).  Here the
+    hand-written forms are checked against the torch modules themselves in fp32: gate order i,f,g,o, both biases,
+    reverse direction, multi-layer stacking, time-major output, stride-3 transposed convolution."""
+    import numpy as np
+    import torch
+    from aliparaformerasr_amd import weights as W
+    from oracle import model as om
+    torch.manual_seed(0)
+    cfg = W.seaco_paraformer_config(enc_layers=1, dec_layers=1, vocab=40, seaco_layers=1)
+    w = W.synth_weights(cfg, 17)
+    orc = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32")
+    D = 512
+    # --- SeACo embedder: Embedding -> nn.LSTM(D, D, 2) fed time-major
+    hw = np.asarray([[3, 4, 5, 0, 0, 0, 0, 0, 0, 0], [9, 8, 7, 6, 5, 4, 3, 2, 1, 11], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.int64)
+    lstm = torch.nn.LSTM(D, D, 2)
+    with torch.no_grad():
+        for l in range(2):
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                getattr(lstm, "%s_l%d" % (nm, l)).copy_(torch.as_tensor(w["seaco.lstm.l%d.%s" % (l, nm)]))
+        x = torch.as_tensor(w["seaco.embed.weight"])[torch.as_tensor(hw)].transpose(0, 1)          # [10, N, D]
+        ref, _ = lstm(x)
+    got = orc.seaco_embed(hw)
+    assert got.shape == ref.shape and torch.allclose(got, ref, atol=2e-5, rtol=1e-4)
+    # --- BiCIF: ConvTranspose1d(D, D, 3, 3) -> bidirectional nn.LSTM(D, D) -> Linear(2D, 1) ...
+    H = torch.randn(2, 7, D)
+    tnum = np.asarray([3, 2])
+    up = torch.nn.ConvTranspose1d(D, D, 3, 3)
+    bl = torch.nn.LSTM(D, D, 1, batch_first=True, bidirectional=True)
+    with torch.no_grad():
+        up.weight.copy_(torch.as_tensor(w["predictor.upsample.weight"])); up.bias.copy_(torch.as_tensor(w["predictor.upsample.bias"]))
+        for sfx in ("", "_reverse"):
+            for nm in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                getattr(bl, "%s_l0%s" % (nm, sfx)).copy_(torch.as_tensor(w["predictor.blstm.%s%s" % (nm, sfx)]))
+        y = up(H.transpose(1, 2)).transpose(1, 2)                                   # [B, 3T, D]
+        hcat, _ = bl(y)
+        z = (hcat @ torch.as_tensor(w["predictor.out2.weight"]).t()).squeeze(-1) + torch.as_tensor(w["predictor.out2.bias"])
+        a2 = torch.relu(torch.sigmoid(z) * 0.25 - 0.01).numpy()
+    a2 = a2 * (tnum / a2.sum(1))[:, None]
+    us_alphas, us_peak = orc.us_alphas_peak(H, tnum)
+    assert np.allclose(us_alphas, a2, atol=2e-6, rtol=2e-4)
+    assert us_peak.shape == (2, 21) and np.all(np.diff(np.nonzero(us_peak[0] > 1 - 1e-4)[0]) > 0)
