@@ -254,3 +254,36 @@ def test_oracle_lstm_and_transposed_conv_match_torch_modules():
     us_alphas, us_peak = orc.us_alphas_peak(H, tnum)
     assert np.allclose(us_alphas, a2, atol=2e-6, rtol=2e-4)
     assert us_peak.shape == (2, 21) and np.all(np.diff(np.nonzero(us_peak[0] > 1 - 1e-4)[0]) > 0)
+
+
+def test_oracle_building_blocks_match_independent_forms():
+    """layer_norm / mha / fsmn / sinusoidal_pe of the oracle against independent formulations
+    (torch.nn.functional and explicit loops) in fp32."""
+    import math
+    import numpy as np
+    import torch
+    import torch.nn.functional as Fn
+    from oracle import model as om
+    torch.manual_seed(1)
+    x = torch.randn(3, 9, 512) * 3 + 0.7
+    g, b = torch.randn(512), torch.randn(512)
+    assert torch.allclose(om.layer_norm(x, g, b), Fn.layer_norm(x, (512,), g, b, eps=1e-12), atol=3e-5, rtol=1e-5)
+    q, k, v = torch.randn(2, 7, 512), torch.randn(2, 11, 512), torch.randn(2, 11, 512)
+    ref = Fn.scaled_dot_product_attention(q.view(2, 7, 4, 128).transpose(1, 2), k.view(2, 11, 4, 128).transpose(1, 2),
+                                          v.view(2, 11, 4, 128).transpose(1, 2), scale=1.0).transpose(1, 2).reshape(2, 7, 512)
+    assert torch.allclose(om.mha(q, k, v, 4), ref, atol=2e-5, rtol=1e-4)
+    # FSMN: y[t] = v[t] + sum_j w[:, j] * v[t + j - 5]  (zero outside), masked variant multiplies inputs and output... inputs only
+    vv, w = torch.randn(2, 13, 512), torch.randn(512, 11) * 0.1
+    exp = vv.clone()
+    for t in range(13):
+        for j in range(11):
+            tt = t + j - 5
+            if 0 <= tt < 13:
+                exp[:, t] += w[:, j] * vv[:, tt]
+    assert torch.allclose(om.fsmn(vv, w, 11), exp, atol=1e-5)
+    # SinusoidalPositionEncoder (FunASR): positions 1..T, inv_ts[i] = exp(-i * ln(1e4) / (depth/2 - 1)), [sin | cos]
+    pe = om.sinusoidal_pe(6, 560).numpy()
+    inc = math.log(10000.0) / (280 - 1)
+    inv = np.exp(np.arange(280) * -inc)
+    pos = np.arange(1, 7)[:, None] * inv[None, :]
+    assert np.allclose(pe, np.concatenate([np.sin(pos), np.cos(pos)], 1), atol=1e-5)
