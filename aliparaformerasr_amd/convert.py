@@ -13,6 +13,8 @@ mismatch with a real file fails loudly instead of producing a silently wrong mod
 
     python -m aliparaformerasr_amd.convert model.pt out.pfw [--kind paraformer|seacoparaformer|sensevoicesmall]
                                                            [--timestamp]
+    python -m aliparaformerasr_amd.convert model.int8.onnx out.pfw [--eb model_eb.int8.onnx] [--kind ...]
+        (ONNX graph walk, see onnx_to_state_dict; int8 files are de-quantised)
 """
 from __future__ import annotations
 
@@ -144,17 +146,140 @@ def state_dict_to_pfw(sd: dict, cfg: dict) -> dict:
     return out
 
 
+# ------------------------------------------------------------------ ONNX ingestion ---------
+_LSTM_IOFC_TO_IFGO = (0, 2, 3, 1)      # ONNX LSTM gate blocks are i,o,f,c; PyTorch (and the engine) use i,f,g(=c),o
+
+
+def _reorder_gates(a, H):
+    blocks = [a[k * H:(k + 1) * H] for k in range(4)]
+    return np.concatenate([blocks[k] for k in _LSTM_IOFC_TO_IFGO], axis=0)
+
+
+def onnx_to_state_dict(graph, expected_names) -> dict:
+    """Initializers of a FunASR ONNX export -> {FunASR parameter name: float32 array}.
+
+    * `X_quantized` + `X_scale` + `X_zero_point` (onnxruntime quantize_dynamic naming) are de-quantised to X —
+      the int8 files are therefore run with their de-quantised weights in the f16 path, not with ORT's dynamic
+      int8 activation arithmetic.
+    * torch.onnx exports nn.Linear on 3-D inputs as MatMul(x, W^T) with an anonymous initializer followed by
+      Add(bias): the weight is named after the bias it feeds; the bias-free decoder `feed_forward.w_2` is named
+      after the `feed_forward.norm` LayerNorm that produces its input.
+    * LSTM nodes carry W/R/B in ONNX layout [dirs, 4H, ...] with gate order i,o,f,c: split per direction, gates
+      re-ordered; bidirectional -> predictor.blstm (BiCIF), unidirectional -> bias_encoder layers in graph order.
+    * names are matched on suffixes against `expected_names` (export wrappers prepend / insert module names).
+    Unvalidated against a real export (none exists in the build image); everything unmatched is ignored here and
+    reported by state_dict_to_pfw as missing."""
+    ini = dict(graph.initializers)
+    flt = {}
+    for name, arr in ini.items():
+        if name.endswith("_quantized") and (name[:-10] + "_scale") in ini:
+            base = name[:-10]
+            scale = np.asarray(ini[base + "_scale"], np.float32)
+            zp = np.asarray(ini.get(base + "_zero_point", 0)).astype(np.float32)
+            flt[base] = ((arr.astype(np.float32) - zp) * scale).astype(np.float32)
+        elif arr.dtype in (np.float32, np.float16, np.float64) and not name.endswith(("_scale", "_zero_point")):
+            flt[name] = arr.astype(np.float32)
+
+    def base_of(n):
+        return n[:-10] if n.endswith("_quantized") else n
+
+    sd = dict(flt)
+    through = ("Cast", "Mul", "Add", "Reshape", "DynamicQuantizeLinear", "Identity")
+    for node in graph.nodes:
+        if node.op_type in ("MatMul", "MatMulInteger") and len(node.inputs) >= 2 and base_of(node.inputs[1]) in flt:
+            wt = flt[base_of(node.inputs[1])]
+            target = None
+            frontier, depth = [node.outputs[0]], 0
+            while frontier and depth < 5 and target is None:              # forward: the bias Add
+                nxt = []
+                for val in frontier:
+                    for c in graph.consumers(val):
+                        if c.op_type == "Add":
+                            for i in c.inputs:
+                                if i in flt and i.endswith(".bias") and flt[i].ndim == 1 and flt[i].shape[0] == wt.shape[-1]:
+                                    target = i[:-4] + "weight"
+                        if c.op_type in through:
+                            nxt += c.outputs
+                frontier, depth = nxt, depth + 1
+            if target is None:                                             # backward: bias-free w_2 after feed_forward.norm
+                val, depth = node.inputs[0], 0
+                while val and depth < 8 and target is None:
+                    pr = graph.producer(val)
+                    if pr is None:
+                        break
+                    for i in pr.inputs:
+                        if i in flt and ".feed_forward.norm." in i:
+                            target = i.split(".feed_forward.norm.")[0] + ".feed_forward.w_2.weight"
+                    val, depth = (pr.inputs[0] if pr.inputs else None), depth + 1
+            if target is not None and target not in sd:
+                sd[target] = np.ascontiguousarray(wt.T)
+    uni = 0
+    for node in graph.nodes:
+        if node.op_type != "LSTM" or len(node.inputs) < 3:
+            continue
+        Wt, Rt = flt.get(base_of(node.inputs[1])), flt.get(base_of(node.inputs[2]))
+        Bt = flt.get(base_of(node.inputs[3])) if len(node.inputs) > 3 and node.inputs[3] else None
+        if Wt is None or Rt is None:
+            continue
+        H = Rt.shape[-1]
+        bidir = str(node.attrs.get("direction", "forward")) == "bidirectional" or Wt.shape[0] == 2
+        for d in range(Wt.shape[0]):
+            if bidir:
+                pre, sfx = "predictor.blstm.", "_l0" + ("_reverse" if d == 1 else "")
+            else:
+                pre, sfx = "bias_encoder.", "_l%d" % uni
+            sd[pre + "weight_ih" + sfx] = _reorder_gates(Wt[d], H)
+            sd[pre + "weight_hh" + sfx] = _reorder_gates(Rt[d], H)
+            if Bt is not None:
+                sd[pre + "bias_ih" + sfx] = _reorder_gates(Bt[d][:4 * H], H)
+                sd[pre + "bias_hh" + sfx] = _reorder_gates(Bt[d][4 * H:], H)
+        if not bidir:
+            uni += 1
+    # suffix normalisation onto the expected FunASR names
+    out = {}
+    aliases = {"embedding.weight": "bias_embed.weight", "embed.weight": "embed.weight"}
+    exp = sorted(expected_names, key=len, reverse=True)
+    for k, v in sd.items():
+        cands = {k, k.replace(".model.", "."), aliases.get(k, k)}
+        for e in exp:
+            if any(c == e or c.endswith("." + e) for c in cands):
+                out.setdefault(e, v)
+                break
+    return out
+
+
+def onnx_to_pfw(model_path, eb_path=None, kind="paraformer", timestamp=None):
+    """model.onnx / model.int8.onnx (+ model_eb*.onnx for SeACo) -> (cfg, PFW weights)."""
+    from . import onnx_reader as R
+    graphs = [R.load(model_path)] + ([R.load(eb_path)] if eb_path else [])
+    # every name any supported geometry could ask for (layer indices bounded generously; unmatched ones are simply absent)
+    probe = W.make_config(kind=kind, enc_layers=64, tp_layers=32 if kind == "sensevoicesmall" else 0, dec_layers=32,
+                          timestamp_head=True, seaco=(kind == "seacoparaformer"), seaco_layers=8, seaco_lstm_layers=4)
+    expected = set(name_map(probe).values())
+    sd = {}
+    for g in graphs:
+        sd.update(onnx_to_state_dict(g, expected))
+    cfg = infer_config(sd, kind, timestamp)
+    return cfg, state_dict_to_pfw(sd, cfg)
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if len(argv) < 2:
         print(__doc__)
         return 2
-    import torch
     kind, ts = "paraformer", None
     if "--kind" in argv:
         kind = argv[argv.index("--kind") + 1]
     if "--timestamp" in argv:
         ts = True
+    if argv[0].endswith(".onnx"):
+        eb = argv[argv.index("--eb") + 1] if "--eb" in argv else None
+        cfg, wts = onnx_to_pfw(argv[0], eb, kind, ts)
+        W.save_pfw(argv[1], cfg, wts)
+        print("wrote %s (%s, %d tensors, from ONNX)" % (argv[1], cfg["kind"], len(wts)))
+        return 0
+    import torch
     sd = torch.load(argv[0], map_location="cpu")
     sd = sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd
     sd = {k: v.float().numpy() for k, v in sd.items() if hasattr(v, "numpy")}

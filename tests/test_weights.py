@@ -79,3 +79,95 @@ def test_funasr_state_dict_mapping_round_trip():
         bad[k0] = bad[k0][:-1]
         with pytest.raises(ValueError):
             cv.state_dict_to_pfw(bad, cfg)
+
+
+def _synthetic_export(cfg, w, int8_names=()):
+    """Builds ONNX bytes shaped like a torch.onnx export of the FunASR modules: LayerNorm / Conv / bias tensors
+    keep their parameter names (behind an 'encoder.model.'-style wrapper segment), Linear weights are anonymous
+    transposed MatMul operands, LSTMs are ONNX LSTM nodes (gate order i,o,f,c), optionally int8-quantised."""
+    import numpy as np
+    from aliparaformerasr_amd import convert as cv, onnx_reader as R
+    nm = cv.name_map(cfg)
+    nodes, ini = [], {}
+    anon = [0]
+    H = 512
+    def wrap(n):
+        return n.replace("encoder.", "encoder.model.", 1) if n.startswith("encoder.") else n
+    def to_iofc(a):
+        blk = [a[k * H:(k + 1) * H] for k in range(4)]          # i f g o
+        return np.concatenate([blk[0], blk[3], blk[1], blk[2]], 0)
+    lstm_done = set()
+    for k, fn in nm.items():
+        a = w[k]
+        if ".blstm." in fn or fn.startswith("bias_encoder."):
+            grp = "blstm" if ".blstm." in fn else fn.split("_l")[-1].split("_")[0]
+            if grp in lstm_done:
+                continue
+            lstm_done.add(grp)
+            if grp == "blstm":
+                keys = [("predictor.blstm.%s", ""), ("predictor.blstm.%s", "_reverse")]
+                Wt = np.stack([to_iofc(w[p % "weight_ih" + s]) for p, s in keys])
+                Rt = np.stack([to_iofc(w[p % "weight_hh" + s]) for p, s in keys])
+                Bt = np.stack([np.concatenate([to_iofc(w[p % "bias_ih" + s]), to_iofc(w[p % "bias_hh" + s])]) for p, s in keys])
+                attrs = {"direction": "bidirectional", "hidden_size": H}
+            else:
+                l = int(grp)
+                Wt = to_iofc(w["seaco.lstm.l%d.weight_ih" % l])[None]
+                Rt = to_iofc(w["seaco.lstm.l%d.weight_hh" % l])[None]
+                Bt = np.concatenate([to_iofc(w["seaco.lstm.l%d.bias_ih" % l]), to_iofc(w["seaco.lstm.l%d.bias_hh" % l])])[None]
+                attrs = {"hidden_size": H}
+            base = "onnx::LSTM_%d" % anon[0]
+            anon[0] += 3
+            ini[base + "W"], ini[base + "R"], ini[base + "B"] = Wt, Rt, Bt
+            nodes.append(("LSTM", "lstm_%s" % grp, ["x_%s" % grp, base + "W", base + "R", base + "B"], ["y_%s" % grp], attrs))
+            continue
+        is_linear_w = fn.endswith(".weight") and a.ndim == 2 and not fn.endswith(("norm.weight", "norm1.weight", "norm2.weight", "norm3.weight")) \
+            and "fsmn_block" not in fn and fn not in ("bias_embed.weight", "embed.weight") and "cif_output" not in fn
+        if is_linear_w:
+            wn = "onnx::MatMul_%d" % anon[0]
+            anon[0] += 1
+            out = "mm_out_%d" % anon[0]
+            has_bias = (fn[:-6] + "bias") in nm.values()
+            src = "act_%d" % anon[0]
+            if not has_bias:                                                       # w_2: fed by feed_forward.norm
+                src = "ln_out_%d" % anon[0]
+                pre = fn[: -len("w_2.weight")]
+                nodes.append(("LayerNormalization", "ln%d" % anon[0], ["h_%d" % anon[0], wrap(pre + "norm.weight"), wrap(pre + "norm.bias")], [src], {}))
+            if fn in int8_names:
+                scale = np.float32(np.abs(a).max() / 127.0)
+                qv = np.clip(np.round(a.T / scale), -127, 127).astype(np.int8)
+                ini[wn + "_quantized"], ini[wn + "_scale"], ini[wn + "_zero_point"] = qv, np.asarray(scale, np.float32), np.asarray(0, np.int8)
+                w[k] = (qv.astype(np.float32) * scale).T.copy()                  # what ingestion must return
+                nodes.append(("DynamicQuantizeLinear", "dq%d" % anon[0], [src], ["aq%d" % anon[0], "as%d" % anon[0], "az%d" % anon[0]], {}))
+                nodes.append(("MatMulInteger", "mmi%d" % anon[0], ["aq%d" % anon[0], wn + "_quantized", "az%d" % anon[0], wn + "_zero_point"], ["mi%d" % anon[0]], {}))
+                nodes.append(("Cast", "c%d" % anon[0], ["mi%d" % anon[0]], ["mc%d" % anon[0]], {"to": 1}))
+                nodes.append(("Mul", "m%d" % anon[0], ["mc%d" % anon[0], "as%d" % anon[0]], [out], {}))
+            else:
+                ini[wn] = np.ascontiguousarray(a.T)
+                nodes.append(("MatMul", "mm%d" % anon[0], [src, wn], [out], {}))
+            if has_bias:
+                nodes.append(("Add", "add%d" % anon[0], [out, wrap(fn[:-6] + "bias")], ["y_%d" % anon[0]], {}))
+        else:
+            a2 = a[:, None, :] if k.endswith("fsmn.weight") else a
+            ini["embedding.weight" if fn == "bias_embed.weight" else wrap(fn)] = np.ascontiguousarray(a2, np.float32)
+    return R.dump(nodes, ini, ["speech"], ["logits"])
+
+
+def test_onnx_ingestion_round_trip_including_int8():
+    """convert.onnx_to_pfw on synthetic export-shaped graphs (anonymous transposed MatMul weights named through
+    their bias / preceding LayerNorm, ONNX LSTM gate order, quantize_dynamic naming, wrapper name segments)."""
+    import numpy as np
+    from aliparaformerasr_amd import convert as cv, onnx_reader as R, weights as W
+    for cfg, q8 in ((W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=48, timestamp_head=True), ()),
+                    (W.seaco_paraformer_config(enc_layers=2, dec_layers=1, vocab=40, seaco_layers=2),
+                     ("encoder.encoders.0.feed_forward.w_1.weight", "decoder.decoders.0.feed_forward.w_2.weight", "decoder.output_layer.weight")),
+                    (W.sensevoice_small_config(enc_layers=2, tp_layers=1, vocab=30), ("ctc.ctc_lo.weight",))):
+        w = W.synth_weights(cfg, 2)
+        blob = _synthetic_export(cfg, w, set(q8))
+        g = R.load(blob)
+        sd = cv.onnx_to_state_dict(g, set(cv.name_map(cfg).values()))
+        cfg2 = cv.infer_config(sd, cfg["kind"])
+        got = cv.state_dict_to_pfw(sd, cfg2)
+        assert set(got) == set(w)
+        for k in w:
+            assert np.array_equal(got[k], w[k]), k
