@@ -517,7 +517,7 @@ bool Engine::profile_get(const std::string& cls, double* ms, int64_t* launches, 
 
 void Engine::gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
                   half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
-                  int scale_cols, float scale, bool bias) {
+                  int scale_cols, float scale, bool bias, int blocked) {
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = w.w; g.ldw = w.Kpad; g.bias = bias ? w.bias : nullptr;
   g.M = M; g.N = w.N; g.K = w.Kpad;
@@ -525,6 +525,7 @@ void Engine::gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M
   g.resid = resid; g.ldr = ldr; g.add2 = add2; g.ld2 = ld2;
   g.relu = relu ? 1 : 0; g.scale_cols = scale_cols; g.scale = scale;
   g.out_padded = 1;   // every pipeline buffer is carved with round_up(rows,128)+128 rows
+  g.out_blocked = blocked == 1; g.a_blocked = blocked == 2;
   prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   launch_gemm(stream_, g);
   prof_end(cls);
@@ -694,8 +695,11 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
   prof_begin("layernorm", 0);
   launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
   prof_end("layernorm");
-  gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f);
-  gemm("gemm_ffn2", L.w2, h16_, F, M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f);
+  // the FFN hidden lives in the blocked activation layout (kernels.h): FFN-up stores its fragments as whole
+  // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
+  const int blk = (F % 64 == 0) ? 1 : 0;
+  gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
+  gemm("gemm_ffn2", L.w2, h16_, F, M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, true, blk ? 2 : 0);
 }
 
 void Engine::encoder(const float* speech_dev, int B, int T) {

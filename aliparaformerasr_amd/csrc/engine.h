@@ -134,7 +134,7 @@ class Engine {
   void seaco_head(int B, int L, const float* e0, const float* hid32, bool want_logits);
   void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
             half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
-            int scale_cols, float scale, bool bias = true);
+            int scale_cols, float scale, bool bias = true, int blocked = 0);   // blocked: 1 = out_f16 blocked, 2 = A blocked
   void prof_begin(const char* cls, double flops);
   void prof_end(const char* cls);
 

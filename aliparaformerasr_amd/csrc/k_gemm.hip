@@ -65,6 +65,7 @@ struct GemmDev {
   int M, N, K, tiles_m, tiles_n;
   int relu, scale_cols; float scale;
   int out_padded;
+  int out_blocked, a_blocked;
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -94,6 +95,7 @@ constexpr int gemm_lds_bytes(int mi) { return GEMM_S * (128 * mi + GEMM_BN) * GE
 
 // KIND 1: f16-only results (deferred packed epilogue; direct epilogue only for wave tiles straddling N)
 // KIND 2: fp32 results / residual / FSMN add (LDS row-segment epilogue; direct epilogue for edge tiles)
+// KIND 3: f16-only results in the blocked activation layout (kernels.h): fragments stored as whole lines, no transposition
 // MI: 32-row MFMA blocks per wave (2 -> 256-row tiles; 1 -> 128-row tiles for GEMMs whose 256-row
 //     tile count would leave most CUs idle, i.e. the decoder's M = B*L rows)
 template <int KIND, int MI>
@@ -133,6 +135,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   for (int i = 0; i < A_PW; ++i) {
     const int row = (wave + NW * i) * RPI + srow;
     a_vo[i] = (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
+    if (p.a_blocked) {                               // piece pi = 1 KiB = 2 column groups of one 32-row block
+      const int pi = wave + NW * i;
+      a_vo[i] = (unsigned)((pi >> 2) * (p.K >> 3) * 512 + (pi & 3) * 1024 + lane * 16);
+    }
   }
 #pragma unroll
   for (int i = 0; i < B_PW; ++i) {
@@ -145,7 +151,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   const char* is_w;
   auto set_issue_tile = [&]() __attribute__((always_inline)) {
     const int tm = is_tile / p.tiles_n, tn = is_tile - tm * p.tiles_n;
-    is_a = reinterpret_cast<const char*>(p.A + (size_t)tm * BM * p.lda);
+    is_a = p.a_blocked ? reinterpret_cast<const char*>(p.A) + (size_t)tm * (BM / 32) * (size_t)(p.K >> 3) * 512
+                       : reinterpret_cast<const char*>(p.A + (size_t)tm * BM * p.lda);
     is_w = reinterpret_cast<const char*>(p.W + (size_t)tn * BN * p.ldw);
   };
   set_issue_tile();
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   auto issue_advance = [&]() __attribute__((always_inline)) {
     is_lds = (is_lds + STAGE == smem + wave * 1024 + S * STAGE) ? smem + wave * 1024 : is_lds + STAGE;
     if (--is_left > 0) {
-      is_a += BK * 2; is_w += BK * 2;
+      is_a += p.a_blocked ? (BK / 8) * 512 : BK * 2; is_w += BK * 2;
       if (++is_kt == nk) { is_kt = 0; is_tile += G; set_issue_tile(); }
     }
   };
@@ -175,7 +182,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     const int rb = wn * 64 + i * 32 + (lane & 31);
 #pragma unroll
     for (int s = 0; s < KSUB; ++s) {
-      if (i < MI) fa[s][i < MI ? i : 0] = (unsigned)(ra * ROWB + (((2 * s + lh) ^ swz(ra)) << 4));
+      if (i < MI)
+        fa[s][i < MI ? i : 0] = p.a_blocked ? (unsigned)((((ra >> 5) * 8 + 2 * s + lh) * 32 + (ra & 31)) * 16)
+                                            : (unsigned)(ra * ROWB + (((2 * s + lh) ^ swz(ra)) << 4));
       fb[s][i] = (unsigned)(A_BYTES + rb * ROWB + (((2 * s + lh) ^ swz(rb)) << 4));
     }
   }
@@ -199,11 +208,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 
   // ---- deferred f16 epilogue state
   char* const scr = smem + S * STAGE + wave * 2048;            // [0,1152) transpose rows, [1152,1408) bias line
-  const bool fast_kind = KIND == 1;   // launch_gemm checked: f16 only, no residual/add, padded rows, ldc16 % 8 == 0
+  constexpr bool BLK = KIND == 3;
+  const bool fast_kind = KIND == 1 || KIND == 3;   // launch_gemm checked: f16 only, no residual/add, padded rows, ldc16 % 8 == 0
   const float lo = p.relu ? 0.f : -INFINITY;
   char* const wp = scr + (lane & 7) * 144 + lh * 8;
   const char* const rp = scr + (lane >> 3) * 144 + (lane & 7) * 16;
   int pend = 0;                                      // passes of the finished tile still to emit
+  char* ob = nullptr;                                // blocked layout: output pointer of the finished tile (this lane)
   half_t* op = nullptr;                              // its output pointer (row lane>>3, col (lane&7)*8)
   h8 rowv;
   half_t* rowp = nullptr;
@@ -268,8 +279,31 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   };
   auto pass = [&](int idx) __attribute__((always_inline)) { pass_write(idx); pass_read(idx); };
   auto pass_store = [&]() __attribute__((always_inline)) { if constexpr (!(ABL & 8)) *reinterpret_cast<h8*>(rowp) = rowv; };     // padded rows: always issued
+  // blocked layout: "pass" idx = the two stores of (i = idx >> 2, g = idx & 3), j = 0, 1 — straight from hq
+  auto blk_store = [&](int idx) __attribute__((always_inline)) {
+    auto body = [&](auto IC, auto GC) __attribute__((always_inline)) {
+      constexpr int i = decltype(IC)::value, g = decltype(GC)::value;
+      char* o = ob + ((size_t)i * (p.N >> 3) + g) * 512;
+      *reinterpret_cast<h4*>(o) = hq[i][0][g];
+      *reinterpret_cast<h4*>(o + 4 * 512) = hq[i][1][g];
+    };
+    constexpr int I1 = MI - 1;
+    switch (idx) {
+      case 0: body(ic<0>{}, ic<0>{}); break;
+      case 1: body(ic<0>{}, ic<1>{}); break;
+      case 2: body(ic<0>{}, ic<2>{}); break;
+      case 3: body(ic<0>{}, ic<3>{}); break;
+      case 4: body(ic<I1>{}, ic<0>{}); break;
+      case 5: body(ic<I1>{}, ic<1>{}); break;
+      case 6: body(ic<I1>{}, ic<2>{}); break;
+      default: body(ic<I1>{}, ic<3>{}); break;
+    }
+  };
   auto flush = [&]() __attribute__((always_inline)) {
-    while (pend > 0) { pass(4 * MI - pend); --pend; pass_store(); }
+    while (pend > 0) {
+      if constexpr (BLK) { blk_store(4 * MI - pend); --pend; }
+      else { pass(4 * MI - pend); --pend; pass_store(); }
+    }
   };
 
   // direct epilogue (fp32 results, residual / FSMN add, or a wave tile that straddles N)
@@ -409,8 +443,16 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
           for (int g = 0; g < 4; ++g)
             hq[i][j][g] = h4{(half_t)fmaxf(acc[i][j][4 * g + 0] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 1] * sc, lo),
                              (half_t)fmaxf(acc[i][j][4 * g + 2] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 3] * sc, lo)};
-      op = p.out_f16 + (size_t)(m0 + (lane >> 3)) * p.ldc16 + n0 + (lane & 7) * 8;
-      pend = 4 * MI;
+      if constexpr (BLK) {
+        // D^T fragment -> blocked layout: lanes 0..31 (rows) x {lh} (column half) = 512 contiguous bytes per store,
+        // no transposition; the 16*MI stores are spread over the next k-steps, two per step (blk_store)
+        ob = reinterpret_cast<char*>(p.out_f16) + ((size_t)(m0 >> 5) * (size_t)(p.N >> 3) * 32 + (lane & 31)) * 16 + lh * 8 +
+             (size_t)(n0 >> 3) * 512;
+        pend = 4 * MI;
+      } else {
+        op = p.out_f16 + (size_t)(m0 + (lane >> 3)) * p.ldc16 + n0 + (lane & 7) * 8;
+        pend = 4 * MI;
+      }
     } else if (KIND == 2 && m0 + WM <= p.M && n0 + 64 <= p.N) {
       lds_epilogue32(tile);
     } else {
@@ -430,12 +472,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     for (int s = 0; s < KSUB; ++s)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        if (s * MI + i == (MI == 2 ? 1 : 0) && pass_idx >= 0) {
+        if (s * MI + i == (MI == 2 ? 1 : 0) && pass_idx >= 0 && !BLK) {
           __builtin_amdgcn_sched_barrier(0);
           pass_write(pass_idx);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (s * MI + i == (MI == 2 ? 3 : 1) && pass_idx >= 0) {
+        if (s * MI + i == (MI == 2 ? 3 : 1) && pass_idx >= 0 && !BLK) {
           __builtin_amdgcn_sched_barrier(0);
           pass_read(pass_idx);
           __builtin_amdgcn_sched_barrier(0);
@@ -482,10 +524,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
         load_frags();
         __builtin_amdgcn_s_barrier();
         burst(pidx, [&]() __attribute__((always_inline)) {
-          if (sA) pass_store();
+          if (sA) { if constexpr (BLK) blk_store(pidx); else pass_store(); }
           // younger than DMA(k+1) [issued in COMPUTE(k-1)]: store(k-1), DMA(k+2), store(k)
-          const int ns = sA + s_prev;
-          if (ns == 2) wait_vmcnt<WAITN + 2>();
+          const int ns = (sA + s_prev) * (BLK ? 2 : 1);              // blocked: two stores per step
+          if (ns == 4) wait_vmcnt<WAITN + 4>();
+          else if (ns == 2) wait_vmcnt<WAITN + 2>();
           else if (ns == 1) wait_vmcnt<WAITN + 1>();
           else wait_vmcnt<WAITN>();
           s_prev = sA;
@@ -509,15 +552,16 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
         load_frags();
         {
           // younger than DMA(k+1) [issued in COMPUTE(k-2)]: store(k-2), DMA(k+2), store(k-1)
-          const int ns = s_prev + s_prev2;
-          if (ns == 2) wait_vmcnt<WAITN + 2>();
+          const int ns = (s_prev + s_prev2) * (BLK ? 2 : 1);
+          if (ns == 4) wait_vmcnt<WAITN + 4>();
+          else if (ns == 2) wait_vmcnt<WAITN + 2>();
           else if (ns == 1) wait_vmcnt<WAITN + 1>();
           else wait_vmcnt<WAITN>();
           s_prev2 = s_prev; s_prev = sB;
         }
         __builtin_amdgcn_s_barrier();
         burst(pidx, [&]() __attribute__((always_inline)) {
-          if (sB) pass_store();
+          if (sB) { if constexpr (BLK) blk_store(pidx); else pass_store(); }
           if (k + 1 < T) __builtin_amdgcn_s_barrier();
         });
       }
@@ -541,6 +585,10 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   d.M = a.M; d.N = a.N; d.K = a.K;
   d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
   d.out_padded = a.out_padded;
+  d.out_blocked = a.out_blocked; d.a_blocked = a.a_blocked;
+  PF_CHECK(!a.out_blocked || (a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && a.N % 64 == 0),
+           PF_ERR_INVALID_ARG, "gemm: blocked output needs an f16-only padded result with N % 64 == 0");
+  PF_CHECK(!a.a_blocked || a.K % 64 == 0, PF_ERR_INVALID_ARG, "gemm: blocked A operand needs K % 64 == 0");
   // 128-row tiles when 256-row tiles would leave CUs idle (decoder GEMMs with N = 512: 84 tiles); measured
   // A/B in one session: x = 0.9 -> 14.85 ms/step, x = 0 -> 15.15, x >= 1.5 (also the encoder N = 512 GEMMs) -> 15.9
   static int cus[64] = {0};
@@ -565,13 +613,18 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
     PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
     PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
     attr[dev] = true;
   }
   int grid = cus[dev];
   if (grid > total) grid = total;
-  const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && (a.ldc16 & 7) == 0;
+  const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && ((a.ldc16 & 7) == 0 || a.out_blocked);
   const int lds = gemm_lds_bytes(mi);
-  if (f16_only) {
+  if (f16_only && a.out_blocked) {
+    if (mi == 2) hipLaunchKernelGGL((gemm_f16_pp3<3, 2>), dim3(grid), dim3(512), lds, s, d);
+    else hipLaunchKernelGGL((gemm_f16_pp3<3, 1>), dim3(grid), dim3(512), lds, s, d);
+  } else if (f16_only) {
     if (mi == 2) hipLaunchKernelGGL((gemm_f16_pp3<1, 2>), dim3(grid), dim3(512), lds, s, d);
     else hipLaunchKernelGGL((gemm_f16_pp3<1, 1>), dim3(grid), dim3(512), lds, s, d);
   } else {

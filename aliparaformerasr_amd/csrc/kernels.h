@@ -21,6 +21,13 @@ struct GemmArgs {
   int relu;                      // max(v,0) after bias/resid
   int scale_cols; float scale;   // columns n < scale_cols are multiplied by scale (after bias); multiple of 64
   int out_padded;                // out_f16 has >= round_up(M,256) writable rows (enables whole-tile stores)
+  // "blocked" f16 activation layout, element (m, n) of an [M, N] matrix at
+  //   ((m/32 * N/8 + n/8) * 32 + m%32) * 8 + n%8      (32 rows x 8 columns = 512 contiguous bytes)
+  // It is what a D^T MFMA fragment stores as whole lines WITHOUT a transposition and what the A-operand
+  // LDS-DMA reads as 1 KiB contiguous pieces that land conflict-free (no swizzle).  Used for the FFN hidden:
+  // FFN-up writes it (out_blocked, f16-only results, N % 64 == 0), FFN-down reads it (a_blocked, lda ignored).
+  int out_blocked;
+  int a_blocked;
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 
