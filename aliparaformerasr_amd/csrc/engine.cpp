@@ -71,7 +71,8 @@ Engine::~Engine() {
   profile_reset();
   fbank_tables_destroy(fb_);
   for (void* p : owned_) hipFree(p);
-  DevBuf* bufs[] = {&ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_};
+  DevBuf* bufs[] = {&ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_,
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (blob_owned_ && blob_dev_) hipFree(blob_dev_);

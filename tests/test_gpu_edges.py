@@ -139,3 +139,26 @@ def test_concurrent_callers_on_one_engine_are_serialised(small):
     for k in range(4):
         assert np.array_equal(got[k].token_ids, expect[k].token_ids)
         assert np.array_equal(got[k].logits, expect[k].logits)
+
+
+def test_engine_lifecycle_releases_device_memory():
+    """Create / use / destroy engines repeatedly (each with growing and shrinking shapes): device memory
+    returns to its starting level (grow-only arenas, hipGraph, per-thread slots are all owned by the engine)."""
+    import torch
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=1, vocab=64, timestamp_head=True)
+    w = W.synth_weights(cfg, 3)
+    w["predictor.out.bias"] = np.asarray([0.0], np.float32)
+    blob = W.pack_pfw(cfg, w)
+    cmvn = W.synth_cmvn()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rep in range(4):
+        eng = Engine(weights=blob, cmvn=cmvn, device=0)
+        for n, B in ((16000, 1), (160000, 6), (8000, 2), (64000, 3)):
+            r = eng.recognize([W.synth_audio(n, 10 * rep + u) for u in range(B)])
+            assert r.token_ids.shape[0] == B
+        eng.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free0 - free1) < 64 << 20, (free0, free1)
