@@ -162,3 +162,25 @@ def test_engine_lifecycle_releases_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
+
+
+def test_malformed_weight_containers_fail_loudly():
+    """Truncated / corrupted / incomplete PFW containers must raise, never crash or half-load."""
+    from aliparaformerasr_amd._native import PfError
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=32)
+    w = W.synth_weights(cfg, 4)
+    good = W.pack_pfw(cfg, w)
+    cmvn = W.synth_cmvn()
+    bad = [b"", b"PFW1", good[:100], good[: len(good) // 2], b"XXXX" + good[4:], good[:16] + b"{" * 40 + good[56:]]
+    w2 = dict(w); w2.pop("encoder.layers.0.ffn.w1.bias")
+    bad.append(W.pack_pfw(cfg, w2))                                   # missing tensor
+    w3 = dict(w); w3["decoder.output.weight"] = w3["decoder.output.weight"][:-1]
+    bad.append(W.pack_pfw(cfg, w3))                                   # vocab mismatch
+    bad.append(W.pack_pfw(dict(cfg, d_model=256), w))                 # unsupported geometry
+    for blob in bad:
+        with pytest.raises(PfError):
+            Engine(weights=np.frombuffer(blob, np.uint8) if blob else np.zeros(0, np.uint8), cmvn=cmvn, device=0)
+    Engine(weights=good, cmvn=cmvn, device=0).close()                 # the device is still usable afterwards
+    with pytest.raises(PfError):
+        Engine(weights=good, cmvn=(cmvn[0][:100], cmvn[1][:100]), device=0).recognize([W.synth_audio(16000, 1)])
