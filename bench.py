@@ -41,7 +41,7 @@ SAMPLES = SECONDS * 16000
 LCAP = 512
 DOMINANT = "gemm_ffn1"
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "round1_c_gemm_ffn1_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round1_f_gemm_ffn1_pmc.json")
 
 
 def pmc_traffic():
@@ -235,11 +235,11 @@ def main():
             "host_audio_ms_per_batch": host_ms,     # one GPU's batch incl. H2D of the audio and D2H of the ids
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp3 (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp3<3,2> (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
                          % (DOMINANT, B * int(res.L if sv else eng.num_frames(samples))), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS,
                          "traffic": pmc_traffic() if (not sv and B == BATCH_PER_GPU and seconds == SECONDS) else None,
-                         "traffic_unit": "bytes/launch (PMC, profiles/round1_c_gemm_ffn1_pmc.json)",
+                         "traffic_unit": "bytes/launch (PMC, profiles/round1_f_gemm_ffn1_pmc.json)",
                          "algorithmic_bytes_per_launch": int(fpl_dom / (2 * 512 * 2048)) * (512 + 2048) * 2 + 2048 * 512 * 2,
                          "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
                          "flops_per_launch": fpl_dom},
