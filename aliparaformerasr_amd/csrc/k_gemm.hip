@@ -89,6 +89,31 @@ __device__ __forceinline__ void wait_vmcnt() {
 #define PF_ABL 0
 #endif
 constexpr int ABL = PF_ABL;
+// cache policy of the deferred f16 result stores: 0 plain, 1 nt, 2 sc1 (write-through, line dropped from the
+// XCD's L2).  66 MB of results per launch otherwise churn the 8 x 4 MB L2s that hold the A panels and W tiles.
+// A/B in one session (tools/gemm_st.sh): plain 14.88-14.96 ms/step, nt 14.96-14.99 (the consumers then miss),
+// sc1 14.81 (QKV -5 %, FFN-up -3 %, attention / FSMN / FFN-down unchanged).
+#ifndef PF_GEMM_ST
+#define PF_GEMM_ST 2
+#endif
+__device__ __forceinline__ void st16(void* p, h8 v) {
+#if PF_GEMM_ST == 1
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif PF_GEMM_ST == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<h8*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st8(void* p, h4 v) {
+#if PF_GEMM_ST == 1
+  asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif PF_GEMM_ST == 2
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<h4*>(p) = v;
+#endif
+}
 constexpr int GEMM_BN = 128, GEMM_BK = 64, GEMM_S = 3;   // tile rows: 128 * MI (MI = 32-row MFMA blocks per wave)
 constexpr int GEMM_SCRATCH = 8 * 2048;                                   // 2 KiB per wave
 constexpr int gemm_lds_bytes(int mi) { return GEMM_S * (128 * mi + GEMM_BN) * GEMM_BK * 2 + GEMM_SCRATCH; }   // MI=2: 160 KiB
@@ -278,14 +303,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     rowp = op + (size_t)(idx * 8) * p.ldc16;
   };
   auto pass = [&](int idx) __attribute__((always_inline)) { pass_write(idx); pass_read(idx); };
-  auto pass_store = [&]() __attribute__((always_inline)) { if constexpr (!(ABL & 8)) *reinterpret_cast<h8*>(rowp) = rowv; };     // padded rows: always issued
+  auto pass_store = [&]() __attribute__((always_inline)) { if constexpr (!(ABL & 8)) st16(rowp, rowv); };     // padded rows: always issued
   // blocked layout: "pass" idx = the two stores of (i = idx >> 2, g = idx & 3), j = 0, 1 — straight from hq
   auto blk_store = [&](int idx) __attribute__((always_inline)) {
     auto body = [&](auto IC, auto GC) __attribute__((always_inline)) {
       constexpr int i = decltype(IC)::value, g = decltype(GC)::value;
       char* o = ob + ((size_t)i * (p.N >> 3) + g) * 512;
-      *reinterpret_cast<h4*>(o) = hq[i][0][g];
-      *reinterpret_cast<h4*>(o + 4 * 512) = hq[i][1][g];
+      st8(o, hq[i][0][g]);
+      st8(o + 4 * 512, hq[i][1][g]);
     };
     constexpr int I1 = MI - 1;
     switch (idx) {
