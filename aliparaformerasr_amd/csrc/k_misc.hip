@@ -30,6 +30,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #ifndef FS_CH
 #define FS_CH 4
 #endif
+#ifndef FS_ST
+#define FS_ST 2      // cache policy of the fp32 result stores: 0 plain, 1 nt, 2 sc1 (read two kernels later; A/B tools/fsmn_rows.sh: -3 %)
+#endif
 template <int K>
 __global__ __launch_bounds__(256) void fsmn_enc_kernel(const half_t* __restrict__ v, int ldv,
                                                        const float* __restrict__ wT, int B, int T, int D,
@@ -88,7 +91,17 @@ __global__ __launch_bounds__(256) void fsmn_enc_kernel(const half_t* __restrict_
     if (t0 + q < T) {
       float4* o = reinterpret_cast<float4*>(f + ((int64_t)b * T + t0 + q) * D + c0);
 #pragma unroll
-      for (int e = 0; e < C; e += 4) o[e / 4] = make_float4(acc[q][e], acc[q][e + 1], acc[q][e + 2], acc[q][e + 3]);
+      for (int e = 0; e < C; e += 4) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v4 = {acc[q][e], acc[q][e + 1], acc[q][e + 2], acc[q][e + 3]};
+#if FS_ST == 2
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o + e / 4), "v"(v4) : "memory");
+#elif FS_ST == 1
+        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(o + e / 4), "v"(v4) : "memory");
+#else
+        *reinterpret_cast<f4v*>(o + e / 4) = v4;
+#endif
+      }
     }
   }
 }
