@@ -184,3 +184,15 @@ def test_malformed_weight_containers_fail_loudly():
     Engine(weights=good, cmvn=cmvn, device=0).close()                 # the device is still usable afterwards
     with pytest.raises(PfError):
         Engine(weights=good, cmvn=(cmvn[0][:100], cmvn[1][:100]), device=0).recognize([W.synth_audio(16000, 1)])
+
+
+def test_five_minute_utterance(small):
+    """T = 5000 LFR frames: 40 query tiles x 79 key tiles per head, L ~ 900 tokens, CIF scan over 5001 frames."""
+    eng, orc, cfg, w, cmvn = small
+    a = [W.synth_audio(4800000, 123)]
+    speech = _speech(a, cmvn)
+    assert speech.shape[1] == 5000
+    ref = orc.paraformer(speech)
+    res = eng.recognize(a, want_logits=True)
+    assert res.L == ref["logits"].shape[1] > 500
+    _cmp(res, ref, 3e-2)
