@@ -37,6 +37,15 @@ class PfEngineConfig(C.Structure):
     ]
 
 
+class PfGemmDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("relu", C.c_int32), ("out_kind", C.c_int32), ("a_blocked", C.c_int32), ("tile_rows", C.c_int32),
+        ("scale_cols", C.c_int32), ("scale", C.c_float),
+        ("bias", C.POINTER(C.c_float)), ("resid", C.POINTER(C.c_float)), ("add2", C.POINTER(C.c_float)),
+    ]
+
+
 class PfBatchOut(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("l_cap", C.c_int32), ("logits_cap", C.c_int64), ("cif_peak_cap", C.c_int64),
@@ -82,6 +91,11 @@ SIGNATURES = {
     "pf_op_lfr_cmvn_pad": (C.c_int, [_vp, _P(_f), _i32, C.c_int32, C.c_int32, _f, C.c_int64, _i32]),
     "pf_op_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _i64]),
     "pf_op_gemm": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_gemm_ex": (C.c_int, [_vp, _P(PfGemmDesc), _f, _f, _f]),
+    "pf_op_ffn": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_fsmn_enc": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_fsmn_dec": (C.c_int, [_vp, _f, _f, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_logsoftmax_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _f, _i64]),
     "pf_op_layernorm": (C.c_int, [_vp, _f, _f, _f, C.c_int64, C.c_int32, _f]),
     "pf_op_attention": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),

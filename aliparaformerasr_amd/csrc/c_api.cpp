@@ -263,6 +263,55 @@ int pf_op_gemm(pf_engine* h, const float* A, const float* W, const float* bias, 
   return PF_OK;
   PF_CATCH
 }
+int pf_op_gemm_ex(pf_engine* h, const pf_gemm_desc* d, const float* A, const float* W, float* C) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(d); NEED(A); NEED(W); NEED(C);
+  PF_CHECK(d->struct_size == (int32_t)sizeof(pf_gemm_desc), PF_ERR_INVALID_ARG, "pf_gemm_desc.struct_size mismatch");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_gemm_ex(*d, A, W, C);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_ffn(pf_engine* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+              const float* resid, int32_t M, int32_t D, int32_t F, float* y) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(x); NEED(w1); NEED(b1); NEED(w2); NEED(b2); NEED(resid); NEED(y);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_ffn(x, w1, b1, w2, b2, resid, M, D, F, y);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_fsmn_enc(pf_engine* h, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(v); NEED(w); NEED(y);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_fsmn_enc(v, w, B, T, D, k, y);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_fsmn_dec(pf_engine* h, const float* tn, const float* w, const int32_t* token_num, int32_t B, int32_t L,
+                   int32_t D, int32_t k, float* x) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(tn); NEED(w); NEED(token_num); NEED(x);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_fsmn_dec(tn, w, token_num, B, L, D, k, x);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_logsoftmax_argmax(pf_engine* h, const float* x, int64_t rows, int32_t V, float* y, int64_t* ids) {
+  PF_TRY
+  Engine* e = E(h);
+  NEED(x); NEED(ids);
+  PF_CHECK(rows >= 0 && V > 0, PF_ERR_INVALID_ARG, "logsoftmax_argmax: bad shape");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_logsoftmax_argmax(x, rows, V, y, ids);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_layernorm(pf_engine* h, const float* x, const float* g, const float* b, int64_t rows, int32_t D, float* y) {
   PF_TRY
   Engine* e = E(h);

@@ -855,7 +855,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
   gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
-  launch_argmax(stream_, logits_, Md, V, logits_ld_, want_logits ? 1 : 0, ids_dev_);
+  launch_argmax(stream_, logits_, Md, V, logits_ld_, want_logits ? 2 : 1, ids_dev_);
   prof_end("argmax");
   if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
@@ -973,7 +973,7 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   prof_end("seaco_merge");
   gemm("gemm_seaco", seaco_out_, m16, D, Md, dha, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("seaco_merge", 0);
-  launch_argmax(stream_, dha, Md, V, ldV, want_logits ? 1 : 0, dha_ids);
+  launch_argmax(stream_, dha, Md, V, ldV, 2, dha_ids);   // the NO-BIAS decision below is taken on the log-probs too
   launch_seaco_merge(stream_, dha, ldV, dha_ids, Md, V, mc_.seaco_nobias, want_logits ? 1 : 0, logits_, logits_ld_, ids_dev_);
   prof_end("seaco_merge");
 }
@@ -1042,7 +1042,7 @@ void Engine::sensevoice_head(int B, int T, bool want_logits) {
   logits_ld_ = (int)round_up(V, 4);
   gemm("gemm_vocab", ctc_, H16_, D, M, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
-  launch_argmax(stream_, logits_, M, V, logits_ld_, want_logits ? 1 : 0, ids_dev_);
+  launch_argmax(stream_, logits_, M, V, logits_ld_, want_logits ? 2 : 1, ids_dev_);
   prof_end("argmax");
   last_.B = B; last_.L = T; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)M, 0);
@@ -1241,6 +1241,182 @@ void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, i
     PF_HIP(hipMemcpyAsync(C, base + oC, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
     PF_HIP(hipStreamSynchronize(stream_));
   }
+}
+
+// GEMM exactly as the pipeline launches it: kernel kind (fp32 / f16 row-major / f16 blocked result), tile height,
+// blocked A operand, residual / second addend, column scaling — the stand-alone counterpart of Engine::gemm().
+void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, float* C) {
+  PF_HIP(hipSetDevice(device_));
+  const int M = ds.M, N = ds.N, K = ds.K;
+  PF_CHECK(M > 0 && N > 0 && K > 0, PF_ERR_INVALID_ARG, "gemm_ex: empty problem");
+  PF_CHECK(ds.out_kind >= 0 && ds.out_kind <= 2, PF_ERR_INVALID_ARG, "gemm_ex: out_kind must be 0, 1 or 2");
+  PF_CHECK(ds.tile_rows == 0 || ds.tile_rows == 128 || ds.tile_rows == 256, PF_ERR_INVALID_ARG, "gemm_ex: tile_rows must be 0, 128 or 256");
+  PF_CHECK(ds.out_kind == 0 || (!ds.resid && !ds.add2), PF_ERR_INVALID_ARG, "gemm_ex: residual / addend need the fp32 result kind");
+  PF_CHECK(ds.out_kind != 2 || N % 64 == 0, PF_ERR_INVALID_ARG, "gemm_ex: blocked result needs N % 64 == 0");
+  const int Kp = (int)round_up(K, 64);
+  const int64_t Mp = round_up(M, 256) + 128, Np = round_up(N, 256);
+  const int ld32 = (int)round_up(N, 4), ld16 = (int)round_up(N, 8);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t oA = carve((size_t)M * K * 4), oW = carve((size_t)N * K * 4), ob = carve((size_t)N * 4);
+  const size_t oA16 = carve((size_t)Mp * Kp * 2), oW16 = carve((size_t)Np * Kp * 2);
+  const size_t oR = carve((size_t)Mp * ld32 * 4), oD = carve((size_t)Mp * ld32 * 4), oC = carve((size_t)Mp * std::max(ld32, ld16) * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + oA16, 0, (size_t)Mp * Kp * 2, stream_));
+  PF_HIP(hipMemsetAsync(base + oW16, 0, (size_t)Np * Kp * 2, stream_));
+  std::vector<half_t> ablk;
+  if (ds.a_blocked) {
+    // host-side re-layout (independent of the kernel's own index arithmetic): element (m, k) at
+    // ((m/32 * Kp/8 + k/8) * 32 + m%32) * 8 + k%8
+    ablk.assign((size_t)Mp * Kp, (half_t)0.f);
+    for (int m = 0; m < M; ++m)
+      for (int k = 0; k < K; ++k)
+        ablk[(((size_t)(m >> 5) * (Kp >> 3) + (k >> 3)) * 32 + (m & 31)) * 8 + (k & 7)] = (half_t)A[(size_t)m * K + k];
+    PF_HIP(hipMemcpyAsync(base + oA16, ablk.data(), ablk.size() * 2, hipMemcpyHostToDevice, stream_));
+  } else {
+    PF_HIP(hipMemcpyAsync(base + oA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + oA), M, K, K, (half_t*)(base + oA16), Kp);
+  }
+  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
+  launch_f32_to_f16(stream_, (const float*)(base + oW), N, K, K, (half_t*)(base + oW16), Kp);
+  if (ds.bias) PF_HIP(hipMemcpyAsync(base + ob, ds.bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+  if (ds.resid)
+    PF_HIP(hipMemcpy2DAsync(base + oR, (size_t)ld32 * 4, ds.resid, (size_t)N * 4, (size_t)N * 4, M, hipMemcpyHostToDevice, stream_));
+  if (ds.add2)
+    PF_HIP(hipMemcpy2DAsync(base + oD, (size_t)ld32 * 4, ds.add2, (size_t)N * 4, (size_t)N * 4, M, hipMemcpyHostToDevice, stream_));
+  GemmArgs g{};
+  g.A = (half_t*)(base + oA16); g.lda = Kp; g.W = (half_t*)(base + oW16); g.ldw = Kp;
+  g.bias = ds.bias ? (const float*)(base + ob) : nullptr;
+  g.M = M; g.N = N; g.K = Kp; g.relu = ds.relu ? 1 : 0;
+  g.scale_cols = ds.scale_cols; g.scale = ds.scale;
+  g.out_padded = 1;
+  g.a_blocked = ds.a_blocked ? 1 : 0;
+  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : 0);
+  if (ds.out_kind == 0) {
+    g.out_f32 = (float*)(base + oC); g.ldc32 = ld32;
+    if (ds.resid) { g.resid = (const float*)(base + oR); g.ldr = ld32; }
+    if (ds.add2) { g.add2 = (const float*)(base + oD); g.ld2 = ld32; }
+  } else {
+    g.out_f16 = (half_t*)(base + oC); g.ldc16 = ds.out_kind == 2 ? N : ld16;
+    g.out_blocked = ds.out_kind == 2;
+  }
+  prof_begin("gemm_op", 2.0 * M * (double)N * K);
+  launch_gemm(stream_, g);
+  prof_end("gemm_op");
+  if (ds.out_kind == 0) {
+    PF_HIP(hipMemcpy2DAsync(C, (size_t)N * 4, base + oC, (size_t)ld32 * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
+    PF_HIP(hipStreamSynchronize(stream_));
+  } else {
+    const size_t rows = ds.out_kind == 2 ? (size_t)round_up(M, 32) : (size_t)M;
+    const size_t ld = ds.out_kind == 2 ? (size_t)N : (size_t)ld16;
+    std::vector<half_t> tmp(rows * ld);
+    PF_HIP(hipMemcpyAsync(tmp.data(), base + oC, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
+    PF_HIP(hipStreamSynchronize(stream_));
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        const size_t idx = ds.out_kind == 2 ? (((size_t)(m >> 5) * (N >> 3) + (n >> 3)) * 32 + (m & 31)) * 8 + (n & 7)
+                                            : (size_t)m * ld + n;
+        C[(size_t)m * N + n] = (float)tmp[idx];
+      }
+  }
+}
+
+// Encoder FFN as enc_layer() runs it: FFN-up writes the hidden in the blocked activation layout (kind 3),
+// FFN-down reads it as a blocked A operand and adds bias + residual (kind 2).  y = resid + W2 relu(W1 x + b1) + b2.
+void Engine::op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                    const float* resid, int M, int D, int F, float* y) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(M > 0 && D % 64 == 0 && F % 64 == 0, PF_ERR_INVALID_ARG, "ffn: D and F must be multiples of 64");
+  const int64_t Mp = round_up(M, 256) + 128, Fp = round_up(F, 256), Dp = round_up(D, 256);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * D, (int64_t)F * D) * 4);
+  const size_t ox16 = carve((size_t)Mp * D * 2), ow1 = carve((size_t)Fp * D * 2), ow2 = carve((size_t)Dp * F * 2);
+  const size_t ob1 = carve((size_t)F * 4), ob2 = carve((size_t)D * 4), oh = carve((size_t)Mp * F * 2);
+  const size_t oxr = carve((size_t)Mp * D * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + ox16, 0, oxr - ox16, stream_));
+  auto up16 = [&](const float* src, int rows, int cols, size_t dst) {
+    PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), cols);
+    PF_HIP(hipStreamSynchronize(stream_));
+  };
+  up16(x, M, D, ox16); up16(w1, F, D, ow1); up16(w2, D, F, ow2);
+  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + oxr, resid, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
+  Lin L1, L2;
+  L1.w = (half_t*)(base + ow1); L1.bias = (const float*)(base + ob1); L1.N = F; L1.K = D; L1.Kpad = D;
+  L2.w = (half_t*)(base + ow2); L2.bias = (const float*)(base + ob2); L2.N = D; L2.K = F; L2.Kpad = F;
+  float* xr = (float*)(base + oxr);
+  gemm("gemm_ffn1", L1, (half_t*)(base + ox16), D, M, nullptr, 0, (half_t*)(base + oh), F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, 1);
+  gemm("gemm_ffn2", L2, (half_t*)(base + oh), F, M, xr, D, nullptr, 0, xr, D, nullptr, 0, false, 0, 1.f, true, 2);
+  PF_HIP(hipMemcpyAsync(y, xr, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+// Encoder FSMN exactly as enc_layer() launches it: the f16 V slice of a [M, 3D] QKV buffer (row stride 3D).
+void Engine::op_fsmn_enc(const float* v, const float* w, int B, int T, int D, int k, float* y) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(D % 8 == 0 && B > 0 && T > 0, PF_ERR_INVALID_ARG, "fsmn_enc: bad shape");
+  const size_t n = (size_t)B * T * D;
+  std::vector<float> wT((size_t)D * k);
+  for (int c = 0; c < D; ++c)
+    for (int j = 0; j < k; ++j) wT[(size_t)j * D + c] = w[(size_t)c * k + j];
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
+  const size_t ov = carve(n * 4), oq = carve(((size_t)B * T + 128) * 3 * D * 2), ow = carve(wT.size() * 4), oy = carve(n * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + oq, 0, ((size_t)B * T + 128) * 3 * D * 2, stream_));
+  PF_HIP(hipMemcpyAsync(base + ov, v, n * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ow, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
+  half_t* vs = (half_t*)(base + oq) + 2 * D;
+  launch_f32_to_f16(stream_, (const float*)(base + ov), (int64_t)B * T, D, D, vs, 3 * D);
+  launch_fsmn_enc(stream_, vs, 3 * D, (const float*)(base + ow), B, T, D, k, (float*)(base + oy));
+  PF_HIP(hipMemcpyAsync(y, base + oy, n * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+// Decoder FSMN exactly as the decoder launches it: x += (dwconv(tn*m) + tn*m)*m, m = (l < token_num[b]).
+void Engine::op_fsmn_dec(const float* tn, const float* w, const int32_t* token_num, int B, int L, int D, int k, float* x) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(D % 4 == 0 && B > 0 && L > 0, PF_ERR_INVALID_ARG, "fsmn_dec: bad shape");
+  const size_t n = (size_t)B * L * D;
+  std::vector<float> wT((size_t)D * k);
+  for (int c = 0; c < D; ++c)
+    for (int j = 0; j < k; ++j) wT[(size_t)j * D + c] = w[(size_t)c * k + j];
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
+  const size_t ot = carve(n * 4), ox = carve(n * 4), ow = carve(wT.size() * 4), on = carve((size_t)B * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemcpyAsync(base + ot, tn, n * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ox, x, n * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ow, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + on, token_num, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+  launch_fsmn_dec(stream_, (const float*)(base + ot), (const float*)(base + ow), (const int32_t*)(base + on), B, L, D, k,
+                  (float*)(base + ox));
+  PF_HIP(hipMemcpyAsync(x, base + ox, n * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+// The pipeline's vocabulary tail: log-probs y = (x - max) - log(sum exp(x - max)) and the reference's last-index
+// arg-max over y (OfflineRecognizer.cs:139-152 scans the graph OUTPUT).  y == nullptr: ids only (mode 1).
+void Engine::op_logsoftmax_argmax(const float* x, int64_t rows, int V, float* y, int64_t* ids) {
+  PF_HIP(hipSetDevice(device_));
+  if (rows == 0) return;
+  const int ld = (int)round_up(V, 4);
+  ensure(ws_tmp_, (size_t)rows * ld * 4 + (size_t)rows * 8 + 256);
+  float* xd = (float*)ws_tmp_.p;
+  int64_t* idd = (int64_t*)((char*)ws_tmp_.p + round_up((int64_t)rows * ld * 4, 256));
+  PF_HIP(hipMemcpy2DAsync(xd, (size_t)ld * 4, x, (size_t)V * 4, (size_t)V * 4, rows, hipMemcpyHostToDevice, stream_));
+  launch_argmax(stream_, xd, rows, V, ld, y ? 2 : 1, idd);
+  if (y) PF_HIP(hipMemcpy2DAsync(y, (size_t)V * 4, xd, (size_t)ld * 4, (size_t)V * 4, rows, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(ids, idd, (size_t)rows * 8, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y) {

@@ -93,6 +93,12 @@ class Engine {
                        int64_t cap, int32_t* tmax);
   void op_argmax(const float* x, int64_t rows, int V, int64_t* ids);
   void op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C);
+  void op_gemm_ex(const pf_gemm_desc& d, const float* A, const float* W, float* C);
+  void op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
+              int M, int D, int F, float* y);
+  void op_fsmn_enc(const float* v, const float* w, int B, int T, int D, int k, float* y);
+  void op_fsmn_dec(const float* tn, const float* w, const int32_t* token_num, int B, int L, int D, int k, float* x);
+  void op_logsoftmax_argmax(const float* x, int64_t rows, int V, float* y, int64_t* ids);
   void op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y);
   void op_attention(const float* q, const float* k, const float* v, int B, int Lq, int Lk, int H, float* o);
   void op_fsmn(const float* v, const float* w, const float* mask, int B, int T, int D, int k, float* y);

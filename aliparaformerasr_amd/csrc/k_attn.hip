@@ -21,6 +21,8 @@
 //   V: 16-byte chunk ^= ((key & 3) << 2)    -> the 4 key rows of a tr-read hit 4 bank quarters
 #include "kernels.h"
 
+#include <mutex>
+
 namespace pf {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -333,13 +335,17 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk;
   PF_CHECK(a.q_rstride % 8 == 0 && a.k_rstride % 8 == 0 && a.v_rstride % 8 == 0 && a.o_rstride % 4 == 0,
            PF_ERR_INVALID_ARG, "attention: row strides must keep 16-byte alignment");
+  static std::mutex init_mu;                         // engines on different devices launch from different threads
   static bool attr_set[64] = {false};
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
-  if (!attr_set[dev & 63]) {
-    PF_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               ATT_LDS_BYTES));
-    attr_set[dev & 63] = true;
+  {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!attr_set[dev & 63]) {
+      PF_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 ATT_LDS_BYTES));
+      attr_set[dev & 63] = true;
+    }
   }
   dim3 grid((a.Lq + ATT_BQ - 1) / ATT_BQ, a.B * a.H);
   hipLaunchKernelGGL(attn_kernel, grid, dim3(256), ATT_LDS_BYTES, s, d);

@@ -43,6 +43,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace pf {
@@ -616,32 +617,35 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   PF_CHECK(!a.a_blocked || a.K % 64 == 0, PF_ERR_INVALID_ARG, "gemm: blocked A operand needs K % 64 == 0");
   // 128-row tiles when 256-row tiles would leave CUs idle (decoder GEMMs with N = 512: 84 tiles); measured
   // A/B in one session: x = 0.9 -> 14.85 ms/step, x = 0 -> 15.15, x >= 1.5 (also the encoder N = 512 GEMMs) -> 15.9
-  static int cus[64] = {0};
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
   dev &= 63;
-  if (!cus[dev]) {
-    hipDeviceProp_t prop;
-    PF_HIP(hipGetDeviceProperties(&prop, dev));
-    cus[dev] = prop.multiProcessorCount;
-  }
+  // per-device launch facts, initialised once per device under a lock: engines on different devices launch
+  // from different host threads (one engine per GPU, include/paraformer_hip.h pf_group_*)
+  static std::mutex init_mu;
+  static int cus[64] = {0};
   static float mi_x = -1.f;                          // PF_GEMM_MI_X: tuning knob for tools/ (tiles < x * CUs -> 128-row tiles)
-  if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.9f; }
-  const int mi = ((float)(cdiv(d.M, 256) * cdiv(d.N, GEMM_BN)) < mi_x * cus[dev]) ? 1 : 2;
+  {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!cus[dev]) {
+      hipDeviceProp_t prop;
+      PF_HIP(hipGetDeviceProperties(&prop, dev));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+      cus[dev] = prop.multiProcessorCount;
+    }
+    if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.9f; }
+  }
+  const int mi = a.force_mi ? (a.force_mi == 1 ? 1 : 2)
+                            : (((float)(cdiv(d.M, 256) * cdiv(d.N, GEMM_BN)) < mi_x * cus[dev]) ? 1 : 2);
   d.tiles_m = cdiv(d.M, 128 * mi);
   d.tiles_n = cdiv(d.N, GEMM_BN);
   const int total = d.tiles_m * d.tiles_n;
   if (total == 0) return;
-  static bool attr[64] = {false};
-  if (!attr[dev]) {
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
-    PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
-    attr[dev] = true;
-  }
   int grid = cus[dev];
   if (grid > total) grid = total;
   const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && ((a.ldc16 & 7) == 0 || a.out_blocked);

@@ -511,17 +511,26 @@ void launch_seaco_merge(hipStream_t s, const float* dha, int ld_dha, const int64
 }
 
 // ------------------------------------------------------------------ arg-max ---------------
+// The reference scans the tensor the graph RETURNS, i.e. the log-probs (OfflineRecognizer.cs:139-152 reads
+// out[0]; the FunASR export ends in LogSoftmax), not the raw logits: x - lse rounds at a coarser ulp than x
+// when |lse| > |x|, two distinct logits can become EQUAL log-probs, and the loop then keeps the LARGER index
+// (quirk Q4).  So the pipeline forms y = (x - max) - log(sum exp(x - max)) — the two-step form of onnxruntime's
+// CPU LogSoftmax (MLAS: (Input + NegativeMaximum) - Logarithm) — and runs the reference loop on y, whether or
+// not the caller wants the log-probs stored.
 struct VI { float v; int i; };
-// reference combine for "a scanned before b": keep a only if a.v > b.v, else b  (ties/NaN -> later)
+// combine of two partial scans over disjoint index sets: larger value, then larger index
 __device__ __forceinline__ VI vi_later(VI a, VI b) {
-  // a, b may come from disjoint index sets in any order: prefer larger value, then larger index
   if (a.v > b.v) return a;
   if (b.v > a.v) return b;
   return a.i > b.i ? a : b;
 }
 
+// MODE 0: scan the values as given (stand-alone op).  MODE 1: scan the log-probs, do not store them.
+// MODE 2: scan the log-probs and store them in place.  NV > 0: the row (V <= 256 * NV) is held in registers
+// (one global read); NV == 0: the row is re-read (it stays in this CU's L1/L2).
+template <int MODE, int NV>
 __global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ x, int64_t rows, int V, int ldx,
-                                                     int do_logsoftmax, int64_t* __restrict__ ids) {
+                                                     int64_t* __restrict__ ids) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   __shared__ int s_nan[4];
@@ -529,13 +538,66 @@ __global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ x, int6
   const int64_t row = blockIdx.x;
   float* xr = x + row * (int64_t)ldx;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // pass 1: last NaN position (the reference scan restarts after every NaN) + plain arg-max
+  float reg[NV > 0 ? NV : 1];
+  if constexpr (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = tid + 256 * j;
+      reg[j] = k < V ? xr[k] : 0.f;
+    }
+  }
+  auto raw = [&](int j, int k) __attribute__((always_inline)) -> float {
+    if constexpr (NV > 0) return reg[j];
+    else return xr[k];
+  };
+  float mx = 0.f, lg = 0.f;
+  if constexpr (MODE != 0) {
+    // max (NaN ignored by fmaxf; it resurfaces through the sum), then sum of exp(x - max)
+    float m = -INFINITY;
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) if (tid + 256 * j < V) m = fmaxf(m, reg[j]);
+    } else {
+      for (int k = tid; k < V; k += 256) m = fmaxf(m, xr[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) s_f[wv] = m;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_f[0], s_f[1]), fmaxf(s_f[2], s_f[3]));
+    __syncthreads();
+    float sum = 0.f;
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) if (tid + 256 * j < V) sum += expf(reg[j] - mx);
+    } else {
+      for (int k = tid; k < V; k += 256) sum += expf(xr[k] - mx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) s_f[wv] = sum;
+    __syncthreads();
+    lg = logf((s_f[0] + s_f[1]) + (s_f[2] + s_f[3]));
+  }
+  auto val = [&](int j, int k) __attribute__((always_inline)) -> float {
+    const float v = raw(j, k);
+    if constexpr (MODE != 0) return sub_rn(sub_rn(v, mx), lg);
+    else return v;
+  };
+  // pass 1: last NaN position (the reference scan restarts after every NaN) + plain last-index arg-max
   int last_nan = -1;
   VI best = {-INFINITY, -1};
-  for (int k = tid; k < V; k += 256) {
-    const float v = xr[k];
+  auto visit = [&](int j, int k) __attribute__((always_inline)) {
+    const float v = val(j, k);
+    if constexpr (MODE == 2) xr[k] = v;
     if (v != v) last_nan = k;
-    else if (v > best.v || (v == best.v)) { best.v = v; best.i = k; }   // k ascending per thread
+    else if (v >= best.v) { best.v = v; best.i = k; }   // k ascending per thread
+  };
+  if constexpr (NV > 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) if (tid + 256 * j < V) visit(j, tid + 256 * j);
+  } else {
+    for (int k = tid, j = 0; k < V; k += 256, ++j) visit(j, k);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -555,9 +617,18 @@ __global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ x, int6
   if (last_nan >= 0) {                       // rare path: redo over the suffix after the last NaN
     __syncthreads();
     VI b2 = {-INFINITY, -1};
-    for (int k = last_nan + 1 + tid; k < V; k += 256) {
-      const float v = xr[k];
-      if (v > b2.v || v == b2.v) { b2.v = v; b2.i = k; }
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int k = tid + 256 * j;
+        if (k < V && k > last_nan) { const float v = val(j, k); if (v >= b2.v) { b2.v = v; b2.i = k; } }
+      }
+    } else {
+      for (int k = tid; k < V; k += 256)
+        if (k > last_nan) {                  // MODE 2 already stored y over the row (own k's only: visible)
+          const float v = MODE == 2 ? xr[k] : val(0, k);
+          if (v >= b2.v) { b2.v = v; b2.i = k; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -577,23 +648,21 @@ __global__ __launch_bounds__(256) void argmax_kernel(float* __restrict__ x, int6
     result = V - 1;                          // row of -inf only
   }
   if (tid == 0) ids[row] = result;
-  if (do_logsoftmax) {
-    const float mx = best.v;
-    float sum = 0.f;
-    for (int k = tid; k < V; k += 256) sum += expf(xr[k] - mx);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    __syncthreads();
-    if (lane == 0) s_f[wv] = sum;
-    __syncthreads();
-    const float lse = mx + logf((s_f[0] + s_f[1]) + (s_f[2] + s_f[3]));
-    for (int k = tid; k < V; k += 256) xr[k] = xr[k] - lse;
-  }
 }
 
-void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int do_logsoftmax, int64_t* ids) {
+void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int mode, int64_t* ids) {
   if (rows == 0) return;
-  hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, rows, V, ldx, do_logsoftmax, ids);
+  const dim3 g((unsigned)rows), b(256);
+  const bool small = V <= 256 * 36;          // paraformer's 8404-entry vocabulary: 33 values per thread
+#define PF_AM(MODE)                                                                                    \
+  do {                                                                                                 \
+    if (small) hipLaunchKernelGGL((argmax_kernel<MODE, 36>), g, b, 0, s, x, rows, V, ldx, ids);      \
+    else hipLaunchKernelGGL((argmax_kernel<MODE, 0>), g, b, 0, s, x, rows, V, ldx, ids);             \
+  } while (0)
+  if (mode == 0) PF_AM(0);
+  else if (mode == 1) PF_AM(1);
+  else PF_AM(2);
+#undef PF_AM
   PF_HIP(hipGetLastError());
 }
 

@@ -28,6 +28,7 @@ struct GemmArgs {
   // FFN-up writes it (out_blocked, f16-only results, N % 64 == 0), FFN-down reads it (a_blocked, lda ignored).
   int out_blocked;
   int a_blocked;
+  int force_mi;                  // 0 = choose by tile count; 1 / 2 = 128- / 256-row tiles (stand-alone op tests)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 
@@ -116,7 +117,8 @@ void launch_add_to_f16(hipStream_t s, const float* a, const float* b, int64_t ro
 // (copy_logits) logits[row, 0:V] = dha[row, 0:V]
 void launch_seaco_merge(hipStream_t s, const float* dha, int ld_dha, const int64_t* dha_ids, int64_t rows, int V,
                         int nobias, int copy_logits, float* logits, int ld_logits, int64_t* ids);
-// last-index arg-max (+ optional in-place log_softmax) over rows of width V
-void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int do_logsoftmax, int64_t* ids);
+// last-index arg-max over rows of width V.  mode 0: over the values as given; 1: over the log-probs
+// y = (x - max) - log(sum exp(x - max)) (what the reference scans), y not stored; 2: same, y stored in place
+void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int mode, int64_t* ids);
 
 }  // namespace pf

@@ -260,6 +260,56 @@ class Engine:
                                      2 if f16_out else (1 if relu else 0), _fp(out)))
         return out
 
+    def op_gemm_ex(self, A, W, bias=None, resid=None, add2=None, relu=False, out_kind=0, a_blocked=False,
+                   tile_rows=0, scale_cols=0, scale=1.0) -> np.ndarray:
+        """The GEMM as the pipeline launches it (out_kind 0 fp32 / 1 f16 / 2 f16 blocked)."""
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        Nn = W.shape[0]
+        d = N.PfGemmDesc()
+        d.struct_size = C.sizeof(N.PfGemmDesc)
+        d.M, d.N, d.K = M, Nn, K
+        d.relu, d.out_kind, d.a_blocked, d.tile_rows = int(relu), out_kind, int(a_blocked), tile_rows
+        d.scale_cols, d.scale = scale_cols, scale
+        keep = [_f32(t) if t is not None else None for t in (bias, resid, add2)]
+        d.bias, d.resid, d.add2 = [_fp(t) if t is not None else None for t in keep]
+        out = np.zeros((M, Nn), np.float32)
+        N.check(self._lib.pf_op_gemm_ex(self._h, C.byref(d), _fp(A), _fp(W), _fp(out)))
+        return out
+
+    def op_ffn(self, x, w1, b1, w2, b2, resid) -> np.ndarray:
+        x, w1, b1, w2, b2, resid = map(_f32, (x, w1, b1, w2, b2, resid))
+        M, D = x.shape
+        F = w1.shape[0]
+        y = np.zeros((M, D), np.float32)
+        N.check(self._lib.pf_op_ffn(self._h, _fp(x), _fp(w1), _fp(b1), _fp(w2), _fp(b2), _fp(resid), M, D, F, _fp(y)))
+        return y
+
+    def op_fsmn_enc(self, v, w) -> np.ndarray:
+        v, w = _f32(v), _f32(w)
+        B, T, D = v.shape
+        y = np.zeros_like(v)
+        N.check(self._lib.pf_op_fsmn_enc(self._h, _fp(v), _fp(w), B, T, D, w.shape[1], _fp(y)))
+        return y
+
+    def op_fsmn_dec(self, tn, w, token_num, x) -> np.ndarray:
+        tn, w, x = _f32(tn), _f32(w), _f32(x).copy()
+        B, L, D = tn.shape
+        t = np.ascontiguousarray(token_num, dtype=np.int32)
+        N.check(self._lib.pf_op_fsmn_dec(self._h, _fp(tn), _fp(w), t.ctypes.data_as(C.POINTER(C.c_int32)), B, L, D,
+                                         w.shape[1], _fp(x)))
+        return x
+
+    def op_logsoftmax_argmax(self, x, store=True):
+        a = _f32(x)
+        V = a.shape[-1]
+        rows = a.size // V
+        ids = np.zeros(rows, np.int64)
+        y = np.zeros_like(a) if store else None
+        N.check(self._lib.pf_op_logsoftmax_argmax(self._h, _fp(a), rows, V, _fp(y) if store else None,
+                                                  ids.ctypes.data_as(C.POINTER(C.c_int64))))
+        return (y, ids.reshape(a.shape[:-1])) if store else ids.reshape(a.shape[:-1])
+
     def op_layernorm(self, x, gamma, beta) -> np.ndarray:
         x, g, b = _f32(x), _f32(gamma), _f32(beta)
         D = x.shape[-1]

@@ -24,8 +24,11 @@ The JSON line also carries
                  in the image) timed on the host cores on a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,6 +45,31 @@ LCAP = 512
 DOMINANT = "gemm_ffn1"
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 PMC_FILE = os.path.join(ROOT, "profiles", "round1_f_gemm_ffn1_pmc.json")
+
+
+def ids_checksum(ids) -> str:
+    """Order-sensitive checksum of the [B, L] arg-max ids of a step (tests/test_gpu_baseline_sizes.py pins it to
+    the oracle for a depth-reduced 32 x 30 s run)."""
+    return hashlib.sha1(np.ascontiguousarray(ids, dtype=np.int64).tobytes()).hexdigest()
+
+
+def respawn_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves, one process per GPU,
+    exactly as the documented launch line does (RCCL rendezvous on 127.0.0.1), and relay rank 0's JSON line."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible\n" % (n, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PF_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def pmc_traffic():
@@ -87,7 +115,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="utterances per GPU (default: 32 = BASELINE.json configs[1]; 64 for --model sensevoice = configs[2]; "
+                         "128 at --gpus 8 = the per-GPU shard of configs[3], 1024 x 30 s over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed step with per-class kernel times")
     ap.add_argument("--model", choices=("paraformer", "sensevoice", "seaco"), default="paraformer",
@@ -98,6 +128,9 @@ def main():
                     help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args.gpus))
+
     import torch
     import torch.distributed as dist
     from aliparaformerasr_amd import weights as W
@@ -106,6 +139,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
+                         "(or plain `python bench.py --gpus %d`, which spawns the ranks itself)" % (args.gpus, world, args.gpus, args.gpus))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -113,7 +149,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     dev = torch.device("cuda", local)
 
     # ---- weights: rank 0 builds the synthetic paraformer-large image, RCCL-broadcasts it
@@ -121,10 +156,10 @@ def main():
     sv = args.model == "sensevoice"
     seconds = args.seconds or (10 if sv else SECONDS)
     samples = seconds * 16000
+    if args.batch <= 0:
+        args.batch = 64 if sv else (128 if (world == 8 and args.model == "paraformer") else BATCH_PER_GPU)
     if sv:
         cfg = W.sensevoice_small_config(use_itn=True)
-        if args.batch == BATCH_PER_GPU:
-            args.batch = 64
     elif args.model == "seaco":
         cfg = W.seaco_paraformer_config()
         args.timestamp_head = True
@@ -189,6 +224,13 @@ def main():
         dt = float(tmax.item())
     res = eng.fetch()
     ms_dom, n_dom, fpl_dom = eng.profile_get(DOMINANT)
+    # the timed steps must have produced a real transcript-shaped result: every utterance decoded, ids in range
+    assert res.L > 0 and res.token_ids.shape == (B, res.L), (res.L, res.token_ids.shape)
+    assert (res.token_ids >= 0).all() and (res.token_ids < eng.vocab).all()
+    assert (res.token_num > 0).all()
+    if world > 1:
+        g = gathered["ids"]
+        assert g.shape == (world * B, LCAP) and (g[rank * B:(rank + 1) * B, :res.L] == res.token_ids).all()
 
     # PCIe-inclusive rate (never `value`): host float32 audio in, ids back on the host, per batch
     host_ms = None
@@ -231,10 +273,13 @@ def main():
                                    "(BASELINE.json configs[%d]), seeded synthetic weights"
                                    % ("sensevoice-small (use_itn on)" if sv else ("SeACo-paraformer, 21 hotwords" if args.model == "seaco" else "paraformer-large-zh"),
                                       " + BiCIF timestamp head" if args.timestamp_head else "", B, seconds,
-                                      2 if sv else (4 if args.timestamp_head else 1)),
+                                      2 if sv else (4 if args.timestamp_head else (3 if world * B == 1024 else 1))),
                        "global_batch": world * B, "samples_per_utt": samples, "T_lfr": eng.num_frames(samples), "L": int(res.L),
                        "parallelism": "dp%d (utterance shards, no data-path collective)" % world},
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
+            "rccl_ranks": world if world > 1 else 0,
+            "ids_sha1": ids_checksum(res.token_ids),   # rank 0's [B, L] ids of the last timed step
+            "token_num_sum": int(res.token_num.sum()),
             "host_audio_ms_per_batch": host_ms,     # one GPU's batch incl. H2D of the audio and D2H of the ids
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,

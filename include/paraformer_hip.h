@@ -186,7 +186,12 @@ int pf_last_flops(pf_engine* e, double* flops);
 
 /* ------------------------------------------------------------------------ */
 /* 5. Stand-alone device ops exposed for parity tests (tests/ call these through
- *    the C ABI; they are the same kernels the pipeline launches).            */
+ *    the C ABI).  pf_op_gemm_ex / pf_op_ffn / pf_op_fsmn_enc / pf_op_fsmn_dec /
+ *    pf_op_logsoftmax_argmax / pf_op_attention / pf_op_layernorm / pf_op_cif /
+ *    pf_op_lfr_cmvn_pad launch exactly the kernels (and kernel variants) the
+ *    pipeline launches; pf_op_gemm chooses its variant by shape like the
+ *    pipeline does; pf_op_fsmn is a generic fp32 FSMN (arbitrary mask) that the
+ *    pipeline itself does not launch; pf_op_argmax scans the values as given. */
 /* ------------------------------------------------------------------------ */
 /* LFR + CMVN + right-pad + sentinel: fbank rows of B utterances -> [B, Tmax, lfr_m*80]. */
 int pf_op_lfr_cmvn_pad(pf_engine* e, const float* const* fbank, const int32_t* t80, int32_t B,
@@ -197,6 +202,35 @@ int pf_op_argmax(pf_engine* e, const float* x, int64_t rows, int32_t V, int64_t*
    2 = f16 result store (the path the pipeline uses), returned widened to fp32. */
 int pf_op_gemm(pf_engine* e, const float* A, const float* W, const float* bias,
                int32_t M, int32_t N, int32_t K, int32_t epilogue, float* C);
+/* The GEMM as the pipeline launches it, every variant selectable. */
+typedef struct pf_gemm_desc {
+  int32_t struct_size;
+  int32_t M, N, K;
+  int32_t relu;
+  int32_t out_kind;           /* 0 fp32 result (+ residual / addend), 1 f16 row-major, 2 f16 blocked layout
+                                 (32 rows x 8 columns = 512 contiguous bytes; the encoder FFN hidden)         */
+  int32_t a_blocked;          /* A is handed to the kernel in the blocked layout (FFN-down's operand)         */
+  int32_t tile_rows;          /* 0 = by tile count as the pipeline does, 128, 256                             */
+  int32_t scale_cols;         /* columns n < scale_cols are multiplied by scale after the bias (q scaling)    */
+  float scale;
+  const float* bias;          /* [N] or NULL                                                                  */
+  const float* resid;         /* [M,N] fp32 or NULL (out_kind 0)                                              */
+  const float* add2;          /* [M,N] fp32 or NULL (out_kind 0): the FSMN memory added by the out-projection */
+} pf_gemm_desc;
+/* C [M,N] fp32 (f16 results widened, blocked results de-blocked on the host). */
+int pf_op_gemm_ex(pf_engine* e, const pf_gemm_desc* d, const float* A, const float* W, float* C);
+/* Encoder FFN with the blocked hand-off of the hidden: y = resid + W2 relu(W1 x + b1) + b2;
+   x [M,D], w1 [F,D], w2 [D,F], resid / y [M,D]. */
+int pf_op_ffn(pf_engine* e, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+              const float* resid, int32_t M, int32_t D, int32_t F, float* y);
+/* Encoder FSMN kernel (f16 V slice of a [B*T, 3D] buffer in, fp32 out): y = dwconv_k(v) + v. */
+int pf_op_fsmn_enc(pf_engine* e, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y);
+/* Decoder FSMN kernel: x += (dwconv_k(tn*m) + tn*m)*m, m = (l < token_num[b]); x in/out [B,L,D]. */
+int pf_op_fsmn_dec(pf_engine* e, const float* tn, const float* w, const int32_t* token_num, int32_t B, int32_t L,
+                   int32_t D, int32_t k, float* x);
+/* The pipeline's vocabulary tail: y = log_softmax(x) (two-step form, see k_misc.hip) and the last-index arg-max
+   over y — what OfflineRecognizer.cs:139-152 scans.  y_out may be NULL (ids-only variant of the kernel). */
+int pf_op_logsoftmax_argmax(pf_engine* e, const float* x, int64_t rows, int32_t V, float* y_out, int64_t* ids_out);
 /* LayerNorm over the last dim (eps 1e-12), fp32. */
 int pf_op_layernorm(pf_engine* e, const float* x, const float* gamma, const float* beta,
                     int64_t rows, int32_t dim, float* y);

@@ -90,6 +90,15 @@ def layer_norm(x, w, b):
     return y.to(torch.float32)
 
 
+def log_softmax(x):
+    """LogSoftmax as onnxruntime's CPU kernel forms it (MLAS: (Input + NegativeMaximum) - Logarithm), float32:
+    y = (x - max) - log(sum(exp(x - max))).  The reference's arg-max loop (OfflineRecognizer.cs:139-152) scans THIS
+    tensor, so distinct logits whose log-probs round to the same float32 tie (and resolve to the larger index)."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    d = x - x.max(dim=-1, keepdim=True).values
+    return d - torch.log(torch.exp(d).sum(dim=-1, keepdim=True))
+
+
 def sinusoidal_pe(T: int, depth: int) -> torch.Tensor:
     """SinusoidalPositionEncoder.encode: positions 1..T, [sin || cos], float32."""
     half = depth // 2
@@ -326,7 +335,7 @@ class Oracle:
         """E [B,L,512] acoustic embeds, H [B,T,512] memory, token_num [B] -> logits [B,L,V]
         (log_softmax applied, as the ONNX graph does)."""
         hid = self._sanm_decoder(E, H, token_num, "decoder", self.cfg.dec_layers, self.cfg.kernel)
-        logp = torch.log_softmax(self.lin(hid, "decoder.output"), dim=-1)
+        logp = log_softmax(self.lin(hid, "decoder.output"))
         return (logp, hid) if return_hidden else logp
 
     # -- SeACo ---------------------------------------------------------------
@@ -375,7 +384,7 @@ class Oracle:
             bias = hw_embed.transpose(0, 1).reshape(1, N * J, D).expand(B, N * J, D)   # row n*10+j (EmbedSeacoModel / :83-111)
             cif_att = self._sanm_decoder(E, bias, tnum, "seaco.decoder", c.seaco_layers, c.seaco_kernel)
             dec_att = self._sanm_decoder(hid, bias, tnum, "seaco.decoder", c.seaco_layers, c.seaco_kernel)
-            dha = torch.log_softmax(self.lin(cif_att + dec_att, "seaco.output"), dim=-1)
+            dha = log_softmax(self.lin(cif_att + dec_att, "seaco.output"))
             nobias = (torch.argmax(dha, dim=-1) == c.seaco_nobias).unsqueeze(-1)
             logp = torch.where(nobias, logp, dha)
             out["dha_logits"] = dha.numpy()
@@ -403,7 +412,7 @@ class Oracle:
         encoder (50 + 20 tp blocks) -> CTC linear -> log_softmax, [B,T+4,V]."""
         H = self.encoder(speech)
         logits = self.lin(H, "ctc")
-        return {"logits": torch.log_softmax(logits, dim=-1).numpy(), "H": H.numpy(),
+        return {"logits": log_softmax(logits).numpy(), "H": H.numpy(),
                 "token_num": np.full((H.shape[0],), H.shape[1], np.int32)}
 
 

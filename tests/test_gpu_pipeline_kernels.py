@@ -1,0 +1,238 @@
+"""GPU: the kernel VARIANTS the benchmark's pipeline actually launches, at the benchmark's row count
+(M = 32 x 500 = 16 000), each called through the C ABI and compared with an independent numpy / oracle
+statement on the same seeded inputs:
+
+  * gemm_f16_pp3<kind, MI> for kind 1 (f16 row-major), 2 (fp32 + residual + FSMN addend), 3 (f16 blocked
+    layout) x MI 1 / 2 (128- / 256-row tiles), incl. the blocked A operand and the q-column scaling;
+  * the FFN-up (blocked out) -> FFN-down (blocked in) hand-off as enc_layer() runs it;
+  * fsmn_enc_kernel<11> (f16 V slice with row stride 3D) and fsmn_dec_kernel<11 / 21>;
+  * the vocabulary tail: log-softmax + last-index arg-max over the LOG-PROBS (what
+    AliParaformerAsr/OfflineRecognizer.cs:139-152 scans), both kernel variants (row in registers / re-read).
+
+Tolerances: f16 x f16 products are exact in fp32, so GEMM results differ from the float64 product of the
+f16-rounded operands only by fp32 accumulation order (1e-4 rel) plus, for f16 results, one f16 rounding
+(2^-11 rel); index work is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from aliparaformerasr_amd import weights as W
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+M_BENCH = 16000
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=128)
+    w = W.synth_weights(cfg, seed=5)
+    e = Engine(weights=W.pack_pfw(cfg, w), cmvn=W.synth_cmvn(), device=0)
+    yield e
+    e.close()
+
+
+def h16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def _ref(A, Wm, bias):
+    # float32 BLAS product of the f16-rounded operands (products exact, accumulation order differs)
+    return h16(A) @ h16(Wm).T + bias
+
+
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_gemm_kind1_f16_rowmajor_with_q_scale(eng, tile_rows):
+    """QKV projection shape: [16000 x 512] x [512 x 1536], q columns (first 512) scaled by 1/sqrt(128)."""
+    rng = np.random.default_rng(100 + tile_rows)
+    M, N, K = M_BENCH, 1536, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wm += (np.arange(N)[:, None] * 1e-4).astype(np.float32)            # asymmetric: detects transposes
+    bias = rng.standard_normal(N).astype(np.float32)
+    sc = np.float32(128 ** -0.5)
+    ref = _ref(A, Wm, bias)
+    ref[:, :512] *= sc
+    got = eng.op_gemm_ex(A, Wm, bias, out_kind=1, tile_rows=tile_rows, scale_cols=512, scale=float(sc))
+    np.testing.assert_allclose(got, ref, rtol=1.5e-3, atol=1.5e-3)
+    assert np.array_equal(got, eng.op_gemm_ex(A, Wm, bias, out_kind=1, tile_rows=tile_rows, scale_cols=512, scale=float(sc)))
+
+
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_gemm_kind2_fp32_residual_and_fsmn_addend(eng, tile_rows):
+    """Out-projection shape: [16000 x 512] x [512 x 512] + bias + fp32 residual + fp32 FSMN memory."""
+    rng = np.random.default_rng(200 + tile_rows)
+    M, N, K = M_BENCH, 512, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32) * 3
+    add2 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = _ref(A, Wm, bias) + add2 + resid
+    got = eng.op_gemm_ex(A, Wm, bias, resid=resid, add2=add2, out_kind=0, tile_rows=tile_rows)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=3e-4)
+    got2 = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, tile_rows=tile_rows)
+    np.testing.assert_allclose(got2, _ref(A, Wm, bias) + resid, rtol=1e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_gemm_kind3_blocked_output(eng, tile_rows):
+    """FFN-up shape: [16000 x 512] x [512 x 2048] + bias + ReLU into the blocked activation layout (de-blocked by
+    the host side of the op with index arithmetic written independently of the kernel's)."""
+    rng = np.random.default_rng(300 + tile_rows)
+    M, N, K = M_BENCH, 2048, 512
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wm += (np.arange(N)[:, None] * 1e-4).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = np.maximum(_ref(A, Wm, bias), 0)
+    got = eng.op_gemm_ex(A, Wm, bias, relu=True, out_kind=2, tile_rows=tile_rows)
+    np.testing.assert_allclose(got, ref, rtol=1.5e-3, atol=1.5e-3)
+
+
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_gemm_blocked_a_operand(eng, tile_rows):
+    """FFN-down shape: blocked A [16000 x 2048] x [2048 x 512] + bias + fp32 residual (K = 2048: 32 k-steps)."""
+    rng = np.random.default_rng(400 + tile_rows)
+    M, N, K = M_BENCH, 512, 2048
+    A = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    A += (np.arange(K)[None, :] * 1e-4).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    ref = _ref(A, Wm, bias) + resid
+    got = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=True, tile_rows=tile_rows)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
+
+
+def test_gemm_ragged_edges_all_kinds(eng):
+    """M and N that are not multiples of the tile, every kind x tile height."""
+    rng = np.random.default_rng(77)
+    for (M, N, K) in ((5344, 512, 512), (333, 576, 2048), (5000, 2048, 512), (83, 1536, 576)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        ref = _ref(A, Wm, bias)
+        for tr in (128, 256):
+            np.testing.assert_allclose(eng.op_gemm_ex(A, Wm, bias, out_kind=0, tile_rows=tr), ref, rtol=1e-4, atol=6e-4)
+            np.testing.assert_allclose(eng.op_gemm_ex(A, Wm, bias, out_kind=1, tile_rows=tr), ref, rtol=1.5e-3, atol=1.5e-3)
+            np.testing.assert_allclose(eng.op_gemm_ex(A, Wm, bias, out_kind=2, relu=True, tile_rows=tr), np.maximum(ref, 0),
+                                       rtol=1.5e-3, atol=1.5e-3)
+
+
+def test_ffn_blocked_handoff_at_bench_rows(eng):
+    """FFN-up (kind 3, blocked out) -> FFN-down (blocked A, kind 2) exactly as enc_layer() chains them."""
+    rng = np.random.default_rng(9)
+    M, D, F = M_BENCH, 512, 2048
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    resid = rng.standard_normal((M, D)).astype(np.float32) * 2
+    h = h16(np.maximum(h16(x) @ h16(w1).T + b1, 0))                   # the hidden is stored as f16
+    ref = h @ h16(w2).T + b2 + resid
+    got = eng.op_ffn(x, w1, b1, w2, b2, resid)
+    # hidden values that sit on an f16 rounding boundary may round the other way (fp32 accumulation order):
+    # each flips one operand by 2^-11 relative
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-3)
+    assert np.abs(got - ref).mean() < 1e-4
+
+
+def test_fsmn_enc_kernel_f16_strided(eng):
+    rng = np.random.default_rng(10)
+    for (B, T) in ((32, 500), (2, 83), (3, 7), (1, 1), (2, 166)):
+        v = rng.standard_normal((B, T, 512)).astype(np.float32)
+        w = (0.1 * rng.standard_normal((512, 11))).astype(np.float32)
+        ref = om.fsmn(torch.from_numpy(h16(v)), torch.from_numpy(w), 11).numpy()
+        got = eng.op_fsmn_enc(v, w)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_fsmn_dec_kernel(eng):
+    rng = np.random.default_rng(11)
+    for (B, L, k) in ((32, 167, 11), (2, 25, 11), (64, 150, 21), (1, 3, 21), (3, 40, 11)):
+        tn = rng.standard_normal((B, L, 512)).astype(np.float32)
+        x = rng.standard_normal((B, L, 512)).astype(np.float32)
+        w = (0.1 * rng.standard_normal((512, k))).astype(np.float32)
+        n = rng.integers(0, L + 1, B).astype(np.int32)
+        n[0] = L
+        mask = (np.arange(L)[None, :] < n[:, None]).astype(np.float32)[..., None]
+        ref = x + om.fsmn(torch.from_numpy(tn), torch.from_numpy(w), k, torch.from_numpy(mask)).numpy()
+        got = eng.op_fsmn_dec(tn, w, n, x)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------- vocabulary tail
+def test_logsoftmax_argmax_scans_the_log_probs(eng):
+    rng = np.random.default_rng(12)
+    for V in (8404, 25055, 512, 37, 1):
+        x = (rng.standard_normal((300, V)) * 2).astype(np.float32)
+        x[5, :] = 0.25                               # all equal -> V-1
+        if V > 100:
+            x[7, 50] = x[7].max() + 1                # clear winner
+            x[9, 10] = x[9, 90] = x[9].max() + 2     # exact tie in the logits -> later index
+        y, ids = eng.op_logsoftmax_argmax(x)
+        ref = om.log_softmax(torch.from_numpy(x)).numpy()
+        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
+        # index work is bit-exact ON THE TENSOR THE DEVICE RETURNS (= what the reference loop would scan)
+        np.testing.assert_array_equal(ids, om.argmax_last(y))
+        # ids-only variant of the kernel (log-probs formed on the fly, never stored): identical ids
+        np.testing.assert_array_equal(eng.op_logsoftmax_argmax(x, store=False), ids)
+        assert ids[5] == V - 1
+        if V > 100:
+            assert ids[7] == 50 and ids[9] == 90
+
+
+def test_logsoftmax_argmax_collision_kat(eng):
+    """Two logits one ulp apart whose log-probs are the SAME float32: the raw arg-max says the earlier index,
+    the reference (scanning log-probs, ties -> larger index) says the later one."""
+    V = 8404
+    x = np.full((4, V), -1.0, np.float32)
+    hi = np.nextafter(np.float32(0.5), np.float32(1.0))
+    x[:, 3] = hi          # the larger logit, earlier
+    x[:, 7] = 0.5         # one ulp smaller, later
+    x[1, 7] = hi; x[1, 3] = 0.5                      # mirrored: larger one later anyway
+    x[2, 7] = np.float32(0.6)                        # clear margin: no collision
+    assert (np.argmax(x[0]) == 3) and x[0, 3] > x[0, 7]
+    y, ids = eng.op_logsoftmax_argmax(x)
+    ref = om.log_softmax(torch.from_numpy(x)).numpy()
+    # lse ~ 8.1: ulp(y) = 9.5e-7 >> ulp(x) = 6e-8, so the two log-probs collide in the oracle as well
+    assert ref[0, 3] == ref[0, 7] and y[0, 3] == y[0, 7]
+    np.testing.assert_array_equal(ids, om.argmax_last(y))
+    np.testing.assert_array_equal(ids, om.argmax_last(ref))
+    assert list(ids) == [7, 7, 7, 7]
+    np.testing.assert_array_equal(eng.op_logsoftmax_argmax(x, store=False), ids)
+
+
+def test_logsoftmax_argmax_adversarial_rows(eng):
+    """Many near-tie rows: flat distributions (lse >> |x|) with clusters of logits a few ulps apart."""
+    rng = np.random.default_rng(13)
+    R, V = 20000, 512
+    base = rng.uniform(-0.5, 0.5, (R, 1)).astype(np.float32)
+    x = np.repeat(base, V, axis=1)
+    steps = rng.integers(0, 3, (R, V)).astype(np.int32)
+    xi = x.view(np.int32) + steps * np.sign(x).astype(np.int32)        # 0..2 ulps away from the base value
+    x = xi.view(np.float32).copy()
+    y, ids = eng.op_logsoftmax_argmax(x)
+    np.testing.assert_array_equal(ids, om.argmax_last(y))
+    np.testing.assert_array_equal(eng.op_logsoftmax_argmax(x, store=False), ids)
+    raw = om.argmax_last(x)
+    assert (raw != ids).mean() > 0.2          # the raw-logit arg-max really is a different function here
+
+
+def test_logsoftmax_argmax_nan_and_inf(eng):
+    V = 300
+    x = np.random.default_rng(14).standard_normal((6, V)).astype(np.float32)
+    x[0, 17] = np.nan          # NaN poisons the sum -> every log-prob NaN -> the loop ends on V-1
+    x[1, :] = -np.inf          # -inf - (-inf) = NaN everywhere
+    x[2, 5] = np.inf           # inf - inf = NaN
+    x[3, 100] = -np.inf        # harmless
+    y, ids = eng.op_logsoftmax_argmax(x)
+    np.testing.assert_array_equal(ids, om.argmax_last(y))
+    assert ids[0] == V - 1 and ids[1] == V - 1 and ids[2] == V - 1
+    assert np.isnan(y[0]).all() and np.isneginf(y[3, 100])
+    np.testing.assert_array_equal(eng.op_logsoftmax_argmax(x, store=False), ids)

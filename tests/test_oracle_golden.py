@@ -287,3 +287,22 @@ def test_oracle_building_blocks_match_independent_forms():
     inv = np.exp(np.arange(280) * -inc)
     pos = np.arange(1, 7)[:, None] * inv[None, :]
     assert np.allclose(pe, np.concatenate([np.sin(pos), np.cos(pos)], 1), atol=1e-5)
+
+
+def test_log_softmax_two_step_form_and_collision():
+    """oracle.log_softmax = (x - max) - log(sum exp(x - max)) in float32 (onnxruntime's CPU LogSoftmax form): equal
+    to torch's within rounding, and two logits one ulp apart collide into ONE log-prob when lse >> |x| — the
+    reference loop (ties -> larger index) then returns the later index, not the raw arg-max."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((50, 8404)).astype(np.float32) * 3
+    a = om.log_softmax(torch.from_numpy(x)).numpy()
+    b = torch.log_softmax(torch.from_numpy(x).double(), dim=-1).numpy()
+    assert np.abs(a - b).max() < 5e-6
+    V = 8404
+    r = np.full((1, V), -1.0, np.float32)
+    r[0, 3] = np.nextafter(np.float32(0.5), np.float32(1.0))
+    r[0, 7] = 0.5
+    y = om.log_softmax(torch.from_numpy(r)).numpy()
+    assert r[0, 3] > r[0, 7] and y[0, 3] == y[0, 7]
+    assert int(om.argmax_last(r)[0]) == 3 and int(om.argmax_last(y)[0]) == 7
