@@ -33,7 +33,8 @@ class PfEngineConfig(C.Structure):
         ("cmvn_dim", C.c_int32),
         ("fs", C.c_int32), ("n_mels", C.c_int32), ("lfr_m", C.c_int32), ("lfr_n", C.c_int32),
         ("snip_edges", C.c_int32), ("dither", C.c_float), ("window", C.c_char_p), ("use_itn", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("frame_length_ms", C.c_int32), ("frame_shift_ms", C.c_int32), ("dither_seed", C.c_int32),
+        ("math_mode", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -111,6 +112,7 @@ SIGNATURES = {
     "pf_stream_get_hotwords": (C.c_int, [_vp, _i32, C.c_int32, _i32, C.c_int32, _i32]),
     "pf_stream_num_feature_floats": (C.c_int, [_vp, _i32]),
     "pf_stream_dispose": (None, [_vp]),
+    "pf_stream_free": (None, [_vp]),
     "pf_recognizer_get_results": (C.c_int, [_vp, _P(_vp), C.c_int32]),
     "pf_result_text": (C.c_int, [_vp, C.c_int32, _cpp, _i32]),
     "pf_result_num_tokens": (C.c_int, [_vp, C.c_int32, _i32]),

@@ -1,6 +1,7 @@
 // c_api.cpp — extern "C" boundary (include/paraformer_hip.h).  Every entry point converts C++
 // exceptions into a negative pf_status + thread-local message; no exception crosses the ABI.
 #include <cstring>
+#include <memory>
 #include <mutex>
 
 #include "engine.h"
@@ -13,9 +14,22 @@ void set_last_error(const std::string& m) { g_last_error = m; }
 
 using namespace pf;
 
-struct pf_engine { Engine* e; };
-struct pf_recognizer { Recognizer* r; pf_engine eng; };
-struct pf_stream { Stream* s; std::vector<int32_t> hw_flat; };
+// Handle shells are never returned to the allocator: a second pf_engine_destroy / pf_recognizer_free /
+// pf_stream_free on the same handle (Dispose followed by a finaliser, OfflineRecognizer.cs:448-476) finds an
+// empty shell instead of freed memory.  A shell is a few dozen bytes; the device state it pointed to IS released.
+struct pf_engine {
+  std::mutex mu;
+  std::shared_ptr<Engine> e;
+};
+struct pf_recognizer {
+  std::mutex mu;
+  std::shared_ptr<Recognizer> r;
+  pf_engine eng;
+};
+struct pf_stream {
+  std::shared_ptr<Stream> s;
+  bool freed = false;
+};
 struct pf_decoded { ResultEntity r; };
 
 #define PF_TRY try {
@@ -37,28 +51,43 @@ int pf_engine_create(const pf_engine_config* cfg, pf_engine** out) {
   NEED(cfg); NEED(out);
   PF_CHECK(cfg->struct_size == (int32_t)sizeof(pf_engine_config), PF_ERR_INVALID_ARG, "pf_engine_config.struct_size mismatch");
   *out = nullptr;
-  Engine* e = new Engine(*cfg);
-  *out = new pf_engine{e};
+  pf_engine* h = new pf_engine();
+  try {
+    h->e = std::make_shared<Engine>(*cfg);
+  } catch (...) {
+    delete h;
+    throw;
+  }
+  *out = h;
   return PF_OK;
   PF_CATCH
 }
 
 void pf_engine_destroy(pf_engine* h) {
   if (!h) return;
-  try { delete h->e; } catch (...) {}
-  h->e = nullptr;
-  delete h;
+  std::shared_ptr<Engine> e;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    e.swap(h->e);
+  }
+  if (!e) return;                                   // second destroy: nothing left to do
+  try {
+    { std::lock_guard<std::mutex> lk(e->mutex()); } // a call in flight on another thread finishes first
+    e.reset();
+  } catch (...) {}
 }
 
-static Engine* E(pf_engine* h) {
+static std::shared_ptr<Engine> E(pf_engine* h) {
   PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null engine");
+  std::lock_guard<std::mutex> lk(h->mu);
   PF_CHECK(h->e != nullptr, PF_ERR_DISPOSED, "OfflineRecognizer");
-  return h->e;
+  return h->e;                                      // the caller's copy keeps the engine alive for the call
 }
 
 int pf_engine_info(pf_engine* h, int32_t* kind, int32_t* vocab, int32_t* feat_dim, int32_t* has_ts) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   if (kind) *kind = e->model().kind_id();
   if (vocab) *vocab = e->model().vocab;
   if (feat_dim) *feat_dim = e->model().feat_dim;
@@ -77,7 +106,8 @@ int pf_frontend_num_frames(pf_engine* h, int64_t n, int32_t* t) {
 
 int pf_frontend(pf_engine* h, const float* samples, int64_t n, float* feats, int64_t cap, int32_t* t_out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
   std::lock_guard<std::mutex> lk(e->mutex());
   std::vector<float> f;
@@ -92,7 +122,8 @@ int pf_frontend(pf_engine* h, const float* samples, int64_t n, float* feats, int
 
 int pf_fbank(pf_engine* h, const float* samples, int64_t n, float* out, int64_t cap, int32_t* t80_out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
   std::lock_guard<std::mutex> lk(e->mutex());
   std::vector<float> f;
@@ -110,7 +141,8 @@ static bool want_logits(const pf_batch_out* o) { return o && o->logits && o->log
 int pf_forward_feats(pf_engine* h, const float* speech, int32_t B, int32_t Tmax, const int32_t* hotwords,
                      int32_t n_hotwords, pf_batch_out* out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(out);
   std::lock_guard<std::mutex> lk(e->mutex());
   if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
@@ -124,7 +156,8 @@ int pf_forward_feats(pf_engine* h, const float* speech, int32_t B, int32_t Tmax,
 int pf_model_proj(pf_engine* h, const float* const* speech, const int32_t* lens, int32_t B,
                   const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(out); NEED(speech); NEED(lens);
   std::lock_guard<std::mutex> lk(e->mutex());
   if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
@@ -138,7 +171,8 @@ int pf_model_proj(pf_engine* h, const float* const* speech, const int32_t* lens,
 int pf_recognize(pf_engine* h, const float* const* samples, const int64_t* n, int32_t B, const int32_t* hotwords,
                  int32_t n_hotwords, pf_batch_out* out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(out); NEED(samples); NEED(n);
   std::lock_guard<std::mutex> lk(e->mutex());
   if (e->model().seaco) e->set_hotwords(hotwords, hotwords ? n_hotwords : 0);
@@ -152,7 +186,8 @@ int pf_recognize(pf_engine* h, const float* const* samples, const int64_t* n, in
 
 int pf_engine_set_hotwords(pf_engine* h, const int32_t* hotwords, int32_t n_hotwords) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   PF_CHECK(n_hotwords >= 0 && (n_hotwords == 0 || hotwords), PF_ERR_INVALID_ARG, "set_hotwords: bad arguments");
   std::lock_guard<std::mutex> lk(e->mutex());
   if (e->model().seaco) e->set_hotwords(hotwords, n_hotwords);
@@ -162,7 +197,8 @@ int pf_engine_set_hotwords(pf_engine* h, const int32_t* hotwords, int32_t n_hotw
 
 int pf_stage_audio(pf_engine* h, const float* const* samples, const int64_t* n, int32_t B) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(samples); NEED(n);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->stage_audio(samples, n, B);
@@ -172,7 +208,8 @@ int pf_stage_audio(pf_engine* h, const float* const* samples, const int64_t* n, 
 
 int pf_run_staged(pf_engine* h) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   std::lock_guard<std::mutex> lk(e->mutex());
   e->drop_thread_result();               // pf_fetch after this call reads the engine's staged result
   e->run_staged(false);
@@ -189,7 +226,8 @@ int pf_sync(pf_engine* h) {
 
 int pf_fetch(pf_engine* h, pf_batch_out* out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   std::lock_guard<std::mutex> lk(e->mutex());
   e->fetch(out);
   return PF_OK;
@@ -237,7 +275,8 @@ int pf_last_flops(pf_engine* h, double* f) {
 int pf_op_lfr_cmvn_pad(pf_engine* h, const float* const* fbank, const int32_t* t80, int32_t B, int32_t sentinel,
                        float* out, int64_t cap, int32_t* tmax) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(fbank); NEED(t80);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_lfr_cmvn_pad(fbank, t80, B, sentinel, out, cap, tmax);
@@ -246,7 +285,8 @@ int pf_op_lfr_cmvn_pad(pf_engine* h, const float* const* fbank, const int32_t* t
 }
 int pf_op_argmax(pf_engine* h, const float* x, int64_t rows, int32_t V, int64_t* ids) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(x); NEED(ids);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_argmax(x, rows, V, ids);
@@ -256,7 +296,8 @@ int pf_op_argmax(pf_engine* h, const float* x, int64_t rows, int32_t V, int64_t*
 int pf_op_gemm(pf_engine* h, const float* A, const float* W, const float* bias, int32_t M, int32_t N, int32_t K,
                int32_t epi, float* C) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(A); NEED(W); NEED(C);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_gemm(A, W, bias, M, N, K, epi, C);
@@ -265,7 +306,8 @@ int pf_op_gemm(pf_engine* h, const float* A, const float* W, const float* bias, 
 }
 int pf_op_gemm_ex(pf_engine* h, const pf_gemm_desc* d, const float* A, const float* W, float* C) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(d); NEED(A); NEED(W); NEED(C);
   PF_CHECK(d->struct_size == (int32_t)sizeof(pf_gemm_desc), PF_ERR_INVALID_ARG, "pf_gemm_desc.struct_size mismatch");
   std::lock_guard<std::mutex> lk(e->mutex());
@@ -276,7 +318,8 @@ int pf_op_gemm_ex(pf_engine* h, const pf_gemm_desc* d, const float* A, const flo
 int pf_op_ffn(pf_engine* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
               const float* resid, int32_t M, int32_t D, int32_t F, float* y) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(x); NEED(w1); NEED(b1); NEED(w2); NEED(b2); NEED(resid); NEED(y);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_ffn(x, w1, b1, w2, b2, resid, M, D, F, y);
@@ -285,7 +328,8 @@ int pf_op_ffn(pf_engine* h, const float* x, const float* w1, const float* b1, co
 }
 int pf_op_fsmn_enc(pf_engine* h, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(v); NEED(w); NEED(y);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_fsmn_enc(v, w, B, T, D, k, y);
@@ -295,7 +339,8 @@ int pf_op_fsmn_enc(pf_engine* h, const float* v, const float* w, int32_t B, int3
 int pf_op_fsmn_dec(pf_engine* h, const float* tn, const float* w, const int32_t* token_num, int32_t B, int32_t L,
                    int32_t D, int32_t k, float* x) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(tn); NEED(w); NEED(token_num); NEED(x);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_fsmn_dec(tn, w, token_num, B, L, D, k, x);
@@ -304,7 +349,8 @@ int pf_op_fsmn_dec(pf_engine* h, const float* tn, const float* w, const int32_t*
 }
 int pf_op_logsoftmax_argmax(pf_engine* h, const float* x, int64_t rows, int32_t V, float* y, int64_t* ids) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(x); NEED(ids);
   PF_CHECK(rows >= 0 && V > 0, PF_ERR_INVALID_ARG, "logsoftmax_argmax: bad shape");
   std::lock_guard<std::mutex> lk(e->mutex());
@@ -314,7 +360,8 @@ int pf_op_logsoftmax_argmax(pf_engine* h, const float* x, int64_t rows, int32_t 
 }
 int pf_op_layernorm(pf_engine* h, const float* x, const float* g, const float* b, int64_t rows, int32_t D, float* y) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(x); NEED(g); NEED(b); NEED(y);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_layernorm(x, g, b, rows, D, y);
@@ -324,7 +371,8 @@ int pf_op_layernorm(pf_engine* h, const float* x, const float* g, const float* b
 int pf_op_attention(pf_engine* h, const float* q, const float* k, const float* v, int32_t B, int32_t Lq, int32_t Lk,
                     int32_t heads, float* out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(q); NEED(k); NEED(v); NEED(out);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_attention(q, k, v, B, Lq, Lk, heads, out);
@@ -334,7 +382,8 @@ int pf_op_attention(pf_engine* h, const float* q, const float* k, const float* v
 int pf_op_fsmn(pf_engine* h, const float* v, const float* w, const float* mask, int32_t B, int32_t T, int32_t D,
                int32_t k, float* y) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(v); NEED(w); NEED(y);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_fsmn(v, w, mask, B, T, D, k, y);
@@ -344,7 +393,8 @@ int pf_op_fsmn(pf_engine* h, const float* v, const float* w, const float* mask, 
 int pf_op_cif(pf_engine* h, const float* H, const float* alphas, int32_t B, int32_t T, int32_t D, float thr,
               int32_t Lcap, float* E_, int32_t* fire_count, int32_t* token_num, int32_t* L_out) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   NEED(H); NEED(alphas); NEED(fire_count); NEED(token_num);
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_cif(H, alphas, B, T, D, thr, Lcap, E_, fire_count, token_num, L_out);
@@ -353,7 +403,8 @@ int pf_op_cif(pf_engine* h, const float* H, const float* alphas, int32_t B, int3
 }
 int pf_op_encoder(pf_engine* h, const float* speech, int32_t B, int32_t T, float* Hout) {
   PF_TRY
-  Engine* e = E(h);
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
   std::lock_guard<std::mutex> lk(e->mutex());
   e->op_encoder(speech, B, T, Hout);
   return PF_OK;
@@ -368,43 +419,62 @@ int pf_recognizer_create(const char* model, const char* config, const char* mvn,
   NEED(out);
   *out = nullptr;
   auto s = [](const char* p) { return std::string(p ? p : ""); };
-  Recognizer* r = new Recognizer(s(model), s(config), s(mvn), s(tokens), s(modeleb), s(hotword), batch_size,
-                                 threads_num, device);
-  *out = new pf_recognizer{r, {r->engine()}};
+  std::shared_ptr<Recognizer> r = std::make_shared<Recognizer>(s(model), s(config), s(mvn), s(tokens), s(modeleb),
+                                                               s(hotword), batch_size, threads_num, device);
+  pf_recognizer* h = new pf_recognizer();
+  h->r = r;
+  h->eng.e = r->engine();
+  *out = h;
   return PF_OK;
   PF_CATCH
 }
 
 void pf_recognizer_dispose(pf_recognizer* h) {
-  if (!h || !h->r) return;
-  try { h->r->Dispose(); } catch (...) {}
-  h->eng.e = nullptr;
+  if (!h) return;
+  std::shared_ptr<Recognizer> r;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    r = h->r;
+  }
+  if (!r) return;
+  { std::lock_guard<std::mutex> lk(h->eng.mu); h->eng.e.reset(); }
+  try { r->Dispose(); } catch (...) {}
 }
 
 void pf_recognizer_free(pf_recognizer* h) {
   if (!h) return;
-  try { delete h->r; } catch (...) {}
-  delete h;
+  pf_recognizer_dispose(h);                         // releases the engine even while streams are still alive
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->r.reset();                                     // the object itself goes with its last stream
 }
 
-pf_engine* pf_recognizer_engine(pf_recognizer* h) { return (h && h->r && h->eng.e) ? &h->eng : nullptr; }
+pf_engine* pf_recognizer_engine(pf_recognizer* h) {
+  if (!h) return nullptr;
+  std::lock_guard<std::mutex> lk(h->eng.mu);
+  return h->eng.e ? &h->eng : nullptr;
+}
 
-static Recognizer* R(pf_recognizer* h) {
-  PF_CHECK(h != nullptr && h->r != nullptr, PF_ERR_INVALID_ARG, "null recognizer");
+static std::shared_ptr<Recognizer> R(pf_recognizer* h) {
+  PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null recognizer");
+  std::lock_guard<std::mutex> lk(h->mu);
+  PF_CHECK(h->r != nullptr, PF_ERR_DISPOSED, "OfflineRecognizer");
   return h->r;
 }
 static Stream* S(pf_stream* h) {
-  PF_CHECK(h != nullptr && h->s != nullptr, PF_ERR_INVALID_ARG, "null stream");
-  PF_CHECK(!h->s->disposed, PF_ERR_DISPOSED, "OfflineStream");
-  return h->s;
+  PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null stream");
+  PF_CHECK(!h->freed && h->s != nullptr, PF_ERR_DISPOSED, "OfflineStream");
+  PF_CHECK(!h->s->disposed, PF_ERR_DISPOSED, "OfflineStream");         // ObjectDisposedException
+  return h->s.get();
 }
 
 int pf_recognizer_create_stream(pf_recognizer* h, pf_stream** out) {
   PF_TRY
   NEED(out);
   *out = nullptr;
-  Stream* s = R(h)->CreateOfflineStream();
-  *out = new pf_stream{s, {}};
+  std::shared_ptr<Stream> s = R(h)->CreateOfflineStream();
+  pf_stream* sh = new pf_stream();
+  sh->s = s;
+  *out = sh;
   return PF_OK;
   PF_CATCH
 }
@@ -462,18 +532,22 @@ int pf_stream_num_feature_floats(pf_stream* h, int32_t* n) {
 }
 
 void pf_stream_dispose(pf_stream* h) {
-  if (!h) return;
-  if (h->s) {
-    h->s->disposed = true;
-    h->s->Speech.clear();
-    h->s->Speech.shrink_to_fit();
-  }
-  delete h;
+  // DisposeOfflineStream (OfflineRecognizer.cs:441): the buffers go, the handle stays valid and every later
+  // call on it answers PF_ERR_DISPOSED (ObjectDisposedException) until pf_stream_free
+  if (!h || h->freed || !h->s) return;
+  h->s->Dispose();
+}
+
+void pf_stream_free(pf_stream* h) {
+  if (!h || h->freed) return;
+  if (h->s) h->s->Dispose();
+  h->s.reset();                                     // drops this stream's share of the recognizer object
+  h->freed = true;                                  // the shell stays (double free / use after free -> PF_ERR_DISPOSED)
 }
 
 int pf_recognizer_get_results(pf_recognizer* h, pf_stream* const* streams, int32_t n) {
   PF_TRY
-  Recognizer* r = R(h);
+  std::shared_ptr<Recognizer> r = R(h);
   std::vector<Stream*> ss;
   for (int i = 0; i < n; ++i) { NEED(streams); ss.push_back(S(streams[i])); }
   r->GetResults(ss);
@@ -482,9 +556,9 @@ int pf_recognizer_get_results(pf_recognizer* h, pf_stream* const* streams, int32
 }
 
 static const ResultEntity& RES(pf_recognizer* h, int32_t i) {
-  Recognizer* r = R(h);
-  PF_CHECK(i >= 0 && i < (int32_t)r->results.size(), PF_ERR_INVALID_ARG, "result index out of range");
-  return r->results[(size_t)i];
+  const std::vector<ResultEntity>& res = R(h)->results_of_this_thread();   // thread-local: outlives this call
+  PF_CHECK(i >= 0 && i < (int32_t)res.size(), PF_ERR_INVALID_ARG, "result index out of range");
+  return res[(size_t)i];
 }
 
 int pf_result_text(pf_recognizer* h, int32_t i, const char** utf8, int32_t* len16) {

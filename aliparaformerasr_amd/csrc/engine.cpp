@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <set>
 
 #include "hostutil.h"
 
@@ -28,7 +29,6 @@ Engine::Engine(const pf_engine_config& cfg) {
   PF_HIP(hipGetDeviceProperties(&prop, device_));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw Error(PF_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-  PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
 
   fc_.fs = cfg.fs > 0 ? cfg.fs : 16000;
   fc_.n_mels = cfg.n_mels > 0 ? cfg.n_mels : 80;
@@ -36,15 +36,18 @@ Engine::Engine(const pf_engine_config& cfg) {
   fc_.lfr_n = cfg.lfr_n > 0 ? cfg.lfr_n : 6;
   fc_.snip_edges = cfg.snip_edges != 0;
   fc_.dither = cfg.dither;
+  fc_.dither_seed = (uint32_t)cfg.dither_seed;
   fc_.window = cfg.window ? cfg.window : "hamming";
-  PF_CHECK(fc_.dither == 0.f, PF_ERR_UNSUPPORTED,
-           "dither != 0 is not supported by the device fbank (set frontend_conf.dither: 0)");
+  PF_CHECK(fc_.dither >= 0.f && fc_.dither == fc_.dither, PF_ERR_INVALID_ARG, "dither must be >= 0");
   PF_CHECK(fc_.fs == 16000, PF_ERR_UNSUPPORTED, "only fs = 16000 is supported");
+  // the fbank kernel is built for 25 ms / 10 ms frames (400 / 160 samples, 512-point FFT): any other framing in
+  // the configuration must be refused, not silently ignored
+  PF_CHECK((cfg.frame_length_ms == 0 || cfg.frame_length_ms == 25) && (cfg.frame_shift_ms == 0 || cfg.frame_shift_ms == 10),
+           PF_ERR_UNSUPPORTED, "only frame_length = 25 ms and frame_shift = 10 ms are supported");
+  PF_CHECK(cfg.math_mode == 0 || cfg.math_mode == 1, PF_ERR_INVALID_ARG, "math_mode must be 0 (f16 MFMA) or 1 (fp32 MFMA)");
+  fp32_mode_ = cfg.math_mode == 1;
 
-  load_weights(cfg);
-  mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
-
-  fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
+  // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
   if (cfg.mvn_path && cfg.mvn_path[0]) {
     parse_mvn_text(read_text_file(cfg.mvn_path), shift, scale);
@@ -54,29 +57,46 @@ Engine::Engine(const pf_engine_config& cfg) {
   }
   if (!shift.empty()) {
     PF_CHECK(shift.size() == scale.size(), PF_ERR_FORMAT, "am.mvn: shift/scale length mismatch");
-    PF_CHECK((int)shift.size() == fc_.lfr_m * fc_.n_mels, PF_ERR_FORMAT,
-             "am.mvn: CMVN dim must equal lfr_m * n_mels");
-    cmvn_dim_ = (int)shift.size();
-    cmvn_shift_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
-    cmvn_scale_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
-    PF_HIP(hipMemcpy(cmvn_shift_, shift.data(), sizeof(float) * cmvn_dim_, hipMemcpyHostToDevice));
-    PF_HIP(hipMemcpy(cmvn_scale_, scale.data(), sizeof(float) * cmvn_dim_, hipMemcpyHostToDevice));
+    PF_CHECK((int)shift.size() == fc_.lfr_m * fc_.n_mels, PF_ERR_FORMAT, "am.mvn: CMVN dim must equal lfr_m * n_mels");
+  }
+
+  uid_ = register_uid();
+  try {
+    PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    load_weights(cfg);
+    mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
+    fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
+    if (!shift.empty()) {
+      cmvn_dim_ = (int)shift.size();
+      cmvn_shift_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
+      cmvn_scale_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
+      PF_HIP(hipMemcpy(cmvn_shift_, shift.data(), sizeof(float) * cmvn_dim_, hipMemcpyHostToDevice));
+      PF_HIP(hipMemcpy(cmvn_scale_, scale.data(), sizeof(float) * cmvn_dim_, hipMemcpyHostToDevice));
+    }
+  } catch (...) {
+    release();                                       // ~Engine does not run for a throwing constructor
+    throw;
   }
 }
 
-Engine::~Engine() {
+Engine::~Engine() { release(); }
+
+void Engine::release() {
+  if (uid_) { unregister_uid(uid_); uid_ = 0; }
   hipSetDevice(device_);
   if (stream_) hipStreamSynchronize(stream_);
-  if (lstm_graph_exec_) hipGraphExecDestroy(lstm_graph_exec_);
+  if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
   profile_reset();
-  fbank_tables_destroy(fb_);
+  if (fb_) { fbank_tables_destroy(fb_); fb_ = nullptr; }
   for (void* p : owned_) hipFree(p);
+  owned_.clear();
   DevBuf* bufs[] = {&ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_,
                     &ws_ts_, &ws_seaco_, &ws_seaco_in_};
   for (DevBuf* b : bufs)
-    if (b->p) hipFree(b->p);
+    if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
   if (blob_owned_ && blob_dev_) hipFree(blob_dev_);
-  if (stream_) hipStreamDestroy(stream_);
+  blob_dev_ = nullptr;
+  if (stream_) { hipStreamDestroy(stream_); stream_ = nullptr; }
 }
 
 void* Engine::dalloc(size_t bytes) {
@@ -136,7 +156,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   PF_CHECK(std::memcmp(h16, "PFW1", 4) == 0, PF_ERR_FORMAT, "weights: bad magic (expected PFW1 container)");
   uint64_t hlen = 0;
   std::memcpy(&hlen, h16 + 8, 8);
-  PF_CHECK((int64_t)(16 + hlen) <= nbytes, PF_ERR_FORMAT, "weights: truncated header");
+  PF_CHECK(hlen <= (uint64_t)nbytes - 16u, PF_ERR_FORMAT, "weights: truncated header");   // unsigned: a huge hlen cannot wrap
   std::string hdr;
   if (host) hdr.assign(host + 16, hlen);
   else {
@@ -205,7 +225,14 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     tt.dev = (const float*)(data_dev + off);
     tt.numel = 1;
     if (const Json* sh = t.get("shape"))
-      for (const Json& d : sh->arr) { tt.shape.push_back((int64_t)d.num); tt.numel *= (int64_t)d.num; }
+      for (const Json& d : sh->arr) {
+        const double dv = d.type == Json::Num ? d.num : -1.0;
+        PF_CHECK(dv >= 1.0 && dv <= 2147483647.0 && dv == (double)(int64_t)dv, PF_ERR_FORMAT,
+                 "weights: bad dimension in the shape of '" + name + "'");
+        PF_CHECK(tt.numel <= (int64_t)1 << 40, PF_ERR_FORMAT, "weights: shape of '" + name + "' overflows");
+        tt.shape.push_back((int64_t)dv);
+        tt.numel *= (int64_t)dv;
+      }
     PF_CHECK(tt.numel * 4 == nb, PF_ERR_FORMAT, "weights: shape/nbytes mismatch for '" + name + "'");
     tensors_[name] = tt;
   }
@@ -215,21 +242,23 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   auto enc_layer = [&](const std::string& p, int d_in) {
     EncLayer L;
     L.d_in = d_in;
-    L.norm1 = make_ln(p + ".norm1");
+    L.norm1 = make_ln(p + ".norm1", d_in);
     L.qkv = make_lin(p + ".attn.qkv", true);
     L.fsmn_wT = make_fsmn_wT(p + ".attn.fsmn.weight");
     L.out = make_lin(p + ".attn.out", true);
-    L.norm2 = make_ln(p + ".norm2");
+    L.norm2 = make_ln(p + ".norm2", D);
     L.w1 = make_lin(p + ".ffn.w1", true);
     L.w2 = make_lin(p + ".ffn.w2", true);
     PF_CHECK(L.qkv.K == d_in && L.qkv.N == 3 * D, PF_ERR_FORMAT, "weights: qkv shape mismatch in " + p);
+    PF_CHECK(L.out.N == D && L.out.K == D && L.w1.K == D && L.w1.N == mc_.ffn && L.w2.N == D && L.w2.K == L.w1.N,
+             PF_ERR_FORMAT, "weights: attn.out / ffn shape mismatch in " + p);
     return L;
   };
   for (int i = 0; i < mc_.enc_layers; ++i)
     enc_.push_back(enc_layer("encoder.layers." + std::to_string(i), i == 0 ? mc_.feat_dim : D));
-  enc_after_ = make_ln("encoder.after_norm");
+  enc_after_ = make_ln("encoder.after_norm", D);
   for (int i = 0; i < mc_.tp_layers; ++i) tp_.push_back(enc_layer("encoder.tp_layers." + std::to_string(i), D));
-  if (mc_.tp_layers) tp_norm_ = make_ln("encoder.tp_norm");
+  if (mc_.tp_layers) tp_norm_ = make_ln("encoder.tp_norm", D);
 
   if (mc_.kind == "sensevoicesmall") {
     ctc_ = make_lin("ctc", true);
@@ -274,6 +303,9 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     PF_HIP(hipStreamSynchronize(stream_));
     PF_HIP(hipFree(tmp));
     cif_conv_.bias = tensor("predictor.conv.bias").dev;
+    PF_CHECK(tensor("predictor.conv.bias").numel == D && tensor("predictor.out.weight").numel == D &&
+                 tensor("predictor.out.bias").numel == 1,
+             PF_ERR_FORMAT, "weights: predictor.conv.bias / predictor.out.* sizes");
     cif_out_w_ = tensor("predictor.out.weight").dev;
     cif_out_b_ = tensor("predictor.out.bias").dev;
   }
@@ -327,6 +359,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     ts_ih_.bias = gb;
     const Tensor& ow = tensor("predictor.out2.weight");
     PF_CHECK(ow.numel == 2 * D, PF_ERR_FORMAT, "weights: predictor.out2.weight shape");
+    PF_CHECK(tensor("predictor.out2.bias").numel == 1, PF_ERR_FORMAT, "weights: predictor.out2.bias shape");
     ts_out_w_ = ow.dev;
     ts_out_b_ = tensor("predictor.out2.bias").dev;
     PF_HIP(hipStreamSynchronize(stream_));
@@ -343,15 +376,18 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     for (int i = 0; i < nd; ++i) {
       const std::string p = "decoder.layers." + std::to_string(i);
       DecLayer L;
-      L.norm1 = make_ln(p + ".norm1");
+      L.norm1 = make_ln(p + ".norm1", D);
       L.w1 = make_lin(p + ".ffn.w1", true);
-      L.ffn_norm = make_ln(p + ".ffn.norm");
+      L.ffn_norm = make_ln(p + ".ffn.norm", L.w1.N);
       L.w2 = make_lin(p + ".ffn.w2", false);
-      L.norm2 = make_ln(p + ".norm2");
+      L.norm2 = make_ln(p + ".norm2", D);
       L.fsmn_wT = make_fsmn_wT(p + ".fsmn.weight");
-      L.norm3 = make_ln(p + ".norm3");
+      L.norm3 = make_ln(p + ".norm3", D);
       L.q = make_lin(p + ".src.q", true);
       L.out = make_lin(p + ".src.out", true);
+      PF_CHECK(L.w1.K == D && L.w1.N == mc_.ffn && L.w2.N == D && L.w2.K == L.w1.N && L.q.N == D && L.q.K == D &&
+                   L.out.N == D && L.out.K == D,
+               PF_ERR_FORMAT, "weights: decoder layer shape mismatch in " + p);
       const Tensor& kvw = tensor(p + ".src.kv.weight");
       const Tensor& kvbias = tensor(p + ".src.kv.bias");
       PF_CHECK(kvw.numel == (int64_t)2 * D * D && kvbias.numel == 2 * D, PF_ERR_FORMAT, "weights: src.kv shape in " + p);
@@ -360,13 +396,15 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       dec_.push_back(L);
     }
   }
-  dec_final_norm1_ = make_ln("decoder.final.norm1");
+  dec_final_norm1_ = make_ln("decoder.final.norm1", D);
   dec_final_w1_ = make_lin("decoder.final.ffn.w1", true);
-  dec_final_ffn_norm_ = make_ln("decoder.final.ffn.norm");
+  dec_final_ffn_norm_ = make_ln("decoder.final.ffn.norm", dec_final_w1_.N);
   dec_final_w2_ = make_lin("decoder.final.ffn.w2", false);
-  dec_after_ = make_ln("decoder.after_norm");
+  dec_after_ = make_ln("decoder.after_norm", D);
   dec_out_ = make_lin("decoder.output", true);
-  PF_CHECK(dec_out_.N == mc_.vocab, PF_ERR_FORMAT, "weights: decoder.output rows != vocab");
+  PF_CHECK(dec_out_.N == mc_.vocab && dec_out_.K == D && dec_final_w1_.K == D && dec_final_w1_.N == mc_.ffn &&
+               dec_final_w2_.N == D && dec_final_w2_.K == dec_final_w1_.N,
+           PF_ERR_FORMAT, "weights: decoder.final / decoder.output shapes");
   // SeACo: hotword embedder (Embedding + LSTM stack) and the bias decoder
   if (mc_.seaco) {
     const int ns = mc_.seaco_layers;
@@ -405,15 +443,17 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       for (int i = 0; i < ns; ++i) {
         const std::string p = "seaco.decoder.layers." + std::to_string(i);
         DecLayer L;
-        L.norm1 = make_ln(p + ".norm1");
+        L.norm1 = make_ln(p + ".norm1", D);
         L.w1 = make_lin(p + ".ffn.w1", true);
-        L.ffn_norm = make_ln(p + ".ffn.norm");
+        L.ffn_norm = make_ln(p + ".ffn.norm", L.w1.N);
         L.w2 = make_lin(p + ".ffn.w2", false);
-        L.norm2 = make_ln(p + ".norm2");
+        L.norm2 = make_ln(p + ".norm2", D);
         L.fsmn_wT = make_fsmn_wT(p + ".fsmn.weight", mc_.seaco_kernel);
-        L.norm3 = make_ln(p + ".norm3");
+        L.norm3 = make_ln(p + ".norm3", D);
         L.q = make_lin(p + ".src.q", true);
         L.out = make_lin(p + ".src.out", true);
+        PF_CHECK(L.w1.K == D && L.w2.N == D && L.w2.K == L.w1.N && L.q.N == D && L.q.K == D && L.out.N == D && L.out.K == D,
+                 PF_ERR_FORMAT, "weights: seaco decoder layer shape mismatch in " + p);
         const Tensor& kvw = tensor(p + ".src.kv.weight");
         const Tensor& kvbias = tensor(p + ".src.kv.bias");
         PF_CHECK(kvw.numel == (int64_t)2 * D * D && kvbias.numel == 2 * D, PF_ERR_FORMAT, "weights: src.kv shape in " + p);
@@ -423,11 +463,11 @@ void Engine::load_weights(const pf_engine_config& cfg) {
         sdec_.push_back(L);
       }
     }
-    seaco_final_norm1_ = make_ln("seaco.decoder.final.norm1");
+    seaco_final_norm1_ = make_ln("seaco.decoder.final.norm1", D);
     seaco_final_w1_ = make_lin("seaco.decoder.final.ffn.w1", true);
-    seaco_final_ffn_norm_ = make_ln("seaco.decoder.final.ffn.norm");
+    seaco_final_ffn_norm_ = make_ln("seaco.decoder.final.ffn.norm", seaco_final_w1_.N);
     seaco_final_w2_ = make_lin("seaco.decoder.final.ffn.w2", false);
-    seaco_after_ = make_ln("seaco.decoder.after_norm");
+    seaco_after_ = make_ln("seaco.decoder.after_norm", D);
     seaco_out_ = make_lin("seaco.output", true);
     PF_CHECK(seaco_out_.N == mc_.vocab, PF_ERR_FORMAT, "weights: seaco.output rows != vocab");
   }
@@ -453,11 +493,14 @@ Lin Engine::make_lin(const std::string& prefix, bool bias) {
   return L;
 }
 
-LNp Engine::make_ln(const std::string& prefix) {
+LNp Engine::make_ln(const std::string& prefix, int width) {
   LNp p;
   const Tensor& g = tensor(prefix + ".weight");
   const Tensor& b = tensor(prefix + ".bias");
   PF_CHECK(g.numel == b.numel, PF_ERR_FORMAT, "weights: LayerNorm size mismatch for " + prefix);
+  // the kernel normalises rows of `width` floats: a shorter gamma / beta would be read out of bounds
+  PF_CHECK(g.numel == width, PF_ERR_FORMAT, "weights: '" + prefix + "' has " + std::to_string(g.numel) +
+                                                " elements, the layer is " + std::to_string(width) + " wide");
   p.g = g.dev; p.b = b.dev; p.D = (int)g.numel;
   return p;
 }
@@ -591,7 +634,7 @@ void Engine::run_staged(bool want_logits) {
   ensure(ws_speech_, (size_t)B * (T + P) * W * 4);
   prof_begin("fbank", 0);
   launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + (B + 1), meta + 2 * (B + 1), B,
-               st_total_frames_, fc_.snip_edges ? 1 : 0, (float*)ws_fbank_.p);
+               st_total_frames_, fc_.snip_edges ? 1 : 0, (float*)ws_fbank_.p, fc_.dither, next_dither_seed());
   prof_end("fbank");
   prof_begin("lfr_cmvn_pad", 0);
   launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, meta + 2 * (B + 1), t80d, B, T, fc_.lfr_m, fc_.lfr_n,
@@ -611,7 +654,7 @@ void Engine::fbank_host(const float* samples, int64_t n, std::vector<float>& out
   const int64_t* meta = (const int64_t*)ws_meta_.p;
   ensure(ws_fbank_, (size_t)t80 * fc_.n_mels * 4);
   launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + 2, meta + 4, 1, t80, fc_.snip_edges ? 1 : 0,
-               (float*)ws_fbank_.p);
+               (float*)ws_fbank_.p, fc_.dither, next_dither_seed());
   PF_HIP(hipMemcpyAsync(out.data(), ws_fbank_.p, out.size() * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
 }
@@ -633,7 +676,7 @@ void Engine::frontend_host(const float* samples, int64_t n, std::vector<float>& 
   ensure(ws_fbank_, (size_t)t80 * fc_.n_mels * 4);
   ensure(ws_speech_, feats.size() * 4);
   launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + 2, meta + 4, 1, t80, fc_.snip_edges ? 1 : 0,
-               (float*)ws_fbank_.p);
+               (float*)ws_fbank_.p, fc_.dither, next_dither_seed());
   const bool cm = cmvn_shift_ && cmvn_dim_ == W;
   launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, meta + 4, t80d, 1, t_lfr, m, nn_, fc_.n_mels, cmvn_shift_,
                       cmvn_scale_, cm ? 1 : 0, 0, (float*)ws_speech_.p);
@@ -1111,9 +1154,33 @@ void Engine::model_proj_host(const float* const* speech, const int32_t* n_floats
   forward_device((const float*)ws_speech_.p, B, T, want_logits);
 }
 
+// Per-thread result slots live in thread-local storage keyed by the engine's uid: a slot dies with its thread
+// (no growth under thread-pool churn; a new thread that happens to re-use an OS thread id starts empty), is
+// released by the pf_fetch that delivers token_ids, and slots of engines that no longer exist are purged here.
+static std::mutex g_live_mu;
+static std::set<uint64_t> g_live;
+static uint64_t g_next_uid = 1;
+static thread_local std::map<uint64_t, HostBatchOut> t_slots;
+
+uint64_t Engine::register_uid() {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  const uint64_t id = g_next_uid++;
+  g_live.insert(id);
+  return id;
+}
+void Engine::unregister_uid(uint64_t id) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  g_live.erase(id);
+}
+
 void Engine::publish_thread_result() {
   PF_HIP(hipStreamSynchronize(stream_));
-  HostBatchOut& sl = slots_[std::this_thread::get_id()];
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (auto it = t_slots.begin(); it != t_slots.end();)
+      it = g_live.count(it->first) ? std::next(it) : t_slots.erase(it);
+  }
+  HostBatchOut& sl = t_slots[uid_];
   sl = last_;
   sl.has_logits = last_logits_;
   sl.logits.clear();
@@ -1125,13 +1192,13 @@ void Engine::publish_thread_result() {
   }
 }
 
-void Engine::drop_thread_result() { slots_.erase(std::this_thread::get_id()); }
+void Engine::drop_thread_result() { t_slots.erase(uid_); }
 
 void Engine::fetch(pf_batch_out* out) {
   PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");
   PF_HIP(hipStreamSynchronize(stream_));
-  auto it = slots_.find(std::this_thread::get_id());
-  const bool slot = it != slots_.end();
+  auto it = t_slots.find(uid_);
+  const bool slot = it != t_slots.end();
   const HostBatchOut& r = slot ? it->second : last_;
   const int B = r.B, L = r.L, V = r.V;
   out->L = L; out->V = V; out->cif_peak_len = r.peak_len;
@@ -1157,6 +1224,9 @@ void Engine::fetch(pf_batch_out* out) {
                            hipMemcpyDeviceToHost));
     }
   }
+  // the call that receives the ids completes the learn-L-then-fetch protocol: release the slot (a B*L*V host
+  // copy of the log-probs may hang off it)
+  if (slot && out->token_ids) t_slots.erase(it);
 }
 
 // ------------------------------------------------------------------ stand-alone ops -------

@@ -30,6 +30,7 @@ struct FrontendCfg {
   int fs = 16000, n_mels = 80, lfr_m = 7, lfr_n = 6;
   bool snip_edges = false;
   float dither = 0.f;
+  uint32_t dither_seed = 0;
   std::string window = "hamming";
 };
 
@@ -127,7 +128,8 @@ class Engine {
   const Tensor& tensor(const std::string& name) const;
   bool has_tensor(const std::string& name) const { return tensors_.count(name) != 0; }
   Lin make_lin(const std::string& prefix, bool bias);
-  LNp make_ln(const std::string& prefix);
+  LNp make_ln(const std::string& prefix, int width);
+  void release();
   float* make_fsmn_wT(const std::string& name, int K = 0);
   void* dalloc(size_t bytes);
   void ensure(DevBuf& b, size_t bytes);
@@ -144,8 +146,13 @@ class Engine {
   void prof_begin(const char* cls, double flops);
   void prof_end(const char* cls);
 
+  // dither stream: seed of call c = hash(dither_seed, c); an engine built with the same seed replays the same
+  // features for the same sequence of front-end calls
+  uint32_t dither_calls_ = 0;
+  uint32_t next_dither_seed() { return fc_.dither_seed * 2654435761u + (dither_calls_++) * 40503u; }
   int device_ = 0;
   hipStream_t stream_ = nullptr;
+  bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   ModelCfg mc_;
   FrontendCfg fc_;
   std::mutex mu_;
@@ -198,7 +205,9 @@ class Engine {
   std::vector<int64_t> st_n_; std::vector<int32_t> st_t80_; int st_B_ = 0, st_T_ = 0;
   int64_t st_total_frames_ = 0;
   HostBatchOut last_;
-  std::map<std::thread::id, HostBatchOut> slots_;
+  uint64_t uid_ = 0;                 // key of this engine in the per-thread result store
+  static uint64_t register_uid();
+  static void unregister_uid(uint64_t id);
   bool last_logits_ = false;
   double last_flops_ = 0;
 

@@ -60,7 +60,15 @@ class JsonParser {
   void ws() {
     while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\r' || *p_ == '\t')) ++p_;
   }
+  int depth_ = 0;
+  struct Depth {                                  // containers nest at most 64 deep (a "[[[[..." header must
+    int& d;                                       // fail with PF_ERR_FORMAT, not overflow the stack)
+    explicit Depth(int& x) : d(x) { ++d; }
+    ~Depth() { --d; }
+  };
   Json value() {
+    Depth guard(depth_);
+    if (depth_ > 64) fail("nesting too deep");
     ws();
     if (p_ >= e_) fail("unexpected end");
     Json v;

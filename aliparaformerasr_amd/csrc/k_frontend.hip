@@ -101,6 +101,23 @@ void fbank_tables_destroy(FbankTables* t) {
   delete t;
 }
 
+// Dither (kaldi feature-window.cc Dither(): window[i] += RandGauss() * dither, per extracted frame window,
+// before the DC removal; reference default 1.0, Model/FrontendConfEntity.cs:12).  The reference's draw is not
+// reproducible, so the device draws from a counter-based generator: normal(seed, frame, sample) by Box-Muller
+// over two 32-bit hashes — stateless (any launch geometry gives the same features for the same seed) and
+// independent across frames as kaldi's per-window draw is.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {    // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float gauss_at(uint32_t seed, uint64_t frame, uint32_t i) {
+  const uint32_t k = mix32(seed ^ 0x9e3779b9u) ^ mix32((uint32_t)frame * 0x27d4eb2fu + (uint32_t)(frame >> 32));
+  const uint32_t a = mix32(k + 2u * i + 0x165667b1u), b = mix32((k ^ 0x5bd1e995u) + 2u * i + 1u);
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -115,8 +132,8 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
                                                     const float2* __restrict__ tw512,
                                                     const int* __restrict__ mel_start,
                                                     const int* __restrict__ mel_off,
-                                                    const float* __restrict__ mel_w,
-                                                    float* __restrict__ out) {
+                                                    const float* __restrict__ mel_w, float dither,
+                                                    uint32_t dither_seed, float* __restrict__ out) {
   __shared__ float2 lds[4][2][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t gf = (int64_t)blockIdx.x * 4 + wv;       // global frame index
@@ -149,6 +166,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
       int64_t sidx = start + i;
       while (sidx < 0 || sidx >= n) sidx = sidx < 0 ? -sidx - 1 : 2 * n - 1 - sidx;
       v = wav[sidx] * 32768.0f;
+      if (dither != 0.f) v = add_rn(v, mul_rn(gauss_at(dither_seed, (uint64_t)gf, (uint32_t)i), dither));
       part += v;
     }
     fr[i] = v;
@@ -223,11 +241,11 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
 
 void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, const int64_t* audio_off,
                   const int64_t* n_samples, const int64_t* frame_off, int B, int64_t total_frames,
-                  int snip_edges, float* fbank) {
+                  int snip_edges, float* fbank, float dither, uint32_t dither_seed) {
   if (total_frames <= 0) return;
   hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total_frames + 3) / 4)), dim3(256), 0, s, audio, audio_off,
                      n_samples, frame_off, B, total_frames, snip_edges, tb->n_mels, tb->window, tb->tw512,
-                     tb->mel_start, tb->mel_off, tb->mel_w, fbank);
+                     tb->mel_start, tb->mel_off, tb->mel_w, dither, dither_seed, fbank);
   PF_HIP(hipGetLastError());
 }
 

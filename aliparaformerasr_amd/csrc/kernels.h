@@ -39,7 +39,7 @@ void fbank_tables_destroy(FbankTables*);
 // audio: B device pointers are expressed as base + offsets; out [sum T80, n_mels]
 void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, const int64_t* audio_off,
                   const int64_t* n_samples, const int64_t* frame_off, int B, int64_t total_frames,
-                  int snip_edges, float* fbank);
+                  int snip_edges, float* fbank, float dither = 0.f, uint32_t dither_seed = 0);
 // LFR (m,n) + CMVN + right pad + sentinel: fbank rows (per-utt offsets) -> [B,Tmax,m*80]
 void launch_lfr_cmvn_pad(hipStream_t s, const float* fbank, const int64_t* frame_off, const int32_t* t80,
                          int B, int Tmax, int lfr_m, int lfr_n, int n_mels, const float* shift,

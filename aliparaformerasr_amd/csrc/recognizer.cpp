@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <set>
 
 namespace pf {
 
@@ -193,12 +194,28 @@ std::vector<std::vector<int32_t>> hotword_ids(const std::vector<std::string>& to
   return hw;
 }
 
+// Results live in thread-local storage keyed by the recognizer's uid: they die with the calling thread (no
+// growth under thread-pool churn, no stale hit when the OS re-uses a thread id) and entries of recognizers that
+// no longer exist are purged on the next call.
+static std::mutex g_live_mu;
+static std::set<uint64_t> g_live;
+static uint64_t g_next_uid = 1;
+static thread_local std::map<uint64_t, std::vector<ResultEntity>> t_results;
+
+static uint64_t register_recognizer() {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  const uint64_t id = g_next_uid++;
+  g_live.insert(id);
+  return id;
+}
+
 // ------------------------------------------------------------------ Stream ----------------
-Stream::Stream(Recognizer* r) : owner(r) {}
+Stream::Stream(std::shared_ptr<Recognizer> r) : owner(std::move(r)) {}
 
 void Stream::AddSamples(const float* samples, int64_t n) {
+  if (disposed) throw Error(PF_ERR_DISPOSED, "OfflineStream");
   if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");       // ArgumentNullException("source")
-  Engine* e = owner->engine();
+  std::shared_ptr<Engine> e = owner->engine();                     // keeps the engine alive across this call
   if (!e) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
   std::lock_guard<std::mutex> lk(e->mutex());                      // process-wide lock in the reference
   std::vector<float> feats;
@@ -207,6 +224,16 @@ void Stream::AddSamples(const float* samples, int64_t n) {
   Speech.insert(Speech.end(), feats.begin(), feats.end());
   has_speech = true;
   SpeechLength = (int)Speech.size();
+}
+
+void Stream::Dispose() {
+  disposed = true;
+  std::vector<float>().swap(Speech);
+  std::vector<int64_t>().swap(Tokens);
+  std::vector<std::vector<int32_t>>().swap(Timestamps);
+  std::vector<std::vector<int32_t>>().swap(Hotwords);
+  has_speech = false;
+  SpeechLength = 0;
 }
 
 void Stream::RemoveChunk() {
@@ -241,29 +268,38 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   ec.fs = conf_.fs; ec.n_mels = conf_.n_mels; ec.lfr_m = conf_.lfr_m; ec.lfr_n = conf_.lfr_n;
   ec.snip_edges = conf_.snip_edges ? 1 : 0;
   ec.dither = conf_.dither;
+  ec.frame_length_ms = conf_.frame_length;
+  ec.frame_shift_ms = conf_.frame_shift;
   ec.window = conf_.window.c_str();
   ec.use_itn = conf_.use_itn ? 1 : 0;
-  engine_.reset(new Engine(ec));
+  engine_ = std::make_shared<Engine>(ec);
+  uid_ = register_recognizer();
 }
 
-Stream* Recognizer::CreateOfflineStream() {
+std::shared_ptr<Stream> Recognizer::CreateOfflineStream() {
   if (disposed_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");   // ObjectDisposedException
-  streams_.emplace_back(new Stream(this));
-  return streams_.back().get();
+  return std::make_shared<Stream>(shared_from_this());
 }
 
 void Recognizer::Dispose() {
-  if (disposed_) return;
-  engine_.reset();
-  tokens_.clear();
-  disposed_ = true;
+  std::shared_ptr<Engine> e;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (disposed_.exchange(true)) return;
+    e.swap(engine_);
+  }
+  // a call that fetched the engine before this point still owns a reference; wait for it on the engine mutex so
+  // that Dispose returns with the device idle, then drop ours (the last owner frees the device memory)
+  if (e) { std::lock_guard<std::mutex> lk(e->mutex()); }
+  e.reset();                                       // tokens_ stays: a concurrent GetResults may still be decoding
 }
 
 void Recognizer::Forward(const std::vector<Stream*>& streams) {
   if (streams.empty()) return;                                      // :120-123
   try {
-    if (disposed_ || !engine_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
-    Engine* e = engine_.get();
+    std::shared_ptr<Engine> eh = engine();
+    if (disposed_ || !eh) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+    Engine* e = eh.get();
     std::lock_guard<std::mutex> lk(e->mutex());
     const ModelCfg& mc = e->model();
     const int W = mc.feat_dim;
@@ -339,10 +375,27 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
   }
 }
 
+Recognizer::~Recognizer() {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  g_live.erase(uid_);
+}
+
 void Recognizer::GetResults(const std::vector<Stream*>& streams) {
   Forward(streams);
-  results.clear();
-  for (Stream* s : streams) results.push_back(decode_multi_one(tokens_, s->Tokens, s->Timestamps));
+  std::vector<ResultEntity> out;
+  for (Stream* s : streams) out.push_back(decode_multi_one(tokens_, s->Tokens, s->Timestamps));
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (auto it = t_results.begin(); it != t_results.end();)
+      it = g_live.count(it->first) ? std::next(it) : t_results.erase(it);
+  }
+  t_results[uid_] = std::move(out);
+}
+
+const std::vector<ResultEntity>& Recognizer::results_of_this_thread() {
+  static const std::vector<ResultEntity> kEmpty;
+  auto it = t_results.find(uid_);
+  return it == t_results.end() ? kEmpty : it->second;
 }
 
 }  // namespace pf

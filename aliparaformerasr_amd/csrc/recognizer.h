@@ -2,8 +2,12 @@
 // (AliParaformerAsr/OfflineRecognizer.cs:13-477) and OfflineStream
 // (AliParaformerAsr/OfflineStream.cs:7-121) above the device engine.
 #pragma once
+#include <atomic>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -31,10 +35,15 @@ std::vector<std::vector<int32_t>> hotword_ids(const std::vector<std::string>& to
 
 class Recognizer;
 
+// Ownership: a stream shares ownership of its recognizer OBJECT (so a stream handle that outlives
+// pf_recognizer_free still reaches valid memory and answers PF_ERR_DISPOSED), the recognizer does not track
+// its streams (the reference's CreateOfflineStream does not either, OfflineRecognizer.cs:92-100), and the
+// device engine is released by Dispose() — never by the last stream going away.
 class Stream {
  public:
-  explicit Stream(Recognizer* r);
+  explicit Stream(std::shared_ptr<Recognizer> r);
   void AddSamples(const float* samples, int64_t n);          // OfflineStream.cs:36-57
+  void Dispose();                                             // OfflineStream.cs:81-121: drops the buffers
   std::vector<float> Speech;                                  // OfflineInputEntity.Speech
   bool has_speech = false;                                    // Speech != null
   int SpeechLength = 0;                                       // float count
@@ -44,30 +53,35 @@ class Stream {
   std::vector<std::vector<int32_t>> Timestamps;
   void RemoveChunk();                                         // OfflineStream.cs:69-79
   bool disposed = false;
-  Recognizer* owner;
+  std::shared_ptr<Recognizer> owner;
 };
 
-class Recognizer {
+class Recognizer : public std::enable_shared_from_this<Recognizer> {
  public:
   Recognizer(const std::string& model, const std::string& config, const std::string& mvn,
              const std::string& tokens, const std::string& modeleb, const std::string& hotword, int batch_size,
              int threads_num, int device);
-  Stream* CreateOfflineStream();                              // OfflineRecognizer.cs:92-100
-  void GetResults(const std::vector<Stream*>& streams);       // :110-116 (results kept in `results`)
-  void Dispose();
-  bool disposed() const { return disposed_; }
-  Engine* engine() { return engine_.get(); }
-  std::vector<ResultEntity> results;
+  ~Recognizer();
+  std::shared_ptr<Stream> CreateOfflineStream();              // OfflineRecognizer.cs:92-100
+  // GetResults (:110-116).  The result list belongs to the CALLING THREAD until its next GetResults on this
+  // recognizer (the reference returns a fresh List per call; concurrent callers must not share one).
+  void GetResults(const std::vector<Stream*>& streams);
+  const std::vector<ResultEntity>& results_of_this_thread();
+  void Dispose();                                             // waits for calls in flight, then frees the engine
+  bool disposed() const { return disposed_.load(); }
+  // the engine for the duration of one call (nullptr once disposed); callers lock engine->mutex() themselves
+  std::shared_ptr<Engine> engine() { std::lock_guard<std::mutex> lk(mu_); return engine_; }
   const std::vector<std::string>& tokens() const { return tokens_; }
 
  private:
   void Forward(const std::vector<Stream*>& streams);          // :118-198
-  std::unique_ptr<Engine> engine_;
+  std::mutex mu_;                                             // guards engine_
+  std::shared_ptr<Engine> engine_;
   std::vector<std::string> tokens_;
   ConfEntity conf_;
   std::vector<std::vector<int32_t>> hotwords_;
-  std::vector<std::unique_ptr<Stream>> streams_;
-  bool disposed_ = false;
+  uint64_t uid_ = 0;                                          // key of this recognizer in the per-thread result store
+  std::atomic<bool> disposed_{false};
   friend class Stream;
 };
 

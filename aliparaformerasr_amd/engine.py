@@ -31,7 +31,8 @@ class Engine:
 
     def __init__(self, weights=None, weights_path=None, weights_device_ptr=None, weights_bytes=0,
                  cmvn=None, mvn_path=None, device=0, dither=0.0, snip_edges=False, lfr_m=7, lfr_n=6,
-                 n_mels=80, fs=16000, window="hamming", use_itn=False):
+                 n_mels=80, fs=16000, window="hamming", use_itn=False, frame_length_ms=0, frame_shift_ms=0,
+                 dither_seed=0, math_mode=0):
         self._lib = N.load()
         cfg = N.PfEngineConfig()
         cfg.struct_size = C.sizeof(N.PfEngineConfig)
@@ -64,6 +65,8 @@ class Engine:
         cfg.dither = dither
         cfg.window = window.encode()
         cfg.use_itn = 1 if use_itn else 0
+        cfg.frame_length_ms, cfg.frame_shift_ms = frame_length_ms, frame_shift_ms
+        cfg.dither_seed, cfg.math_mode = dither_seed, math_mode
         h = C.c_void_p()
         N.check(self._lib.pf_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -65,9 +65,10 @@ class OfflineRecognizerResultEntity:
 
 
 class OfflineStream:
-    def __init__(self, lib, handle):
+    def __init__(self, lib, handle, recognizer=None):
         self._lib = lib
         self._h = handle
+        self._recognizer = recognizer       # keeps the recognizer wrapper (and its native handle) alive
 
     def AddSamples(self, samples) -> None:
         if samples is None:
@@ -114,9 +115,18 @@ class OfflineStream:
         return n.value
 
     def Dispose(self) -> None:
+        # the native handle stays valid: later calls raise the reference's ObjectDisposedException
+        # (PF_ERR_DISPOSED "OfflineStream"), not a null-handle error
         if self._h:
             self._lib.pf_stream_dispose(self._h)
-            self._h = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.pf_stream_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 class OfflineRecognizer:
@@ -134,7 +144,7 @@ class OfflineRecognizer:
     def CreateOfflineStream(self) -> OfflineStream:
         s = C.c_void_p()
         _ck(self._lib.pf_recognizer_create_stream(self._h, C.byref(s)))
-        return OfflineStream(self._lib, s)
+        return OfflineStream(self._lib, s, self)
 
     def GetResult(self, stream: OfflineStream) -> OfflineRecognizerResultEntity:
         return self.GetResults([stream])[0]

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+#define PF_ABI_VERSION 2
 
 typedef enum pf_status {
   PF_OK = 0,
@@ -85,15 +85,22 @@ typedef struct pf_engine_config {
   int32_t lfr_m;              /* 7                                                             */
   int32_t lfr_n;              /* 6                                                             */
   int32_t snip_edges;         /* 0 (false)                                                     */
-  float dither;               /* only 0 is accepted by the device fbank (reference default 1.0
-                                 is non-deterministic)                          */
+  float dither;               /* kaldi dither: N(0,1) * dither added to every sample of every frame
+                                 (reference default 1.0, Model/FrontendConfEntity.cs:12); drawn on the
+                                 device from a counter-based generator seeded by dither_seed          */
   const char* window;         /* "hamming"                                                     */
   int32_t use_itn;            /* SenseVoice: conf.use_itn (OfflineRecognizer.cs:27)            */
-  int32_t reserved[7];
+  int32_t frame_length_ms;    /* 0 = 25; anything but 25 -> PF_ERR_UNSUPPORTED                 */
+  int32_t frame_shift_ms;     /* 0 = 10; anything but 10 -> PF_ERR_UNSUPPORTED                 */
+  int32_t dither_seed;        /* seed of the dither stream (same seed + same audio = same features) */
+  int32_t math_mode;          /* 0 = f16 operands on the MFMA (default); 1 = fp32 MFMA parity mode
+                                 (v_mfma_f32_32x32x2_f32: exact fp32 products, ~1/16 of the speed) */
+  int32_t reserved[3];
 } pf_engine_config;
 
 int pf_engine_create(const pf_engine_config* cfg, pf_engine** out);
-/* Idempotent-safe teardown (Dispose(bool) pattern, OfflineRecognizer.cs:448-476). */
+/* Idempotent teardown (Dispose(bool) pattern, OfflineRecognizer.cs:448-476: Dispose() and a later finaliser
+   may both call it); waits for a call in flight on another thread.  Later calls on the handle -> PF_ERR_DISPOSED. */
 void pf_engine_destroy(pf_engine* e);
 
 /* Model facts the managed side needs. */
@@ -265,8 +272,9 @@ int pf_recognizer_create(const char* model_path, const char* config_path, const 
                          const char* tokens_path, const char* modeleb_path,
                          const char* hotword_path, int32_t batch_size, int32_t threads_num,
                          int32_t device, pf_recognizer** out);
-void pf_recognizer_dispose(pf_recognizer* r);   /* Dispose(): later calls -> PF_ERR_DISPOSED */
-void pf_recognizer_free(pf_recognizer* r);      /* releases the object itself                */
+void pf_recognizer_dispose(pf_recognizer* r);   /* Dispose(): frees the engine; later calls -> PF_ERR_DISPOSED   */
+void pf_recognizer_free(pf_recognizer* r);      /* Dispose() + drops the handle's reference; streams created from it
+                                                   stay valid handles (their calls answer PF_ERR_DISPOSED)        */
 pf_engine* pf_recognizer_engine(pf_recognizer* r);
 
 int pf_recognizer_create_stream(pf_recognizer* r, pf_stream** out);     /* CreateOfflineStream :92 */
@@ -276,7 +284,9 @@ int pf_stream_set_hotwords(pf_stream* s, const int32_t* ids, const int32_t* lens
 int pf_stream_get_hotwords(pf_stream* s, int32_t* ids, int32_t ids_cap, int32_t* lens,
                            int32_t lens_cap, int32_t* n_hotwords /* -1 = null */);
 int pf_stream_num_feature_floats(pf_stream* s, int32_t* n);  /* OfflineInputEntity.SpeechLength */
-void pf_stream_dispose(pf_stream* s);            /* DisposeOfflineStream :441 */
+void pf_stream_dispose(pf_stream* s);            /* DisposeOfflineStream :441: drops the buffers; the handle stays
+                                                    valid and later calls answer PF_ERR_DISPOSED           */
+void pf_stream_free(pf_stream* s);               /* releases the handle (and its share of the recognizer)   */
 
 /* GetResults(List<OfflineStream>) (OfflineRecognizer.cs:110): Forward + DecodeMulti.
    Results stay owned by the recognizer until the next GetResults call / dispose. */

@@ -134,24 +134,27 @@ def extract_frames(wave: np.ndarray, snip_edges: bool) -> np.ndarray:
 
 
 def kaldi_fbank(samples: np.ndarray, conf: FrontendConf | None = None,
-                scale_to_int16: bool = True) -> np.ndarray:
+                scale_to_int16: bool = True, dither_rng=None) -> np.ndarray:
     """GetFbank (WavFrontend.cs:31-37): x*32768, then kaldi fbank -> [T80, n_mels] f32.
 
-    dither != 0 is rejected: the reference is itself non-deterministic there
-    (quirk Q11); all parity work runs with dither = 0.
+    dither != 0 (the reference default is 1.0, Model/FrontendConfEntity.cs:12): kaldi's ProcessWindow adds
+    `dither * N(0,1)` to every sample of every extracted frame window (overlapping frames draw independently)
+    BEFORE the DC removal; the reference is itself non-deterministic there (quirk Q11), so parity with it can
+    only be statistical.  `dither_rng` seeds the draw (numpy Generator); bit-parity work runs with dither = 0.
     """
     conf = conf or FrontendConf(dither=0.0)
     if samples is None:
         # LINQ Select on null -> ArgumentNullException("source") (WavFrontend.cs:34)
         raise ValueError("source")
-    if conf.dither != 0.0:
-        raise NotImplementedError("oracle runs with dither=0 only")
     x = np.asarray(samples, dtype=F32)
     if scale_to_int16:
         x = (x * F32(32768.0)).astype(F32)
     frames = extract_frames(x, conf.snip_edges)              # [T,400]
     if frames.shape[0] == 0:
         return np.zeros((0, conf.n_mels), dtype=F32)
+    if conf.dither != 0.0:
+        rng = dither_rng if dither_rng is not None else np.random.default_rng()
+        frames = (frames + F32(conf.dither) * rng.standard_normal(frames.shape, dtype=F32)).astype(F32)
     # remove_dc_offset: window->Add(-window->Sum() / frame_length)
     mean = (frames.sum(axis=1, dtype=F32) / F32(FRAME_LEN)).astype(F32)
     frames = (frames - mean[:, None]).astype(F32)

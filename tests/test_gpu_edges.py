@@ -196,3 +196,82 @@ def test_five_minute_utterance(small):
     res = eng.recognize(a, want_logits=True)
     assert res.L == ref["logits"].shape[1] > 500
     _cmp(res, ref, 3e-2)
+
+
+def test_handles_are_idempotent_and_answer_disposed():
+    """pf_engine_destroy twice (Dispose() + finaliser, OfflineRecognizer.cs:448-476) and calls on a destroyed
+    handle: PF_ERR_DISPOSED, never a crash."""
+    import ctypes as C
+    from aliparaformerasr_amd import _native as N
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=32)
+    eng = Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, 4)), cmvn=W.synth_cmvn(), device=0)
+    h = eng._h
+    lib = N.load()
+    lib.pf_engine_destroy(h)
+    lib.pf_engine_destroy(h)                     # second destroy of the same handle
+    t = C.c_int32()
+    assert lib.pf_frontend_num_frames(h, 16000, t) == N.PF_ERR_DISPOSED
+    assert lib.pf_sync(h) == N.PF_ERR_DISPOSED
+    eng._h = None
+
+
+def test_malformed_containers_round2():
+    """Containers that used to reach the device or the stack: mismatched LayerNorm width, predictor.out sizes,
+    negative dims, a header nested 10 000 deep, a header length that wraps, unsupported framing."""
+    import json
+    import struct
+    from aliparaformerasr_amd._native import PfError, PF_ERR_FORMAT, PF_ERR_UNSUPPORTED
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=32)
+    w = W.synth_weights(cfg, 4)
+    good = W.pack_pfw(cfg, w)
+    cmvn = W.synth_cmvn()
+
+    def fails(blob, code=PF_ERR_FORMAT, **kw):
+        with pytest.raises(PfError) as ei:
+            Engine(weights=np.frombuffer(blob, np.uint8), cmvn=cmvn, device=0, **kw)
+        assert ei.value.code == code, ei.value
+
+    for name, cut in (("encoder.layers.0.norm2.weight", 100), ("decoder.layers.0.ffn.norm.weight", 512),
+                      ("predictor.out.weight", 100), ("decoder.after_norm.bias", 511)):
+        w2 = dict(w)
+        w2[name] = w2[name].reshape(-1)[:cut].copy()
+        if name.endswith(".weight") and "norm" in name:
+            w2[name.replace(".weight", ".bias")] = w2[name.replace(".weight", ".bias")][:cut].copy()
+        if name.endswith(".bias") and "norm" in name:
+            w2[name.replace(".bias", ".weight")] = w2[name.replace(".bias", ".weight")][:cut].copy()
+        fails(W.pack_pfw(cfg, w2))
+    # header surgery
+    hlen = struct.unpack("<Q", good[8:16])[0]
+    hdr = json.loads(good[16:16 + hlen])
+    def rebuild(h):
+        hb = json.dumps(h).encode()
+        assert len(hb) <= hlen
+        return good[:16] + hb + b" " * (hlen - len(hb)) + good[16 + hlen:]
+    h2 = json.loads(json.dumps(hdr)); h2["tensors"][0]["shape"][0] = -h2["tensors"][0]["shape"][0]
+    fails(rebuild(h2))
+    fails(good[:8] + struct.pack("<Q", (1 << 64) - 8) + good[16:])           # 16 + hlen wraps to 8
+    deep = b"[" * 10000
+    fails(good[:8] + struct.pack("<Q", len(deep)) + deep + good[16:])
+    fails(good, code=PF_ERR_UNSUPPORTED, frame_length_ms=20)
+    fails(good, code=PF_ERR_UNSUPPORTED, frame_shift_ms=5)
+    Engine(weights=good, cmvn=cmvn, device=0, frame_length_ms=25, frame_shift_ms=10).close()
+
+
+def test_result_slot_is_released_by_the_fetch_that_delivers_ids(small):
+    """learn-L-then-fetch: the forward publishes a per-thread slot (it may carry a B*L*V host copy of the
+    log-probs), the pf_fetch that receives token_ids releases it; a thread that dies takes its slot with it."""
+    import threading
+    eng = small[0]
+    a = [W.synth_audio(32000, 5)]
+    r1 = eng.recognize(a, want_logits=True)
+    r2 = eng.recognize(a, want_logits=True)
+    np.testing.assert_array_equal(r1.logits, r2.logits)
+    out = {}
+    def work():
+        out["r"] = eng.recognize(a, want_logits=True)
+    ts = [threading.Thread(target=work) for _ in range(3)]
+    for t in ts:
+        t.start(); t.join()                                # three short-lived threads, possibly one re-used OS id
+    np.testing.assert_array_equal(out["r"].logits, r1.logits)

@@ -200,3 +200,46 @@ def test_frontend_seam(eng):
         assert got.shape == ref.shape == (eng.num_frames(n), 560)
         if ref.size:
             assert np.abs(got - ref).max() < 1e-3     # CMVN scale <= 0.3 shrinks the fbank error
+
+
+def test_fbank_dither_statistics():
+    """dither != 0 (the reference default is 1.0, Model/FrontendConfEntity.cs:12): the reference's own draw is
+    not reproducible, so parity is statistical — per-bin mean and spread of the log-mel energies over ~6000 frames
+    of pure dither noise (silence in) against the oracle's kaldi restatement with the same sigma; plus determinism
+    under a fixed seed and near-invisibility on audio at normal levels."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=128)
+    blob = W.pack_pfw(cfg, W.synth_weights(cfg, seed=5))
+    for sigma in (1.0, 3.0):
+        e1 = Engine(weights=blob, cmvn=W.synth_cmvn(), device=0, dither=sigma, dither_seed=7)
+        z = np.zeros(960000, np.float32)
+        got = e1.fbank(z)                                             # [6000, 80]
+        conf = fe.FrontendConf(dither=sigma, snip_edges=False)
+        ref = fe.kaldi_fbank(z, conf, dither_rng=np.random.default_rng(1))
+        assert got.shape == ref.shape == (6000, 80)
+        assert np.isfinite(got).all() and got.std() > 0.1
+        n = got.shape[0]
+        se = np.sqrt(got.var(axis=0) / n + ref.var(axis=0) / n)
+        zscore = np.abs(got.mean(axis=0) - ref.mean(axis=0)) / se
+        assert zscore.max() < 5.0, zscore.max()                       # 80 bins, 5 sigma
+        ratio = got.std(axis=0) / ref.std(axis=0)
+        assert np.abs(ratio - 1).max() < 0.1, ratio
+        # frames are independent draws: lag-1 correlation of a bin across frames ~ the oracle's (overlap only)
+        c_dev = np.corrcoef(got[:-3, 40], got[3:, 40])[0, 1]
+        assert abs(c_dev) < 0.06
+        # same seed + same call sequence = same features; another seed differs
+        e2 = Engine(weights=blob, cmvn=W.synth_cmvn(), device=0, dither=sigma, dither_seed=7)
+        np.testing.assert_array_equal(e2.fbank(z), got)
+        e3 = Engine(weights=blob, cmvn=W.synth_cmvn(), device=0, dither=sigma, dither_seed=8)
+        assert np.abs(e3.fbank(z) - got).max() > 0.1
+        # successive calls on one engine draw fresh noise
+        assert np.abs(e1.fbank(z) - got).max() > 0.1
+        for e in (e1, e2, e3):
+            e.close()
+    # at speech levels (|x| ~ 0.1 => ~3000 LSB) one LSB of dither barely moves the log-mel energies
+    x = W.synth_audio(80000, 3)
+    ed = Engine(weights=blob, cmvn=W.synth_cmvn(), device=0, dither=1.0, dither_seed=1)
+    e0 = Engine(weights=blob, cmvn=W.synth_cmvn(), device=0, dither=0.0)
+    d = np.abs(ed.fbank(x) - e0.fbank(x))
+    assert 0 < d.max() < 0.05 and d.mean() < 2e-3, (d.max(), d.mean())
+    ed.close(); e0.close()

@@ -153,3 +153,44 @@ def test_end_to_end_text_matches_oracle(model_dir):
     from aliparaformerasr_amd.offline_recognizer import RecognizerException
     with pytest.raises(RecognizerException):
         r.GetResults(streams[:1])
+
+
+def test_stream_outlives_its_recognizer(model_dir):
+    """A stream handle used after its recognizer was freed answers ObjectDisposedException — it does not
+    dereference freed memory (the stream shares ownership of the recognizer object, not of the device engine)."""
+    import gc
+    from aliparaformerasr_amd.offline_recognizer import ObjectDisposedException
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    s.AddSamples(np.zeros(16000, np.float32))
+    s._recognizer = None                           # drop the Python-side keep-alive: the native side must cope alone
+    r._lib.pf_recognizer_free(r._h)
+    r._h = None
+    del r
+    gc.collect()
+    with pytest.raises(ObjectDisposedException) as ei:
+        s.AddSamples(np.zeros(16000, np.float32))
+    assert ei.value.ObjectName == "OfflineRecognizer"
+    assert s.SpeechLength > 0                      # host-side state is still readable
+    s.Dispose()
+    with pytest.raises(ObjectDisposedException) as ei:
+        s.SpeechLength
+    assert ei.value.ObjectName == "OfflineStream"
+    s.Dispose()                                    # idempotent
+
+
+def test_disposed_stream_answers_object_disposed(model_dir):
+    from aliparaformerasr_amd.offline_recognizer import ObjectDisposedException
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    r.DisposeOfflineStream(s)
+    for call in (lambda: s.AddSamples(np.zeros(100, np.float32)), lambda: s.Tokens, lambda: s.Hotwords):
+        with pytest.raises(ObjectDisposedException) as ei:
+            call()
+        assert ei.value.ObjectName == "OfflineStream"
+    # a recognizer that creates one stream per utterance does not accumulate them
+    for _ in range(200):
+        t = r.CreateOfflineStream()
+        t.AddSamples(np.zeros(1600, np.float32))
+        r.DisposeOfflineStream(t)
+    r.Dispose()
