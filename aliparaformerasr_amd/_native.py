@@ -82,6 +82,12 @@ SIGNATURES = {
     "pf_host_wav_read": (C.c_int, [C.c_char_p, _f, C.c_int64, _i64, _i32, _i32, C.POINTER(C.c_double)]),
     "pf_host_resample": (C.c_int, [_f, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int64, _i64]),
     "pf_host_is_audio": (C.c_int, [C.c_char_p, _i32]),
+    "pf_group_create": (C.c_int, [_P(PfEngineConfig), _i32, C.c_int32, _P(_vp)]),
+    "pf_group_destroy": (None, [_vp]),
+    "pf_group_info": (C.c_int, [_vp, _i32, _i32]),
+    "pf_group_engine": (_vp, [_vp, C.c_int32]),
+    "pf_group_recognize": (C.c_int, [_vp, _P(_f), _i64, C.c_int32, _i32, C.c_int32, _P(PfBatchOut)]),
+    "pf_group_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
     "pf_sync": (C.c_int, [_vp]),
     "pf_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
     "pf_profile_enable": (C.c_int, [_vp, C.c_int32]),

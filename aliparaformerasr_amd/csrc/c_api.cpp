@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "engine.h"
+#include "group.h"
 #include "recognizer.h"
 
 namespace pf {
@@ -31,6 +32,11 @@ struct pf_stream {
   bool freed = false;
 };
 struct pf_decoded { ResultEntity r; };
+struct pf_group {
+  std::mutex mu;
+  std::shared_ptr<Group> g;
+  std::vector<std::unique_ptr<pf_engine>> views;    // borrowed engine handles (pf_group_engine)
+};
 
 #define PF_TRY try {
 #define PF_CATCH                                                          \
@@ -267,6 +273,83 @@ int pf_last_flops(pf_engine* h, double* f) {
   PF_TRY
   NEED(f);
   *f = E(h)->last_flops();
+  return PF_OK;
+  PF_CATCH
+}
+
+// ---- multi-device group ---------------------------------------------------
+int pf_group_create(const pf_engine_config* cfg, const int32_t* devices, int32_t n_devices, pf_group** out) {
+  PF_TRY
+  NEED(cfg); NEED(out); NEED(devices);
+  PF_CHECK(cfg->struct_size == (int32_t)sizeof(pf_engine_config), PF_ERR_INVALID_ARG, "pf_engine_config.struct_size mismatch");
+  *out = nullptr;
+  std::shared_ptr<Group> g = std::make_shared<Group>(*cfg, devices, n_devices);
+  pf_group* h = new pf_group();
+  h->g = g;
+  for (int i = 0; i < g->size(); ++i) {
+    h->views.emplace_back(new pf_engine());
+    h->views.back()->e = g->engine(i);
+  }
+  *out = h;
+  return PF_OK;
+  PF_CATCH
+}
+
+void pf_group_destroy(pf_group* h) {
+  if (!h) return;
+  std::shared_ptr<Group> g;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    g.swap(h->g);
+    for (auto& v : h->views) { std::lock_guard<std::mutex> lk2(v->mu); v->e.reset(); }
+  }
+  if (!g) return;
+  try {
+    { std::lock_guard<std::mutex> lk(g->mutex()); }
+    g.reset();
+  } catch (...) {}
+}
+
+static std::shared_ptr<Group> GR(pf_group* h) {
+  PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null group");
+  std::lock_guard<std::mutex> lk(h->mu);
+  PF_CHECK(h->g != nullptr, PF_ERR_DISPOSED, "OfflineRecognizer");
+  return h->g;
+}
+
+int pf_group_info(pf_group* h, int32_t* n_engines, int32_t* uses_rccl) {
+  PF_TRY
+  std::shared_ptr<Group> g = GR(h);
+  if (n_engines) *n_engines = g->size();
+  if (uses_rccl) *uses_rccl = g->uses_rccl() ? 1 : 0;
+  return PF_OK;
+  PF_CATCH
+}
+
+pf_engine* pf_group_engine(pf_group* h, int32_t i) {
+  if (!h) return nullptr;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->g || i < 0 || i >= (int32_t)h->views.size()) return nullptr;
+  return h->views[(size_t)i].get();
+}
+
+int pf_group_recognize(pf_group* h, const float* const* samples, const int64_t* n, int32_t B, const int32_t* hotwords,
+                       int32_t n_hotwords, pf_batch_out* out) {
+  PF_TRY
+  std::shared_ptr<Group> g = GR(h);
+  NEED(out);
+  std::lock_guard<std::mutex> lk(g->mutex());
+  g->recognize(samples, n, B, hotwords, n_hotwords, want_logits(out));
+  g->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_group_fetch(pf_group* h, pf_batch_out* out) {
+  PF_TRY
+  std::shared_ptr<Group> g = GR(h);
+  std::lock_guard<std::mutex> lk(g->mutex());
+  g->fetch(out);
   return PF_OK;
   PF_CATCH
 }

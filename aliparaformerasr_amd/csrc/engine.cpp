@@ -586,7 +586,7 @@ int Engine::num_lfr_frames(int64_t n) const {
   return t80 / fc_.lfr_n;
 }
 
-void Engine::stage_audio(const float* const* samples, const int64_t* n, int B) {
+void Engine::stage_audio(const float* const* samples, const int64_t* n, int B, int force_T) {
   PF_CHECK(B >= 0, PF_ERR_INVALID_ARG, "negative batch");
   PF_HIP(hipSetDevice(device_));
   st_B_ = B;
@@ -608,7 +608,7 @@ void Engine::stage_audio(const float* const* samples, const int64_t* n, int B) {
   }
   meta[2 * (B + 1) + B] = frames;
   st_total_frames_ = frames;
-  st_T_ = tmax;
+  st_T_ = std::max(tmax, force_T);
   ensure(ws_audio_, (size_t)std::max<int64_t>(tot, 1) * 4);
   ensure(ws_meta_, meta.size() * 8 + (size_t)B * 4 + 64);
   for (int b = 0; b < B; ++b)
@@ -817,6 +817,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
+  if (l_hook_) L = l_hook_(L);                       // shard of a multi-device batch: the batch-wide maximum
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);
   if (L == 0) return;
@@ -1193,6 +1194,15 @@ void Engine::publish_thread_result() {
 }
 
 void Engine::drop_thread_result() { t_slots.erase(uid_); }
+
+void Engine::copy_logits(HostBatchOut& r) {
+  const int64_t need = (int64_t)last_.B * last_.L * last_.V;
+  r.logits.assign((size_t)std::max<int64_t>(need, 0), 0.f);
+  r.has_logits = last_logits_;
+  if (!last_logits_ || need <= 0) return;
+  PF_HIP(hipMemcpy2D(r.logits.data(), (size_t)last_.V * 4, logits_, (size_t)logits_ld_ * 4, (size_t)last_.V * 4,
+                     (size_t)last_.B * last_.L, hipMemcpyDeviceToHost));
+}
 
 void Engine::fetch(pf_batch_out* out) {
   PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");

@@ -2,6 +2,7 @@
 // Replaces OfflineModel (ORT session, AliParaformerAsr/OfflineModel.cs:35-70) and the numeric
 // body of IOfflineProj.ModelProj (AliParaformerAsr/IOfflineProj.cs:38).
 #pragma once
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -75,7 +76,8 @@ class Engine {
   void forward_device(const float* speech_dev, int B, int T, bool want_logits);
   void forward_feats_host(const float* speech, int B, int T, bool want_logits);
   void model_proj_host(const float* const* speech, const int32_t* n_floats, int B, bool want_logits);
-  void stage_audio(const float* const* samples, const int64_t* n, int B);
+  // force_T > 0: pad to at least force_T LFR frames (a shard of a larger batch pads to the GLOBAL maximum, PadHelper.cs:25)
+  void stage_audio(const float* const* samples, const int64_t* n, int B, int force_T = 0);
   void run_staged(bool want_logits);
   void fetch(pf_batch_out* out);
   // Results are kept per CALLING THREAD: a forward entry point (pf_forward_feats / pf_model_proj / pf_recognize)
@@ -85,6 +87,13 @@ class Engine {
   void publish_thread_result();
   void drop_thread_result();
   void sync();
+  // multi-device groups (group.h): the decoder length becomes the maximum over all shards of the batch
+  void set_l_hook(std::function<int(int)> h) { l_hook_ = std::move(h); }
+  const HostBatchOut& last_result() const { return last_; }
+  void copy_logits(HostBatchOut& r);                 // host copy of the last forward's log-probs into r.logits
+  const int64_t* ids_device() const { return ids_dev_; }
+  const int32_t* token_num_device() const { return plan_.token_num; }
+  hipStream_t stream() const { return stream_; }
   // SeACo: hotword ids [n, 10] (PadList output, EmbedSeacoModel.cs:70-123) used by the following forwards;
   // n = 0 -> bias_embed [B,0,512]: the bias branch is skipped and the ASR log-probs are returned
   void set_hotwords(const int32_t* hw, int n);
@@ -211,6 +220,7 @@ class Engine {
   bool last_logits_ = false;
   double last_flops_ = 0;
 
+  std::function<int(int)> l_hook_;
   bool prof_on_ = false;
   std::string prof_only_;
   std::map<std::string, ProfClass> prof_;

@@ -1,0 +1,384 @@
+// group.cpp — see group.h.
+#include "group.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <set>
+
+#include <rccl/rccl.h>   // types and enums only: every entry point is resolved with dlsym
+
+#include "hostutil.h"
+
+namespace pf {
+
+// ------------------------------------------------------------------ RCCL (dlopen) ---------
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  ~Rccl() { if (lib) dlclose(lib); }
+  static std::unique_ptr<Rccl> open() {
+    std::unique_ptr<Rccl> r(new Rccl());
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {
+      r->lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (r->lib) break;
+    }
+    if (!r->lib) throw Error(PF_ERR_UNSUPPORTED, std::string("pf_group: librccl.so not found (") + dlerror() + ")");
+#define PF_SYM(field, name)                                                                        \
+  r->field = reinterpret_cast<decltype(r->field)>(dlsym(r->lib, name));                            \
+  if (!r->field) throw Error(PF_ERR_UNSUPPORTED, std::string("pf_group: librccl lacks ") + name)
+    PF_SYM(CommInitAll, "ncclCommInitAll");
+    PF_SYM(CommDestroy, "ncclCommDestroy");
+    PF_SYM(Broadcast, "ncclBroadcast");
+    PF_SYM(AllGather, "ncclAllGather");
+    PF_SYM(GroupStart, "ncclGroupStart");
+    PF_SYM(GroupEnd, "ncclGroupEnd");
+    PF_SYM(GetErrorString, "ncclGetErrorString");
+#undef PF_SYM
+    return r;
+  }
+  void check(ncclResult_t rc, const char* what) const {
+    if (rc != ncclSuccess) throw Error(PF_ERR_DEVICE, std::string("rccl: ") + what + ": " + GetErrorString(rc));
+  }
+};
+
+// ------------------------------------------------------------------ MaxBarrier ------------
+int MaxBarrier::arrive_and_max(int v) {
+  std::unique_lock<std::mutex> lk(mu_);
+  if (broken_) throw Error(PF_ERR_RECOGNITION, "another device of the group failed");
+  const int gen = gen_;
+  cur_ = std::max(cur_, v);
+  if (++count_ == n_) {
+    result_ = cur_;
+    cur_ = 0;
+    count_ = 0;
+    ++gen_;
+    cv_.notify_all();
+    return result_;
+  }
+  cv_.wait(lk, [&] { return gen_ != gen || broken_; });
+  if (gen_ == gen) throw Error(PF_ERR_RECOGNITION, "another device of the group failed");
+  return result_;
+}
+void MaxBarrier::abort() {
+  std::lock_guard<std::mutex> lk(mu_);
+  broken_ = true;
+  cv_.notify_all();
+}
+void MaxBarrier::reset() {
+  std::lock_guard<std::mutex> lk(mu_);
+  broken_ = false;
+  count_ = 0;
+  cur_ = 0;
+}
+
+// ------------------------------------------------------------------ Group ------------------
+Group::Group(const pf_engine_config& cfg, const int32_t* devices, int n) {
+  PF_CHECK(devices && n > 0 && n <= 64, PF_ERR_INVALID_ARG, "pf_group: device list must name 1..64 devices");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    throw Error(PF_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  for (int i = 0; i < n; ++i) {
+    PF_CHECK(devices[i] >= 0 && devices[i] < ndev, PF_ERR_DEVICE, "pf_group: device ordinal out of range");
+    devs_.push_back(devices[i]);
+  }
+  const std::set<int> uniq(devs_.begin(), devs_.end());
+  const bool distinct = (int)uniq.size() == n;
+
+  // ---- the weight image: host -> devices[0] once, then GPU -> GPU
+  std::vector<char> file;
+  const char* host = nullptr;
+  int64_t nbytes = 0;
+  if (cfg.weights_path && cfg.weights_path[0]) {
+    read_binary_file(cfg.weights_path, file);
+    host = file.data();
+    nbytes = (int64_t)file.size();
+  } else if (cfg.weights_host) {
+    host = (const char*)cfg.weights_host;
+    nbytes = cfg.weights_bytes;
+  }
+  PF_CHECK(host || cfg.weights_device, PF_ERR_INVALID_ARG, "pf_group: no weight source");
+  if (!host) nbytes = cfg.weights_bytes;
+  PF_CHECK(nbytes >= 16, PF_ERR_FORMAT, "weights: image too small");
+  try {
+    images_.assign((size_t)n, nullptr);
+    image_owned_.assign((size_t)n, false);
+    for (int i = 0; i < n; ++i) {
+      int first = i;                                  // engines on one device share one image
+      for (int j = 0; j < i; ++j)
+        if (devs_[(size_t)j] == devs_[(size_t)i]) { first = j; break; }
+      if (first != i) { images_[(size_t)i] = images_[(size_t)first]; continue; }
+      if (i == 0 && !host) { images_[0] = const_cast<void*>(cfg.weights_device); continue; }
+      PF_HIP(hipSetDevice(devs_[(size_t)i]));
+      PF_HIP(hipMalloc(&images_[(size_t)i], (size_t)nbytes));
+      image_owned_[(size_t)i] = true;
+    }
+    PF_HIP(hipSetDevice(devs_[0]));
+    if (host) PF_HIP(hipMemcpy(images_[0], host, (size_t)nbytes, hipMemcpyHostToDevice));
+    if (distinct) {
+      // one communicator over the device list (n == 1: a one-rank communicator — the same calls, no traffic)
+      rccl_ = Rccl::open();
+      std::vector<ncclComm_t> cs((size_t)n);
+      rccl_->check(rccl_->CommInitAll(cs.data(), n, devs_.data()), "ncclCommInitAll");
+      for (ncclComm_t c : cs) comms_.push_back((void*)c);
+      comms_ready_ = true;
+      if (n > 1) {
+        std::vector<hipStream_t> ss((size_t)n);
+        for (int i = 0; i < n; ++i) {
+          PF_HIP(hipSetDevice(devs_[(size_t)i]));
+          PF_HIP(hipStreamCreateWithFlags(&ss[(size_t)i], hipStreamNonBlocking));
+        }
+        rccl_->check(rccl_->GroupStart(), "ncclGroupStart");
+        for (int i = 0; i < n; ++i)
+          rccl_->check(rccl_->Broadcast(images_[0], images_[(size_t)i], (size_t)nbytes, ncclUint8, 0, (ncclComm_t)comms_[(size_t)i],
+                                        ss[(size_t)i]),
+                       "ncclBroadcast");
+        rccl_->check(rccl_->GroupEnd(), "ncclGroupEnd");
+        for (int i = 0; i < n; ++i) {
+          PF_HIP(hipSetDevice(devs_[(size_t)i]));
+          PF_HIP(hipStreamSynchronize(ss[(size_t)i]));
+          PF_HIP(hipStreamDestroy(ss[(size_t)i]));
+        }
+      }
+    } else {
+      for (int i = 1; i < n; ++i)
+        if (image_owned_[(size_t)i])
+          PF_HIP(hipMemcpyPeer(images_[(size_t)i], devs_[(size_t)i], images_[0], devs_[0], (size_t)nbytes));
+    }
+    // ---- one engine per entry, each adopting its device image in place
+    for (int i = 0; i < n; ++i) {
+      pf_engine_config ec = cfg;
+      ec.device = devs_[(size_t)i];
+      ec.weights_path = nullptr;
+      ec.weights_host = nullptr;
+      ec.weights_device = images_[(size_t)i];
+      ec.weights_bytes = nbytes;
+      eng_.push_back(std::make_shared<Engine>(ec));
+    }
+    lbar_.reset(new MaxBarrier(n));
+    gsend_.assign((size_t)n, nullptr); grecv_.assign((size_t)n, nullptr);
+    gsend_bytes_.assign((size_t)n, 0); grecv_bytes_.assign((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+      workers_.emplace_back(new Worker());
+      workers_.back()->th = std::thread([this, i] { worker_loop(i); });
+    }
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+Group::~Group() { release(); }
+
+void Group::release() {
+  for (auto& w : workers_) {
+    { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+  }
+  workers_.clear();
+  eng_.clear();                                       // engines first: they borrow the images
+  for (size_t i = 0; i < gsend_.size(); ++i) {
+    hipSetDevice(devs_[i]);
+    if (gsend_[i]) hipFree(gsend_[i]);
+    if (grecv_[i]) hipFree(grecv_[i]);
+  }
+  gsend_.clear(); grecv_.clear();
+  if (rccl_)
+    for (void* c : comms_) rccl_->CommDestroy((ncclComm_t)c);
+  comms_.clear();
+  comms_ready_ = false;
+  for (size_t i = 0; i < images_.size(); ++i)
+    if (image_owned_[i] && images_[i]) { hipSetDevice(devs_[i]); hipFree(images_[i]); }
+  images_.clear();
+  rccl_.reset();
+}
+
+void Group::worker_loop(int i) {
+  Worker& w = *workers_[(size_t)i];
+  hipSetDevice(devs_[(size_t)i]);
+  for (;;) {
+    std::function<void()> job;
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.has_job || w.stop; });
+      if (w.stop) return;
+      job = std::move(w.job);
+      w.has_job = false;
+    }
+    int code = 0;
+    std::string err;
+    try {
+      job();
+    } catch (const Error& ex) {
+      code = ex.code; err = ex.what();
+    } catch (const std::exception& ex) {
+      code = PF_ERR_DEVICE; err = ex.what();
+    }
+    if (code) lbar_->abort();                         // nobody may wait for this device's L any longer
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.code = code; w.error = err; w.done = true;
+    }
+    w.cv.notify_all();
+  }
+}
+
+void Group::run_on_all(const std::function<void(int)>& fn) {
+  for (size_t i = 0; i < workers_.size(); ++i) {
+    Worker& w = *workers_[i];
+    std::lock_guard<std::mutex> lk(w.mu);
+    const int gi = (int)i;
+    w.job = [fn, gi] { fn(gi); };
+    w.has_job = true; w.done = false; w.code = 0; w.error.clear();
+    w.cv.notify_all();
+  }
+  int code = 0;
+  std::string err;
+  for (auto& wp : workers_) {
+    std::unique_lock<std::mutex> lk(wp->mu);
+    wp->cv.wait(lk, [&] { return wp->done; });
+    // report the root cause, not the "another device failed" echoes
+    if (wp->code && (!code || (code == PF_ERR_RECOGNITION && err.find("another device") != std::string::npos))) {
+      code = wp->code; err = wp->error;
+    }
+  }
+  if (code) throw Error(code, err);
+}
+
+void Group::recognize(const float* const* samples, const int64_t* n, int B, const int32_t* hotwords, int n_hotwords,
+                      bool want_logits) {
+  PF_CHECK(B >= 0 && (B == 0 || (samples && n)), PF_ERR_INVALID_ARG, "pf_group_recognize: bad arguments");
+  const int G = size();
+  merged_ = HostBatchOut();
+  merged_logits_ = want_logits;
+  if (B == 0) return;
+  const int per = (B + G - 1) / G;                    // contiguous blocks of ceil(B/G)
+  int Tg = 0;                                         // the reference pads to the BATCH maximum (PadHelper.cs:25)
+  for (int b = 0; b < B; ++b) {
+    if (!samples[b] && n[b] > 0) throw Error(PF_ERR_NULL_SAMPLES, "source");
+    Tg = std::max(Tg, eng_[0]->num_lfr_frames(n[b]));
+  }
+  const bool has_cif = eng_[0]->model().kind != "sensevoicesmall";
+  std::vector<HostBatchOut> part((size_t)G);
+  lbar_->reset();
+  run_on_all([&](int g) {
+    Engine& e = *eng_[(size_t)g];
+    const int lo = std::min(g * per, B), hi = std::min(lo + per, B), Bg = hi - lo;
+    std::lock_guard<std::mutex> lk(e.mutex());
+    HostBatchOut& r = part[(size_t)g];
+    int Lg = 0;
+    if (Bg == 0) {
+      if (has_cif) Lg = lbar_->arrive_and_max(0);
+    } else {
+      if (e.model().seaco) e.set_hotwords(hotwords, hotwords ? n_hotwords : 0);
+      if (has_cif) e.set_l_hook([this](int L) { return lbar_->arrive_and_max(L); });
+      try {
+        e.stage_audio(samples + lo, n + lo, Bg, Tg);
+        e.run_staged(want_logits);
+      } catch (...) {
+        e.set_l_hook(nullptr);
+        throw;
+      }
+      e.set_l_hook(nullptr);
+      e.sync();
+      r = e.last_result();
+      Lg = r.L;
+      if (want_logits && (int64_t)r.B * r.L * r.V > 0) e.copy_logits(r);
+    }
+    // ---- gather of the hypotheses over RCCL: fixed-shape [per, L] int64 ids + [per] int32 token_num
+    if (comms_ready_) {
+      const size_t ids_b = (size_t)per * (size_t)std::max(Lg, 1) * 8, blk = (size_t)round_up((int64_t)(ids_b + (size_t)per * 4), 256);
+      auto grow = [&](void*& p, size_t& have, size_t want) {
+        if (have >= want) return;
+        if (p) { PF_HIP(hipStreamSynchronize(e.stream())); PF_HIP(hipFree(p)); p = nullptr; }
+        PF_HIP(hipMalloc(&p, want));
+        have = want;
+      };
+      grow(gsend_[(size_t)g], gsend_bytes_[(size_t)g], blk);
+      grow(grecv_[(size_t)g], grecv_bytes_[(size_t)g], blk * (size_t)G);
+      char* sb = (char*)gsend_[(size_t)g];
+      PF_HIP(hipMemsetAsync(sb, 0xFF, blk, e.stream()));           // absent rows: id -1, token_num -1
+      if (Bg > 0 && Lg > 0) {
+        PF_HIP(hipMemcpyAsync(sb, e.ids_device(), (size_t)Bg * Lg * 8, hipMemcpyDeviceToDevice, e.stream()));
+        if (has_cif)
+          PF_HIP(hipMemcpyAsync(sb + ids_b, e.token_num_device(), (size_t)Bg * 4, hipMemcpyDeviceToDevice, e.stream()));
+      }
+      rccl_->check(rccl_->AllGather(sb, grecv_[(size_t)g], blk, ncclUint8, (ncclComm_t)comms_[(size_t)g], e.stream()),
+                   "ncclAllGather");
+      PF_HIP(hipStreamSynchronize(e.stream()));
+    }
+  });
+  // ---- merge in the caller's order
+  int L = 0, V = eng_[0]->model().vocab, P = 0;
+  for (auto& r : part) { L = std::max(L, r.L); P = std::max(P, r.peak_len); }
+  merged_.B = B; merged_.L = L; merged_.V = V; merged_.T = Tg; merged_.peak_len = P;
+  merged_.ids.assign((size_t)B * L, 0);
+  merged_.token_num.assign((size_t)B, 0);
+  merged_.fire_count.assign((size_t)B, 0);
+  if (P > 0) merged_.cif_peak.assign((size_t)B * P, 0.f);
+  if (want_logits) merged_.logits.assign((size_t)B * L * V, 0.f);
+  merged_.has_logits = want_logits;
+  std::vector<char> gathered;
+  size_t blk = 0, ids_b = 0;
+  if (comms_ready_ && L > 0) {
+    ids_b = (size_t)per * (size_t)L * 8;
+    blk = (size_t)round_up((int64_t)(ids_b + (size_t)per * 4), 256);
+    gathered.resize(blk * (size_t)G);
+    PF_HIP(hipSetDevice(devs_[0]));
+    PF_HIP(hipMemcpy(gathered.data(), grecv_[0], gathered.size(), hipMemcpyDeviceToHost));   // ONE read-back
+  }
+  for (int g = 0; g < G; ++g) {
+    const HostBatchOut& r = part[(size_t)g];
+    const int lo = std::min(g * per, B), hi = std::min(lo + per, B), Bg = hi - lo;
+    if (Bg == 0) continue;
+    PF_CHECK(r.L == L || !has_cif, PF_ERR_DEVICE, "pf_group: shards disagree on the decoder length");
+    for (int b = 0; b < Bg; ++b) {
+      if (!gathered.empty()) {
+        std::memcpy(&merged_.ids[(size_t)(lo + b) * L], gathered.data() + blk * (size_t)g + (size_t)b * L * 8, (size_t)L * 8);
+        if (has_cif) std::memcpy(&merged_.token_num[(size_t)(lo + b)], gathered.data() + blk * (size_t)g + ids_b + (size_t)b * 4, 4);
+        else merged_.token_num[(size_t)(lo + b)] = r.token_num[(size_t)b];
+      } else {
+        if (L > 0) std::memcpy(&merged_.ids[(size_t)(lo + b) * L], &r.ids[(size_t)b * r.L], (size_t)L * 8);
+        merged_.token_num[(size_t)(lo + b)] = r.token_num[(size_t)b];
+      }
+      merged_.fire_count[(size_t)(lo + b)] = r.fire_count[(size_t)b];
+      if (P > 0 && r.peak_len == P) std::memcpy(&merged_.cif_peak[(size_t)(lo + b) * P], &r.cif_peak[(size_t)b * P], (size_t)P * 4);
+      if (want_logits && L > 0)
+        std::memcpy(&merged_.logits[(size_t)(lo + b) * L * V], &r.logits[(size_t)b * L * V], (size_t)L * V * 4);
+    }
+  }
+}
+
+void Group::fetch(pf_batch_out* out) {
+  PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");
+  const HostBatchOut& r = merged_;
+  const int B = r.B, L = r.L, V = r.V;
+  out->L = L; out->V = V; out->cif_peak_len = r.peak_len;
+  if (out->cif_peak && out->cif_peak_cap > 0 && r.peak_len > 0) {
+    PF_CHECK(out->cif_peak_cap >= (int64_t)r.cif_peak.size(), PF_ERR_CAPACITY, "cif_peak capacity < B*3T");
+    std::memcpy(out->cif_peak, r.cif_peak.data(), r.cif_peak.size() * 4);
+  }
+  if (out->token_ids) {
+    PF_CHECK(out->l_cap >= L, PF_ERR_CAPACITY, "token_ids capacity " + std::to_string(out->l_cap) + " < L = " + std::to_string(L));
+    for (int b = 0; b < B; ++b)
+      std::memcpy(out->token_ids + (size_t)b * out->l_cap, r.ids.data() + (size_t)b * L, (size_t)L * 8);
+  }
+  if (out->token_num && B > 0) std::memcpy(out->token_num, r.token_num.data(), (size_t)B * 4);
+  if (out->logits && out->logits_cap > 0) {
+    PF_CHECK(merged_logits_, PF_ERR_INVALID_ARG, "logits were not requested for the last pf_group_recognize");
+    const int64_t need = (int64_t)B * L * V;
+    PF_CHECK(out->logits_cap >= need, PF_ERR_CAPACITY, "logits capacity < B*L*V = " + std::to_string(need));
+    if (need > 0) std::memcpy(out->logits, r.logits.data(), (size_t)need * 4);
+  }
+}
+
+}  // namespace pf

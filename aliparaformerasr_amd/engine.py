@@ -26,6 +26,70 @@ class BatchResult:
         self.cif_peak = cif_peak        # [B, 3*Tmax] float32 us_cif_peak (timestamp models) or None
 
 
+def _build_config(weights, weights_path, weights_device_ptr, weights_bytes, cmvn, mvn_path, device, dither, snip_edges,
+                  lfr_m, lfr_n, n_mels, fs, window, use_itn, frame_length_ms, frame_shift_ms, dither_seed, math_mode):
+    """pf_engine_config + the Python objects whose memory it points into."""
+    cfg = N.PfEngineConfig()
+    cfg.struct_size = C.sizeof(N.PfEngineConfig)
+    cfg.device = device
+    keep = []
+    if weights_path is not None:
+        cfg.weights_path = weights_path.encode()
+    elif weights_device_ptr is not None:
+        cfg.weights_device = C.c_void_p(weights_device_ptr)
+        cfg.weights_bytes = weights_bytes
+    elif weights is not None:
+        buf = (C.c_char * len(weights)).from_buffer_copy(weights) if not isinstance(weights, np.ndarray) else None
+        if buf is None:
+            arr = np.ascontiguousarray(weights, dtype=np.uint8)
+            keep.append(arr)
+            cfg.weights_host = arr.ctypes.data_as(C.c_void_p)
+            cfg.weights_bytes = arr.nbytes
+        else:
+            keep.append(buf)
+            cfg.weights_host = C.cast(buf, C.c_void_p)
+            cfg.weights_bytes = len(weights)
+    if mvn_path is not None:
+        cfg.mvn_path = mvn_path.encode()
+    elif cmvn is not None:
+        sh, sc = _f32(cmvn[0]), _f32(cmvn[1])
+        keep += [sh, sc]
+        cfg.cmvn_shift, cfg.cmvn_scale, cfg.cmvn_dim = _fp(sh), _fp(sc), sh.shape[0]
+    cfg.fs, cfg.n_mels, cfg.lfr_m, cfg.lfr_n = fs, n_mels, lfr_m, lfr_n
+    cfg.snip_edges = 1 if snip_edges else 0
+    cfg.dither = dither
+    cfg.window = window.encode()
+    cfg.use_itn = 1 if use_itn else 0
+    cfg.frame_length_ms, cfg.frame_shift_ms = frame_length_ms, frame_shift_ms
+    cfg.dither_seed, cfg.math_mode = dither_seed, math_mode
+    return cfg, keep
+
+
+def _collect_result(lib, fetch_fn, call, B, want_logits):
+    """The learn-L-then-fetch protocol shared by pf_engine and pf_group handles."""
+    out = N.PfBatchOut()
+    out.struct_size = C.sizeof(N.PfBatchOut)
+    N.check(call(out))                       # first pass: learn L, V (no buffers)
+    L, V, P = out.L, out.V, out.cif_peak_len
+    peak = None
+    if P > 0:
+        peak = np.zeros((B, P), np.float32)
+        out.cif_peak = _fp(peak)
+        out.cif_peak_cap = peak.size
+    ids = np.zeros((B, max(L, 1)), np.int64)
+    tn = np.zeros(B, np.int32)
+    out.token_ids = ids.ctypes.data_as(C.POINTER(C.c_int64))
+    out.token_num = tn.ctypes.data_as(C.POINTER(C.c_int32))
+    out.l_cap = max(L, 1)
+    logits = None
+    if want_logits:
+        logits = np.zeros((B, L, V), np.float32)
+        out.logits = _fp(logits)
+        out.logits_cap = logits.size
+    N.check(fetch_fn(C.byref(out)))
+    return BatchResult(ids[:, :L].copy(), tn, L, V, logits, peak)
+
+
 class Engine:
     """Device engine = OfflineModel + WavFrontend replacement (see include/paraformer_hip.h)."""
 
@@ -34,39 +98,9 @@ class Engine:
                  n_mels=80, fs=16000, window="hamming", use_itn=False, frame_length_ms=0, frame_shift_ms=0,
                  dither_seed=0, math_mode=0):
         self._lib = N.load()
-        cfg = N.PfEngineConfig()
-        cfg.struct_size = C.sizeof(N.PfEngineConfig)
-        cfg.device = device
-        self._keep = []
-        if weights_path is not None:
-            cfg.weights_path = weights_path.encode()
-        elif weights_device_ptr is not None:
-            cfg.weights_device = C.c_void_p(weights_device_ptr)
-            cfg.weights_bytes = weights_bytes
-        elif weights is not None:
-            buf = (C.c_char * len(weights)).from_buffer_copy(weights) if not isinstance(weights, np.ndarray) else None
-            if buf is None:
-                arr = np.ascontiguousarray(weights, dtype=np.uint8)
-                self._keep.append(arr)
-                cfg.weights_host = arr.ctypes.data_as(C.c_void_p)
-                cfg.weights_bytes = arr.nbytes
-            else:
-                self._keep.append(buf)
-                cfg.weights_host = C.cast(buf, C.c_void_p)
-                cfg.weights_bytes = len(weights)
-        if mvn_path is not None:
-            cfg.mvn_path = mvn_path.encode()
-        elif cmvn is not None:
-            sh, sc = _f32(cmvn[0]), _f32(cmvn[1])
-            self._keep += [sh, sc]
-            cfg.cmvn_shift, cfg.cmvn_scale, cfg.cmvn_dim = _fp(sh), _fp(sc), sh.shape[0]
-        cfg.fs, cfg.n_mels, cfg.lfr_m, cfg.lfr_n = fs, n_mels, lfr_m, lfr_n
-        cfg.snip_edges = 1 if snip_edges else 0
-        cfg.dither = dither
-        cfg.window = window.encode()
-        cfg.use_itn = 1 if use_itn else 0
-        cfg.frame_length_ms, cfg.frame_shift_ms = frame_length_ms, frame_shift_ms
-        cfg.dither_seed, cfg.math_mode = dither_seed, math_mode
+        cfg, self._keep = _build_config(weights, weights_path, weights_device_ptr, weights_bytes, cmvn, mvn_path, device,
+                                        dither, snip_edges, lfr_m, lfr_n, n_mels, fs, window, use_itn, frame_length_ms,
+                                        frame_shift_ms, dither_seed, math_mode)
         h = C.c_void_p()
         N.check(self._lib.pf_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -110,27 +144,7 @@ class Engine:
 
     # ---- forward ------------------------------------------------------------
     def _collect(self, call, B, want_logits):
-        out = N.PfBatchOut()
-        out.struct_size = C.sizeof(N.PfBatchOut)
-        N.check(call(out))                       # first pass: learn L, V (no buffers)
-        L, V, P = out.L, out.V, out.cif_peak_len
-        peak = None
-        if P > 0:
-            peak = np.zeros((B, P), np.float32)
-            out.cif_peak = _fp(peak)
-            out.cif_peak_cap = peak.size
-        ids = np.zeros((B, max(L, 1)), np.int64)
-        tn = np.zeros(B, np.int32)
-        out.token_ids = ids.ctypes.data_as(C.POINTER(C.c_int64))
-        out.token_num = tn.ctypes.data_as(C.POINTER(C.c_int32))
-        out.l_cap = max(L, 1)
-        logits = None
-        if want_logits:
-            logits = np.zeros((B, L, V), np.float32)
-            out.logits = _fp(logits)
-            out.logits_cap = logits.size
-        N.check(self._lib.pf_fetch(self._h, C.byref(out)))
-        return BatchResult(ids[:, :L].copy(), tn, L, V, logits, peak)
+        return _collect_result(self._lib, lambda o: self._lib.pf_fetch(self._h, o), call, B, want_logits)
 
     @staticmethod
     def _hw(hotwords):
@@ -354,3 +368,48 @@ class Engine:
         H = np.zeros((B, T, 512), np.float32)
         N.check(self._lib.pf_op_encoder(self._h, _fp(sp), B, T, _fp(H)))
         return H
+
+
+class EngineGroup:
+    """pf_group: one engine per listed device inside this process, utterance shards, RCCL weight broadcast and
+    hypothesis gather (include/paraformer_hip.h section 4b).  `devices` may repeat a device."""
+
+    def __init__(self, devices, weights=None, weights_path=None, cmvn=None, mvn_path=None, dither=0.0, snip_edges=False,
+                 lfr_m=7, lfr_n=6, n_mels=80, fs=16000, window="hamming", use_itn=False, dither_seed=0, math_mode=0):
+        self._lib = N.load()
+        cfg, self._keep = _build_config(weights, weights_path, None, 0, cmvn, mvn_path, 0, dither, snip_edges, lfr_m,
+                                        lfr_n, n_mels, fs, window, use_itn, 0, 0, dither_seed, math_mode)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        N.check(self._lib.pf_group_create(C.byref(cfg), devs, len(devices), C.byref(h)))
+        self._h = h
+        n, r = C.c_int32(), C.c_int32()
+        N.check(self._lib.pf_group_info(self._h, n, r))
+        self.size, self.uses_rccl = n.value, bool(r.value)
+
+    def recognize(self, samples_list, want_logits=False, hotwords=None) -> BatchResult:
+        hp, hn, _keep = Engine._hw(hotwords)
+        arrs = [_f32(s) for s in samples_list]
+        B = len(arrs)
+        ptrs = (C.POINTER(C.c_float) * max(B, 1))(*[_fp(a) for a in arrs])
+        ns = (C.c_int64 * max(B, 1))(*[a.shape[0] for a in arrs])
+        dummy = np.zeros(1, np.float32)
+
+        def call(out):
+            if want_logits:
+                out.logits = _fp(dummy)
+                out.logits_cap = 1
+            rc = self._lib.pf_group_recognize(self._h, ptrs, ns, B, hp, hn, C.byref(out))
+            return 0 if (want_logits and rc == N.PF_ERR_CAPACITY) else rc
+        return _collect_result(self._lib, lambda o: self._lib.pf_group_fetch(self._h, o), call, B, want_logits)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

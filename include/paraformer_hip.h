@@ -179,6 +179,29 @@ int pf_sync(pf_engine* e);            /* waits for the engine stream            
    staged API is engine state: one caller at a time). */
 int pf_fetch(pf_engine* e, pf_batch_out* out);
 
+/* ------------------------------------------------------------------------ */
+/* 4b. Multi-GPU inside one process: one engine, one host thread and one HIP stream per listed
+ *     device.  The reference builds a single ORT session (OfflineRecognizer.cs:23); what shards is the utterance
+ *     list handed to GetResults (OfflineRecognizer.cs:110-116) — utterances are independent (the batch is dim 0 of
+ *     every tensor, OfflineProjOfParaformer.cs:49).  RCCL (dlopen'ed librccl) carries the one-off weight broadcast
+ *     devices[0] -> all and the per-call all-gather of the fixed-shape hypotheses; there is no data-path collective.
+ *     Every shard is padded to the batch-wide maximum length (PadHelper.cs:25) and decodes the batch-wide maximum
+ *     token count, so ids / token_num / cif_peak equal the single-device result position by position.
+ *     A device may be listed more than once (several engines on one GPU; no communicator is created then).     */
+/* ------------------------------------------------------------------------ */
+typedef struct pf_group pf_group;
+int pf_group_create(const pf_engine_config* cfg /* .device ignored */, const int32_t* devices, int32_t n_devices,
+                    pf_group** out);
+void pf_group_destroy(pf_group* g);               /* idempotent, like pf_engine_destroy                       */
+int pf_group_info(pf_group* g, int32_t* n_engines, int32_t* uses_rccl);
+/* Engine i of the group (borrowed: valid until pf_group_destroy), e.g. for pf_engine_info / profiling.      */
+pf_engine* pf_group_engine(pf_group* g, int32_t i);
+/* pf_recognize over the whole group: contiguous shards of ceil(B / n_engines) utterances run concurrently, the
+   result comes back in the caller's order.  Same two-call protocol as pf_recognize + pf_group_fetch.          */
+int pf_group_recognize(pf_group* g, const float* const* samples, const int64_t* n_samples, int32_t B,
+                       const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out);
+int pf_group_fetch(pf_group* g, pf_batch_out* out);
+
 /* Per-kernel-class device time, measured with HIP events on the engine stream while
    profiling is enabled (bench.py roofline leg).  class_name e.g. "gemm_ffn1". */
 int pf_profile_enable(pf_engine* e, int32_t on);
