@@ -47,6 +47,15 @@ class PfGemmDesc(C.Structure):
     ]
 
 
+class PfGemmRcDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("M", C.c_int32), ("K", C.c_int32), ("a_blocked", C.c_int32), ("T", C.c_int32),
+        ("fsmn_k", C.c_int32),
+        ("bias", C.POINTER(C.c_float)), ("resid", C.POINTER(C.c_float)), ("fsmn_v", C.POINTER(C.c_float)),
+        ("fsmn_w", C.POINTER(C.c_float)), ("ln_gamma", C.POINTER(C.c_float)), ("ln_beta", C.POINTER(C.c_float)),
+    ]
+
+
 class PfBatchOut(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32), ("l_cap", C.c_int32), ("logits_cap", C.c_int64), ("cif_peak_cap", C.c_int64),
@@ -99,6 +108,7 @@ SIGNATURES = {
     "pf_op_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _i64]),
     "pf_op_gemm": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_gemm_ex": (C.c_int, [_vp, _P(PfGemmDesc), _f, _f, _f]),
+    "pf_op_gemm_rc": (C.c_int, [_vp, _P(PfGemmRcDesc), _f, _f, _f, _f, _f]),
     "pf_op_ffn": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn_enc": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn_dec": (C.c_int, [_vp, _f, _f, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),

@@ -398,6 +398,19 @@ int pf_op_gemm_ex(pf_engine* h, const pf_gemm_desc* d, const float* A, const flo
   return PF_OK;
   PF_CATCH
 }
+int pf_op_gemm_rc(pf_engine* h, const pf_gemm_rc_desc* d, const float* A, const float* W, float* x_out, float* n16_out,
+                  float* n32_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(d); NEED(A); NEED(W);
+  PF_CHECK(d->struct_size == (int32_t)sizeof(pf_gemm_rc_desc), PF_ERR_INVALID_ARG, "pf_gemm_rc_desc.struct_size mismatch");
+  PF_CHECK(x_out || n16_out || n32_out, PF_ERR_INVALID_ARG, "gemm_rc: no output requested");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_gemm_rc(*d, A, W, x_out, n16_out, n32_out);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_ffn(pf_engine* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
               const float* resid, int32_t M, int32_t D, int32_t F, float* y) {
   PF_TRY

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 
@@ -46,6 +47,7 @@ Engine::Engine(const pf_engine_config& cfg) {
            PF_ERR_UNSUPPORTED, "only frame_length = 25 ms and frame_shift = 10 ms are supported");
   PF_CHECK(cfg.math_mode == 0 || cfg.math_mode == 1, PF_ERR_INVALID_ARG, "math_mode must be 0 (f16 MFMA) or 1 (fp32 MFMA)");
   fp32_mode_ = cfg.math_mode == 1;
+  { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
@@ -708,7 +710,12 @@ void Engine::build_pe(int T) {
   pe_T_ = Tn;
 }
 
-void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T) {
+// One SAN-M encoder layer = 5 launches: [LayerNorm fused into the previous launch] QKV GEMM -> attention ->
+// row-complete out-projection (+ bias + residual + FSMN memory from the V slice + LayerNorm norm2 -> xn16) ->
+// FFN-up (blocked hidden) -> row-complete FFN-down (+ bias + residual + the NEXT LayerNorm `nx` -> its outputs).
+// Entry: xn16_ holds LayerNorm norm1 of the residual stream (written by the previous layer's FFN-down, by the
+// position-encoding kernel for layer 0, or by the stand-alone LayerNorm for the first tp layer).
+void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T, const EncNext& nx) {
   const int D = mc_.d_model, M = B * T, F = mc_.ffn;
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
   const int lda = first ? L.qkv.Kpad : D;
@@ -717,15 +724,8 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
     launch_posenc_ln_tab(stream_, speech_dev, B, T, mc_.feat_dim, std::sqrt((float)D), (const float*)ws_pe_.p,
                          L.norm1.g, L.norm1.b, xn16_, lda);
     prof_end("layernorm");
-  } else {
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, x_, M, D, L.norm1.g, L.norm1.b, xn16_, D, nullptr, 0);
-    prof_end("layernorm");
   }
   gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
-  prof_begin("fsmn", 0);
-  launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
-  prof_end("fsmn");
   AttnArgs a{};
   a.q = qkv16_; a.k = qkv16_ + D; a.v = qkv16_ + 2 * D; a.o = ctx16_;
   a.q_bstride = a.k_bstride = a.v_bstride = (int64_t)T * 3 * D;
@@ -735,15 +735,40 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
   prof_begin("attn_self", 4.0 * B * (double)T * T * D);
   launch_attention(stream_, a);
   prof_end("attn_self");
+  const bool rc = mc_.kernel == 11 && T >= 8 && F % 64 == 0 && !no_rc_;
+  if (rc) {
+    GemmRcArgs g{};
+    g.A = ctx16_; g.lda = D; g.W = L.out.w; g.ldw = L.out.Kpad; g.bias = L.out.bias; g.M = M; g.K = L.out.Kpad;
+    g.resid = first ? nullptr : x_; g.ldr = D; g.out_x = x_; g.ldx = D;
+    g.fsmn_v = qkv16_ + 2 * D; g.ldv = 3 * D; g.fsmn_wT = L.fsmn_wT; g.fsmn_k = mc_.kernel; g.T = T;
+    g.ln_g = L.norm2.g; g.ln_b = L.norm2.b; g.eps = 1e-12f; g.out_n16 = xn16_; g.ldn16 = D;
+    prof_begin("gemm_out", 2.0 * M * (double)D * D);
+    launch_gemm_rc(stream_, g);
+    prof_end("gemm_out");
+    gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, 1);
+    GemmRcArgs f{};
+    f.A = h16_; f.lda = F; f.a_blocked = 1; f.W = L.w2.w; f.ldw = L.w2.Kpad; f.bias = L.w2.bias; f.M = M; f.K = L.w2.Kpad;
+    f.resid = x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
+    f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
+    prof_begin("gemm_ffn2", 2.0 * M * (double)D * F);
+    launch_gemm_rc(stream_, f);
+    prof_end("gemm_ffn2");
+    return;
+  }
+  // fallback (FSMN kernel size other than 11, utterances shorter than 8 frames, PF_NO_RC=1): the unfused sequence
+  prof_begin("fsmn", 0);
+  launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
+  prof_end("fsmn");
   gemm("gemm_out", L.out, ctx16_, D, M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
   prof_begin("layernorm", 0);
   launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
   prof_end("layernorm");
-  // the FFN hidden lives in the blocked activation layout (kernels.h): FFN-up stores its fragments as whole
-  // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
   const int blk = (F % 64 == 0) ? 1 : 0;
   gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
   gemm("gemm_ffn2", L.w2, h16_, F, M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, true, blk ? 2 : 0);
+  prof_begin("layernorm", 0);
+  launch_layernorm(stream_, x_, M, D, nx.ln.g, nx.ln.b, nx.n16, D, nx.n32, D);
+  prof_end("layernorm");
 }
 
 void Engine::encoder(const float* speech_dev, int B, int T) {
@@ -770,21 +795,25 @@ void Engine::encoder(const float* speech_dev, int B, int T) {
   plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
   plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
 
-  for (size_t i = 0; i < enc_.size(); ++i) enc_layer(enc_[i], i == 0, speech_dev, B, T);
+  // the LayerNorm that FOLLOWS layer i's FFN-down is the next layer's norm1, or after_norm behind the last one
   const bool has_tp = !tp_.empty();
-  prof_begin("layernorm", 0);
-  if (has_tp) {
-    // after_norm output continues as the residual stream of the tp blocks
-    launch_layernorm(stream_, x_, M, D, enc_after_.g, enc_after_.b, nullptr, 0, x_, D);
-  } else {
-    launch_layernorm(stream_, x_, M, D, enc_after_.g, enc_after_.b, H16_, D, H32_, D);
+  for (size_t i = 0; i < enc_.size(); ++i) {
+    EncNext nx;
+    if (i + 1 < enc_.size()) { nx.ln = enc_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; }
+    else if (has_tp) { nx.ln = enc_after_; nx.n32 = x_; nx.keep_x = false; }     // after_norm output = the tp residual stream
+    else { nx.ln = enc_after_; nx.n16 = H16_; nx.n32 = H32_; nx.keep_x = false; }
+    enc_layer(enc_[i], i == 0, speech_dev, B, T, nx);
   }
-  prof_end("layernorm");
   if (has_tp) {
-    for (size_t i = 0; i < tp_.size(); ++i) enc_layer(tp_[i], false, nullptr, B, T);
     prof_begin("layernorm", 0);
-    launch_layernorm(stream_, x_, M, D, tp_norm_.g, tp_norm_.b, H16_, D, H32_, D);
+    launch_layernorm(stream_, x_, M, D, tp_[0].norm1.g, tp_[0].norm1.b, xn16_, D, nullptr, 0);
     prof_end("layernorm");
+    for (size_t i = 0; i < tp_.size(); ++i) {
+      EncNext nx;
+      if (i + 1 < tp_.size()) { nx.ln = tp_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; }
+      else { nx.ln = tp_norm_; nx.n16 = H16_; nx.n32 = H32_; nx.keep_x = false; }
+      enc_layer(tp_[i], false, nullptr, B, T, nx);
+    }
   }
 }
 
@@ -1400,6 +1429,80 @@ void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, 
         C[(size_t)m * N + n] = (float)tmp[idx];
       }
   }
+}
+
+void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* W, float* x_out, float* n16_out,
+                        float* n32_out) {
+  PF_HIP(hipSetDevice(device_));
+  const int M = ds.M, K = ds.K, N = 512;
+  PF_CHECK(M > 0 && K > 0 && K % 64 == 0, PF_ERR_INVALID_ARG, "gemm_rc: K must be a positive multiple of 64");
+  PF_CHECK(!ds.fsmn_v || (ds.fsmn_w && ds.fsmn_k > 0), PF_ERR_INVALID_ARG, "gemm_rc: FSMN needs weights");
+  PF_CHECK((ds.ln_gamma != nullptr) == (ds.ln_beta != nullptr), PF_ERR_INVALID_ARG, "gemm_rc: gamma and beta go together");
+  const int64_t Mp = round_up(M, 256) + 128;
+  const int k = ds.fsmn_k;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * std::max(K, N), (int64_t)N * K) * 4);
+  const size_t oA16 = carve((size_t)Mp * K * 2), oW16 = carve((size_t)N * K * 2), ob = carve((size_t)N * 4);
+  const size_t oR = carve((size_t)Mp * N * 4), oV = carve((size_t)(Mp + 128) * 3 * N * 2), owT = carve((size_t)std::max(k, 1) * N * 4);
+  const size_t og = carve((size_t)N * 4), obe = carve((size_t)N * 4), oX = carve((size_t)Mp * N * 4), oN16 = carve((size_t)Mp * N * 2);
+  const size_t oN32 = carve((size_t)Mp * N * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + oA16, 0, (size_t)Mp * K * 2, stream_));
+  std::vector<half_t> ablk;
+  if (ds.a_blocked) {
+    ablk.assign((size_t)Mp * K, (half_t)0.f);
+    for (int m = 0; m < M; ++m)
+      for (int kk = 0; kk < K; ++kk)
+        ablk[(((size_t)(m >> 5) * (K >> 3) + (kk >> 3)) * 32 + (m & 31)) * 8 + (kk & 7)] = (half_t)A[(size_t)m * K + kk];
+    PF_HIP(hipMemcpyAsync(base + oA16, ablk.data(), ablk.size() * 2, hipMemcpyHostToDevice, stream_));
+  } else {
+    PF_HIP(hipMemcpyAsync(base + o32, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + o32), M, K, K, (half_t*)(base + oA16), K);
+    PF_HIP(hipStreamSynchronize(stream_));
+  }
+  PF_HIP(hipMemcpyAsync(base + o32, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
+  launch_f32_to_f16(stream_, (const float*)(base + o32), N, K, K, (half_t*)(base + oW16), K);
+  PF_HIP(hipStreamSynchronize(stream_));
+  GemmRcArgs g{};
+  g.A = (half_t*)(base + oA16); g.lda = K; g.a_blocked = ds.a_blocked ? 1 : 0;
+  g.W = (half_t*)(base + oW16); g.ldw = K; g.M = M; g.K = K;
+  if (ds.bias) { PF_HIP(hipMemcpyAsync(base + ob, ds.bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_)); g.bias = (const float*)(base + ob); }
+  if (ds.resid) { PF_HIP(hipMemcpyAsync(base + oR, ds.resid, (size_t)M * N * 4, hipMemcpyHostToDevice, stream_)); g.resid = (const float*)(base + oR); g.ldr = N; }
+  std::vector<float> wT;
+  if (ds.fsmn_v) {
+    // the V slice of a [M, 3*512] QKV buffer, as in the pipeline (row stride 1536 halves)
+    PF_HIP(hipMemsetAsync(base + oV, 0, (size_t)(Mp + 128) * 3 * N * 2, stream_));
+    PF_HIP(hipMemcpyAsync(base + o32, ds.fsmn_v, (size_t)M * N * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + o32), M, N, N, (half_t*)(base + oV) + 2 * N, 3 * N);
+    wT.resize((size_t)k * N);
+    for (int c = 0; c < N; ++c)
+      for (int j = 0; j < k; ++j) wT[(size_t)j * N + c] = ds.fsmn_w[(size_t)c * k + j];
+    PF_HIP(hipMemcpyAsync(base + owT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
+    g.fsmn_v = (half_t*)(base + oV) + 2 * N; g.ldv = 3 * N; g.fsmn_wT = (const float*)(base + owT); g.fsmn_k = k;
+  }
+  g.T = ds.T > 0 ? ds.T : M;
+  if (ds.ln_gamma) {
+    PF_HIP(hipMemcpyAsync(base + og, ds.ln_gamma, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+    PF_HIP(hipMemcpyAsync(base + obe, ds.ln_beta, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+    g.ln_g = (const float*)(base + og); g.ln_b = (const float*)(base + obe); g.eps = 1e-12f;
+    if (n16_out) { g.out_n16 = (half_t*)(base + oN16); g.ldn16 = N; }
+    if (n32_out) { g.out_n32 = (float*)(base + oN32); g.ldn32 = N; }
+  }
+  if (x_out) { g.out_x = (float*)(base + oX); g.ldx = N; }
+  prof_begin("gemm_op", 2.0 * M * (double)N * K);
+  launch_gemm_rc(stream_, g);
+  prof_end("gemm_op");
+  if (x_out) PF_HIP(hipMemcpyAsync(x_out, base + oX, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
+  if (g.out_n32) PF_HIP(hipMemcpyAsync(n32_out, base + oN32, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
+  std::vector<half_t> tmp;
+  if (g.out_n16) {
+    tmp.resize((size_t)M * N);
+    PF_HIP(hipMemcpyAsync(tmp.data(), base + oN16, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
+  }
+  PF_HIP(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < tmp.size(); ++i) n16_out[i] = (float)tmp[i];
 }
 
 // Encoder FFN as enc_layer() runs it: FFN-up writes the hidden in the blocked activation layout (kind 3),

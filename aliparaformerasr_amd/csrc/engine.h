@@ -104,6 +104,7 @@ class Engine {
   void op_argmax(const float* x, int64_t rows, int V, int64_t* ids);
   void op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C);
   void op_gemm_ex(const pf_gemm_desc& d, const float* A, const float* W, float* C);
+  void op_gemm_rc(const pf_gemm_rc_desc& d, const float* A, const float* W, float* x_out, float* n16_out, float* n32_out);
   void op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
               int M, int D, int F, float* y);
   void op_fsmn_enc(const float* v, const float* w, int B, int T, int D, int k, float* y);
@@ -144,7 +145,9 @@ class Engine {
   void ensure(DevBuf& b, size_t bytes);
   void build_pe(int T);
   void encoder(const float* speech_dev, int B, int T);
-  void enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T);
+  // the LayerNorm applied to the residual stream right after a layer's FFN-down, and where its results go
+  struct EncNext { LNp ln; half_t* n16 = nullptr; float* n32 = nullptr; bool keep_x = true; };
+  void enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T, const EncNext& nx);
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
   void timestamp_head(int B, int T);
@@ -161,6 +164,7 @@ class Engine {
   uint32_t next_dither_seed() { return fc_.dither_seed * 2654435761u + (dither_calls_++) * 40503u; }
   int device_ = 0;
   hipStream_t stream_ = nullptr;
+  bool no_rc_ = false;
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   ModelCfg mc_;
   FrontendCfg fc_;

@@ -32,6 +32,23 @@ struct GemmArgs {
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 
+// Row-complete GEMM for N = 512 (k_gemm_rc.hip): x = resid + A W^T + bias + FSMN(V); n = LayerNorm(x).
+// One workgroup = 64 complete rows, so the residual add, the FSMN memory and the following LayerNorm are its epilogue.
+struct GemmRcArgs {
+  const half_t* A; int lda; int a_blocked;       // [M,K] f16 (row-major, or the blocked activation layout)
+  const half_t* W; int ldw;                      // [512, K] f16, K-contiguous
+  const float* bias;                             // [512] or null
+  int M, K;
+  const float* resid; int ldr;                   // fp32 [M,512] or null; may alias out_x
+  float* out_x; int ldx;                         // fp32 [M,512] result x, or null when only LayerNorm(x) is kept
+  const half_t* fsmn_v; int ldv;                 // f16 V slice [M, ldv] (null = no FSMN term)
+  const float* fsmn_wT; int fsmn_k; int T;       // taps [k][512]; utterances are runs of T rows
+  const float* ln_g; const float* ln_b; float eps;   // LayerNorm over the 512 columns (null = none)
+  half_t* out_n16; int ldn16;                    // f16 LayerNorm result (next GEMM's operand) or null
+  float* out_n32; int ldn32;                     // fp32 LayerNorm result or null
+};
+void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a);
+
 // ------------------------------------------------------------- frontend -----
 struct FbankTables;   // device tables (window, twiddles, mel weights)
 FbankTables* fbank_tables_create(int n_mels, int fs, const char* window);

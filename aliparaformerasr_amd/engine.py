@@ -294,6 +294,27 @@ class Engine:
         N.check(self._lib.pf_op_gemm_ex(self._h, C.byref(d), _fp(A), _fp(W), _fp(out)))
         return out
 
+    def op_gemm_rc(self, A, W, bias=None, resid=None, fsmn_v=None, fsmn_w=None, T=0, ln=None, a_blocked=False):
+        """Row-complete GEMM (N = 512) + fused epilogue; returns (x, n16, n32) (n* = None without `ln`)."""
+        A, W = _f32(A), _f32(W)
+        M, K = A.shape
+        d = N.PfGemmRcDesc()
+        d.struct_size = C.sizeof(N.PfGemmRcDesc)
+        d.M, d.K, d.a_blocked, d.T = M, K, int(a_blocked), T
+        keep = [_f32(t) if t is not None else None for t in (bias, resid, fsmn_v, fsmn_w)]
+        d.bias, d.resid, d.fsmn_v, d.fsmn_w = [_fp(t) if t is not None else None for t in keep]
+        d.fsmn_k = keep[3].shape[1] if keep[3] is not None else 0
+        g = b = None
+        if ln is not None:
+            g, b = _f32(ln[0]), _f32(ln[1])
+            d.ln_gamma, d.ln_beta = _fp(g), _fp(b)
+        x = np.zeros((M, 512), np.float32)
+        n16 = np.zeros((M, 512), np.float32) if ln is not None else None
+        n32 = np.zeros((M, 512), np.float32) if ln is not None else None
+        N.check(self._lib.pf_op_gemm_rc(self._h, C.byref(d), _fp(A), _fp(W), _fp(x),
+                                        _fp(n16) if n16 is not None else None, _fp(n32) if n32 is not None else None))
+        return x, n16, n32
+
     def op_ffn(self, x, w1, b1, w2, b2, resid) -> np.ndarray:
         x, w1, b1, w2, b2, resid = map(_f32, (x, w1, b1, w2, b2, resid))
         M, D = x.shape

@@ -216,7 +216,7 @@ int pf_last_flops(pf_engine* e, double* flops);
 
 /* ------------------------------------------------------------------------ */
 /* 5. Stand-alone device ops exposed for parity tests (tests/ call these through
- *    the C ABI).  pf_op_gemm_ex / pf_op_ffn / pf_op_fsmn_enc / pf_op_fsmn_dec /
+ *    the C ABI).  pf_op_gemm_ex / pf_op_gemm_rc / pf_op_ffn / pf_op_fsmn_enc / pf_op_fsmn_dec /
  *    pf_op_logsoftmax_argmax / pf_op_attention / pf_op_layernorm / pf_op_cif /
  *    pf_op_lfr_cmvn_pad launch exactly the kernels (and kernel variants) the
  *    pipeline launches; pf_op_gemm chooses its variant by shape like the
@@ -249,6 +249,25 @@ typedef struct pf_gemm_desc {
 } pf_gemm_desc;
 /* C [M,N] fp32 (f16 results widened, blocked results de-blocked on the host). */
 int pf_op_gemm_ex(pf_engine* e, const pf_gemm_desc* d, const float* A, const float* W, float* C);
+/* Row-complete GEMM (N = 512) with its fused epilogue, as the encoder launches it for the attention output
+   projection and the FFN down-projection: x = resid + A W^T + bias + FSMN_k(v) ; n = LayerNorm(x). */
+typedef struct pf_gemm_rc_desc {
+  int32_t struct_size;
+  int32_t M, K;
+  int32_t a_blocked;          /* A handed over in the blocked activation layout                                */
+  int32_t T;                  /* utterance length in rows (FSMN zero padding at utterance edges); 0 = M        */
+  int32_t fsmn_k;             /* taps of fsmn_w (11), 0 = no FSMN term                                          */
+  const float* bias;          /* [512] or NULL                                                                 */
+  const float* resid;         /* [M,512] or NULL                                                               */
+  const float* fsmn_v;        /* [M,512] (rounded to f16 on the device, as the V slice is) or NULL             */
+  const float* fsmn_w;        /* [512, fsmn_k]                                                                 */
+  const float* ln_gamma;      /* [512] or NULL (no LayerNorm outputs)                                          */
+  const float* ln_beta;
+} pf_gemm_rc_desc;
+/* x_out [M,512] fp32 (may be NULL), n16_out [M,512] (the f16 LayerNorm result widened to fp32, may be NULL),
+   n32_out [M,512] fp32 LayerNorm result (may be NULL). */
+int pf_op_gemm_rc(pf_engine* e, const pf_gemm_rc_desc* d, const float* A, const float* W, float* x_out,
+                  float* n16_out, float* n32_out);
 /* Encoder FFN with the blocked hand-off of the hidden: y = resid + W2 relu(W1 x + b1) + b2;
    x [M,D], w1 [F,D], w2 [D,F], resid / y [M,D]. */
 int pf_op_ffn(pf_engine* e, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,

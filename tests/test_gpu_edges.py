@@ -246,9 +246,11 @@ def test_malformed_containers_round2():
     hlen = struct.unpack("<Q", good[8:16])[0]
     hdr = json.loads(good[16:16 + hlen])
     def rebuild(h):
-        hb = json.dumps(h).encode()
-        assert len(hb) <= hlen
-        return good[:16] + hb + b" " * (hlen - len(hb)) + good[16 + hlen:]
+        hb = json.dumps(h, separators=(",", ":")).encode()
+        old_off = (16 + hlen + 255) // 256 * 256
+        new_off = (16 + len(hb) + 255) // 256 * 256
+        return good[:8] + struct.pack("<Q", len(hb)) + hb + b"\0" * (new_off - 16 - len(hb)) + good[old_off:]
+    Engine(weights=np.frombuffer(rebuild(hdr), np.uint8), cmvn=cmvn, device=0).close()   # the surgery itself is sound
     h2 = json.loads(json.dumps(hdr)); h2["tensors"][0]["shape"][0] = -h2["tensors"][0]["shape"][0]
     fails(rebuild(h2))
     fails(good[:8] + struct.pack("<Q", (1 << 64) - 8) + good[16:])           # 16 + hlen wraps to 8

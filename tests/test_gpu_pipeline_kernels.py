@@ -236,3 +236,81 @@ def test_logsoftmax_argmax_nan_and_inf(eng):
     assert ids[0] == V - 1 and ids[1] == V - 1 and ids[2] == V - 1
     assert np.isnan(y[0]).all() and np.isneginf(y[3, 100])
     np.testing.assert_array_equal(eng.op_logsoftmax_argmax(x, store=False), ids)
+
+
+# ---------------------------------------------------------------- row-complete GEMM (k_gemm_rc.hip)
+def _ln_ref(x, g, b):
+    return om.layer_norm(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b)).numpy()
+
+
+def _fsmn_ref(v, w, T):
+    M = v.shape[0]
+    out = np.zeros_like(v)
+    for lo in range(0, M, T):                       # utterances are runs of T rows (the last one may be short)
+        seg = h16(v[lo:lo + T])[None]
+        out[lo:lo + T] = om.fsmn(torch.from_numpy(seg), torch.from_numpy(w), w.shape[1]).numpy()[0]
+    return out
+
+
+def test_gemm_rc_out_projection_with_fsmn_and_layernorm(eng):
+    """Attention output projection as enc_layer() launches it: [16000 x 512] x [512 x 512] + bias + fp32 residual +
+    FSMN(11 taps over the f16 V slice, zero padding at the 32 utterance edges) and the LayerNorm that follows."""
+    rng = np.random.default_rng(500)
+    M, K, T = M_BENCH, 512, 500
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
+    Wm += (np.arange(512)[:, None] * 1e-4).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    resid = (rng.standard_normal((M, 512)) * 3).astype(np.float32)
+    v = rng.standard_normal((M, 512)).astype(np.float32)
+    fw = (0.1 * rng.standard_normal((512, 11))).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    x_ref = _ref(A, Wm, bias) + resid + _fsmn_ref(v, fw, T)
+    x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, fsmn_v=v, fsmn_w=fw, T=T, ln=(g, b))
+    np.testing.assert_allclose(x, x_ref, rtol=1e-4, atol=5e-4)
+    n_ref = _ln_ref(x, g, b)                        # LayerNorm of the x the device produced: isolates the LN stage
+    np.testing.assert_allclose(n32, n_ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(n16, n_ref, rtol=1.5e-3, atol=1.5e-3)
+    np.testing.assert_array_equal(n16, h16(n32))    # the f16 output is the rounded fp32 output
+    # first layer: no residual
+    x0, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, fsmn_v=v, fsmn_w=fw, T=T)
+    np.testing.assert_allclose(x0, x_ref - resid, rtol=1e-4, atol=5e-4)
+
+
+def test_gemm_rc_ffn_down_blocked_a(eng):
+    """FFN down-projection: blocked A [16000 x 2048] x [2048 x 512] + bias + residual, then the NEXT LayerNorm."""
+    rng = np.random.default_rng(501)
+    M, K = M_BENCH, 2048
+    A = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    A += (np.arange(K)[None, :] * 1e-4).astype(np.float32)
+    Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    resid = rng.standard_normal((M, 512)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True)
+    np.testing.assert_allclose(x, _ref(A, Wm, bias) + resid, rtol=1e-4, atol=6e-4)
+    np.testing.assert_allclose(n32, _ln_ref(x, g, b), rtol=2e-5, atol=2e-5)
+    x2, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, a_blocked=False)
+    np.testing.assert_array_equal(x2, x)            # the operand layout does not change the arithmetic
+
+
+def test_gemm_rc_ragged_shapes_and_utterance_edges(eng):
+    """M not a multiple of 64 / of T, utterances shorter than a tile, T = 8 (every wave straddles an utterance edge),
+    one k-step only, and rows whose LayerNorm is ill-conditioned in fp32 (large common offset)."""
+    rng = np.random.default_rng(502)
+    for (M, K, T) in ((83, 512, 83), (166, 64, 83), (1000, 576, 40), (333, 2048, 8), (64, 512, 9), (5000, 512, 5000)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(512).astype(np.float32)
+        resid = rng.standard_normal((M, 512)).astype(np.float32)
+        resid[M // 2] += 300.0                          # mean >> spread on one row
+        v = rng.standard_normal((M, 512)).astype(np.float32)
+        fw = (0.1 * rng.standard_normal((512, 11))).astype(np.float32)
+        g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+        x_ref = _ref(A, Wm, bias) + resid + _fsmn_ref(v, fw, T)
+        x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, fsmn_v=v, fsmn_w=fw, T=T, ln=(g, b))
+        np.testing.assert_allclose(x, x_ref, rtol=1e-4, atol=6e-4)
+        np.testing.assert_allclose(n32, _ln_ref(x, g, b), rtol=3e-5, atol=3e-5)
