@@ -47,7 +47,8 @@ Engine::Engine(const pf_engine_config& cfg) {
            PF_ERR_UNSUPPORTED, "only frame_length = 25 ms and frame_shift = 10 ms are supported");
   PF_CHECK(cfg.math_mode == 0 || cfg.math_mode == 1, PF_ERR_INVALID_ARG, "math_mode must be 0 (f16 MFMA) or 1 (fp32 MFMA)");
   fp32_mode_ = cfg.math_mode == 1;
-  { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
+  { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
+  { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
@@ -735,7 +736,7 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
   prof_begin("attn_self", 4.0 * B * (double)T * T * D);
   launch_attention(stream_, a);
   prof_end("attn_self");
-  const bool rc = mc_.kernel == 11 && T >= 8 && F % 64 == 0 && !no_rc_;
+  const bool rc = mc_.kernel == 11 && T >= 8 && !no_rc_;
   if (rc) {
     GemmRcArgs g{};
     g.A = ctx16_; g.lda = D; g.W = L.out.w; g.ldw = L.out.Kpad; g.bias = L.out.bias; g.M = M; g.K = L.out.Kpad;
@@ -745,7 +746,24 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
     prof_begin("gemm_out", 2.0 * M * (double)D * D);
     launch_gemm_rc(stream_, g);
     prof_end("gemm_out");
-    gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, 1);
+  } else {
+    // fallback (FSMN kernel size other than 11, utterances shorter than 8 frames, PF_NO_RC=1): the unfused sequence
+    prof_begin("fsmn", 0);
+    launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
+    prof_end("fsmn");
+    gemm("gemm_out", L.out, ctx16_, D, M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
+    prof_end("layernorm");
+  }
+  // the FFN hidden lives in the blocked activation layout (kernels.h): FFN-up stores its fragments as whole
+  // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
+  const int blk = (F % 64 == 0) ? 1 : 0;
+  gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
+  if (rc && rc_ffn2_ && blk) {
+    // row-complete FFN-down (+ the next LayerNorm): measured SLOWER than the persistent 256 x 128 kernel + a
+    // LayerNorm launch at K = 2048 (67.7 vs 57.5 us per layer at M = 16 000: every workgroup streams the 2 MB W
+    // panel) — kept behind PF_RC_FFN2=1 for experiments
     GemmRcArgs f{};
     f.A = h16_; f.lda = F; f.a_blocked = 1; f.W = L.w2.w; f.ldw = L.w2.Kpad; f.bias = L.w2.bias; f.M = M; f.K = L.w2.Kpad;
     f.resid = x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
@@ -755,16 +773,6 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
     prof_end("gemm_ffn2");
     return;
   }
-  // fallback (FSMN kernel size other than 11, utterances shorter than 8 frames, PF_NO_RC=1): the unfused sequence
-  prof_begin("fsmn", 0);
-  launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
-  prof_end("fsmn");
-  gemm("gemm_out", L.out, ctx16_, D, M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
-  prof_begin("layernorm", 0);
-  launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
-  prof_end("layernorm");
-  const int blk = (F % 64 == 0) ? 1 : 0;
-  gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
   gemm("gemm_ffn2", L.w2, h16_, F, M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, true, blk ? 2 : 0);
   prof_begin("layernorm", 0);
   launch_layernorm(stream_, x_, M, D, nx.ln.g, nx.ln.b, nx.n16, D, nx.n32, D);

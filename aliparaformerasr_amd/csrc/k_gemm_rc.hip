@@ -61,33 +61,38 @@ __device__ __forceinline__ void rc_wait_vmcnt() {
 }
 __device__ __forceinline__ void rc_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }   // vmcnt 63, expcnt 7, lgkmcnt 0
 
+// wave-wide sum, broadcast to every lane: four DPP steps give every lane its 16-lane row total (VALU only, no LDS
+// crossbar as ds_bpermute-based shuffles use), the four row totals are read through SGPRs
 __device__ __forceinline__ float rc_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
 }
 
 // FSMN accumulation for 8 consecutive output rows x 4 columns of one lane.  MASKED: rows near an utterance edge
 // (or the end of the buffer) — taps reaching outside the utterance contribute nothing (zero padding of the
 // depthwise conv); the condition is wave-uniform, so the masks are scalar selects.
 template <int FK, bool MASKED>
-__device__ __forceinline__ void rc_fsmn(float4 (&x)[8], const half_t* __restrict__ vcol, int ldv,
-                                        const float* __restrict__ wT, int mb, int t_first, int T, int M) {
+__device__ __forceinline__ void rc_fsmn(float4 (&x)[8], const h4 (&win)[FK > 0 ? 8 + FK - 1 : 1], const float* __restrict__ wT,
+                                        int mb, int t_first, int T, int M) {
   constexpr int left = (FK - 1) / 2;
   float4 w[FK];
 #pragma unroll
   for (int j = 0; j < FK; ++j) w[j] = *reinterpret_cast<const float4*>(wT + (size_t)j * RC_BN);
 #pragma unroll
   for (int s = 0; s < 8 + FK - 1; ++s) {
-    int mm = mb - left + s;                                // input row
-    bool inb = true;
-    if (MASKED) {
-      inb = mm >= 0 && mm < M;
-      mm = inb ? mm : (mm < 0 ? 0 : M - 1);
-    }
-    const h4 hv = *reinterpret_cast<const h4*>(vcol + (size_t)mm * ldv);
+    const h4 hv = win[s];
     float4 xf = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
-    if (MASKED && !inb) xf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MASKED) {
+      const int mm = mb - left + s;                        // input row: outside the buffer -> contributes nothing
+      if (mm < 0 || mm >= M) xf = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int j = 0; j < FK; ++j) {
       const int r = s - j;                                 // output row fed by (input s, tap j)
@@ -105,7 +110,11 @@ __device__ __forceinline__ void rc_fsmn(float4 (&x)[8], const half_t* __restrict
       }
     }
     const int rc = s - left;                               // identity term: the row itself
-    if (rc >= 0 && rc < 8) { x[rc].x += xf.x; x[rc].y += xf.y; x[rc].z += xf.z; x[rc].w += xf.w; }
+    if (rc >= 0 && rc < 8) {
+      bool ok = true;
+      if (MASKED) { const int mm = mb + rc; ok = mm < M; }
+      if (ok) { x[rc].x += xf.x; x[rc].y += xf.y; x[rc].z += xf.z; x[rc].w += xf.w; }
+    }
   }
 }
 
@@ -166,9 +175,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- main loop: 2-stage ring; stage k+1 stays in flight across the barriers of step k (counted vmcnt)
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  // ---- main loop: 2-stage ring; stage k+1 stays in flight across the barriers of step k (counted vmcnt).
+  // Every workgroup streams the SAME W panel: they start at different k-steps (rotation by workgroup index) so that
+  // the CUs of one XCD do not hit the same L2 lines in the same microsecond; the 9 DMA pieces of a step are slotted
+  // between the 16 MFMAs (issued as one burst they stall the CU's address unit in front of the matrix pipe).
+  const int rot = (int)((blockIdx.x >> 3) % (unsigned)nk);
+  auto kk = [&](int k) __attribute__((always_inline)) -> int { const int q = k + rot; return q >= nk ? q - nk : q; };
+  issue(kk(0), 0);
+  if (nk > 1) issue(kk(1), 1);
   for (int k = 0; k < nk; ++k) {
     if (k + 1 < nk) rc_wait_vmcnt<9>(); else rc_wait_vmcnt<0>();      // this wave's 9 pieces of stage k have landed
     __builtin_amdgcn_s_barrier();                                      // ... and everybody else's
@@ -184,20 +198,69 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
     rc_wait_lgkm0();                                                   // fragments are in registers
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                                      // nobody reads this stage any more
-    if (k + 2 < nk) issue(k + 2, k & 1);
+    const bool more = k + 2 < nk;
+    const int kn = more ? kk(k + 2) : 0;
+    char* st = smem + (k & 1) * RC_STAGE + wave * 1024;
+    const char* an = a_base + (size_t)kn * a_step + a_vo;
+    const char* wn_ = w_base + (size_t)kn * (RC_BK * 2);
     __builtin_amdgcn_s_setprio(1);
+    int piece = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        // 9 pieces over the 8 (s, i) slots: two in the first slot, one in each of the others
+#pragma unroll
+        for (int pp = 0; pp < (s == 0 && i == 0 ? 2 : 1); ++pp) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            if (piece == 0) rc_glds16(an, st);
+            else rc_glds16(wn_ + w_vo[piece > 0 ? piece - 1 : 0], st + RC_A_BYTES + (piece - 1) * 8192);
+          }
+          ++piece;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
   }
 
-  // ---- epilogue 1: the 64 x 512 fp32 tile, row-major in LDS (every stage read has retired behind the last
-  // barrier and no DMA is outstanding).  D^T fragment: lane = row (lane & 31), 4 consecutive columns per quad.
+  // ---- epilogue.  Wave w owns rows 8w .. 8w+7 COMPLETELY; lane: columns 4*lane and 256 + 4*lane.
+  // The residual rows (and the first half of the FSMN window) are requested BEFORE the accumulators are exchanged
+  // through LDS: their HBM round trip overlaps the dump and the barrier.
+  const int r0 = wave * 8;
+  const int mb = m0 + r0;                                  // first output row of this wave
+  float4 xv[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.resid && mb + r < p.M)
+        xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane);
+    }
+  constexpr int FKW = FK > 0 ? 8 + FK - 1 : 1;             // input rows of the FSMN window
+  constexpr int left = FK > 0 ? (FK - 1) / 2 : 0, right = FK > 0 ? FK - 1 - left : 0;
+  h4 vwin[2][FKW];
+  int t_first = 0;
+  bool interior = true;
+  if constexpr (FK > 0) {
+    t_first = mb % p.T;                                    // position of row mb inside its utterance
+    // interior: the 8 rows and their halo lie inside ONE utterance and inside [0, M): no masks at all
+    interior = t_first >= left && t_first + 7 + right < p.T && mb + 7 + right < p.M;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < FKW; ++s) {
+        int mm = mb - left + s;
+        mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);      // address clamp only; validity is decided by the masks
+        vwin[h][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + h * 256 + 4 * lane);
+      }
+  }
+  // the 64 x 512 fp32 tile, row-major in LDS (every stage read has retired behind the last barrier and no DMA is
+  // outstanding).  D^T fragment: lane = row (lane & 31), 4 consecutive columns per quad.
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     char* rowp = smem + (size_t)(i * 32 + (lane & 31)) * RC_XROW + (wave * 64 + 4 * lh) * 4;
@@ -209,10 +272,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
             make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
   }
   __syncthreads();
-
-  // ---- epilogue 2: wave w owns rows 8w .. 8w+7 COMPLETELY; lane: columns c0 = 4*lane and c1 = 256 + 4*lane
-  const int r0 = wave * 8;
-  float4 xv[2][8];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int col = h * 256 + 4 * lane;
@@ -220,66 +279,53 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
     if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * RC_XROW + col * 4);
-      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      xv[h][r] = v;
-    }
-    if (p.resid) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int m = m0 + r0 + r;
-        if (m < p.M) {
-          const float4 q = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + col);
-          xv[h][r].x += q.x; xv[h][r].y += q.y; xv[h][r].z += q.z; xv[h][r].w += q.w;
-        }
-      }
+      const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * RC_XROW + col * 4);
+      xv[h][r].x += v.x + b4.x; xv[h][r].y += v.y + b4.y; xv[h][r].z += v.z + b4.z; xv[h][r].w += v.w + b4.w;
     }
     if constexpr (FK > 0) {
-      // FSMN memory of rows mb .. mb+7 (mb = m0 + r0): input row mm = m + j - left contributes tap j to output
-      // row m when both lie in the same utterance (rows b*T .. b*T+T-1) — accumulated straight into xv.
-      constexpr int left = (FK - 1) / 2, right = FK - 1 - left;
-      const int mb = m0 + r0;
-      const int t_first = mb % p.T;                        // position of row mb inside its utterance
-      const half_t* vcol = p.fsmn_v + col;
-      // interior: the 8 rows and their halo lie inside ONE utterance and inside [0, M): no masks at all
-      const bool interior = t_first >= left && t_first + 7 + right < p.T && mb + 7 + right < p.M;
-      __builtin_amdgcn_sched_barrier(0);
-      if (interior) rc_fsmn<FK, false>(xv[h], vcol, p.ldv, p.fsmn_wT + col, mb, t_first, p.T, p.M);
-      else rc_fsmn<FK, true>(xv[h], vcol, p.ldv, p.fsmn_wT + col, mb, t_first, p.T, p.M);
-      __builtin_amdgcn_sched_barrier(0);
+      if (interior) rc_fsmn<FK, false>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+      else rc_fsmn<FK, true>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
     }
     if (p.out_x) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int m = m0 + r0 + r;
-        if (m < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)m * p.ldx + col) = xv[h][r];
-      }
+      for (int r = 0; r < 8; ++r)
+        if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[h][r];
     }
   }
   if (!p.ln_g) return;
 
-  // ---- epilogue 3: LayerNorm of the complete rows (two-pass statistics, one wave per row)
+  // ---- LayerNorm of the complete rows (two-pass statistics; one wave = one row, reductions on the VALU via DPP)
   float4 g4[2], be4[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     g4[h] = *reinterpret_cast<const float4*>(p.ln_g + h * 256 + 4 * lane);
     be4[h] = *reinterpret_cast<const float4*>(p.ln_b + h * 256 + 4 * lane);
   }
+  float mean[8], rstd[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const int m = m0 + r0 + r;
-    float s = ((xv[0][r].x + xv[0][r].y) + (xv[0][r].z + xv[0][r].w)) + ((xv[1][r].x + xv[1][r].y) + (xv[1][r].z + xv[1][r].w));
-    const float mean = rc_wave_sum(s) * (1.0f / RC_BN);
-    float4 d0 = make_float4(xv[0][r].x - mean, xv[0][r].y - mean, xv[0][r].z - mean, xv[0][r].w - mean);
-    float4 d1 = make_float4(xv[1][r].x - mean, xv[1][r].y - mean, xv[1][r].z - mean, xv[1][r].w - mean);
-    float q = ((d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w)) + ((d1.x * d1.x + d1.y * d1.y) + (d1.z * d1.z + d1.w * d1.w));
-    const float var = rc_wave_sum(q) * (1.0f / RC_BN);
-    const float rstd = 1.0f / sqrtf(var + p.eps);
+    const float s = ((xv[0][r].x + xv[0][r].y) + (xv[0][r].z + xv[0][r].w)) + ((xv[1][r].x + xv[1][r].y) + (xv[1][r].z + xv[1][r].w));
+    mean[r] = rc_wave_sum(s) * (1.0f / RC_BN);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float m = mean[r];
+    xv[0][r].x -= m; xv[0][r].y -= m; xv[0][r].z -= m; xv[0][r].w -= m;
+    xv[1][r].x -= m; xv[1][r].y -= m; xv[1][r].z -= m; xv[1][r].w -= m;
+    const float q = ((xv[0][r].x * xv[0][r].x + xv[0][r].y * xv[0][r].y) + (xv[0][r].z * xv[0][r].z + xv[0][r].w * xv[0][r].w)) +
+                    ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
+    rstd[r] = 1.0f / sqrtf(rc_wave_sum(q) * (1.0f / RC_BN) + p.eps);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = mb + r;
     if (m < p.M) {
-      const float4 y0 = make_float4(d0.x * rstd * g4[0].x + be4[0].x, d0.y * rstd * g4[0].y + be4[0].y,
-                                    d0.z * rstd * g4[0].z + be4[0].z, d0.w * rstd * g4[0].w + be4[0].w);
-      const float4 y1 = make_float4(d1.x * rstd * g4[1].x + be4[1].x, d1.y * rstd * g4[1].y + be4[1].y,
-                                    d1.z * rstd * g4[1].z + be4[1].z, d1.w * rstd * g4[1].w + be4[1].w);
+      const float k = rstd[r];
+      const float4 d0 = xv[0][r], d1 = xv[1][r];
+      const float4 y0 = make_float4(d0.x * k * g4[0].x + be4[0].x, d0.y * k * g4[0].y + be4[0].y,
+                                    d0.z * k * g4[0].z + be4[0].z, d0.w * k * g4[0].w + be4[0].w);
+      const float4 y1 = make_float4(d1.x * k * g4[1].x + be4[1].x, d1.y * k * g4[1].y + be4[1].y,
+                                    d1.z * k * g4[1].z + be4[1].z, d1.w * k * g4[1].w + be4[1].w);
       if (p.out_n16) {
         half_t* o = p.out_n16 + (size_t)m * p.ldn16 + 4 * lane;
         *reinterpret_cast<h4*>(o) = h4{(half_t)y0.x, (half_t)y0.y, (half_t)y0.z, (half_t)y0.w};

@@ -294,7 +294,8 @@ class Engine:
         N.check(self._lib.pf_op_gemm_ex(self._h, C.byref(d), _fp(A), _fp(W), _fp(out)))
         return out
 
-    def op_gemm_rc(self, A, W, bias=None, resid=None, fsmn_v=None, fsmn_w=None, T=0, ln=None, a_blocked=False):
+    def op_gemm_rc(self, A, W, bias=None, resid=None, fsmn_v=None, fsmn_w=None, T=0, ln=None, a_blocked=False,
+                   want_x=True, want_n16=True, want_n32=True):
         """Row-complete GEMM (N = 512) + fused epilogue; returns (x, n16, n32) (n* = None without `ln`)."""
         A, W = _f32(A), _f32(W)
         M, K = A.shape
@@ -308,10 +309,10 @@ class Engine:
         if ln is not None:
             g, b = _f32(ln[0]), _f32(ln[1])
             d.ln_gamma, d.ln_beta = _fp(g), _fp(b)
-        x = np.zeros((M, 512), np.float32)
-        n16 = np.zeros((M, 512), np.float32) if ln is not None else None
-        n32 = np.zeros((M, 512), np.float32) if ln is not None else None
-        N.check(self._lib.pf_op_gemm_rc(self._h, C.byref(d), _fp(A), _fp(W), _fp(x),
+        x = np.zeros((M, 512), np.float32) if (want_x or ln is None) else None
+        n16 = np.zeros((M, 512), np.float32) if (ln is not None and want_n16) else None
+        n32 = np.zeros((M, 512), np.float32) if (ln is not None and want_n32) else None
+        N.check(self._lib.pf_op_gemm_rc(self._h, C.byref(d), _fp(A), _fp(W), _fp(x) if x is not None else None,
                                         _fp(n16) if n16 is not None else None, _fp(n32) if n32 is not None else None))
         return x, n16, n32
 

@@ -1,0 +1,118 @@
+// OfflineRecognizerHip.cs — drop-in classes with the public signatures of OfflineRecognizer
+// (AliParaformerAsr/OfflineRecognizer.cs:23,92,102,110,441,468) and OfflineStream (OfflineStream.cs:20,34,36), backed
+// by the native mirror pf_recognizer_* / pf_stream_*: front-end, model, arg-max, time_stamp_lfr6_onnx and
+// DecodeMulti all run behind the C ABI; only ids, timestamps and text cross it.
+using System;
+using System.Collections.Generic;
+using System.Runtime.InteropServices;
+using AliParaformerAsr.Model;
+using AliParaformerAsr.Native;
+
+namespace AliParaformerAsr.Hip
+{
+    public sealed class OfflineStream : IDisposable
+    {
+        internal IntPtr Handle;
+        internal OfflineStream(IntPtr h) { Handle = h; }
+
+        public void AddSamples(float[] samples)
+            => ParaformerHip.Check(ParaformerHip.pf_stream_add_samples(Handle, samples, samples == null ? 0 : samples.LongLength));
+
+        public List<int[]>? Hotwords
+        {
+            get
+            {
+                var ids = new int[4096]; var lens = new int[1024];
+                ParaformerHip.Check(ParaformerHip.pf_stream_get_hotwords(Handle, ids, ids.Length, lens, lens.Length, out int n));
+                if (n < 0) return null;
+                var r = new List<int[]>(); int off = 0;
+                for (int i = 0; i < n; i++) { r.Add(ids[off..(off + lens[i])]); off += lens[i]; }
+                return r;
+            }
+            set
+            {
+                if (value == null) { ParaformerHip.Check(ParaformerHip.pf_stream_set_hotwords(Handle, null, null, -1)); return; }
+                var flat = new List<int>(); var lens = new int[Math.Max(value.Count, 1)];
+                for (int i = 0; i < value.Count; i++) { flat.AddRange(value[i]); lens[i] = value[i].Length; }
+                ParaformerHip.Check(ParaformerHip.pf_stream_set_hotwords(Handle, flat.ToArray(), lens, value.Count));
+            }
+        }
+
+        public List<Int64> Tokens
+        {
+            get
+            {
+                ParaformerHip.Check(ParaformerHip.pf_stream_tokens(Handle, out IntPtr p, out int n));
+                var a = new long[n];
+                if (n > 0) Marshal.Copy(p, a, 0, n);
+                return new List<Int64>(a);
+            }
+        }
+
+        public void Dispose()
+        {   // later calls answer ObjectDisposedException("OfflineStream"); the finaliser releases the handle
+            if (Handle != IntPtr.Zero) ParaformerHip.pf_stream_dispose(Handle);
+        }
+        ~OfflineStream() { if (Handle != IntPtr.Zero) { ParaformerHip.pf_stream_free(Handle); Handle = IntPtr.Zero; } }
+    }
+
+    public sealed class OfflineRecognizer : IDisposable
+    {
+        private IntPtr _r;
+
+        public OfflineRecognizer(string modelFilePath, string configFilePath, string mvnFilePath, string tokensFilePath,
+                                 string modelebFilePath = "", string hotwordFilePath = "", int batchSize = 1, int threadsNum = 1,
+                                 int device = 0)
+            => ParaformerHip.Check(ParaformerHip.pf_recognizer_create(modelFilePath, configFilePath, mvnFilePath, tokensFilePath,
+                                                                      modelebFilePath ?? "", hotwordFilePath ?? "", batchSize,
+                                                                      threadsNum, device, out _r));
+
+        public OfflineStream CreateOfflineStream()
+        {
+            ParaformerHip.Check(ParaformerHip.pf_recognizer_create_stream(_r, out IntPtr s));
+            return new OfflineStream(s);
+        }
+
+        public OfflineRecognizerResultEntity GetResult(OfflineStream stream) => GetResults(new List<OfflineStream> { stream })[0];
+
+        public List<OfflineRecognizerResultEntity> GetResults(List<OfflineStream> streams)
+        {
+            var hs = new IntPtr[Math.Max(streams.Count, 1)];
+            for (int i = 0; i < streams.Count; i++) hs[i] = streams[i].Handle;
+            ParaformerHip.Check(ParaformerHip.pf_recognizer_get_results(_r, hs, streams.Count));
+            var res = new List<OfflineRecognizerResultEntity>();
+            for (int i = 0; i < streams.Count; i++)
+            {
+                var e = new OfflineRecognizerResultEntity();
+                ParaformerHip.Check(ParaformerHip.pf_result_text(_r, i, out IntPtr txt, out int len16));
+                e.Text = Marshal.PtrToStringUTF8(txt);
+                e.TextLen = len16;
+                ParaformerHip.Check(ParaformerHip.pf_result_num_tokens(_r, i, out int nt));
+                for (int j = 0; j < nt; j++)
+                {
+                    ParaformerHip.Check(ParaformerHip.pf_result_token(_r, i, j, out IntPtr t));
+                    e.Tokens.Add(Marshal.PtrToStringUTF8(t) ?? "");
+                }
+                ParaformerHip.Check(ParaformerHip.pf_result_num_timestamps(_r, i, out int nts));
+                for (int j = 0; j < nts; j++)
+                {
+                    ParaformerHip.Check(ParaformerHip.pf_result_timestamp(_r, i, j, out IntPtr p, out int k));
+                    var a = new int[k];
+                    if (k > 0) Marshal.Copy(p, a, 0, k);
+                    e.Timestamps.Add(a);
+                }
+                res.Add(e);
+            }
+            return res;
+        }
+
+        public void DisposeOfflineStream(OfflineStream offlineStream) => offlineStream?.Dispose();
+
+        public void Dispose()
+        {
+            if (_r != IntPtr.Zero) ParaformerHip.pf_recognizer_dispose(_r);      // later calls: ObjectDisposedException
+            GC.SuppressFinalize(this);
+        }
+        ~OfflineRecognizer() { if (_r != IntPtr.Zero) { ParaformerHip.pf_recognizer_free(_r); _r = IntPtr.Zero; } }
+    }
+}

@@ -141,7 +141,11 @@ def mha(q, k, v, heads):
 
 
 class Oracle:
-    def __init__(self, cfg: ModelConfig, weights: dict, quant: str = "fp32"):
+    def __init__(self, cfg: ModelConfig, weights: dict, quant: str = "fp32", fast: bool = False):
+        """fast=True: the same graph with torch's fused fp32 CPU kernels (layer_norm, scaled_dot_product_attention)
+        instead of the float64-statistics LayerNorm and the explicit softmax — the leaner CPU stand-in that
+        bench.py times as `cpu_baseline` (parity work always uses fast=False)."""
+        self.fast = fast
         self.cfg = cfg
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()
                   if isinstance(v, np.ndarray) and v.dtype == np.float32}
@@ -157,7 +161,19 @@ class Oracle:
         return y
 
     def ln(self, x, name):
+        if self.fast:
+            w = self.w[name + ".weight"]
+            return Fn.layer_norm(x, (w.shape[0],), w, self.w[name + ".bias"], LN_EPS)
         return layer_norm(x, self.w[name + ".weight"], self.w[name + ".bias"])
+
+    def mha(self, q, k, v):
+        if self.fast:
+            B, Lq, D = q.shape
+            H, dk = self.cfg.heads, D // self.cfg.heads
+            sp = lambda t: t.view(B, t.shape[1], H, dk).transpose(1, 2)
+            o = Fn.scaled_dot_product_attention(sp(q), sp(k), sp(v), scale=1.0)      # q is pre-scaled
+            return o.transpose(1, 2).reshape(B, Lq, D)
+        return mha(q, k, v, self.cfg.heads)
 
     # -- encoder -----------------------------------------------------------
     def enc_layer(self, x, p, first):
@@ -169,7 +185,7 @@ class Oracle:
         vq = q(vh)                                   # engine stores q/k/v as 16-bit
         f = fsmn(vq, self.w[p + ".attn.fsmn.weight"], c.kernel)
         dk = c.d_model // c.heads
-        ctx = mha(q(qh * (dk ** -0.5)), q(kh), vq, c.heads)
+        ctx = self.mha(q(qh * (dk ** -0.5)), q(kh), vq)
         att = self.lin(ctx, p + ".attn.out") + f
         x = att if first else x + att
         xn = self.ln(x, p + ".norm2")
@@ -326,7 +342,7 @@ class Oracle:
             qq = self.lin(xn, p + ".src.q")
             kv = self.lin(memory, p + ".src.kv")
             k, v = torch.split(kv, D, dim=-1)
-            ctx = mha(q(qq * (dk ** -0.5)), q(k), q(v), c.heads)
+            ctx = self.mha(q(qq * (dk ** -0.5)), q(k), q(v))
             x = x + self.lin(ctx, p + ".src.out")
         x = self.ffn_dec(self.ln(x, prefix + ".final.norm1"), prefix + ".final")
         return self.ln(x, prefix + ".after_norm")
