@@ -186,6 +186,12 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   mc_.cif_noise = (float)jc->num_or("cif_noise", mc_.cif_noise);
   mc_.cif_l_order = (int)jc->num_or("cif_l_order", mc_.cif_l_order);
   mc_.cif_r_order = (int)jc->num_or("cif_r_order", mc_.cif_r_order);
+  {
+    const std::string cv = jc->str_or("cif_variant", "loop");
+    PF_CHECK(cv == "loop" || cv == "cumsum", PF_ERR_UNSUPPORTED, "weights: cif_variant must be \"loop\" or \"cumsum\"");
+    mc_.cif_cumsum = cv == "cumsum";
+    PF_CHECK(!mc_.cif_cumsum || mc_.cif_threshold == 1.0f, PF_ERR_UNSUPPORTED, "cif_variant cumsum is defined for threshold 1.0");
+  }
   mc_.timestamp_head = jc->bool_or("timestamp_head", false);
   mc_.seaco = jc->bool_or("seaco", false);
   mc_.use_itn = jc->bool_or("use_itn", false) || cfg.use_itn != 0;
@@ -841,7 +847,8 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   prof_begin("cif_misc", 0);
   launch_cif_alpha(stream_, conv32, B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail,
                    alphas_);
-  launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
+  if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
+  else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
   prof_end("cif_misc");
   last_.peak_len = 0;
   last_.cif_peak.clear();
@@ -880,7 +887,8 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   const int ldkv = nd * 2 * D;
 
   prof_begin("cif_misc", 0);
-  launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
+  if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
+  else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
   prof_end("cif_misc");
   const bool bias_branch = mc_.seaco && n_hotwords_ > 0;
   float* e0 = nullptr;                                 // SeACo: the bias decoder also starts from the CIF embeds
@@ -1704,7 +1712,8 @@ void Engine::op_cif(const float* H, const float* alphas, int B, int T, int D, fl
   p.w_cur = (float*)(base + owc); p.w_rem = (float*)(base + owr); p.max_count = (int32_t*)(base + omx);
   PF_HIP(hipMemcpyAsync(base + oH, H, (size_t)B * T * D * 4, hipMemcpyHostToDevice, stream_));
   PF_HIP(hipMemcpyAsync(base + oa, alphas, (size_t)B * T1 * 4, hipMemcpyHostToDevice, stream_));
-  launch_cif_scan(stream_, (const float*)(base + oa), B, T1, thr, p);
+  if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, (const float*)(base + oa), B, T1, p);
+  else launch_cif_scan(stream_, (const float*)(base + oa), B, T1, thr, p);
   int32_t L = 0;
   PF_HIP(hipMemcpyAsync(&L, p.max_count, 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipMemcpyAsync(fire_count, p.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
@@ -1713,7 +1722,8 @@ void Engine::op_cif(const float* H, const float* alphas, int B, int T, int D, fl
   if (L_out) *L_out = L;
   PF_CHECK(L <= Lcap, PF_ERR_CAPACITY, "cif: Lcap " + std::to_string(Lcap) + " < L = " + std::to_string(L));
   if (Lcap == 0) return;
-  launch_cif_gather(stream_, (const float*)(base + oH), B, T, D, T1, p, Lcap, (float*)(base + oE));
+  if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, (const float*)(base + oH), (const float*)(base + oa), B, T, D, T1, p, Lcap, (float*)(base + oE));
+  else launch_cif_gather(stream_, (const float*)(base + oH), B, T, D, T1, p, Lcap, (float*)(base + oE));
   PF_HIP(hipMemcpyAsync(E, base + oE, (size_t)B * Lcap * D * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
 }

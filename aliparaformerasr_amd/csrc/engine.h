@@ -20,6 +20,7 @@ struct ModelCfg {
   int dec_layers = 16, vocab = 8404;
   float cif_threshold = 1.0f, cif_tail = 0.45f, cif_smooth = 1.0f, cif_noise = 0.0f;
   int cif_l_order = 1, cif_r_order = 1;
+  bool cif_cumsum = false;           // cif_variant = "cumsum": the prefix-sum export (cif_v1_export) instead of the loop
   bool timestamp_head = false, seaco = false, use_itn = false;
   float cif_smooth2 = 0.25f, cif_noise2 = 0.01f;
   int upsample = 3;

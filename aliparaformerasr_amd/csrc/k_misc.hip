@@ -382,6 +382,91 @@ void launch_cif_scan(hipStream_t s, const float* alphas, int B, int T1, float th
   PF_HIP(hipGetLastError());
 }
 
+// ---- the prefix-sum formulation (FunASR cif_v1_export; container key cif_variant = "cumsum") ----------------
+// prefix = float32(cumsum_float64(alpha)); fire at t <=> floor(prefix[t]) > floor(prefix[t-1]);
+// remain[t] = (1 + (prefix[t] - floor(prefix[t]))) - 1.  One lane per utterance (T+1 dependent double adds).
+__global__ __launch_bounds__(64) void cif_scan_cumsum_kernel(const float* __restrict__ alphas, int B, int T1, CifPlan plan) {
+  extern __shared__ float sa[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* a = alphas + (int64_t)b * T1;
+  for (int t = lane; t < T1; t += 64) sa[t] = a[t];
+  __syncthreads();
+  if (lane != 0) return;
+  double dsum = 0.0;
+  float sum = 0.f, prev_floor = 0.f;
+  int count = 0;
+  int32_t* ff = plan.fire_frame + (int64_t)b * T1;
+  float* wr = plan.w_rem + (int64_t)b * T1;
+  for (int t = 0; t < T1; ++t) {
+    const float alpha = sa[t];
+    sum = add_rn(sum, alpha);
+    dsum += (double)alpha;
+    const float prefix = (float)dsum;
+    const float fl = floorf(prefix);
+    if (sub_rn(fl, prev_floor) > 0.f) {
+      const float fires = add_rn(1.0f, sub_rn(prefix, fl));
+      wr[t] = sub_rn(fires, floorf(fires));
+      ff[count++] = t;
+    } else {
+      wr[t] = 0.f;
+    }
+    prev_floor = fl;
+  }
+  plan.fire_count[b] = count;
+  plan.token_num[b] = (int32_t)floorf(sum);
+  atomicMax(plan.max_count, count);
+}
+
+void launch_cif_scan_cumsum(hipStream_t s, const float* alphas, int B, int T1, CifPlan plan) {
+  if (B == 0) return;
+  PF_HIP(hipMemsetAsync(plan.max_count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(cif_scan_cumsum_kernel, dim3(B), dim3(64), sizeof(float) * T1, s, alphas, B, T1, plan);
+  PF_HIP(hipGetLastError());
+}
+
+// E[l] = ((psh[f_l] - psh[f_{l-1}]) + remain[f_{l-1}] H[f_{l-1}]) - remain[f_l] H[f_l], psh = sequential fp32 running sum of
+// alpha[t] H[t] (ONNX CumSum).  One thread per (utterance, 4 channels) walks the T+1 frames; rows l >= fire_count are zero.
+__global__ __launch_bounds__(128) void cif_gather_cumsum_kernel(const float* __restrict__ H, const float* __restrict__ alphas,
+                                                                int B, int T, int D, int T1, CifPlan plan, int L,
+                                                                float* __restrict__ E) {
+  const int b = blockIdx.x;
+  const int cnt = plan.fire_count[b];
+  const int32_t* ff = plan.fire_frame + (int64_t)b * T1;
+  const float* wr = plan.w_rem + (int64_t)b * T1;
+  const float* al = alphas + (int64_t)b * T1;
+  for (int c4 = threadIdx.x * 4; c4 < D; c4 += blockDim.x * 4) {
+    float4 psh = make_float4(0.f, 0.f, 0.f, 0.f), last = psh, lrem = psh;
+    int l = 0;
+    int next = cnt > 0 ? ff[0] : T1;
+    for (int t = 0; t < T1; ++t) {
+      float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < T) h = *reinterpret_cast<const float4*>(H + ((int64_t)b * T + t) * D + c4);
+      const float a = al[t];
+      psh.x = add_rn(psh.x, mul_rn(a, h.x)); psh.y = add_rn(psh.y, mul_rn(a, h.y));
+      psh.z = add_rn(psh.z, mul_rn(a, h.z)); psh.w = add_rn(psh.w, mul_rn(a, h.w));
+      if (t == next) {
+        const float r = wr[t];
+        const float4 rh = make_float4(mul_rn(r, h.x), mul_rn(r, h.y), mul_rn(r, h.z), mul_rn(r, h.w));
+        float4 o;
+        o.x = sub_rn(add_rn(sub_rn(psh.x, last.x), lrem.x), rh.x); o.y = sub_rn(add_rn(sub_rn(psh.y, last.y), lrem.y), rh.y);
+        o.z = sub_rn(add_rn(sub_rn(psh.z, last.z), lrem.z), rh.z); o.w = sub_rn(add_rn(sub_rn(psh.w, last.w), lrem.w), rh.w);
+        if (l < L) *reinterpret_cast<float4*>(E + ((int64_t)b * L + l) * D + c4) = o;
+        last = psh; lrem = rh;
+        ++l;
+        next = l < cnt ? ff[l] : T1;
+      }
+    }
+    for (; l < L; ++l) *reinterpret_cast<float4*>(E + ((int64_t)b * L + l) * D + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+void launch_cif_gather_cumsum(hipStream_t s, const float* H, const float* alphas, int B, int T, int D, int T1, CifPlan plan,
+                              int L, float* E) {
+  if (B == 0 || L == 0) return;
+  hipLaunchKernelGGL(cif_gather_cumsum_kernel, dim3(B), dim3(128), 0, s, H, alphas, B, T, D, T1, plan, L, E);
+  PF_HIP(hipGetLastError());
+}
+
 // E[b,l,:] = w_rem[s]*H[s] + sum_{t in (s,e]} w_cur[t]*H[t], s = fire_frame[l-1], e = fire_frame[l]
 // (l = 0: from frame 0, no carried remainder).  Frames t >= T are the zero tail frame.
 // Products and sums are separately rounded in ascending t, as the sequential loop does.

@@ -110,6 +110,10 @@ struct CifPlan {           // device arrays sized for B utterances
 void launch_cif_scan(hipStream_t s, const float* alphas, int B, int T1, float threshold, CifPlan plan);
 void launch_cif_gather(hipStream_t s, const float* H, int B, int T, int D, int T1, CifPlan plan, int L,
                        float* E);
+// the prefix-sum CIF formulation (FunASR cif_v1_export): fire table + carried remainders, then the embeddings
+void launch_cif_scan_cumsum(hipStream_t s, const float* alphas, int B, int T1, CifPlan plan);
+void launch_cif_gather_cumsum(hipStream_t s, const float* H, const float* alphas, int B, int T, int D, int T1, CifPlan plan,
+                              int L, float* E);
 // ---------------------------------------------------- BiCIF timestamp head ----
 struct LstmArgs {
   const half_t* whh;   // [2 dir][4D][D] f16, PyTorch gate order i,f,g,o

@@ -40,6 +40,8 @@ DEFAULT_CONFIG = dict(
     # SeACo (kind "seacoparaformer", seaco=True): hotword embedder Embedding + LSTM(512) x seaco_lstm_layers,
     # bias decoder = SAN-M decoder without input/output layer attending bias_embed, hotword_output_layer
     seaco_layers=4, seaco_ffn=1024, seaco_kernel=21, seaco_lstm_layers=2, seaco_nobias=8377,
+    # CIF export variant: "loop" = sequential integrate-and-fire, "cumsum" = FunASR cif_v1_export (prefix sums)
+    cif_variant="loop",
 )
 
 

@@ -60,6 +60,7 @@ class ModelConfig:
     seaco_kernel: int = 21
     seaco_lstm_layers: int = 2
     seaco_nobias: int = 8377
+    cif_variant: str = "loop"         # "loop" (sequential integrate-and-fire) | "cumsum" (cif_v1_export)
 
     def to_dict(self):
         return dict(self.__dict__)
@@ -222,6 +223,11 @@ class Oracle:
         a = torch.cat([a, tail], dim=1)
         return a
 
+    def cif(self, H, alphas):
+        if self.cfg.cif_variant == "cumsum":
+            return self.cif_fire_cumsum(H, alphas, self.cfg.cif_threshold)
+        return self.cif_fire(H, alphas, self.cfg.cif_threshold)
+
     @staticmethod
     def cif_fire(H, alphas, threshold=1.0):
         """Sequential integrate-and-fire (same statement as the reference's
@@ -263,6 +269,51 @@ class Oracle:
             if counts[b]:
                 E[b, : counts[b]] = np.stack(frames_all[b])
         return E, np.asarray(counts, np.int32), np.asarray(tnum, np.int32)
+
+    @staticmethod
+    def cif_fire_cumsum(H, alphas, threshold=1.0):
+        """The OTHER CIF formulation found in FunASR exports (`cif_v1_export`: no loop, prefix sums) — SURVEY §8a
+        flags "loop vs cumsum export" as something only the real ONNX graph can settle, so both are built
+        (container key `cif_variant`).  threshold 1:
+          prefix = float32(cumsum_float64(alphas));  fire at t  <=>  floor(prefix[t]) > floor(prefix[t-1])
+          remain[t] = (1 + (prefix[t] - floor(prefix[t]))) - 1        (the part of alpha[t] carried to the NEXT token)
+          psh[t] = fp32 running sum of alpha[t] * H[t]                 (ONNX CumSum: sequential)
+          E[l] = ((psh[f_l] - psh[f_{l-1}]) + remain[f_{l-1}] * H[f_{l-1}]) - remain[f_l] * H[f_l]
+        Fire decisions and embeddings round differently from the sequential definition (`cif_fire`)."""
+        Hn = np.asarray(H, dtype=F32)
+        an = np.asarray(alphas, dtype=F32)
+        B, T1 = an.shape
+        D = Hn.shape[2]
+        Hn = np.concatenate([Hn, np.zeros((B, T1 - Hn.shape[1], D), F32)], axis=1)
+        prefix = np.cumsum(an.astype(np.float64), axis=1).astype(F32)
+        pfl = np.floor(prefix)
+        prev = np.concatenate([np.zeros((B, 1), F32), pfl[:, :-1]], axis=1)
+        fire = (pfl - prev) > 0
+        fires = (fire.astype(F32) + (prefix - pfl).astype(F32)).astype(F32)
+        remain = (fires - np.floor(fires)).astype(F32)
+        counts = fire.sum(axis=1).astype(np.int32)
+        L = int(counts.max()) if B else 0
+        E = np.zeros((B, L, D), F32)
+        for b in range(B):
+            psh = np.zeros(D, F32)
+            last_psh = np.zeros(D, F32)
+            last_rem = np.zeros(D, F32)
+            l = 0
+            for t in range(T1):
+                psh = (psh + (an[b, t] * Hn[b, t]).astype(F32)).astype(F32)
+                if fire[b, t]:
+                    rem_h = (remain[b, t] * Hn[b, t]).astype(F32)
+                    E[b, l] = (((psh - last_psh).astype(F32) + last_rem).astype(F32) - rem_h).astype(F32)
+                    last_psh = psh.copy()
+                    last_rem = rem_h
+                    l += 1
+        tnum = []
+        for b in range(B):                                # token_num: the sequential fp32 sum, as in cif_fire
+            sacc = F32(0.0)
+            for t in range(T1):
+                sacc = F32(sacc + an[b, t])
+            tnum.append(int(np.floor(sacc)))
+        return E, counts, np.asarray(tnum, np.int32)
 
     # -- BiCIF timestamp head ----------------------------------------------
     def us_alphas_peak(self, H, token_num):
@@ -389,7 +440,7 @@ class Oracle:
         c = self.cfg
         H = self.encoder(speech)
         a = self.cif_alphas(H)
-        E, counts, tnum = self.cif_fire(H.numpy(), a.numpy(), c.cif_threshold)
+        E, counts, tnum = self.cif(H.numpy(), a.numpy())
         logp, hid = self.decoder(E, H, tnum, return_hidden=True)
         out = {"token_num": tnum, "fire_count": counts, "asr_logits": logp.numpy()}
         hw = np.asarray(hotwords)
@@ -415,7 +466,7 @@ class Oracle:
         logits [B,L,V] (log-probs), token_num [B], alphas, H, E."""
         H = self.encoder(speech)
         a = self.cif_alphas(H)
-        E, counts, tnum = self.cif_fire(H.numpy(), a.numpy(), self.cfg.cif_threshold)
+        E, counts, tnum = self.cif(H.numpy(), a.numpy())
         logits = self.decoder(E, H, tnum)
         out = {"logits": logits.numpy(), "token_num": tnum, "fire_count": counts,
                "alphas": a.numpy(), "H": H.numpy(), "E": E}

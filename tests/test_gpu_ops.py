@@ -243,3 +243,39 @@ def test_fbank_dither_statistics():
     d = np.abs(ed.fbank(x) - e0.fbank(x))
     assert 0 < d.max() < 0.2 and d.mean() < 2e-3, (d.max(), d.mean())     # the quietest bins move the most
     ed.close(); e0.close()
+
+
+def test_cif_cumsum_variant_bit_exact_and_end_to_end():
+    """cif_variant = "cumsum" (FunASR cif_v1_export, prefix sums): fire table and embeddings bit-exact against the
+    oracle restatement, different roundings from the sequential definition, and a whole-model run through it."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=1, vocab=128, cif_variant="cumsum")
+    w = W.synth_weights(cfg, seed=5)
+    cmvn = W.synth_cmvn()
+    e = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    rng = np.random.default_rng(2)
+    differs = 0
+    for (B, T) in ((3, 83), (2, 500), (1, 7)):
+        H = rng.standard_normal((B, T, 512)).astype(np.float32)
+        a = rng.uniform(0.0, 0.7, (B, T + 1)).astype(np.float32)
+        a[:, -1] = 0.45
+        a[0, : T // 2] = 0.0
+        E, fc, tn = e.op_cif(H, a)
+        Er, fcr, tnr = om.Oracle.cif_fire_cumsum(H, a, 1.0)
+        np.testing.assert_array_equal(fc, fcr)
+        np.testing.assert_array_equal(tn, tnr)
+        np.testing.assert_array_equal(E, Er)
+        El, _, _ = om.Oracle.cif_fire(H, a, 1.0)
+        if El.shape == Er.shape:
+            assert np.abs(El - Er).max() < 1e-4                  # the two exports agree mathematically ...
+            differs += int((El != Er).any())
+    assert differs > 0                                           # ... and round differently
+    audio = [W.synth_audio(n, u) for u, n in enumerate((48000, 32000))]
+    conf = fe.FrontendConf(dither=0.0)
+    feats = [fe.wav_frontend(x, conf, cmvn[0], cmvn[1]) for x in audio]
+    speech = fe.pad_sequence(feats).reshape(2, -1, 560)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").paraformer(speech)
+    res = e.recognize(audio, want_logits=True)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    assert res.logits.shape == ref["logits"].shape and np.abs(res.logits - ref["logits"]).max() < 2e-2
+    e.close()
