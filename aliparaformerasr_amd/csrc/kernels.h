@@ -28,9 +28,14 @@ struct GemmArgs {
   // FFN-up writes it (out_blocked, f16-only results, N % 64 == 0), FFN-down reads it (a_blocked, lda ignored).
   int out_blocked;
   int a_blocked;
-  int force_mi;                  // 0 = choose by tile count; 1 / 2 = 128- / 256-row tiles (stand-alone op tests)
+  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 3 = the 256 x {192,256} kernel
+                                 // (stand-alone op tests; 3 fails when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
+// 256 x {192, 256} tile kernel for wide f16-result GEMMs (k_gemm_big.hip); launch_gemm dispatches to it when
+// applicable (f16-only result, N a multiple of 192 / 256, at least one tile per CU) unless force_mi is set
+bool gemm_big_applicable(const GemmArgs& a, int cus, int* nj_out);
+void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj);
 
 // Row-complete GEMM for N = 512 (k_gemm_rc.hip): x = resid + A W^T + bias + FSMN(V); n = LayerNorm(x).
 // One workgroup = 64 complete rows, so the residual add, the FSMN memory and the following LayerNorm are its epilogue.
