@@ -136,6 +136,24 @@ SIGNATURES = {
     "pf_result_timestamp": (C.c_int, [_vp, C.c_int32, C.c_int32, _P(_i32), _i32]),
     "pf_result_num_timestamps": (C.c_int, [_vp, C.c_int32, _i32]),
     "pf_stream_tokens": (C.c_int, [_vp, _P(_i64), _i32]),
+    "pf_online_recognizer_create": (C.c_int, [C.c_char_p] * 5 + [C.c_int32, C.c_int32, _P(_vp)]),
+    "pf_online_recognizer_dispose": (None, [_vp]),
+    "pf_online_recognizer_free": (None, [_vp]),
+    "pf_online_recognizer_engine": (_vp, [_vp]),
+    "pf_online_create_stream": (C.c_int, [_vp, _P(_vp)]),
+    "pf_online_stream_add_samples": (C.c_int, [_vp, _f, C.c_int64]),
+    "pf_online_get_results": (C.c_int, [_vp, _P(_vp), C.c_int32]),
+    "pf_online_result_text": (C.c_int, [_vp, C.c_int32, _cpp]),
+    "pf_online_stream_tokens": (C.c_int, [_vp, _P(_i64), _i32]),
+    "pf_online_stream_dispose": (None, [_vp]),
+    "pf_online_stream_free": (None, [_vp]),
+    "pf_online_encoder": (C.c_int, [_vp, _f, C.c_int32, C.c_int32, _f, _f]),
+    "pf_online_decoder": (C.c_int, [_vp, _f, C.c_int32, C.c_int32, _f, C.c_int32, _i32, _f, C.c_int32, _f, _i64, _f]),
+    "pf_host_online_lfr": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32, _f, C.c_int64, _i32]),
+    "pf_host_online_posenc": (C.c_int, [_f, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_host_online_dynamic_mask": (C.c_int, [_f, C.c_int32]),
+    "pf_host_online_cif": (C.c_int, [_f, _f, C.c_int32, C.c_int32, C.c_float, _f, C.c_int32, _i32, _f, _f]),
+    "pf_host_online_decode": (C.c_int, [_cpp, C.c_int32, _i64, C.c_int32, C.c_char_p, C.c_int32]),
     "pf_host_timestamps": (C.c_int, [_f, C.c_int32, _i64, C.c_int32, _i32, C.c_int32]),
     "pf_host_hotword_ids": (C.c_int, [_cpp, C.c_int32, _cpp, C.c_int32, _i32, C.c_int32, _i32, C.c_int32, _i32]),
     "pf_host_decode": (C.c_int, [_cpp, C.c_int32, _i64, C.c_int32, _i32, _i32, C.c_int32, _P(_vp)]),

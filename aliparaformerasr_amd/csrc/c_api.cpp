@@ -6,6 +6,7 @@
 
 #include "engine.h"
 #include "group.h"
+#include "online.h"
 #include "recognizer.h"
 
 namespace pf {
@@ -32,6 +33,15 @@ struct pf_stream {
   bool freed = false;
 };
 struct pf_decoded { ResultEntity r; };
+struct pf_online_recognizer {
+  std::mutex mu;
+  std::shared_ptr<OnlineRecognizerM> r;
+  pf_engine eng;
+};
+struct pf_online_stream {
+  std::shared_ptr<OnlineStreamM> s;
+  bool freed = false;
+};
 struct pf_group {
   std::mutex mu;
   std::shared_ptr<Group> g;
@@ -702,6 +712,192 @@ int pf_stream_tokens(pf_stream* h, const int64_t** ids, int32_t* n) {
   Stream* s = S(h);
   if (ids) *ids = s->Tokens.data();
   if (n) *n = (int32_t)s->Tokens.size();
+  return PF_OK;
+  PF_CATCH
+}
+
+// ---- streaming path ---------------------------------------------------------
+static thread_local std::vector<std::string> t_online_texts;
+
+int pf_online_recognizer_create(const char* enc, const char* dec, const char* config, const char* mvn, const char* tokens,
+                                int32_t threads, int32_t device, pf_online_recognizer** out) {
+  PF_TRY
+  NEED(out);
+  *out = nullptr;
+  auto s = [](const char* p) { return std::string(p ? p : ""); };
+  std::shared_ptr<OnlineRecognizerM> r = std::make_shared<OnlineRecognizerM>(s(enc), s(dec), s(config), s(mvn), s(tokens), threads, device);
+  pf_online_recognizer* h = new pf_online_recognizer();
+  h->r = r;
+  h->eng.e = r->engine();
+  *out = h;
+  return PF_OK;
+  PF_CATCH
+}
+void pf_online_recognizer_dispose(pf_online_recognizer* h) {
+  if (!h) return;
+  std::shared_ptr<OnlineRecognizerM> r;
+  { std::lock_guard<std::mutex> lk(h->mu); r = h->r; }
+  if (!r) return;
+  { std::lock_guard<std::mutex> lk(h->eng.mu); h->eng.e.reset(); }
+  try { r->Dispose(); } catch (...) {}
+}
+void pf_online_recognizer_free(pf_online_recognizer* h) {
+  if (!h) return;
+  pf_online_recognizer_dispose(h);
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->r.reset();
+}
+pf_engine* pf_online_recognizer_engine(pf_online_recognizer* h) {
+  if (!h) return nullptr;
+  std::lock_guard<std::mutex> lk(h->eng.mu);
+  return h->eng.e ? &h->eng : nullptr;
+}
+static std::shared_ptr<OnlineRecognizerM> OR(pf_online_recognizer* h) {
+  PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null recognizer");
+  std::lock_guard<std::mutex> lk(h->mu);
+  PF_CHECK(h->r != nullptr, PF_ERR_DISPOSED, "OnlineRecognizer");
+  return h->r;
+}
+static OnlineStreamM* OS(pf_online_stream* h) {
+  PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null stream");
+  PF_CHECK(!h->freed && h->s != nullptr && !h->s->disposed, PF_ERR_DISPOSED, "OnlineStream");
+  return h->s.get();
+}
+int pf_online_create_stream(pf_online_recognizer* h, pf_online_stream** out) {
+  PF_TRY
+  NEED(out);
+  *out = nullptr;
+  std::shared_ptr<OnlineStreamM> s = OR(h)->CreateOnlineStream();
+  pf_online_stream* sh = new pf_online_stream();
+  sh->s = s;
+  *out = sh;
+  return PF_OK;
+  PF_CATCH
+}
+int pf_online_stream_add_samples(pf_online_stream* h, const float* samples, int64_t n) {
+  PF_TRY
+  OnlineStreamM* s = OS(h);
+  PF_CHECK(!s->owner->disposed(), PF_ERR_DISPOSED, "OnlineRecognizer");
+  PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "negative sample count");
+  s->AddSamples(samples, n);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_online_get_results(pf_online_recognizer* h, pf_online_stream* const* streams, int32_t n) {
+  PF_TRY
+  std::shared_ptr<OnlineRecognizerM> r = OR(h);
+  std::vector<OnlineStreamM*> ss;
+  for (int i = 0; i < n; ++i) { NEED(streams); ss.push_back(OS(streams[i])); }
+  t_online_texts = r->GetResults(ss);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_online_result_text(pf_online_recognizer* h, int32_t i, const char** utf8) {
+  PF_TRY
+  OR(h);
+  NEED(utf8);
+  PF_CHECK(i >= 0 && i < (int32_t)t_online_texts.size(), PF_ERR_INVALID_ARG, "result index out of range");
+  *utf8 = t_online_texts[(size_t)i].c_str();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_online_stream_tokens(pf_online_stream* h, const int64_t** ids, int32_t* n) {
+  PF_TRY
+  OnlineStreamM* s = OS(h);
+  if (ids) *ids = s->Tokens.data();
+  if (n) *n = (int32_t)s->Tokens.size();
+  return PF_OK;
+  PF_CATCH
+}
+void pf_online_stream_dispose(pf_online_stream* h) {
+  if (!h || h->freed || !h->s) return;
+  h->s->disposed = true;
+  std::vector<float>().swap(h->s->Speech);
+}
+void pf_online_stream_free(pf_online_stream* h) {
+  if (!h || h->freed) return;
+  if (h->s) h->s->disposed = true;
+  h->s.reset();
+  h->freed = true;
+}
+int pf_online_encoder(pf_engine* h, const float* speech, int32_t B, int32_t Tc, float* enc_out, float* alphas_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  std::lock_guard<std::mutex> lk(eh_->mutex());
+  eh_->online_encoder(speech, B, Tc, enc_out, alphas_out);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_online_decoder(pf_engine* h, const float* enc, int32_t B, int32_t Tc, const float* embeds, int32_t L,
+                      const int32_t* embeds_len, const float* caches_in, int32_t n_caches, float* logits_out,
+                      int64_t* ids_out, float* caches_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  std::lock_guard<std::mutex> lk(eh_->mutex());
+  PF_CHECK(n_caches == eh_->dec_layers(), PF_ERR_INVALID_ARG, "online_decoder: one cache per decoder layer expected");
+  eh_->online_decoder(enc, B, Tc, embeds, L, embeds_len, caches_in, logits_out, ids_out, caches_out);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_host_online_lfr(const float* fbank, int32_t t80, int32_t lfr_m, int32_t lfr_n, float* out, int64_t cap, int32_t* t_lfr) {
+  PF_TRY
+  NEED(t_lfr);
+  PF_CHECK(t80 >= 0 && (t80 == 0 || fbank), PF_ERR_INVALID_ARG, "online_lfr: bad arguments");
+  std::vector<float> in(fbank, fbank + (size_t)t80 * 80);
+  std::vector<float> o = online_apply_lfr(in, 80, lfr_m, lfr_n);
+  *t_lfr = (int32_t)(o.size() / ((size_t)lfr_m * 80));
+  if (out) {
+    PF_CHECK(cap >= (int64_t)o.size(), PF_ERR_CAPACITY, "online_lfr: output capacity too small");
+    std::memcpy(out, o.data(), o.size() * 4);
+  }
+  return PF_OK;
+  PF_CATCH
+}
+int pf_host_online_posenc(float* x, int32_t timesteps, int32_t dim, int32_t start_idx) {
+  PF_TRY
+  NEED(x);
+  std::vector<float> v(x, x + (size_t)timesteps * dim);
+  online_position_encode(v, timesteps, dim, start_idx);
+  std::memcpy(x, v.data(), v.size() * 4);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_host_online_dynamic_mask(float* alphas, int32_t n) {
+  PF_TRY
+  NEED(alphas);
+  std::vector<float> v(alphas, alphas + n);
+  online_dynamic_mask(v);
+  std::memcpy(alphas, v.data(), v.size() * 4);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_host_online_cif(const float* hiddens, const float* alphas, int32_t n, int32_t D, float threshold, float* fired,
+                       int32_t fired_cap, int32_t* n_fired, float* carry_alpha, float* carry_hidden) {
+  PF_TRY
+  NEED(hiddens); NEED(alphas); NEED(n_fired); NEED(carry_alpha); NEED(carry_hidden);
+  std::vector<std::vector<float>> h;
+  for (int i = 0; i < n; ++i) h.emplace_back(hiddens + (size_t)i * D, hiddens + (size_t)(i + 1) * D);
+  std::vector<float> a(alphas, alphas + n), ch;
+  std::vector<std::vector<float>> f;
+  float ca = 0.f;
+  online_cif(h, a, threshold, f, ca, ch);
+  *n_fired = (int32_t)f.size();
+  *carry_alpha = ca;
+  std::memcpy(carry_hidden, ch.data(), (size_t)D * 4);
+  PF_CHECK((int32_t)f.size() <= fired_cap, PF_ERR_CAPACITY, "online_cif: fired capacity too small");
+  for (size_t l = 0; l < f.size(); ++l) { NEED(fired); std::memcpy(fired + l * D, f[l].data(), (size_t)D * 4); }
+  return PF_OK;
+  PF_CATCH
+}
+int pf_host_online_decode(const char* const* tokens, int32_t n_tokens, const int64_t* ids, int32_t n_ids, char* out, int32_t cap) {
+  PF_TRY
+  NEED(out);
+  std::vector<std::string> tk;
+  for (int i = 0; i < n_tokens; ++i) tk.emplace_back(tokens[i]);
+  std::vector<int64_t> idv(ids, ids + n_ids);
+  const std::string t = online_decode_text(tk, idv);
+  PF_CHECK((int32_t)t.size() + 1 <= cap, PF_ERR_CAPACITY, "online_decode: output capacity too small");
+  std::memcpy(out, t.c_str(), t.size() + 1);
   return PF_OK;
   PF_CATCH
 }

@@ -722,14 +722,19 @@ void Engine::build_pe(int T) {
 // FFN-up (blocked hidden) -> row-complete FFN-down (+ bias + residual + the NEXT LayerNorm `nx` -> its outputs).
 // Entry: xn16_ holds LayerNorm norm1 of the residual stream (written by the previous layer's FFN-down, by the
 // position-encoding kernel for layer 0, or by the stand-alone LayerNorm for the first tp layer).
-void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T, const EncNext& nx) {
+void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, int B, int T, const EncNext& nx) {
   const int D = mc_.d_model, M = B * T, F = mc_.ffn;
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
   const int lda = first ? L.qkv.Kpad : D;
-  if (first) {
+  if (first == 1) {
     prof_begin("layernorm", 0);
     launch_posenc_ln_tab(stream_, speech_dev, B, T, mc_.feat_dim, std::sqrt((float)D), (const float*)ws_pe_.p,
                          L.norm1.g, L.norm1.b, xn16_, lda);
+    prof_end("layernorm");
+  } else if (first == 2) {
+    // streaming path: the caller scaled and position-encoded the chunk already (OnlineStream.cs GetDecodeChunk)
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, speech_dev, M, mc_.feat_dim, L.norm1.g, L.norm1.b, xn16_, lda, nullptr, 0);
     prof_end("layernorm");
   }
   gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
@@ -785,12 +790,12 @@ void Engine::enc_layer(const EncLayer& L, bool first, const float* speech_dev, i
   prof_end("layernorm");
 }
 
-void Engine::encoder(const float* speech_dev, int B, int T) {
+void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
   const int D = mc_.d_model, F = mc_.ffn;
   const int64_t M = (int64_t)B * T;
   const int64_t Mp = round_up(M, 128) + 128;
   PF_CHECK(M < (1ll << 31) / (3 * D), PF_ERR_INVALID_ARG, "batch too large for 32-bit row indexing");
-  build_pe(T);
+  if (!pre_encoded) build_pe(T);
   const int k0 = enc_.empty() ? D : enc_[0].qkv.Kpad;
   // carve the encoder arena
   size_t off = 0;
@@ -816,7 +821,7 @@ void Engine::encoder(const float* speech_dev, int B, int T) {
     if (i + 1 < enc_.size()) { nx.ln = enc_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; }
     else if (has_tp) { nx.ln = enc_after_; nx.n32 = x_; nx.keep_x = false; }     // after_norm output = the tp residual stream
     else { nx.ln = enc_after_; nx.n16 = H16_; nx.n32 = H32_; nx.keep_x = false; }
-    enc_layer(enc_[i], i == 0, speech_dev, B, T, nx);
+    enc_layer(enc_[i], i == 0 ? (pre_encoded ? 2 : 1) : 0, speech_dev, B, T, nx);
   }
   if (has_tp) {
     prof_begin("layernorm", 0);
@@ -826,7 +831,7 @@ void Engine::encoder(const float* speech_dev, int B, int T) {
       EncNext nx;
       if (i + 1 < tp_.size()) { nx.ln = tp_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; }
       else { nx.ln = tp_norm_; nx.n16 = H16_; nx.n32 = H32_; nx.keep_x = false; }
-      enc_layer(tp_[i], false, nullptr, B, T, nx);
+      enc_layer(tp_[i], 0, nullptr, B, T, nx);
     }
   }
 }
@@ -948,6 +953,101 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   prof_end("argmax");
   if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+// ------------------------------------------------------------------ streaming seams -------
+// The two ONNX graphs of the reference's streaming path (AliParaformerAsr/OnlineRecognizer.cs:49-124 EncoderProj,
+// :233-334 DecoderProj; sessions built in OnlineModel.cs:23-31).  Their arithmetic is external (FunASR
+// paraformer-online export) and restated in oracle/online.py — parity unpinned like every model graph here:
+//   encoder: speech [B,Tc,560] (already x sqrt(512) + position-encoded by the caller, OnlineStream.cs:214-221)
+//            -> SAN-M encoder WITHOUT the embed stage -> enc [B,Tc,512]; alphas [B,Tc] = CIF weights (no tail frame)
+//   decoder: enc, acoustic_embeds [B,L,512] (+ lengths), 16 FSMN caches [B,512,10] -> log-probs [B,L,V], new caches;
+//            FSMN memory = conv over cat(cache, x) (no padding), cache_out = its last 10 columns.
+void Engine::online_encoder(const float* speech, int B, int Tc, float* enc_out, float* alphas_out) {
+  PF_CHECK(speech && enc_out && alphas_out && B > 0 && Tc > 0, PF_ERR_INVALID_ARG, "online_encoder: bad arguments");
+  PF_CHECK(mc_.kind != "sensevoicesmall", PF_ERR_UNSUPPORTED, "online_encoder: paraformer models only");
+  PF_HIP(hipSetDevice(device_));
+  const int D = mc_.d_model, M = B * Tc;
+  const size_t n = (size_t)M * mc_.feat_dim;
+  ensure(ws_speech_, n * 4);
+  PF_HIP(hipMemcpyAsync(ws_speech_.p, speech, n * 4, hipMemcpyHostToDevice, stream_));
+  encoder((const float*)ws_speech_.p, B, Tc, true);
+  const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
+  launch_cif_im2col(stream_, H16_, B, Tc, D, mc_.cif_l_order, mc_.cif_r_order, h16_);
+  gemm("gemm_cif", cif_conv_, h16_, taps * D, M, fsm_, D, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+  launch_cif_alpha(stream_, fsm_, B, Tc, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
+  PF_HIP(hipMemcpyAsync(enc_out, H32_, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpy2DAsync(alphas_out, (size_t)Tc * 4, alphas_, (size_t)(Tc + 1) * 4, (size_t)Tc * 4, B, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
+void Engine::online_decoder(const float* enc, int B, int Tc, const float* embeds, int L, const int32_t* embeds_len,
+                            const float* caches_in, float* logits_out, int64_t* ids_out, float* caches_out) {
+  PF_CHECK(enc && embeds && embeds_len && caches_in && ids_out && caches_out && B > 0 && Tc > 0 && L > 0, PF_ERR_INVALID_ARG,
+           "online_decoder: bad arguments");
+  PF_CHECK(mc_.kernel == 11, PF_ERR_UNSUPPORTED, "online_decoder: FSMN kernel 11 (cache of 10 columns) only");
+  PF_HIP(hipSetDevice(device_));
+  const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab, nd = (int)dec_.size(), CW = mc_.kernel - 1;
+  const int M = B * Tc, Md = B * L;
+  const int64_t Mp = round_up(M, 128) + 128, Mdp = round_up(Md, 128) + 128;
+  const int ldV = (int)round_up(V, 4);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_e32 = carve((size_t)M * D * 4), o_e16 = carve((size_t)Mp * D * 2), o_kv = carve((size_t)Mp * std::max(nd, 1) * 2 * D * 2);
+  const size_t o_x = carve((size_t)Mdp * D * 4), o_xn = carve((size_t)Mdp * D * 2), o_h32 = carve((size_t)Mdp * F * 4);
+  const size_t o_h16 = carve((size_t)Mdp * F * 2), o_t = carve((size_t)Mdp * D * 4), o_tn = carve((size_t)Mdp * D * 4);
+  const size_t o_q = carve((size_t)Mdp * D * 2), o_ctx = carve((size_t)Mdp * D * 2), o_lg = carve((size_t)Mdp * ldV * 4);
+  const size_t o_ids = carve((size_t)Md * 8), o_len = carve((size_t)B * 4);
+  const size_t o_ci = carve((size_t)nd * B * D * CW * 4), o_co = carve((size_t)nd * B * D * CW * 4);
+  ensure(ws_dec_, off);
+  char* base = (char*)ws_dec_.p;
+  float* e32 = (float*)(base + o_e32); half_t* e16 = (half_t*)(base + o_e16); half_t* kv16 = (half_t*)(base + o_kv);
+  float* xd = (float*)(base + o_x); half_t* xdn16 = (half_t*)(base + o_xn);
+  float* hd32 = (float*)(base + o_h32); half_t* hd16 = (half_t*)(base + o_h16);
+  float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
+  half_t* qd16 = (half_t*)(base + o_q); half_t* ctxd16 = (half_t*)(base + o_ctx);
+  float* lg = (float*)(base + o_lg); int64_t* ids = (int64_t*)(base + o_ids); int32_t* lens = (int32_t*)(base + o_len);
+  float* ci = (float*)(base + o_ci); float* co = (float*)(base + o_co);
+  PF_HIP(hipMemsetAsync(e16, 0, (size_t)Mp * D * 2, stream_));
+  PF_HIP(hipMemcpyAsync(e32, enc, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
+  launch_f32_to_f16(stream_, e32, M, D, D, e16, D);
+  PF_HIP(hipMemcpyAsync(xd, embeds, (size_t)Md * D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(lens, embeds_len, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(ci, caches_in, (size_t)nd * B * D * CW * 4, hipMemcpyHostToDevice, stream_));
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  const int ldkv = nd * 2 * D;
+  if (nd > 0) gemm("gemm_dec_kv", dec_kv_all_, e16, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
+    gemm("gemm_dec_ffn1", w1, xdn16, D, Md, hd32, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    launch_layernorm(stream_, hd32, Md, F, fn.g, fn.b, hd16, F, nullptr, 0);
+    gemm("gemm_dec_ffn2", w2, hd16, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
+  };
+  for (int i = 0; i < nd; ++i) {
+    const DecLayer& Lr = dec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    launch_fsmn_dec_stream(stream_, tn32, Lr.fsmn_wT, lens, ci + (size_t)i * B * D * CW, B, L, D, mc_.kernel, xd,
+                           co + (size_t)i * B * D * CW);
+    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, xdn16, D, nullptr, 0);
+    gemm("gemm_dec_q", Lr.q, xdn16, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
+    AttnArgs a{};
+    a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
+    a.k = kv16 + (size_t)i * 2 * D; a.v = kv16 + (size_t)i * 2 * D + D;
+    a.k_bstride = a.v_bstride = (int64_t)Tc * ldkv; a.k_rstride = a.v_rstride = ldkv;
+    a.o = ctxd16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
+    a.B = B; a.H = mc_.heads; a.Lq = L; a.Lk = Tc;
+    launch_attention(stream_, a);
+    gemm("gemm_dec_out", Lr.out, ctxd16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
+  }
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
+  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, xdn16, D, nullptr, 0);
+  gemm("gemm_vocab", dec_out_, xdn16, D, Md, lg, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  launch_argmax(stream_, lg, Md, V, ldV, logits_out ? 2 : 1, ids);
+  if (logits_out) PF_HIP(hipMemcpy2DAsync(logits_out, (size_t)V * 4, lg, (size_t)ldV * 4, (size_t)V * 4, Md, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(ids_out, ids, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(caches_out, co, (size_t)nd * B * D * CW * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::set_hotwords(const int32_t* hw, int n) {

@@ -98,6 +98,11 @@ class Engine {
   // SeACo: hotword ids [n, 10] (PadList output, EmbedSeacoModel.cs:70-123) used by the following forwards;
   // n = 0 -> bias_embed [B,0,512]: the bias branch is skipped and the ASR log-probs are returned
   void set_hotwords(const int32_t* hw, int n);
+  // ---- streaming seams (OnlineRecognizer.cs EncoderProj / DecoderProj) ------
+  void online_encoder(const float* speech, int B, int Tc, float* enc_out, float* alphas_out);
+  void online_decoder(const float* enc, int B, int Tc, const float* embeds, int L, const int32_t* embeds_len,
+                      const float* caches_in, float* logits_out, int64_t* ids_out, float* caches_out);
+  int dec_layers() const { return (int)dec_.size(); }
 
   // ---- stand-alone ops (parity tests) -------------------------------------
   void op_lfr_cmvn_pad(const float* const* fbank, const int32_t* t80, int B, int sentinel, float* out,
@@ -145,10 +150,11 @@ class Engine {
   void* dalloc(size_t bytes);
   void ensure(DevBuf& b, size_t bytes);
   void build_pe(int T);
-  void encoder(const float* speech_dev, int B, int T);
+  void encoder(const float* speech_dev, int B, int T, bool pre_encoded = false);
   // the LayerNorm applied to the residual stream right after a layer's FFN-down, and where its results go
   struct EncNext { LNp ln; half_t* n16 = nullptr; float* n32 = nullptr; bool keep_x = true; };
-  void enc_layer(const EncLayer& L, bool first, const float* speech_dev, int B, int T, const EncNext& nx);
+  // first: 0 = not the first layer, 1 = first (x sqrt(d) + position encoding fused into norm1), 2 = first, input already encoded
+  void enc_layer(const EncLayer& L, int first, const float* speech_dev, int B, int T, const EncNext& nx);
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
   void timestamp_head(int B, int T);

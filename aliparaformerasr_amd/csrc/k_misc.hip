@@ -263,6 +263,41 @@ void launch_fsmn_dec(hipStream_t s, const float* tn, const float* wT, const int3
   PF_HIP(hipGetLastError());
 }
 
+// One thread per (utterance, channel): walks the K-1 cached columns and the L new positions.  Tiny by construction
+// (a streaming chunk yields a handful of tokens), so clarity over bandwidth.
+__global__ __launch_bounds__(256) void fsmn_dec_stream_kernel(const float* __restrict__ tn, const float* __restrict__ wT,
+                                                              const int32_t* __restrict__ len, const float* __restrict__ cache_in,
+                                                              int B, int L, int D, int K, float* __restrict__ x,
+                                                              float* __restrict__ cache_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * D) return;
+  const int b = (int)(i / D), c = (int)(i - (int64_t)b * D);
+  const int CW = K - 1, nv = len[b];
+  auto xc = [&](int p) -> float {                       // concatenation [cache | masked new positions]
+    if (p < CW) return cache_in[((int64_t)b * D + c) * CW + p];
+    const int l = p - CW;
+    return l < nv ? tn[((int64_t)b * L + l) * D + c] : 0.f;
+  };
+  for (int l = 0; l < L; ++l) {
+    if (l < nv) {
+      float acc = 0.f;
+      for (int j = 0; j < K; ++j) acc += wT[(int64_t)j * D + c] * xc(l + j);
+      acc += tn[((int64_t)b * L + l) * D + c];
+      x[((int64_t)b * L + l) * D + c] += acc;
+    }
+  }
+  for (int q = 0; q < CW; ++q) cache_out[((int64_t)b * D + c) * CW + q] = xc(L + q);
+}
+
+void launch_fsmn_dec_stream(hipStream_t s, const float* tn, const float* wT, const int32_t* len, const float* cache_in,
+                            int B, int L, int D, int k, float* x, float* cache_out) {
+  const int64_t total = (int64_t)B * D;
+  if (total == 0) return;
+  hipLaunchKernelGGL(fsmn_dec_stream_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tn, wT, len, cache_in,
+                     B, L, D, k, x, cache_out);
+  PF_HIP(hipGetLastError());
+}
+
 void launch_fsmn_f32(hipStream_t s, const float* v, const float* wT, const float* mask, int B, int T, int D,
                      int k, float* y) {
   const int64_t total = (int64_t)B * T * (D / 4);

@@ -95,6 +95,10 @@ void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* w, in
 // decoder FSMN: x[B*L,D] += (dwconv(tn*m) + tn*m)*m ; tn fp32 [B*L,D]; valid l < token_num[b]
 void launch_fsmn_dec(hipStream_t s, const float* tn, const float* w, const int32_t* token_num, int B, int L,
                      int D, int k, float* x);
+// streaming decoder FSMN (FunASR MultiHeadedAttentionSANMDecoder export with a cache): xc = cat(cache_in [B,D,K-1],
+// (tn*m)^T); x[b,l,:] += (sum_j w_j * xc[l+j] + tn[l]*m) * m, m = (l < len[b]); cache_out = last K-1 columns of xc
+void launch_fsmn_dec_stream(hipStream_t s, const float* tn, const float* wT, const int32_t* len, const float* cache_in,
+                            int B, int L, int D, int k, float* x, float* cache_out);
 // generic fp32 FSMN for the stand-alone op (mask [B,T] floats or null)
 void launch_fsmn_f32(hipStream_t s, const float* v, const float* w, const float* mask, int B, int T, int D,
                      int k, float* y);

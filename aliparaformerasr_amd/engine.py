@@ -349,6 +349,29 @@ class Engine:
                                                   ids.ctypes.data_as(C.POINTER(C.c_int64))))
         return (y, ids.reshape(a.shape[:-1])) if store else ids.reshape(a.shape[:-1])
 
+    # ---- streaming seams (include/paraformer_hip.h section 7) ----------------------
+    def online_encoder(self, speech):
+        sp = _f32(speech)
+        B, Tc, _ = sp.shape
+        enc = np.zeros((B, Tc, 512), np.float32)
+        al = np.zeros((B, Tc), np.float32)
+        N.check(self._lib.pf_online_encoder(self._h, _fp(sp), B, Tc, _fp(enc), _fp(al)))
+        return enc, al
+
+    def online_decoder(self, enc, embeds, embeds_len, caches, want_logits=True):
+        enc, emb = _f32(enc), _f32(embeds)
+        B, Tc, _ = enc.shape
+        L = emb.shape[1]
+        ln = np.ascontiguousarray(embeds_len, dtype=np.int32)
+        cin = _f32(np.stack(caches))                       # [n_layers, B, 512, 10]
+        cout = np.zeros_like(cin)
+        ids = np.zeros((B, L), np.int64)
+        logits = np.zeros((B, L, self.vocab), np.float32) if want_logits else None
+        N.check(self._lib.pf_online_decoder(self._h, _fp(enc), B, Tc, _fp(emb), L, ln.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            _fp(cin), cin.shape[0], _fp(logits) if want_logits else None,
+                                            ids.ctypes.data_as(C.POINTER(C.c_int64)), _fp(cout)))
+        return logits, ids, [cout[i] for i in range(cout.shape[0])]
+
     def op_layernorm(self, x, gamma, beta) -> np.ndarray:
         x, g, b = _f32(x), _f32(gamma), _f32(beta)
         D = x.shape[-1]

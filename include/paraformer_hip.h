@@ -345,6 +345,51 @@ int pf_result_num_timestamps(pf_recognizer* r, int32_t i, int32_t* n);
 /* stream.Tokens after Forward (raw ids, OfflineRecognizer.cs:187). */
 int pf_stream_tokens(pf_stream* s, const int64_t** ids, int32_t* n);
 
+/* ------------------------------------------------------------------------ */
+/* 7. Streaming path: the reference's OnlineRecognizer / OnlineStream
+ *    (AliParaformerAsr/OnlineRecognizer.cs:14-542, OnlineStream.cs:7-358).  The chunking, the feature caches,
+ *    DynamicMask and the carried-integrator CIF are host code as in the reference (C++ here); the two ONNX
+ *    sessions (OnlineModel.cs:23-31) are the device seams pf_online_encoder / pf_online_decoder.          */
+/* ------------------------------------------------------------------------ */
+typedef struct pf_online_recognizer pf_online_recognizer;
+typedef struct pf_online_stream pf_online_stream;
+/* new OnlineRecognizer(encoderFilePath, decoderFilePath, configFilePath, mvnFilePath, tokensFilePath, threadsNum)
+   (OnlineRecognizer.cs:22): encoder_path names ONE .pfw container holding both graphs' tensors; decoder_path is
+   accepted and unused; device is the extra argument. */
+int pf_online_recognizer_create(const char* encoder_path, const char* decoder_path, const char* config_path,
+                                const char* mvn_path, const char* tokens_path, int32_t threads_num, int32_t device,
+                                pf_online_recognizer** out);
+void pf_online_recognizer_dispose(pf_online_recognizer* r);
+void pf_online_recognizer_free(pf_online_recognizer* r);
+pf_engine* pf_online_recognizer_engine(pf_online_recognizer* r);
+int pf_online_create_stream(pf_online_recognizer* r, pf_online_stream** out);          /* CreateOnlineStream :27 */
+int pf_online_stream_add_samples(pf_online_stream* s, const float* samples, int64_t n); /* OnlineStream.AddSamples */
+/* GetResults(List<OnlineStream>) (:41-48): one chunk per stream that has 60 fbank frames ready; texts are kept for
+   the calling thread until its next call. */
+int pf_online_get_results(pf_online_recognizer* r, pf_online_stream* const* streams, int32_t n_streams);
+int pf_online_result_text(pf_online_recognizer* r, int32_t i, const char** utf8);
+int pf_online_stream_tokens(pf_online_stream* s, const int64_t** ids, int32_t* n);
+void pf_online_stream_dispose(pf_online_stream* s);
+void pf_online_stream_free(pf_online_stream* s);
+/* Device seams = the two InferenceSession.Run calls (OnlineRecognizer.cs:83, :296).
+   encoder: speech [B,Tc,560] (scaled + position-encoded by the caller) -> enc [B,Tc,512], alphas [B,Tc].
+   decoder: enc, acoustic_embeds [B,L,512] + lengths, in_cache [n_caches][B,512,10] -> log-probs [B,L,V] (optional),
+            last-index arg-max ids [B,L], out_cache [n_caches][B,512,10]. */
+int pf_online_encoder(pf_engine* e, const float* speech, int32_t B, int32_t Tc, float* enc_out, float* alphas_out);
+int pf_online_decoder(pf_engine* e, const float* enc, int32_t B, int32_t Tc, const float* embeds, int32_t L,
+                      const int32_t* embeds_len, const float* caches_in, int32_t n_caches, float* logits_out,
+                      int64_t* ids_out, float* caches_out);
+/* Host pieces exposed for parity tests (pure CPU): OnlineWavFrontend.ApplyLfr (:63-80), SinusoidalPositionEncoder
+   (:152-188, in place), the per-stream CIF of PredictorProj (OnlineRecognizer.cs:152-197), DynamicMask
+   (OnlineModel.cs:141-165, in place), DecodeMulti (:405-437). */
+int pf_host_online_lfr(const float* fbank, int32_t t80, int32_t lfr_m, int32_t lfr_n, float* out, int64_t cap, int32_t* t_lfr);
+int pf_host_online_posenc(float* x, int32_t timesteps, int32_t dim, int32_t start_idx);
+int pf_host_online_dynamic_mask(float* alphas, int32_t n);
+int pf_host_online_cif(const float* hiddens, const float* alphas, int32_t n, int32_t D, float threshold, float* fired,
+                       int32_t fired_cap, int32_t* n_fired, float* carry_alpha, float* carry_hidden);
+int pf_host_online_decode(const char* const* tokens, int32_t n_tokens, const int64_t* ids, int32_t n_ids, char* out,
+                          int32_t cap);
+
 /* Host text stage exposed for parity tests (pure CPU, no device): */
 /* time_stamp_lfr6_onnx (OfflineRecognizer.cs:200-302): returns count of [begin,end] ms pairs
    written to out_pairs (cap pairs), or a negative status (no fire -> PF_ERR_RECOGNITION). */
