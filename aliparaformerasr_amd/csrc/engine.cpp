@@ -48,6 +48,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   PF_CHECK(cfg.math_mode == 0 || cfg.math_mode == 1, PF_ERR_INVALID_ARG, "math_mode must be 0 (f16 MFMA) or 1 (fp32 MFMA)");
   fp32_mode_ = cfg.math_mode == 1;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
+  { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
@@ -866,6 +867,12 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
+  if (lstm_err_) {                                   // the persistent recurrence raises this word when a spin timed out
+    unsigned flag = 0;
+    PF_HIP(hipMemcpy(&flag, lstm_err_, 4, hipMemcpyDeviceToHost));
+    lstm_err_ = nullptr;
+    PF_CHECK(flag == 0, PF_ERR_DEVICE, "timestamp head: the persistent LSTM timed out waiting for a workgroup");
+  }
   if (l_hook_) L = l_hook_(L);                       // shard of a multi-device batch: the batch-wide maximum
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);
@@ -1177,7 +1184,7 @@ void Engine::timestamp_head(int B, int T) {
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
   const size_t o_up = carve((size_t)std::max<int64_t>(Mp * up, M3p) * D * 2), o_xg = carve((size_t)M3p * 8 * D * 4);
   const size_t o_ho = carve((size_t)M3 * 2 * D * 4), o_hs = carve((size_t)4 * B * D * 2), o_cs = carve((size_t)2 * B * D * 4);
-  const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4);
+  const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4), o_sw = carve(256);
   ensure(ws_ts_, off);
   char* base = (char*)ws_ts_.p;
   half_t* up16 = (half_t*)(base + o_up);
@@ -1195,19 +1202,28 @@ void Engine::timestamp_head(int B, int T) {
   PF_HIP(hipMemsetAsync(cs, 0, (size_t)2 * B * D * 4, stream_));
   LstmArgs a{};
   a.whh = ts_whh_; a.xg = xg; a.hstate = hs; a.cstate = cs; a.hout = hout; a.B = B; a.T3 = T3; a.D = D; a.ndir = 2;
-  // the 3T dependent launches are a launch-bound inner loop: captured once per (shape, workspace) into a
-  // hipGraph and replayed (the state memsets above stay outside; every node's arguments are frozen)
-  if (!lstm_graph_exec_ || lstm_graph_key_.xg != xg || lstm_graph_key_.B != B || lstm_graph_key_.T3 != T3) {
-    if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
-    hipGraph_t g = nullptr;
-    PF_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-    for (int s = 0; s < T3; ++s) { a.step = s; launch_lstm_step(stream_, a); }
-    PF_HIP(hipStreamEndCapture(stream_, &g));
-    PF_HIP(hipGraphInstantiate(&lstm_graph_exec_, g, nullptr, nullptr, 0));
-    hipGraphDestroy(g);
-    lstm_graph_key_.xg = xg; lstm_graph_key_.B = B; lstm_graph_key_.T3 = T3;
+  // the recurrence: ONE persistent launch (W_hh resident in registers, h exchanged through write-through stores and
+  // an arrival counter, k_bicif.hip) when every workgroup fits on the device at once; otherwise (B > 64, or
+  // PF_LSTM_STEPS=1) the 3T dependent launches, captured once per (shape, workspace) into a hipGraph and replayed
+  bool persistent = false;
+  if (!lstm_steps_) {
+    unsigned* sw = (unsigned*)(base + o_sw);
+    persistent = launch_lstm_persistent(stream_, a, sw);
+    if (persistent) lstm_err_ = sw + 63;
   }
-  PF_HIP(hipGraphLaunch(lstm_graph_exec_, stream_));
+  if (!persistent) {
+    if (!lstm_graph_exec_ || lstm_graph_key_.xg != xg || lstm_graph_key_.B != B || lstm_graph_key_.T3 != T3) {
+      if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
+      hipGraph_t g = nullptr;
+      PF_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      for (int s = 0; s < T3; ++s) { a.step = s; launch_lstm_step(stream_, a); }
+      PF_HIP(hipStreamEndCapture(stream_, &g));
+      PF_HIP(hipGraphInstantiate(&lstm_graph_exec_, g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+      lstm_graph_key_.xg = xg; lstm_graph_key_.B = B; lstm_graph_key_.T3 = T3;
+    }
+    PF_HIP(hipGraphLaunch(lstm_graph_exec_, stream_));
+  }
   prof_end("lstm");
   prof_begin("ts_misc", 0);
   launch_us_alpha(stream_, hout, M3, 2 * D, ts_out_w_, ts_out_b_, mc_.cif_smooth2, mc_.cif_noise2, al);

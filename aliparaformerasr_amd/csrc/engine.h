@@ -171,7 +171,8 @@ class Engine {
   uint32_t next_dither_seed() { return fc_.dither_seed * 2654435761u + (dither_calls_++) * 40503u; }
   int device_ = 0;
   hipStream_t stream_ = nullptr;
-  bool no_rc_ = false, rc_ffn2_ = false;
+  bool no_rc_ = false, rc_ffn2_ = false, lstm_steps_ = false;
+  unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next host sync)
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   ModelCfg mc_;
   FrontendCfg fc_;

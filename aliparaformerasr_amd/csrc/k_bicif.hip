@@ -13,6 +13,8 @@
 // (x 4 gates = one 32-row MFMA tile of W_hh) for a tile of 32 utterances, its 4 waves split K = 512.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "exact.h"
 #include "kernels.h"
 
@@ -79,6 +81,148 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmArgs a) {
   *cp = c;
   hnext[(size_t)b * D + u] = (half_t)h;
   a.hout[((size_t)b * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + u] = h;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// PERSISTENT recurrence: ONE launch runs all T3 steps.  Same work split as lstm_step_kernel (a workgroup = 8 hidden
+// units x 4 gates x one tile of 32 utterances, its 4 waves split K), but
+//   * the workgroup's W_hh slice (32 rows x 512 x f16 = 32 VGPRs per lane) is loaded ONCE and stays in registers,
+//     the cell state lives in a register;
+//   * h is exchanged between the D/8 workgroups of one (direction, utterance tile) through the global ping-pong
+//     buffer, hand-off per the CDNA guide's recipe R1: 16-byte write-through (sc1) stores of the new h slice, every
+//     storing wave drains vmcnt, ONE lane adds to a monotonic arrival counter; consumers poll that word (relaxed,
+//     bounded spin with s_sleep) and then read h with sc1 loads (L2-served, never this CU's stale L1);
+//   * step s may overwrite the buffer step s-1 read: a workgroup arrives at the step-(s-1) counter only AFTER its
+//     reads of that step, and nobody starts step s before all arrivals — no further ordering is needed.
+// All (D/8) * ndir * tiles workgroups must be resident at once (launcher checks against the CU count); every spin
+// is bounded: on time-out the kernel raises *err and every workgroup leaves.
+// eight 16-byte sc1 loads (offsets 0, 32, .., 224 bytes) issued back to back, ONE wait: the loads and their wait live
+// in one asm statement, so the compiler never sees a destination before the data has landed (CDNA guide §5.7 item 1)
+__device__ __forceinline__ void ld8x16_sc1(const half_t* p, h8v (&v)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %2, %8, off offset:64 sc1\n\t"
+      "global_load_dwordx4 %3, %8, off offset:96 sc1\n\t"
+      "global_load_dwordx4 %4, %8, off offset:128 sc1\n\t"
+      "global_load_dwordx4 %5, %8, off offset:160 sc1\n\t"
+      "global_load_dwordx4 %6, %8, off offset:192 sc1\n\t"
+      "global_load_dwordx4 %7, %8, off offset:224 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p)
+      : "memory");
+}
+__device__ __forceinline__ void st16_sc1(half_t* p, h8v v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(256) void lstm_persistent_kernel(LstmArgs a, unsigned* __restrict__ cnt, unsigned* __restrict__ err) {
+  const int D = a.D;
+  const int ub = blockIdx.x, dir = blockIdx.y, bt = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kg = lane >> 5;
+  const int nub = gridDim.x;                                // producers per (direction, tile)
+  unsigned* my_cnt = cnt + (dir * gridDim.z + bt);
+  __shared__ float red[4][16][64];
+  __shared__ _Float16 hx[32][8];                            // new h slice: [utterance][unit] -> 16-byte rows
+  __shared__ int s_abort;
+
+  // W_hh rows of this lane, K slice of this wave: resident for the whole launch
+  const half_t* wrow = a.whh + ((size_t)dir * 4 * D + (size_t)(r & 3) * D + ub * 8 + (r >> 2)) * D;
+  const int kspan = D / 4;                                  // 128 (D = 512)
+  h8v av[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const h8v*>(wrow + wave * kspan + s * 16 + kg * 8);
+
+  const int bb = min(bt * 32 + r, a.B - 1);                 // utterance whose h row this lane feeds to the MFMA
+  const int b = bt * 32 + r;                                // utterance of this lane's cell
+  const int uq = ub * 8 + 2 * wave + kg;                    // hidden unit of this lane's cell
+  float c = 0.f;
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+
+  for (int step = 0; step < a.T3; ++step) {
+    const int t = dir == 0 ? step : a.T3 - 1 - step;
+    const int pp = step & 1;
+    const half_t* hprev = a.hstate + (size_t)(dir * 2 + pp) * a.B * D;
+    half_t* hnext = a.hstate + (size_t)(dir * 2 + (pp ^ 1)) * a.B * D;
+    // the cell's own inputs do not depend on h: requested before the wait
+    const float* xgp = a.xg + ((size_t)bb * a.T3 + t) * (size_t)(a.ndir * 4 * D) + (size_t)dir * 4 * D + uq;
+    const float xi = xgp[0], xf = xgp[D], xc = xgp[2 * D], xo = xgp[3 * D];
+    if (step > 0) {
+      if (threadIdx.x == 0) {
+        const unsigned want = (unsigned)step * (unsigned)nub;
+        unsigned spins = 0;
+        while (__hip_atomic_load(my_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_abort = 1;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (s_abort) return;
+    }
+    const half_t* hrow = hprev + (size_t)bb * D + wave * kspan + kg * 8;
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    h8v bv[8];
+    // one wait per load measured FASTER than eight loads behind one wait (6.5-6.8 vs 7.8 ms for the 1500 steps, same
+    // session, tools/lstm_ab.sh): 512 waves issuing 8 write-through-coherent loads at once queue behind each other and
+    // behind the pollers.  a.step is free in the persistent form: PF_LSTM_VAR=1 selects the batched form for experiments
+    if (a.step == 1) ld8x16_sc1(hrow, bv);
+    else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        h8v v;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(hrow + s * 16) : "memory");
+        bv[s] = v;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      g[q] = (red[0][4 * wave + q][lane] + red[1][4 * wave + q][lane]) + (red[2][4 * wave + q][lane] + red[3][4 * wave + q][lane]);
+    const float gi = g[0] + xi, gf = g[1] + xf, gg = g[2] + xc, go = g[3] + xo;
+    c = sigmoidf_(gf) * c + sigmoidf_(gi) * tanhf(gg);
+    const float h = sigmoidf_(go) * tanhf(c);
+    hx[r][2 * wave + kg] = (_Float16)h;
+    if (b < a.B) a.hout[((size_t)b * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + uq] = h;
+    __syncthreads();
+    if (wave == 0 && lane < 32 && bt * 32 + lane < a.B)       // 32 x 16 bytes, write-through
+      st16_sc1(hnext + (size_t)(bt * 32 + lane) * D + ub * 8, *reinterpret_cast<const h8v*>(&hx[lane][0]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains (R1)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// returns false when the persistent form cannot be used (grid larger than the device, or D != 512): caller falls
+// back to one launch per step
+bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_words /* >= 64 words, device */) {
+  if (a.D != 512 || (a.ndir != 1 && a.ndir != 2)) return false;
+  const int tiles = cdiv(a.B, 32);
+  const int wgs = (a.D / 8) * a.ndir * tiles;
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  int cus = 0;
+  PF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (wgs > cus || a.ndir * tiles > 60) return false;       // every workgroup must be resident: one per CU at most
+  PF_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
+  LstmArgs b = a;
+  { static int var = -1; if (var < 0) { const char* e = getenv("PF_LSTM_VAR"); var = e ? atoi(e) : 0; } b.step = var; }
+  hipLaunchKernelGGL(lstm_persistent_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(256), 0, s, b, sync_words, sync_words + 63);
+  PF_HIP(hipGetLastError());
+  return true;
 }
 
 void launch_lstm_step(hipStream_t s, const LstmArgs& a) {

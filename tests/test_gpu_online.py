@@ -77,7 +77,8 @@ def test_online_encoder_and_decoder_seams(model):
     for l in range(cfg["dec_layers"]):
         assert np.abs(cout[l] - cout_r[l]).max() < 1e-2
         # the cache is the last 10 columns of [old cache | masked new positions]: zeros behind a short utterance
-        assert (cout[l][2] == caches[l][2]).all()                    # no token: cache unchanged (L = 4 < 10 ... shifted)
+        np.testing.assert_array_equal(cout[l][2][:, :6], caches[l][2][:, 4:])   # no token: shifted by L = 4 ...
+        assert (cout[l][2][:, 6:] == 0).all()                                     # ... and filled with masked zeros
     _, ids2, _ = eng.online_decoder(enc_r, emb, lens, caches, want_logits=False)
     np.testing.assert_array_equal(ids2, ids)
     eng.close()
