@@ -94,7 +94,7 @@ void Engine::release() {
   if (fb_) { fbank_tables_destroy(fb_); fb_ = nullptr; }
   for (void* p : owned_) hipFree(p);
   owned_.clear();
-  DevBuf* bufs[] = {&ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_,
+  DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_,
                     &ws_ts_, &ws_seaco_, &ws_seaco_in_};
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
@@ -311,7 +311,8 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     PF_HIP(hipMemsetAsync(cif_conv_.w, 0, (size_t)npad * cif_conv_.Kpad * 2, stream_));
     launch_f32_to_f16(stream_, tmp, D, taps * D, taps * D, cif_conv_.w, cif_conv_.Kpad);
     PF_HIP(hipStreamSynchronize(stream_));
-    PF_HIP(hipFree(tmp));
+    if (fp32_mode_) { cif_conv_w32_ = tmp; owned_.push_back(tmp); }
+    else PF_HIP(hipFree(tmp));
     cif_conv_.bias = tensor("predictor.conv.bias").dev;
     PF_CHECK(tensor("predictor.conv.bias").numel == D && tensor("predictor.out.weight").numel == D &&
                  tensor("predictor.out.bias").numel == 1,
@@ -403,6 +404,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       PF_CHECK(kvw.numel == (int64_t)2 * D * D && kvbias.numel == 2 * D, PF_ERR_FORMAT, "weights: src.kv shape in " + p);
       launch_f32_to_f16(stream_, kvw.dev, 2 * D, D, D, dec_kv_all_.w + (size_t)i * 2 * D * D, D);
       PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
+      L.kv32.w32 = kvw.dev; L.kv32.bias = kvbias.dev; L.kv32.N = 2 * D; L.kv32.K = D;
       dec_.push_back(L);
     }
   }
@@ -495,6 +497,7 @@ Lin Engine::make_lin(const std::string& prefix, bool bias) {
   L.w = (half_t*)dalloc(npad * L.Kpad * 2);
   PF_HIP(hipMemsetAsync(L.w, 0, npad * L.Kpad * 2, stream_));
   launch_f32_to_f16(stream_, w.dev, L.N, L.K, L.K, L.w, L.Kpad);
+  L.w32 = w.dev;
   if (bias) {
     const Tensor& b = tensor(prefix + ".bias");
     PF_CHECK(b.numel == L.N, PF_ERR_FORMAT, "weights: bias length mismatch for " + prefix);
@@ -1260,6 +1263,7 @@ void Engine::forward_device(const float* speech_dev, int B, int T, bool want_log
   PF_HIP(hipSetDevice(device_));
   PF_CHECK(B > 0 && T > 0, PF_ERR_INVALID_ARG, "forward: empty batch");
   last_logits_ = want_logits;
+  if (fp32_mode_) { forward_fp32(speech_dev, B, T, want_logits); return; }
   encoder(speech_dev, B, T);
   if (mc_.kind == "sensevoicesmall") sensevoice_head(B, T, want_logits);
   else predictor_and_decoder(B, T, want_logits);
@@ -1276,6 +1280,149 @@ void Engine::forward_device(const float* speech_dev, int B, int T, bool want_log
           4 * Ld * D * F + 2 * Ld * D * V;
   }
   last_flops_ = fl * B;
+}
+
+// ------------------------------------------------------------------ fp32 parity mode -------
+// math_mode = 1: the same graph with fp32 activations and fp32 weights on the fp32 matrix path (k_fp32.hip).  Supported
+// for the paraformer and SenseVoice graphs (no BiCIF head, no SeACo branch); one launch per graph node, no fusion.
+enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
+
+void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_dev, int B, int T, float** f) {
+  const int D = mc_.d_model, M = B * T, F = mc_.ffn, Fd = mc_.feat_dim;
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  const int din = first ? Fd : D;
+  if (first) {
+    launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), f[F_T]);
+    launch_layernorm(stream_, f[F_T], M, Fd, L.norm1.g, L.norm1.b, nullptr, 0, f[F_XN], Fd);
+  } else {
+    launch_layernorm(stream_, f[F_X], M, D, L.norm1.g, L.norm1.b, nullptr, 0, f[F_XN], D);
+  }
+  const float* Wq = L.qkv.w32;
+  launch_gemm_f32(stream_, f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
+  launch_gemm_f32(stream_, f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f);
+  launch_gemm_f32(stream_, f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f);
+  launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
+  launch_attention_f32(stream_, f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
+                       (int64_t)T * D, D, B, mc_.heads, T, T);
+  if (first) {
+    launch_gemm_f32(stream_, f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
+  } else {
+    launch_gemm_f32(stream_, f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_T], D, f[F_FS], D, false, 0, 1.f);   // att = lin + fsmn
+    launch_add_f32(stream_, f[F_X], f[F_T], (int64_t)M * D);                                                           // x = x + att
+  }
+  launch_layernorm(stream_, f[F_X], M, D, L.norm2.g, L.norm2.b, nullptr, 0, f[F_XN], D);
+  launch_gemm_f32(stream_, f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f);
+  launch_gemm_f32(stream_, f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f);
+}
+
+void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logits) {
+  PF_CHECK(!mc_.timestamp_head && !mc_.seaco, PF_ERR_UNSUPPORTED,
+           "math_mode 1 (fp32 parity mode) covers the paraformer and SenseVoice graphs, not the BiCIF / SeACo heads");
+  const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab, Fd = mc_.feat_dim, M = B * T, T1 = T + 1;
+  const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
+  build_pe(T);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t W = (size_t)std::max(std::max(Fd, D), taps * D);
+  size_t o_f[F_COUNT];
+  o_f[F_X] = carve((size_t)M * D * 4); o_f[F_XN] = carve((size_t)M * W * 4); o_f[F_Q] = carve((size_t)M * D * 4);
+  o_f[F_K] = carve((size_t)M * D * 4); o_f[F_V] = carve((size_t)M * D * 4); o_f[F_CTX] = carve((size_t)M * D * 4);
+  o_f[F_FS] = carve((size_t)M * D * 4); o_f[F_H] = carve((size_t)M * F * 4); o_f[F_T] = carve((size_t)M * W * 4);
+  const size_t o_H = carve((size_t)M * D * 4), o_al = carve((size_t)B * T1 * 4), o_fc = carve((size_t)B * 4), o_tn = carve((size_t)B * 4);
+  const size_t o_ff = carve((size_t)B * T1 * 4), o_wc = carve((size_t)B * T1 * 4), o_wr = carve((size_t)B * T1 * 4), o_mx = carve(256);
+  ensure(ws_f32_, off);
+  char* base = (char*)ws_f32_.p;
+  float* f[F_COUNT];
+  for (int i = 0; i < F_COUNT; ++i) f[i] = (float*)(base + o_f[i]);
+  H32_ = (float*)(base + o_H); alphas_ = (float*)(base + o_al);
+  plan_.fire_count = (int32_t*)(base + o_fc); plan_.token_num = (int32_t*)(base + o_tn);
+  plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
+  plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
+
+  for (size_t i = 0; i < enc_.size(); ++i) enc_layer_fp32(enc_[i], i == 0, speech_dev, B, T, f);
+  if (tp_.empty()) {
+    launch_layernorm(stream_, f[F_X], M, D, enc_after_.g, enc_after_.b, nullptr, 0, H32_, D);
+  } else {
+    launch_layernorm(stream_, f[F_X], M, D, enc_after_.g, enc_after_.b, nullptr, 0, f[F_X], D);
+    for (size_t i = 0; i < tp_.size(); ++i) enc_layer_fp32(tp_[i], false, nullptr, B, T, f);
+    launch_layernorm(stream_, f[F_X], M, D, tp_norm_.g, tp_norm_.b, nullptr, 0, H32_, D);
+  }
+  const int ldV = (int)round_up(V, 4);
+  last_.peak_len = 0;
+  last_.cif_peak.clear();
+  if (mc_.kind == "sensevoicesmall") {
+    size_t o2 = 0;
+    auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+    const size_t o_lg = c2((size_t)M * ldV * 4), o_ids = c2((size_t)M * 8);
+    ensure(ws_dec_, o2);
+    logits_ = (float*)((char*)ws_dec_.p + o_lg); ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids); logits_ld_ = ldV;
+    launch_gemm_f32(stream_, H32_, D, ctc_.w32, D, ctc_.bias, M, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
+    launch_argmax(stream_, logits_, M, V, ldV, want_logits ? 2 : 1, ids_dev_);
+    last_.B = B; last_.L = T; last_.V = V; last_.T = T;
+    last_.ids.assign((size_t)M, 0);
+    last_.token_num.assign(B, T);
+    last_.fire_count.assign(B, T);
+    PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)M * 8, hipMemcpyDeviceToHost, stream_));
+    last_flops_ = 0;
+    return;
+  }
+  // ---- CIF predictor
+  launch_im2col_f32(stream_, H32_, B, T, D, mc_.cif_l_order, mc_.cif_r_order, f[F_T]);
+  launch_gemm_f32(stream_, f[F_T], taps * D, cif_conv_w32_, taps * D, cif_conv_.bias, M, D, taps * D, f[F_FS], D, nullptr, 0, true, 0, 1.f);
+  launch_cif_alpha(stream_, f[F_FS], B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
+  if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
+  else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
+  int32_t L = 0;
+  last_.fire_count.resize(B);
+  last_.token_num.resize(B);
+  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  if (l_hook_) L = l_hook_(L);
+  last_.B = B; last_.L = L; last_.V = V; last_.T = T;
+  last_.ids.assign((size_t)B * L, 0);
+  last_flops_ = 0;
+  if (L == 0) return;
+  // ---- decoder
+  const int Md = B * L;
+  size_t o2 = 0;
+  auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_x = c2((size_t)Md * D * 4), o_xn = c2((size_t)Md * D * 4), o_h = c2((size_t)Md * F * 4), o_hn = c2((size_t)Md * F * 4);
+  const size_t o_t = c2((size_t)Md * D * 4), o_tn2 = c2((size_t)Md * D * 4), o_q = c2((size_t)Md * D * 4), o_ctx = c2((size_t)Md * D * 4);
+  const size_t o_kv = c2((size_t)M * 2 * D * 4), o_lg = c2((size_t)Md * ldV * 4), o_ids = c2((size_t)Md * 8);
+  ensure(ws_dec_, o2);
+  char* b2 = (char*)ws_dec_.p;
+  float* xd = (float*)(b2 + o_x); float* xn = (float*)(b2 + o_xn); float* hd = (float*)(b2 + o_h); float* hn = (float*)(b2 + o_hn);
+  float* t32 = (float*)(b2 + o_t); float* tn32 = (float*)(b2 + o_tn2); float* qd = (float*)(b2 + o_q); float* cx = (float*)(b2 + o_ctx);
+  float* kv = (float*)(b2 + o_kv);
+  logits_ = (float*)(b2 + o_lg); ids_dev_ = (int64_t*)(b2 + o_ids); logits_ld_ = ldV;
+  if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
+  else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, nullptr, 0, xn, D);
+    launch_gemm_f32(stream_, xn, D, w1.w32, D, w1.bias, Md, F, D, hd, F, nullptr, 0, true, 0, 1.f);
+    launch_layernorm(stream_, hd, Md, F, fn.g, fn.b, nullptr, 0, hn, F);
+    launch_gemm_f32(stream_, hn, F, w2.w32, F, nullptr, Md, D, F, t32, D, nullptr, 0, false, 0, 1.f);
+  };
+  for (size_t i = 0; i < dec_.size(); ++i) {
+    const DecLayer& Lr = dec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
+    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
+    launch_gemm_f32(stream_, xn, D, Lr.q.w32, D, Lr.q.bias, Md, D, D, qd, D, nullptr, 0, false, D, qscale);
+    launch_gemm_f32(stream_, H32_, D, Lr.kv32.w32, D, Lr.kv32.bias, M, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
+    launch_attention_f32(stream_, qd, (int64_t)L * D, D, kv, (int64_t)T * 2 * D, 2 * D, kv + D, (int64_t)T * 2 * D, 2 * D, cx,
+                         (int64_t)L * D, D, B, mc_.heads, L, T);
+    launch_gemm_f32(stream_, cx, D, Lr.out.w32, D, Lr.out.bias, Md, D, D, xd, D, xd, D, false, 0, 1.f);
+  }
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
+  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
+  launch_gemm_f32(stream_, xn, D, dec_out_.w32, D, dec_out_.bias, Md, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
+  launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
+  PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
 }
 
 void Engine::forward_feats_host(const float* speech, int B, int T, bool want_logits) {

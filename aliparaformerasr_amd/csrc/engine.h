@@ -40,10 +40,11 @@ struct Lin {          // y = x W^T + b ; W stored f16 [Npad][Kpad]
   half_t* w = nullptr;
   const float* bias = nullptr;
   int N = 0, K = 0, Kpad = 0;
+  const float* w32 = nullptr;         // the fp32 tensor [N][K] as stored in the container (fp32 parity mode)
 };
 struct LNp { const float* g = nullptr; const float* b = nullptr; int D = 0; };
 struct EncLayer { LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512; };
-struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out; float* fsmn_wT = nullptr; };
+struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
 
 struct DevBuf {       // grow-only device allocation
   void* p = nullptr;
@@ -157,6 +158,8 @@ class Engine {
   void enc_layer(const EncLayer& L, int first, const float* speech_dev, int B, int T, const EncNext& nx);
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
+  void forward_fp32(const float* speech_dev, int B, int T, bool want_logits);   // math_mode 1 (k_fp32.hip)
+  void enc_layer_fp32(const EncLayer& L, bool first, const float* speech_dev, int B, int T, float** bufs);
   void timestamp_head(int B, int T);
   void seaco_head(int B, int L, const float* e0, const float* hid32, bool want_logits);
   void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
@@ -211,6 +214,8 @@ class Engine {
   int cmvn_dim_ = 0;
 
   // workspace
+  DevBuf ws_f32_;
+  float* cif_conv_w32_ = nullptr;    // fp32 mode: the CIF conv as a [D][taps*D] GEMM operand
   DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
   int pe_T_ = 0;
   // encoder views (valid after encoder())

@@ -1,0 +1,161 @@
+// k_fp32.hip — the fp32 PARITY mode (pf_engine_config.math_mode = 1; SURVEY.md §7 "hard parts", §8c plan): every
+// product of the graph InferenceSession.Run executes (AliParaformerAsr/OfflineProjOfParaformer.cs:68) is formed from
+// fp32 operands on the fp32 matrix path — v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation, bit-for-bit an
+// fmaf chain in k order (MI355X guide §3) — so the only differences left against an fp32 CPU run of the same graph are
+// accumulation order.  1/16 of the f16 MFMA rate by construction and deliberately simple (LDS-staged 64 x 64 tiles, no
+// software pipelining): this mode exists to check token identity against fp32 references, not to be benchmarked.
+#include "kernels.h"
+#include "exact.h"
+
+namespace pf {
+
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+struct G32Dev {
+  const float* A; const float* W; const float* bias; const float* resid; float* out;
+  int lda, ldw, ldr, ldc, M, N, K, relu, scale_cols;
+  float scale;
+};
+
+// C[M,N] = A[M,K] W[N,K]^T (+ bias) (* scale on columns < scale_cols) (+ resid) (ReLU).  64 x 64 tile per 256-thread
+// workgroup, wave w owns the 32 x 32 block (w >> 1, w & 1); K in steps of 32 staged through LDS (rows padded to 33).
+__global__ __launch_bounds__(256) void gemm_f32_kernel(G32Dev p) {
+  __shared__ float As[64][33], Ws[64][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  f16x acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+    for (int e = tid; e < 64 * 32; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      const int m = m0 + r, n = n0 + r, k = k0 + c;
+      As[r][c] = (m < p.M && k < p.K) ? p.A[(size_t)m * p.lda + k] : 0.f;
+      Ws[r][c] = (n < p.N && k < p.K) ? p.W[(size_t)n * p.ldw + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = As[wr + (lane & 31)][kk + (lane >> 5)];
+      const float b = Ws[wc + (lane & 31)][kk + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wc + (lane & 31);
+  if (n >= p.N) return;
+  const float bv = p.bias ? p.bias[n] : 0.f;
+  const float sc = n < p.scale_cols ? p.scale : 1.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + wr + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    if (m >= p.M) continue;
+    float v = (acc[reg] + bv) * sc;
+    if (p.resid) v += p.resid[(size_t)m * p.ldr + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.out[(size_t)m * p.ldc + n] = v;
+  }
+}
+
+void launch_gemm_f32(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
+                     float* out, int ldc, const float* resid, int ldr, bool relu, int scale_cols, float scale) {
+  if (M <= 0 || N <= 0) return;
+  G32Dev d{A, W, bias, resid, out, lda, ldw, ldr, ldc, M, N, K, relu ? 1 : 0, scale_cols, scale_cols > 0 ? scale : 1.f};
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64)), dim3(256), 0, s, d);
+  PF_HIP(hipGetLastError());
+}
+
+// softmax(q k^T) v for one (query, head) per workgroup, head dim 128, q pre-scaled; element strides as AttnArgs.
+__global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__ q, int64_t q_bs, int q_rs, const float* __restrict__ k,
+                                                       int64_t k_bs, int k_rs, const float* __restrict__ v, int64_t v_bs, int v_rs,
+                                                       float* __restrict__ o, int64_t o_bs, int o_rs, int H, int Lq, int Lk) {
+  extern __shared__ float sm[];                    // [128] q row, [Lk] scores, [4] reductions
+  float* qs = sm; float* sc = sm + 128; float* red = sm + 128 + Lk;
+  const int iq = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H, tid = threadIdx.x;
+  qs[tid] = q[(size_t)b * q_bs + (size_t)iq * q_rs + h * 128 + tid];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = tid; j < Lk; j += 128) {
+    const float* kr = k + (size_t)b * k_bs + (size_t)j * k_rs + h * 128;
+    float s = 0.f;
+    for (int d = 0; d < 128; ++d) s += qs[d] * kr[d];
+    sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(red[0], red[1]);
+  float sum = 0.f;
+  for (int j = tid; j < Lk; j += 128) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[2 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[2] + red[3]);
+  const float* vc = v + (size_t)b * v_bs + h * 128 + tid;
+  float acc = 0.f;
+  for (int j = 0; j < Lk; ++j) acc += (sc[j] * inv) * vc[(size_t)j * v_rs];
+  o[(size_t)b * o_bs + (size_t)iq * o_rs + h * 128 + tid] = acc;
+}
+
+void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
+                          const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk) {
+  if (B == 0 || Lq == 0 || Lk == 0) return;
+  PF_CHECK((size_t)(128 + Lk + 4) * 4 <= 64 * 1024, PF_ERR_UNSUPPORTED, "fp32 mode: more than ~16000 keys per utterance");
+  hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)Lq, (unsigned)(B * H)), dim3(128), (size_t)(128 + Lk + 4) * 4, s, q, q_bs, q_rs,
+                     k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
+  PF_HIP(hipGetLastError());
+}
+
+// im2col of the CIF conv on fp32 rows: out[(b,t), j*D + c] = H[b, t+j-l, c] (0 outside the utterance)
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const float* __restrict__ Hm, int B, int T, int D, int l_order, int taps,
+                                                         float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * taps * D;
+  if (i >= total) return;
+  const int c = (int)(i % D);
+  int64_t r = i / D;
+  const int j = (int)(r % taps);
+  const int64_t row = r / taps;
+  const int t = (int)(row % T), tt = t + j - l_order;
+  out[i] = (tt >= 0 && tt < T) ? Hm[(row + (j - l_order)) * (int64_t)D + c] : 0.f;
+}
+
+void launch_im2col_f32(hipStream_t s, const float* Hm, int B, int T, int D, int l_order, int r_order, float* out) {
+  const int taps = l_order + r_order + 1;
+  const int64_t total = (int64_t)B * T * taps * D;
+  if (total == 0) return;
+  hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Hm, B, T, D, l_order, taps, out);
+  PF_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ x, const float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += y[i];
+}
+void launch_add_f32(hipStream_t s, float* x, const float* y, int64_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+  PF_HIP(hipGetLastError());
+}
+
+// x*sqrt(d_model) + PE (two roundings, as the Mul and Add nodes) -> fp32 rows (the fp32 mode keeps the embed stage apart)
+__global__ __launch_bounds__(256) void posenc_f32_kernel(const float* __restrict__ x, const float* __restrict__ pe, int64_t rows, int T,
+                                                         int F, float xscale, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * F) return;
+  const int64_t row = i / F;
+  const int c = (int)(i - row * F);
+  out[i] = add_rn(mul_rn(x[i], xscale), pe[(row % T) * (int64_t)F + c]);   // no contraction to an FMA: pad rows sit at |x| ~ 1.7e7
+}
+
+void launch_posenc_f32(hipStream_t s, const float* x, const float* pe, int B, int T, int F, float xscale, float* out) {
+  const int64_t n = (int64_t)B * T * F;
+  if (n == 0) return;
+  hipLaunchKernelGGL(posenc_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, pe, (int64_t)B * T, T, F, xscale, out);
+  PF_HIP(hipGetLastError());
+}
+
+}  // namespace pf
