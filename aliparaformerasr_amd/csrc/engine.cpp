@@ -49,6 +49,8 @@ Engine::Engine(const pf_engine_config& cfg) {
   fp32_mode_ = cfg.math_mode == 1;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
+  { const char* e = getenv("PF_DEC_FUSE"); if (e && e[0]) dec_fuse_ = atoi(e) & 7; }
+  { const char* e = getenv("PF_DEC_H32"); dec_h32_ = e && e[0] == '1'; }   // A/B switch for tools/: decoder launch fusions
   { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
@@ -841,6 +843,26 @@ void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
 }
 
 // ------------------------------------------------------------------ CIF + decoder ---------
+// FFN-up of a decoder block and the LayerNorm(F) behind it: leaves the normalised hidden in h16.  FFN-up writes the
+// hidden as f16 (ReLU output, one rounding — the oracle's 16-bit mode rounds at the same point) and the LayerNorm runs
+// in place on it: 40 -> 18 us for the GEMM (no fp32 row-segment epilogue) and a third of the LayerNorm's bytes at
+// M = 5344.  PF_DEC_H32=1 keeps the fp32 round trip (h32 must then be non-null).
+void Engine::dec_ffn_hidden(const char* cls, const Lin& w1, const LNp& fn, const half_t* xn16, int lda, int rows, float* h32,
+                            half_t* h16) {
+  const int F = w1.N;
+  if (dec_h32_ && h32) {
+    gemm(cls, w1, xn16, lda, rows, h32, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, h32, rows, F, fn.g, fn.b, h16, F, nullptr, 0);
+    prof_end("layernorm");
+  } else {
+    gemm(cls, w1, xn16, lda, rows, nullptr, 0, h16, F, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm_f16(stream_, h16, rows, F, fn.g, fn.b, h16);
+    prof_end("layernorm");
+  }
+}
+
 void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab;
   const int M = B * T, T1 = T + 1;
@@ -917,29 +939,56 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   if (nd > 0)
     gemm("gemm_dec_kv", dec_kv_all_, H16_, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
 
-  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
-    prof_end("layernorm");
-    gemm("gemm_dec_ffn1", w1, xdn16, D, Md, hd32, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, hd32, Md, F, fn.g, fn.b, hd16, F, nullptr, 0);
-    prof_end("layernorm");
-    gemm("gemm_dec_ffn2", w2, hd16, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
+  // Decoder layer = 9 launches: norm1 | FFN-up (f16 hidden) | LayerNorm(2048) in place | FFN-down | norm2 | FSMN memory +
+  // norm3 (one kernel, dec_fuse_ bit 1) | q | cross attention | out-projection + residual.  The row-complete GEMM can
+  // take norm2 (bit 4) and the next block's norm1 (bit 2) as epilogues, but at M = B*L = 5344 it runs on 84 CUs only:
+  // measured 47 vs 29.5 + 5.6 us (FFN-down) and 21 vs 16 + 5.6 us (out-projection), so both stay off (PF_DEC_FUSE=7
+  // enables them for experiments).
+  const bool f_fsmn = (dec_fuse_ & 1) != 0, f_out = (dec_fuse_ & 2) != 0, f_ffn2 = (dec_fuse_ & 4) != 0;
+  bool have_n1 = false;                                // xdn16 already holds norm1(xd) of the coming block
+  // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or
+  // post(t) in n32 / n16
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const LNp& post, float* n32, half_t* n16) {
+    if (!have_n1) {
+      prof_begin("layernorm", 0);
+      launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
+      prof_end("layernorm");
+    }
+    have_n1 = false;
+    dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn16, D, Md, hd32, hd16);
+    if (f_ffn2) {
+      GemmRcArgs g{};
+      g.A = hd16; g.lda = F; g.W = w2.w; g.ldw = w2.Kpad; g.bias = nullptr; g.M = Md; g.K = w2.Kpad;
+      g.ln_g = post.g; g.ln_b = post.b; g.eps = 1e-12f;
+      g.out_n32 = n32; g.ldn32 = D; g.out_n16 = n16; g.ldn16 = D;
+      prof_begin("gemm_dec_ffn2", 2.0 * Md * (double)D * F);
+      launch_gemm_rc(stream_, g);
+      prof_end("gemm_dec_ffn2");
+    } else {
+      gemm("gemm_dec_ffn2", w2, hd16, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
+      prof_begin("layernorm", 0);
+      launch_layernorm(stream_, t32, Md, D, post.g, post.b, n16, D, n32, n32 ? D : 0);
+      prof_end("layernorm");
+    }
   };
 
   for (int i = 0; i < nd; ++i) {
     const DecLayer& Lr = dec_[i];
-    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
-    prof_end("layernorm");
-    prof_begin("fsmn", 0);
-    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
-    prof_end("fsmn");
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, xdn16, D, nullptr, 0);
-    prof_end("layernorm");
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2, Lr.norm2, tn32, nullptr);
+    bool fused = false;
+    if (f_fsmn) {
+      prof_begin("fsmn", 0);
+      fused = launch_fsmn_dec_ln(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd, Lr.norm3.g, Lr.norm3.b, xdn16);
+      prof_end("fsmn");
+    }
+    if (!fused) {
+      prof_begin("fsmn", 0);
+      launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
+      prof_end("fsmn");
+      prof_begin("layernorm", 0);
+      launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, xdn16, D, nullptr, 0);
+      prof_end("layernorm");
+    }
     gemm("gemm_dec_q", Lr.q, xdn16, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
     AttnArgs a{};
     a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
@@ -950,12 +999,21 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
     prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
     launch_attention(stream_, a);
     prof_end("attn_cross");
-    gemm("gemm_dec_out", Lr.out, ctxd16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
+    if (f_out) {
+      const LNp& nxt = i + 1 < nd ? dec_[i + 1].norm1 : dec_final_norm1_;
+      GemmRcArgs g{};
+      g.A = ctxd16; g.lda = D; g.W = Lr.out.w; g.ldw = Lr.out.Kpad; g.bias = Lr.out.bias; g.M = Md; g.K = Lr.out.Kpad;
+      g.resid = xd; g.ldr = D; g.out_x = xd; g.ldx = D;
+      g.ln_g = nxt.g; g.ln_b = nxt.b; g.eps = 1e-12f; g.out_n16 = xdn16; g.ldn16 = D;
+      prof_begin("gemm_dec_out", 2.0 * Md * (double)D * D);
+      launch_gemm_rc(stream_, g);
+      prof_end("gemm_dec_out");
+      have_n1 = true;
+    } else {
+      gemm("gemm_dec_out", Lr.out, ctxd16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
+    }
   }
-  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
-  prof_begin("layernorm", 0);
-  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, xdn16, D, hid32, hid32 ? D : 0);
-  prof_end("layernorm");
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_, dec_after_, hid32, xdn16);
   logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
   gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
@@ -1029,8 +1087,7 @@ void Engine::online_decoder(const float* enc, int B, int Tc, const float* embeds
   if (nd > 0) gemm("gemm_dec_kv", dec_kv_all_, e16, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
     launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
-    gemm("gemm_dec_ffn1", w1, xdn16, D, Md, hd32, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
-    launch_layernorm(stream_, hd32, Md, F, fn.g, fn.b, hd16, F, nullptr, 0);
+    dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn16, D, Md, hd32, hd16);
     gemm("gemm_dec_ffn2", w2, hd16, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
   };
   for (int i = 0; i < nd; ++i) {
@@ -1132,10 +1189,7 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
     prof_begin("layernorm", 0);
     launch_layernorm(stream_, xs, R, D, n1.g, n1.b, xn16, D, nullptr, 0);
     prof_end("layernorm");
-    gemm("gemm_seaco", w1, xn16, D, R, h32, Fs, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, h32, R, Fs, fn.g, fn.b, h16, Fs, nullptr, 0);
-    prof_end("layernorm");
+    dec_ffn_hidden("gemm_seaco", w1, fn, xn16, D, R, h32, h16);
     gemm("gemm_seaco", w2, h16, Fs, R, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
   };
   for (int i = 0; i < ns; ++i) {

@@ -138,6 +138,171 @@ void launch_posenc_ln_tab(hipStream_t s, const float* speech, int B, int T, int 
   ln_dispatch<true>(s, speech, (int64_t)B * T, F, gamma, beta, out, ldo, nullptr, 0, pe, T, xscale);
 }
 
+// LayerNorm of an f16 row (the decoder's FFN hidden, D = 2048: written by FFN-up as f16, normalised in place) -> f16.
+// NV = 8-element slots per lane; statistics in fp32, shifted two-pass as above.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const half_t* __restrict__ x, int64_t rows, int D,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            half_t* __restrict__ out) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int no = D >> 3;
+  const h8* xr = reinterpret_cast<const h8*>(x + row * (int64_t)D);
+  float v[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + 64 * i;
+    h8 t = {};
+    if (o < no) t = xr[o];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[i][e] = (float)t[e];
+  }
+  const float x0 = __shfl(v[0][0], 0, 64);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (lane + 64 * i < no) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] -= x0;       // exact: both operands are f16 values
+      s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (lane + 64 * i < no) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] -= mean; ss += v[i][e] * v[i][e]; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + LN_EPS);
+  h8* orow = reinterpret_cast<h8*>(out + row * (int64_t)D);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int o = lane + 64 * i;
+    if (o < no) {
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + 8 * o), gb = *reinterpret_cast<const float4*>(gamma + 8 * o + 4);
+      const float4 ba = *reinterpret_cast<const float4*>(beta + 8 * o), bb = *reinterpret_cast<const float4*>(beta + 8 * o + 4);
+      h8 y;
+      y[0] = (half_t)(v[i][0] * rstd * ga.x + ba.x); y[1] = (half_t)(v[i][1] * rstd * ga.y + ba.y);
+      y[2] = (half_t)(v[i][2] * rstd * ga.z + ba.z); y[3] = (half_t)(v[i][3] * rstd * ga.w + ba.w);
+      y[4] = (half_t)(v[i][4] * rstd * gb.x + bb.x); y[5] = (half_t)(v[i][5] * rstd * gb.y + bb.y);
+      y[6] = (half_t)(v[i][6] * rstd * gb.z + bb.z); y[7] = (half_t)(v[i][7] * rstd * gb.w + bb.w);
+      orow[o] = y;
+    }
+  }
+}
+
+void launch_layernorm_f16(hipStream_t s, const half_t* x, int64_t rows, int D, const float* gamma, const float* beta, half_t* out) {
+  PF_CHECK(D % 8 == 0 && D <= 64 * 8 * 4, PF_ERR_INVALID_ARG, "layernorm_f16: unsupported width");
+  if (rows == 0) return;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const int nv = (D / 8 + 63) / 64;
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_f16_kernel<1>, grid, block, 0, s, x, rows, D, gamma, beta, out); break;
+    case 2: hipLaunchKernelGGL(layernorm_f16_kernel<2>, grid, block, 0, s, x, rows, D, gamma, beta, out); break;
+    case 3: hipLaunchKernelGGL(layernorm_f16_kernel<3>, grid, block, 0, s, x, rows, D, gamma, beta, out); break;
+    default: hipLaunchKernelGGL(layernorm_f16_kernel<4>, grid, block, 0, s, x, rows, D, gamma, beta, out); break;
+  }
+  PF_HIP(hipGetLastError());
+}
+
+// Decoder FSMN memory + the LayerNorm that follows it (decoder layer: norm2 -> FSMN -> +x -> norm3), D = 512:
+//   x[b,l,:] += (sum_j w_j * tn[l+j-left] * m + tn[l] * m) * m_l,  m = (l < token_num[b]);   xn16 = LN(x)  (every row)
+// One wave per FDL_ROWS consecutive positions of one utterance; a lane owns columns 4*lane..+3 and 256+4*lane..+3, the
+// K-1 halo rows are read once per FDL_ROWS outputs (register sliding window, as fsmn_dec_kernel), and the row
+// statistics are the shifted two-pass form of layernorm_kernel.  Saves one launch and one fp32 read of x per layer.
+constexpr int FDL_ROWS = 4;
+template <int K>
+__global__ __launch_bounds__(256) void fsmn_dec_ln_kernel(const float* __restrict__ tn, const float* __restrict__ wT,
+                                                          const int32_t* __restrict__ token_num, int B, int L,
+                                                          float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, half_t* __restrict__ out16) {
+  constexpr int D = 512, left = (K - 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int tb = (L + FDL_ROWS - 1) / FDL_ROWS;
+  const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wv >= (int64_t)B * tb) return;
+  const int b = (int)(wv / tb), t0 = (int)(wv - (int64_t)b * tb) * FDL_ROWS;
+  const int nvalid = token_num[b];
+  const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+  const float* vb = tn + (int64_t)b * L * D;
+  float4 acc[FDL_ROWS][2];
+#pragma unroll
+  for (int q = 0; q < FDL_ROWS; ++q) acc[q][0] = acc[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t0 < nvalid) {                                  // a block of masked outputs adds nothing
+    float4 w[K][2];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      w[j][0] = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c0);
+      w[j][1] = *reinterpret_cast<const float4*>(wT + (int64_t)j * D + c1);
+    }
+#pragma unroll
+    for (int s = 0; s < FDL_ROWS + K - 1; ++s) {
+      const int tt = t0 - left + s;
+      if (tt < 0 || tt >= L || tt >= nvalid) continue;
+      const float4 xa = *reinterpret_cast<const float4*>(vb + (int64_t)tt * D + c0);
+      const float4 xb = *reinterpret_cast<const float4*>(vb + (int64_t)tt * D + c1);
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int q = s - j;
+        if (q >= 0 && q < FDL_ROWS) {
+          acc[q][0].x += w[j][0].x * xa.x; acc[q][0].y += w[j][0].y * xa.y; acc[q][0].z += w[j][0].z * xa.z; acc[q][0].w += w[j][0].w * xa.w;
+          acc[q][1].x += w[j][1].x * xb.x; acc[q][1].y += w[j][1].y * xb.y; acc[q][1].z += w[j][1].z * xb.z; acc[q][1].w += w[j][1].w * xb.w;
+        }
+      }
+      const int q0 = s - left;
+      if (q0 >= 0 && q0 < FDL_ROWS) {
+        acc[q0][0].x += xa.x; acc[q0][0].y += xa.y; acc[q0][0].z += xa.z; acc[q0][0].w += xa.w;
+        acc[q0][1].x += xb.x; acc[q0][1].y += xb.y; acc[q0][1].z += xb.z; acc[q0][1].w += xb.w;
+      }
+    }
+  }
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c1);
+  const float4 e0 = *reinterpret_cast<const float4*>(beta + c0), e1 = *reinterpret_cast<const float4*>(beta + c1);
+#pragma unroll
+  for (int q = 0; q < FDL_ROWS; ++q) {
+    const int l = t0 + q;
+    if (l >= L) break;
+    float* xr = x + ((int64_t)b * L + l) * D;
+    float4 a = *reinterpret_cast<const float4*>(xr + c0), c = *reinterpret_cast<const float4*>(xr + c1);
+    if (l < nvalid) {
+      a = make_float4(a.x + acc[q][0].x, a.y + acc[q][0].y, a.z + acc[q][0].z, a.w + acc[q][0].w);
+      c = make_float4(c.x + acc[q][1].x, c.y + acc[q][1].y, c.z + acc[q][1].z, c.w + acc[q][1].w);
+      *reinterpret_cast<float4*>(xr + c0) = a;
+      *reinterpret_cast<float4*>(xr + c1) = c;
+    }
+    const float x0 = __shfl(a.x, 0, 64);
+    a.x = sub_rn(a.x, x0); a.y = sub_rn(a.y, x0); a.z = sub_rn(a.z, x0); a.w = sub_rn(a.w, x0);
+    c.x = sub_rn(c.x, x0); c.y = sub_rn(c.y, x0); c.z = sub_rn(c.z, x0); c.w = sub_rn(c.w, x0);
+    const float mean = wave_sum(((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w))) / (float)D;
+    a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; c.x -= mean; c.y -= mean; c.z -= mean; c.w -= mean;
+    const float var = wave_sum(((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w))) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    half_t* orow = out16 + ((int64_t)b * L + l) * D;
+    *reinterpret_cast<h4*>(orow + c0) = h4{(half_t)(a.x * rstd * g0.x + e0.x), (half_t)(a.y * rstd * g0.y + e0.y),
+                                           (half_t)(a.z * rstd * g0.z + e0.z), (half_t)(a.w * rstd * g0.w + e0.w)};
+    *reinterpret_cast<h4*>(orow + c1) = h4{(half_t)(c.x * rstd * g1.x + e1.x), (half_t)(c.y * rstd * g1.y + e1.y),
+                                           (half_t)(c.z * rstd * g1.z + e1.z), (half_t)(c.w * rstd * g1.w + e1.w)};
+  }
+}
+
+bool launch_fsmn_dec_ln(hipStream_t s, const float* tn, const float* wT, const int32_t* token_num, int B, int L, int D, int k,
+                        float* x, const float* gamma, const float* beta, half_t* out16) {
+  if (D != 512 || (k != 11 && k != 21)) return false;          // other geometries: the two separate kernels
+  const int64_t waves = (int64_t)B * ((L + FDL_ROWS - 1) / FDL_ROWS);
+  if (waves == 0) return true;
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (k == 11) hipLaunchKernelGGL(fsmn_dec_ln_kernel<11>, grid, block, 0, s, tn, wT, token_num, B, L, x, gamma, beta, out16);
+  else hipLaunchKernelGGL(fsmn_dec_ln_kernel<21>, grid, block, 0, s, tn, wT, token_num, B, L, x, gamma, beta, out16);
+  PF_HIP(hipGetLastError());
+  return true;
+}
+
 // fp32 -> f16 row copy (used for operands that arrive as fp32: stand-alone ops, CIF embeds)
 __global__ void f32_to_f16_kernel(const float* __restrict__ x, int64_t rows, int cols, int ldx,
                                   half_t* __restrict__ y, int ldy) {

@@ -104,6 +104,11 @@ void launch_fsmn_enc(hipStream_t s, const half_t* v, int ldv, const float* w, in
 // decoder FSMN: x[B*L,D] += (dwconv(tn*m) + tn*m)*m ; tn fp32 [B*L,D]; valid l < token_num[b]
 void launch_fsmn_dec(hipStream_t s, const float* tn, const float* w, const int32_t* token_num, int B, int L,
                      int D, int k, float* x);
+// LayerNorm of f16 rows -> f16 (may run in place); D % 8 == 0, D <= 2048
+void launch_layernorm_f16(hipStream_t s, const half_t* x, int64_t rows, int D, const float* gamma, const float* beta, half_t* out);
+// the same followed by LayerNorm(x) -> f16 (norm3): one launch; false = geometry not covered (D != 512 or k not 11/21)
+bool launch_fsmn_dec_ln(hipStream_t s, const float* tn, const float* w, const int32_t* token_num, int B, int L, int D, int k,
+                        float* x, const float* gamma, const float* beta, half_t* out16);
 // streaming decoder FSMN (FunASR MultiHeadedAttentionSANMDecoder export with a cache): xc = cat(cache_in [B,D,K-1],
 // (tn*m)^T); x[b,l,:] += (sum_j w_j * xc[l+j] + tn[l]*m) * m, m = (l < len[b]); cache_out = last K-1 columns of xc
 void launch_fsmn_dec_stream(hipStream_t s, const float* tn, const float* wT, const int32_t* len, const float* cache_in,

@@ -366,7 +366,7 @@ class Oracle:
 
     # -- decoder -----------------------------------------------------------
     def ffn_dec(self, x, p):
-        h = torch.relu(self.lin(x, p + ".ffn.w1"))
+        h = self.q(torch.relu(self.lin(x, p + ".ffn.w1")))     # 16-bit modes: the engine stores this hidden as f16
         h = self.ln(h, p + ".ffn.norm")
         return self.lin(h, p + ".ffn.w2", bias=False)
 

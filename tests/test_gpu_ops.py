@@ -266,7 +266,7 @@ def test_cif_cumsum_variant_bit_exact_and_end_to_end():
         np.testing.assert_array_equal(tn, tnr)
         np.testing.assert_array_equal(E, Er)
         El, _, _ = om.Oracle.cif_fire(H, a, 1.0)
-        if El.shape == Er.shape:
+        if El.shape == Er.shape and El.size:
             assert np.abs(El - Er).max() < 1e-4                  # the two exports agree mathematically ...
             differs += int((El != Er).any())
     assert differs > 0                                           # ... and round differently
