@@ -72,6 +72,8 @@ Engine::Engine(const pf_engine_config& cfg) {
     load_weights(cfg);
     mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
     fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
+    // split partials of the short-input GEMM (k_gemm_small.hip): one per engine = one per stream
+    small_ws_ = (float*)dalloc(gemm_small_ws_bytes());
     if (!shift.empty()) {
       cmvn_dim_ = (int)shift.size();
       cmvn_shift_ = (float*)dalloc(sizeof(float) * cmvn_dim_);
@@ -585,6 +587,7 @@ void Engine::gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M
   g.relu = relu ? 1 : 0; g.scale_cols = scale_cols; g.scale = scale;
   g.out_padded = 1;   // every pipeline buffer is carved with round_up(rows,128)+128 rows
   g.out_blocked = blocked == 1; g.a_blocked = blocked == 2;
+  g.small_ws = small_ws_;
   prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   launch_gemm(stream_, g);
   prof_end(cls);
@@ -753,7 +756,10 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   prof_begin("attn_self", 4.0 * B * (double)T * T * D);
   launch_attention(stream_, a);
   prof_end("attn_self");
-  const bool rc = mc_.kernel == 11 && T >= 8 && !no_rc_;
+  // short inputs: every GEMM goes to the split-K kernel (k_gemm_small.hip), which has no row-complete epilogue and no
+  // blocked layout — the unfused FSMN / LayerNorm kernels run instead (4-5 us each at this size)
+  const bool small = M <= gemm_small_max_rows() && small_ws_;
+  const bool rc = mc_.kernel == 11 && T >= 8 && !no_rc_ && !small;
   if (rc) {
     GemmRcArgs g{};
     g.A = ctx16_; g.lda = D; g.W = L.out.w; g.ldw = L.out.Kpad; g.bias = L.out.bias; g.M = M; g.K = L.out.Kpad;
@@ -775,7 +781,7 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   }
   // the FFN hidden lives in the blocked activation layout (kernels.h): FFN-up stores its fragments as whole
   // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
-  const int blk = (F % 64 == 0) ? 1 : 0;
+  const int blk = (F % 64 == 0 && !small) ? 1 : 0;
   gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
   if (rc && rc_ffn2_ && blk) {
     // row-complete FFN-down (+ the next LayerNorm): measured SLOWER than the persistent 256 x 128 kernel + a
@@ -1692,8 +1698,8 @@ void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, 
   const int M = ds.M, N = ds.N, K = ds.K;
   PF_CHECK(M > 0 && N > 0 && K > 0, PF_ERR_INVALID_ARG, "gemm_ex: empty problem");
   PF_CHECK(ds.out_kind >= 0 && ds.out_kind <= 2, PF_ERR_INVALID_ARG, "gemm_ex: out_kind must be 0, 1 or 2");
-  PF_CHECK(ds.tile_rows == 0 || ds.tile_rows == 128 || ds.tile_rows == 256 || ds.tile_rows == 512, PF_ERR_INVALID_ARG,
-           "gemm_ex: tile_rows must be 0, 128, 256 or 512 (= the 256 x {192,256} tile kernel)");
+  PF_CHECK(ds.tile_rows == 0 || ds.tile_rows == 32 || ds.tile_rows == 128 || ds.tile_rows == 256 || ds.tile_rows == 512, PF_ERR_INVALID_ARG,
+           "gemm_ex: tile_rows must be 0, 32 (= the short-input split-K kernel), 128, 256 or 512 (= the 256 x {192,256} tile kernel)");
   PF_CHECK(ds.out_kind == 0 || (!ds.resid && !ds.add2), PF_ERR_INVALID_ARG, "gemm_ex: residual / addend need the fp32 result kind");
   PF_CHECK(ds.out_kind != 2 || N % 64 == 0, PF_ERR_INVALID_ARG, "gemm_ex: blocked result needs N % 64 == 0");
   const int Kp = (int)round_up(K, 64);
@@ -1735,7 +1741,8 @@ void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, 
   g.scale_cols = ds.scale_cols; g.scale = ds.scale;
   g.out_padded = 1;
   g.a_blocked = ds.a_blocked ? 1 : 0;
-  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 512 ? 3 : 0));
+  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 512 ? 3 : (ds.tile_rows == 32 ? 4 : 0)));
+  g.small_ws = small_ws_;
   if (ds.out_kind == 0) {
     g.out_f32 = (float*)(base + oC); g.ldc32 = ld32;
     if (ds.resid) { g.resid = (const float*)(base + oR); g.ldr = ld32; }

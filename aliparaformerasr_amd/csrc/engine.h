@@ -218,6 +218,7 @@ class Engine {
 
   // workspace
   DevBuf ws_f32_;
+  float* small_ws_ = nullptr;        // short-input GEMM: split partials
   float* cif_conv_w32_ = nullptr;    // fp32 mode: the CIF conv as a [D][taps*D] GEMM operand
   DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
   int pe_T_ = 0;

@@ -615,6 +615,17 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   PF_CHECK(!a.out_blocked || (a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && a.N % 64 == 0),
            PF_ERR_INVALID_ARG, "gemm: blocked output needs an f16-only padded result with N % 64 == 0");
   PF_CHECK(!a.a_blocked || a.K % 64 == 0, PF_ERR_INVALID_ARG, "gemm: blocked A operand needs K % 64 == 0");
+  if (a.force_mi == 4 || (a.force_mi == 0 && a.small_ws && a.M <= gemm_small_max_rows() && !a.out_blocked && !a.a_blocked)) {
+    // short inputs: one-shot bricks over the whole device instead of a handful of tiles walking K (k_gemm_small.hip)
+    GemmSmallArgs g{};
+    g.A = a.A; g.lda = a.lda; g.W = a.W; g.ldw = a.ldw; g.bias = a.bias; g.M = a.M; g.N = a.N; g.K = a.K;
+    g.out_f32 = a.out_f32; g.ldc32 = a.ldc32; g.out_f16 = a.out_f16; g.ldc16 = a.ldc16;
+    g.resid = a.resid; g.ldr = a.ldr; g.add2 = a.add2; g.ld2 = a.ld2;
+    g.relu = a.relu; g.scale_cols = a.scale_cols; g.scale = a.scale; g.ws = a.small_ws;
+    const bool can = !a.out_blocked && !a.a_blocked && gemm_small_applicable(g);
+    PF_CHECK(a.force_mi != 4 || can, PF_ERR_INVALID_ARG, "gemm: the short-input kernel does not apply to this problem");
+    if (can) { launch_gemm_small(s, g); return; }
+  }
   // 128-row tiles when 256-row tiles would leave CUs idle (decoder GEMMs with N = 512: 84 tiles); measured
   // A/B in one session: x = 0.9 -> 14.85 ms/step, x = 0 -> 15.15, x >= 1.5 (also the encoder N = 512 GEMMs) -> 15.9
   int dev = 0;

@@ -28,7 +28,9 @@ struct GemmArgs {
   // FFN-up writes it (out_blocked, f16-only results, N % 64 == 0), FFN-down reads it (a_blocked, lda ignored).
   int out_blocked;
   int a_blocked;
-  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 3 = the 256 x {192,256} kernel
+  float* small_ws;               // scratch of the short-input kernel (k_gemm_small.hip, gemm_small_ws_bytes() bytes, one per
+                                 // stream); null = never dispatch to it
+  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 3 = the 256 x {192,256} kernel, 4 = the short-input split-K kernel
                                  // (stand-alone op tests; 3 fails when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
@@ -52,6 +54,25 @@ struct GemmRcArgs {
   half_t* out_n16; int ldn16;                    // f16 LayerNorm result (next GEMM's operand) or null
   float* out_n32; int ldn32;                     // fp32 LayerNorm result or null
 };
+// short inputs (k_gemm_small.hip): one-shot bricks, K > 576 as split partials + a row-wise reduction that also takes
+// the LayerNorm behind the GEMM; optional LayerNorm-on-load of fp32 rows (K = 512) and FSMN-memory epilogue
+struct GemmSmallArgs {
+  const half_t* A; int lda;                      // f16 operand [M,K] ... or null with:
+  const float* x32; int ldx; const float* ln_g; const float* ln_b;   // fp32 rows [M,512], LayerNorm-ed on load
+  const half_t* W; int ldw; const float* bias;   // [N,K] f16, K-contiguous
+  int M, N, K;
+  float* out_f32; int ldc32; half_t* out_f16; int ldc16;
+  const float* resid; int ldr; const float* add2; int ld2;           // fp32 [M,N]; resid may alias out_f32
+  int relu; int scale_cols; float scale;
+  const half_t* fsmn_v; int ldv; const float* fsmn_wT; int fsmn_k; int T;   // + FSMN memory of the V slice (k = 11, N = 512, K <= 576)
+  const float* post_ln_g; const float* post_ln_b;                    // K > 576 only: LayerNorm of the result ->
+  half_t* post_n16; int ldn16; float* post_n32; int ldn32;           //   f16 / fp32 (out_f32 / out_f16 stay optional)
+  float* ws;                                     // gemm_small_ws_bytes() of scratch (K > 576), one per stream
+};
+size_t gemm_small_ws_bytes();
+int gemm_small_max_rows();                       // rows up to which the pipeline uses this kernel (PF_SMALL_M)
+bool gemm_small_applicable(const GemmSmallArgs& a);
+void launch_gemm_small(hipStream_t s, const GemmSmallArgs& a);
 void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a);
 
 // ---------------------------------------------------------------- fp32 parity mode (k_fp32.hip) ----

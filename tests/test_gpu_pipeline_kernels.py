@@ -238,6 +238,40 @@ def test_logsoftmax_argmax_nan_and_inf(eng):
     np.testing.assert_array_equal(eng.op_logsoftmax_argmax(x, store=False), ids)
 
 
+# ---------------------------------------------------------------- short-input GEMM (k_gemm_small.hip)
+@pytest.mark.parametrize("M,N,K", [(83, 1536, 560), (83, 512, 2048), (23, 2048, 512), (23, 515, 512), (300, 512, 1536),
+                                   (129, 8404, 512), (1, 512, 512), (500, 2048, 512), (500, 512, 2048)])
+def test_gemm_small(eng, M, N, K):
+    """The GEMM the 1 x 5 s path runs (M = 83 encoder rows / 23 decoder rows): every epilogue the pipeline asks of it,
+    K not a multiple of 64 on the caller's side (560 -> 576 padded), N not a multiple of 32 / 4, more than one row
+    tile, the split form (K > 576: partials + row-wise reduction) and bit-identical results over repeated launches."""
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wm += (np.arange(N)[:, None] * 1e-4).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    add2 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = _ref(A, Wm, bias)
+    got = eng.op_gemm_ex(A, Wm, bias, resid=resid, add2=add2, out_kind=0, tile_rows=32)
+    np.testing.assert_allclose(got, ref + add2 + resid, rtol=2e-4, atol=2e-4)
+    for _ in range(3):
+        assert np.array_equal(got, eng.op_gemm_ex(A, Wm, bias, resid=resid, add2=add2, out_kind=0, tile_rows=32))
+    got = eng.op_gemm_ex(A, Wm, bias, relu=True, out_kind=0, tile_rows=32)
+    np.testing.assert_allclose(got, np.maximum(ref, 0), rtol=2e-4, atol=2e-4)
+    sc_cols = 64 * min(N // 64, 8) if K <= 576 else 0             # the q scaling exists on K = 512 projections only
+    sc = np.float32(128 ** -0.5)
+    r2 = ref.copy()
+    r2[:, :sc_cols] *= sc
+    got = eng.op_gemm_ex(A, Wm, bias, out_kind=1, tile_rows=32, scale_cols=sc_cols, scale=float(sc))
+    np.testing.assert_allclose(got, r2, rtol=1.5e-3, atol=1.5e-3)
+    # the dispatcher picks it by itself for short inputs, and the persistent kernel agrees with it
+    auto = eng.op_gemm_ex(A, Wm, bias, out_kind=1, scale_cols=sc_cols, scale=float(sc))
+    assert np.array_equal(auto, got)
+    big = eng.op_gemm_ex(A, Wm, bias, out_kind=1, tile_rows=128, scale_cols=sc_cols, scale=float(sc))
+    np.testing.assert_allclose(big, got, rtol=1.5e-3, atol=1.5e-3)
+
+
 # ---------------------------------------------------------------- row-complete GEMM (k_gemm_rc.hip)
 def _ln_ref(x, g, b):
     return om.layer_norm(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b)).numpy()
