@@ -50,7 +50,8 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_DEC_FUSE"); if (e && e[0]) dec_fuse_ = atoi(e) & 7; }
-  { const char* e = getenv("PF_DEC_H32"); dec_h32_ = e && e[0] == '1'; }   // A/B switch for tools/: decoder launch fusions
+  { const char* e = getenv("PF_DEC_H32"); dec_h32_ = e && e[0] == '1'; }
+  { const char* e = getenv("PF_SMALL_NOFUSE"); no_small_fuse_ = e && e[0] == '1'; }   // A/B: short-input GEMMs without the FSMN epilogue / LayerNorm-in-reduction forms   // A/B switch for tools/: decoder launch fusions
   { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
@@ -593,6 +594,15 @@ void Engine::gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M
   prof_end(cls);
 }
 
+// short-input form of a projection (k_gemm_small.hip): the caller fills operand / epilogue fields of `g`, this adds
+// the weight, shape, scratch and the profile class
+void Engine::gemm_small_call(const char* cls, const Lin& w, GemmSmallArgs g, bool bias) {
+  g.W = w.w; g.ldw = w.Kpad; g.bias = bias ? w.bias : nullptr; g.N = w.N; g.K = w.Kpad; g.ws = small_ws_;
+  prof_begin(cls, 2.0 * g.M * (double)w.N * w.K);
+  launch_gemm_small(stream_, g);
+  prof_end(cls);
+}
+
 // ------------------------------------------------------------------ front-end -------------
 int Engine::num_fbank_frames(int64_t n) const {
   if (fc_.snip_edges) return n < 400 ? 0 : (int)(1 + (n - 400) / 160);
@@ -746,19 +756,42 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
     launch_layernorm(stream_, speech_dev, M, mc_.feat_dim, L.norm1.g, L.norm1.b, xn16_, lda, nullptr, 0);
     prof_end("layernorm");
   }
-  gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
   AttnArgs a{};
   a.q = qkv16_; a.k = qkv16_ + D; a.v = qkv16_ + 2 * D; a.o = ctx16_;
   a.q_bstride = a.k_bstride = a.v_bstride = (int64_t)T * 3 * D;
   a.q_rstride = a.k_rstride = a.v_rstride = 3 * D;
   a.o_bstride = (int64_t)T * D; a.o_rstride = D;
   a.B = B; a.H = mc_.heads; a.Lq = T; a.Lk = T;
+  // short inputs (M <= 512 rows): every GEMM goes to k_gemm_small.hip, which has no row-complete epilogue and no blocked
+  // layout but takes the FSMN memory as an epilogue term and the LayerNorm behind FFN-down in its reduction
+  const bool small = M <= gemm_small_max_rows() && small_ws_;
+  if (small && D == 512 && F % 64 == 0 && F > 576 && mc_.kernel == 11 && !no_small_fuse_) {
+    // 7 launches: QKV | attention | out-projection + FSMN memory + residual | norm2 | FFN-up | FFN-down partials | their
+    // sum + bias + residual + the LayerNorm behind the block (next norm1 / after_norm)
+    gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
+    prof_begin("attn_self", 4.0 * B * (double)T * T * D);
+    launch_attention(stream_, a);
+    prof_end("attn_self");
+    GemmSmallArgs o{};
+    o.M = M; o.A = ctx16_; o.lda = D; o.out_f32 = x_; o.ldc32 = D;
+    if (!first) { o.resid = x_; o.ldr = D; }
+    o.fsmn_v = qkv16_ + 2 * D; o.ldv = 3 * D; o.fsmn_wT = L.fsmn_wT; o.fsmn_k = 11; o.T = T;
+    gemm_small_call("gemm_out", L.out, o);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
+    prof_end("layernorm");
+    gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    GemmSmallArgs dn{};
+    dn.M = M; dn.A = h16_; dn.lda = F; dn.resid = x_; dn.ldr = D;
+    if (nx.keep_x) { dn.out_f32 = x_; dn.ldc32 = D; }
+    dn.post_ln_g = nx.ln.g; dn.post_ln_b = nx.ln.b; dn.post_n16 = nx.n16; dn.ldn16 = D; dn.post_n32 = nx.n32; dn.ldn32 = D;
+    gemm_small_call("gemm_ffn2", L.w2, dn);
+    return;
+  }
+  gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
   prof_begin("attn_self", 4.0 * B * (double)T * T * D);
   launch_attention(stream_, a);
   prof_end("attn_self");
-  // short inputs: every GEMM goes to the split-K kernel (k_gemm_small.hip), which has no row-complete epilogue and no
-  // blocked layout — the unfused FSMN / LayerNorm kernels run instead (4-5 us each at this size)
-  const bool small = M <= gemm_small_max_rows() && small_ws_;
   const bool rc = mc_.kernel == 11 && T >= 8 && !no_rc_ && !small;
   if (rc) {
     GemmRcArgs g{};
@@ -950,11 +983,25 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   // take norm2 (bit 4) and the next block's norm1 (bit 2) as epilogues, but at M = B*L = 5344 it runs on 84 CUs only:
   // measured 47 vs 29.5 + 5.6 us (FFN-down) and 21 vs 16 + 5.6 us (out-projection), so both stay off (PF_DEC_FUSE=7
   // enables them for experiments).
-  const bool f_fsmn = (dec_fuse_ & 1) != 0, f_out = (dec_fuse_ & 2) != 0, f_ffn2 = (dec_fuse_ & 4) != 0;
+  const bool dsmall = Md <= gemm_small_max_rows() && small_ws_ && D == 512 && F % 64 == 0 && F > 576 && !no_small_fuse_;
+  const bool f_fsmn = (dec_fuse_ & 1) != 0, f_out = (dec_fuse_ & 2) != 0 && !dsmall, f_ffn2 = (dec_fuse_ & 4) != 0;
   bool have_n1 = false;                                // xdn16 already holds norm1(xd) of the coming block
   // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or
   // post(t) in n32 / n16
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const LNp& post, float* n32, half_t* n16) {
+    if (dsmall) {
+      // short inputs: norm1 | FFN-up | LayerNorm(2048) in place | FFN-down partials | their sum + the LayerNorm behind it
+      prof_begin("layernorm", 0);
+      launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
+      prof_end("layernorm");
+      dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn16, D, Md, hd32, hd16);
+      GemmSmallArgs dn{};
+      dn.M = Md; dn.A = hd16; dn.lda = F;
+      dn.post_ln_g = post.g; dn.post_ln_b = post.b; dn.post_n16 = n16; dn.ldn16 = D; dn.post_n32 = n32; dn.ldn32 = D;
+      gemm_small_call("gemm_dec_ffn2", w2, dn, false);
+      have_n1 = false;
+      return;
+    }
     if (!have_n1) {
       prof_begin("layernorm", 0);
       launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
@@ -1832,9 +1879,28 @@ void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* 
     if (n32_out) { g.out_n32 = (float*)(base + oN32); g.ldn32 = N; }
   }
   if (x_out) { g.out_x = (float*)(base + oX); g.ldx = N; }
-  prof_begin("gemm_op", 2.0 * M * (double)N * K);
-  launch_gemm_rc(stream_, g);
-  prof_end("gemm_op");
+  if (ds.short_input) {
+    // the short-input forms of the same nodes, as enc_layer / the decoder run them for M <= 512 rows
+    PF_CHECK(!ds.a_blocked, PF_ERR_INVALID_ARG, "gemm_rc: the short-input kernels take a row-major A");
+    GemmSmallArgs q{};
+    q.A = g.A; q.lda = K; q.W = g.W; q.ldw = K; q.bias = g.bias; q.M = M; q.N = N; q.K = K; q.ws = small_ws_;
+    q.resid = g.resid; q.ldr = N;
+    const bool need_x = g.out_x || (g.ln_g && K <= 576);
+    if (need_x) { q.out_f32 = (float*)(base + oX); q.ldc32 = N; }
+    if (K <= 576) {
+      q.fsmn_v = g.fsmn_v; q.ldv = g.ldv; q.fsmn_wT = g.fsmn_wT; q.fsmn_k = g.fsmn_k; q.T = g.T;
+      launch_gemm_small(stream_, q);
+      if (g.ln_g) launch_layernorm(stream_, q.out_f32, M, N, g.ln_g, g.ln_b, g.out_n16, N, g.out_n32, N);
+    } else {
+      PF_CHECK(!g.fsmn_v, PF_ERR_INVALID_ARG, "gemm_rc: the split short-input form has no FSMN term");
+      q.post_ln_g = g.ln_g; q.post_ln_b = g.ln_b; q.post_n16 = g.out_n16; q.ldn16 = N; q.post_n32 = g.out_n32; q.ldn32 = N;
+      launch_gemm_small(stream_, q);
+    }
+  } else {
+    prof_begin("gemm_op", 2.0 * M * (double)N * K);
+    launch_gemm_rc(stream_, g);
+    prof_end("gemm_op");
+  }
   if (x_out) PF_HIP(hipMemcpyAsync(x_out, base + oX, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
   if (g.out_n32) PF_HIP(hipMemcpyAsync(n32_out, base + oN32, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
   std::vector<half_t> tmp;

@@ -165,6 +165,7 @@ class Engine {
   void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
             half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
             int scale_cols, float scale, bool bias = true, int blocked = 0);   // blocked: 1 = out_f16 blocked, 2 = A blocked
+  void gemm_small_call(const char* cls, const Lin& w, GemmSmallArgs g, bool bias = true);
   void dec_ffn_hidden(const char* cls, const Lin& w1, const LNp& fn, const half_t* xn16, int lda, int rows, float* h32, half_t* h16);
   void prof_begin(const char* cls, double flops);
   void prof_end(const char* cls);
@@ -176,6 +177,7 @@ class Engine {
   int device_ = 0;
   hipStream_t stream_ = nullptr;
   bool no_rc_ = false, rc_ffn2_ = false, lstm_steps_ = false;
+  bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)
   int dec_fuse_ = 1;                 // bit 1: FSMN + norm3, bit 2: out-projection + next norm1, bit 4: FFN-down + norm2 (row-complete GEMM)
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next host sync)

@@ -22,9 +22,9 @@
 //     pipeline had anyway.  Partials are summed in split order: results are reproducible run to run.
 //     (A first version reduced inside the GEMM — write-through partials, arrival counter, last workgroup sums — and
 //     measured 12.5 us per launch: three more dependent round trips.)
-//   * The LayerNorm in FRONT of a K = 512 projection (norm1 -> QKV, norm2 -> FFN-up, decoder norm1 / norm3) can be
-//     taken on load: the brick spans the whole row, so every workgroup normalises its own copy of the (<= 128) rows
-//     (fp32 statistics, shifted two-pass form of k_norm.hip) while it writes them to LDS as f16.
+//     (Taking the LayerNorm in FRONT of a K = 512 projection on load — every workgroup normalising its own copy of
+//     the rows — was built and measured: 15.5 us per launch against 9 + 3.9 us for GEMM + LayerNorm kernel, because
+//     the fp32 rows double the brick's bytes and the 48 row reductions sit in front of the first MFMA.  Removed.)
 //   * The encoder's FSMN memory (11 taps over V, channel-local) is an epilogue term of the attention out-projection:
 //     a lane adds sum_j w_j[n] * V[t + j - 5, n] + V[t, n] for its own row and 16 columns.
 #include "kernels.h"
@@ -39,8 +39,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
 struct SmallDev {
-  const half_t* A; int lda;                              // f16 operand rows, or (A == null):
-  const float* X; int ldx; const float* ln_g; const float* ln_b;   // fp32 rows of width K = 512, normalised on load
+  const half_t* A; int lda;
   const half_t* W; int ldw; const float* bias;
   float* out_f32; half_t* out_f16; const float* resid; const float* add2;
   int ldc32, ldc16, ldr, ld2;
@@ -59,14 +58,22 @@ __device__ __forceinline__ int sm_swz(int row, int c) {
   return (CPR & 15) ? (c ^ ((row >> 1) & 7)) : (c ^ (row & 15));
 }
 
+// wave-wide sum broadcast to every lane: four DPP steps + four SGPR reads (VALU only; ds_bpermute-based shuffles cost
+// ~120 cycles each and a LayerNorm is a chain of 12 of them — 15 us for the 24 rows a wave normalises on load)
 __device__ __forceinline__ float sm_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
 }
 
-// CPR: 16-byte chunks per brick row (KC = 8 * CPR).  LNA: A rows are fp32 and LayerNorm-ed on load (CPR = 64).
-template <int CPR, bool LNA>
+// CPR: 16-byte chunks per brick row (KC = 8 * CPR)
+template <int CPR>
 __global__ __launch_bounds__(256) void gemm_small_kernel(SmallDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KC = CPR * 8, rowb = KC * 2;
@@ -117,58 +124,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(SmallDev p) {
 
   // ---- the brick, one shot: every piece is requested before the first one is awaited (rows past M / N are clamped:
   // they only feed result rows / columns nobody stores)
-  if (LNA) {
-    // fp32 rows -> LayerNorm -> f16.  wave w owns rows w, w+4, ..; a lane holds columns 4*lane..+3 and 256+4*lane..+3
-    constexpr int RPW = SM_BM / 4;
-    float4 xa[RPW], xb[RPW];
-    const int nrow = rb_here * 32;
-#pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const int row = wave + 4 * u;
-      if (row < nrow) {
-        const float* xr = p.X + (size_t)min(m0 + row, p.M - 1) * p.ldx;
-        xa[u] = *reinterpret_cast<const float4*>(xr + 4 * lane);
-        xb[u] = *reinterpret_cast<const float4*>(xr + 256 + 4 * lane);
-      }
-    }
-    const float4 g0 = *reinterpret_cast<const float4*>(p.ln_g + 4 * lane), g1 = *reinterpret_cast<const float4*>(p.ln_g + 256 + 4 * lane);
-    const float4 e0 = *reinterpret_cast<const float4*>(p.ln_b + 4 * lane), e1 = *reinterpret_cast<const float4*>(p.ln_b + 256 + 4 * lane);
-    {
-      constexpr int MAXW = SM_BN * CPR / 256;
-      h8 v[MAXW];
-#pragma unroll
-      for (int u = 0; u < MAXW; ++u) {
-        const int i = tid + 256 * u;
-        const int row = i / CPR, c = i - row * CPR;
-        v[u] = *reinterpret_cast<const h8*>(p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + k0 + c * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < MAXW; ++u) {
-        const int i = tid + 256 * u;
-        const int row = i / CPR, c = i - row * CPR;
-        *reinterpret_cast<h8*>(lW + row * rowb + (sm_swz<CPR>(row, c) << 4)) = v[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < RPW; ++u) {
-      const int row = wave + 4 * u;
-      if (row < nrow) {
-        float4 a = xa[u], c = xb[u];
-        const float x0 = __shfl(a.x, 0, 64);
-        a.x -= x0; a.y -= x0; a.z -= x0; a.w -= x0; c.x -= x0; c.y -= x0; c.z -= x0; c.w -= x0;
-        const float mean = sm_wave_sum(((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w))) * (1.0f / 512.0f);
-        a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; c.x -= mean; c.y -= mean; c.z -= mean; c.w -= mean;
-        const float var = sm_wave_sum(((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w))) * (1.0f / 512.0f);
-        const float rstd = 1.0f / sqrtf(var + 1e-12f);
-        const h4 ya = {(half_t)(a.x * rstd * g0.x + e0.x), (half_t)(a.y * rstd * g0.y + e0.y), (half_t)(a.z * rstd * g0.z + e0.z), (half_t)(a.w * rstd * g0.w + e0.w)};
-        const h4 yc = {(half_t)(c.x * rstd * g1.x + e1.x), (half_t)(c.y * rstd * g1.y + e1.y), (half_t)(c.z * rstd * g1.z + e1.z), (half_t)(c.w * rstd * g1.w + e1.w)};
-        // element k lives in chunk k/8 at byte (k%8)*2: columns 4*lane..+3 -> chunk lane/2, half (lane&1)
-        char* base = lA + row * rowb;
-        *reinterpret_cast<h4*>(base + (sm_swz<CPR>(row, lane >> 1) << 4) + (lane & 1) * 8) = ya;
-        *reinterpret_cast<h4*>(base + (sm_swz<CPR>(row, 32 + (lane >> 1)) << 4) + (lane & 1) * 8) = yc;
-      }
-    }
-  } else {
+  {
     constexpr int MAXC = ((SM_BM + SM_BN) * CPR + 255) / 256;
     const int nA = rb_here * 32 * CPR, total = nA + SM_BN * CPR;
     h8 v[MAXC];
@@ -330,7 +286,7 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(ReduceDev p) {
     *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + c1) = h4{(half_t)c.x, (half_t)c.y, (half_t)c.z, (half_t)c.w};
   }
   if (!p.ln_g) return;
-  const float x0 = __shfl(a.x, 0, 64);
+  const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.x)));
   a.x -= x0; a.y -= x0; a.z -= x0; a.w -= x0; c.x -= x0; c.y -= x0; c.z -= x0; c.w -= x0;
   const float mean = sm_wave_sum(((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w))) * (1.0f / 512.0f);
   a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; c.x -= mean; c.y -= mean; c.z -= mean; c.w -= mean;
@@ -371,8 +327,7 @@ bool gemm_small_applicable(const GemmSmallArgs& a) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % 64 != 0) return false;
   const int S = small_split(a);
   if (S == 0) return false;
-  if (a.x32) { if (a.K != 512 || !a.ln_g || !a.ln_b || a.A) return false; }
-  else if (!a.A) return false;
+  if (!a.A) return false;
   if (a.fsmn_v && (S != 1 || a.fsmn_k != 11 || a.N != 512 || a.T <= 0)) return false;
   if (S == 1) return !a.post_ln_g;                           // a LayerNorm behind the GEMM exists only on the split path
   if (a.N != 512 || !a.ws) return false;                     // split path: row-wise reduction over N = 512
@@ -380,7 +335,7 @@ bool gemm_small_applicable(const GemmSmallArgs& a) {
   return (size_t)S * cdiv(a.M, SM_BM) * SM_BM * SM_PART_LD * 4 <= gemm_small_ws_bytes();   // split bricks are 128 rows
 }
 
-template <int CPR, bool LNA>
+template <int CPR>
 static void small_launch(hipStream_t s, const SmallDev& d, int rows_alloc) {
   static std::mutex mu;
   static bool attr[64] = {false};
@@ -389,19 +344,19 @@ static void small_launch(hipStream_t s, const SmallDev& d, int rows_alloc) {
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!attr[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)gemm_small_kernel<CPR, LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_small_kernel<CPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr[dev & 63] = true;
     }
   }
   const int lds = (rows_alloc + SM_BN) * CPR * 16;
-  hipLaunchKernelGGL((gemm_small_kernel<CPR, LNA>), dim3((unsigned)(d.tiles_n * d.tiles_m * d.S)), dim3(256), lds, s, d);
+  hipLaunchKernelGGL((gemm_small_kernel<CPR>), dim3((unsigned)(d.tiles_n * d.tiles_m * d.S)), dim3(256), lds, s, d);
   PF_HIP(hipGetLastError());
 }
 
 void launch_gemm_small(hipStream_t s, const GemmSmallArgs& a) {
   PF_CHECK(gemm_small_applicable(a), PF_ERR_INVALID_ARG, "gemm_small: the short-input kernel does not apply to this problem");
   SmallDev d{};
-  d.A = a.A; d.lda = a.lda; d.X = a.x32; d.ldx = a.ldx; d.ln_g = a.ln_g; d.ln_b = a.ln_b;
+  d.A = a.A; d.lda = a.lda;
   d.W = a.W; d.ldw = a.ldw; d.bias = a.bias;
   d.out_f32 = a.out_f32; d.out_f16 = a.out_f16; d.resid = a.resid; d.add2 = a.add2;
   d.ldc32 = a.ldc32; d.ldc16 = a.ldc16; d.ldr = a.ldr; d.ld2 = a.ld2;
@@ -417,17 +372,16 @@ void launch_gemm_small(hipStream_t s, const GemmSmallArgs& a) {
   if (d.S > 1) {                                             // partials only; bias / residual / LayerNorm in the reduction
     d.bias = nullptr; d.resid = nullptr; d.add2 = nullptr; d.out_f32 = nullptr; d.out_f16 = nullptr; d.relu = 0;
   }
-  if (a.x32) small_launch<64, true>(s, d, rows_alloc);
-  else switch (kc / 64) {
-    case 1: small_launch<8, false>(s, d, rows_alloc); break;
-    case 2: small_launch<16, false>(s, d, rows_alloc); break;
-    case 3: small_launch<24, false>(s, d, rows_alloc); break;
-    case 4: small_launch<32, false>(s, d, rows_alloc); break;
-    case 5: small_launch<40, false>(s, d, rows_alloc); break;
-    case 6: small_launch<48, false>(s, d, rows_alloc); break;
-    case 7: small_launch<56, false>(s, d, rows_alloc); break;
-    case 8: small_launch<64, false>(s, d, rows_alloc); break;
-    default: small_launch<72, false>(s, d, rows_alloc); break;
+  switch (kc / 64) {
+    case 1: small_launch<8>(s, d, rows_alloc); break;
+    case 2: small_launch<16>(s, d, rows_alloc); break;
+    case 3: small_launch<24>(s, d, rows_alloc); break;
+    case 4: small_launch<32>(s, d, rows_alloc); break;
+    case 5: small_launch<40>(s, d, rows_alloc); break;
+    case 6: small_launch<48>(s, d, rows_alloc); break;
+    case 7: small_launch<56>(s, d, rows_alloc); break;
+    case 8: small_launch<64>(s, d, rows_alloc); break;
+    default: small_launch<72>(s, d, rows_alloc); break;
   }
   if (d.S > 1) {
     ReduceDev r{};

@@ -55,10 +55,9 @@ struct GemmRcArgs {
   float* out_n32; int ldn32;                     // fp32 LayerNorm result or null
 };
 // short inputs (k_gemm_small.hip): one-shot bricks, K > 576 as split partials + a row-wise reduction that also takes
-// the LayerNorm behind the GEMM; optional LayerNorm-on-load of fp32 rows (K = 512) and FSMN-memory epilogue
+// the LayerNorm behind the GEMM; optional FSMN-memory epilogue (attention out-projection)
 struct GemmSmallArgs {
-  const half_t* A; int lda;                      // f16 operand [M,K] ... or null with:
-  const float* x32; int ldx; const float* ln_g; const float* ln_b;   // fp32 rows [M,512], LayerNorm-ed on load
+  const half_t* A; int lda;                      // f16 operand [M,K]
   const half_t* W; int ldw; const float* bias;   // [N,K] f16, K-contiguous
   int M, N, K;
   float* out_f32; int ldc32; half_t* out_f16; int ldc16;

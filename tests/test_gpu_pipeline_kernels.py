@@ -404,3 +404,45 @@ def test_gemm_big_refuses_what_it_cannot_do(eng):
         eng.op_gemm_ex(A, Wm, None, out_kind=1, tile_rows=512)
     with pytest.raises(PfError):
         eng.op_gemm_ex(np.zeros((16000, 512), np.float32), np.zeros((512, 512), np.float32), None, out_kind=0, tile_rows=512)
+
+
+@pytest.mark.parametrize("M,T,K", [(83, 83, 512), (166, 83, 512), (23, 23, 2048), (300, 100, 2048), (7, 7, 512)])
+def test_gemm_small_fsmn_epilogue_and_layernorm_in_the_reduction(eng, M, T, K):
+    """The two fused forms of the short-input path: K = 512 — attention out-projection with the 11-tap FSMN memory of
+    the V slice and the residual as epilogue terms (then the LayerNorm kernel); K = 2048 — FFN-down as split partials
+    whose reduction adds bias + residual and applies the LayerNorm behind the block.  Against the same float64 / fp32
+    statement the row-complete kernel is tested with, and against that kernel itself."""
+    rng = np.random.default_rng(M + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    resid = rng.standard_normal((M, 512)).astype(np.float32)
+    g = (1.0 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    x_ref = _ref(A, Wm, bias) + resid
+    kw = {}
+    if K <= 576:
+        v = rng.standard_normal((M, 512)).astype(np.float32)
+        fw = (0.2 * rng.standard_normal((512, 11))).astype(np.float32)
+        vq = h16(v).reshape(M // T, T, 512)
+        mem = vq.copy()
+        for j in range(11):
+            sh = j - 5
+            lo, hi = max(0, -sh), min(T, T - sh)
+            if lo < hi:
+                mem[:, lo:hi] += fw[:, j][None, None, :] * vq[:, lo + sh:hi + sh]
+        x_ref = _ref(A, Wm, bias) + mem.reshape(M, 512) + resid
+        kw = dict(fsmn_v=v, fsmn_w=fw, T=T)
+    x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), short_input=True, **kw)
+    np.testing.assert_allclose(x, x_ref, rtol=3e-4, atol=3e-4)
+    xd = x_ref.astype(np.float64)
+    mu = xd.mean(-1, keepdims=True)
+    ln_ref = ((xd - mu) / np.sqrt(((xd - mu) ** 2).mean(-1, keepdims=True) + 1e-12) * g + b).astype(np.float32)
+    np.testing.assert_allclose(n32, ln_ref, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(n16, ln_ref, rtol=3e-3, atol=3e-3)
+    if T >= 8:
+        x2, _, m32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), **kw)       # the row-complete kernel
+        np.testing.assert_allclose(x, x2, rtol=3e-4, atol=3e-4)
+        np.testing.assert_allclose(n32, m32, rtol=1e-3, atol=1e-3)
+    again = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), short_input=True, **kw)
+    assert np.array_equal(again[0], x) and np.array_equal(again[2], n32)
