@@ -6,6 +6,9 @@ from aliparaformerasr_amd import weights as W
 from aliparaformerasr_amd.engine import Engine
 cfg = W.paraformer_large_config()
 eng = Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, 42)), cmvn=W.synth_cmvn(), device=0)
+_warm = [W.synth_audio(5 * 16000, 0)]
+for _ in range(20):                    # the first calls of a process run ~2 ms slower (clocks, first-touch of the arenas)
+    eng.recognize(_warm)
 for (B, secs) in ((1, 5), (1, 30), (4, 5), (32, 5)):
     audio = [W.synth_audio(secs * 16000, u) for u in range(B)]
     eng.stage_audio(audio)
