@@ -652,6 +652,17 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.9f; }
   }
   {
+    // blocked-layout results (FFN-up): the persistent 256 x 256-tile kernel (k_gemm_big.hip); PF_BIGP=0 keeps this file's kernel
+    static int use_bigp = -1;
+    if (use_bigp < 0) { const char* e = getenv("PF_BIGP"); use_bigp = (e && e[0] == '0') ? 0 : 1; }
+    const bool can = gemm_bigp_applicable(a);
+    PF_CHECK(a.force_mi != 5 || can, PF_ERR_INVALID_ARG, "gemm: the persistent 256 x 256 kernel does not apply to this problem");
+    if (can && (a.force_mi == 5 || (a.force_mi == 0 && use_bigp && cdiv(a.M, 256) * (a.N / 256) >= cus[dev]))) {
+      launch_gemm_bigp(s, a, cus[dev]);
+      return;
+    }
+  }
+  {
     // the 256 x {192,256} one-tile-per-workgroup kernel (k_gemm_big.hip) is OPT-IN (PF_BIG=1 or force_mi = 3): its
     // main loop runs at 0.9 us per k-step, but every tile pays ~9 us of un-overlapped prologue + epilogue, which at
     // K = 512 (8 k-steps per tile) cancels the gain — measured equal to this kernel within +-4 % on every shape

@@ -6,20 +6,26 @@
 // (the MatMul + Add [+ Mul] [+ Relu] nodes of the graph InferenceSession.Run executes,
 // AliParaformerAsr/OfflineProjOfParaformer.cs:68).
 //
-// Why a second kernel next to gemm_f16_pp3 (k_gemm.hip): with K = 512 a 256 x 128 tile has only 8 k-steps, stages
-// 48 KB per 4.2 MFLOP and pays its prologue / epilogue / tile-boundary costs every 8 steps (measured 1.46 us per
-// k-step against 1.05 us for the K = 2048 FFN-down).  A 256 x 256 (256 x 192) tile stages 64 KB (56 KB) per 8.4
-// (6.3) MFLOP — 1.5 x less LDS feed per flop — and halves the number of tile boundaries.  Structure (shared with
-// k_gemm_rc.hip, which showed that at this feed-bound operating point a plain 2-stage ring matches the ping-pong
-// pipeline per k-step): ONE tile per 512-thread workgroup (8 waves as 4 x 2, wave tile 64 x 128 / 64 x 96 =
-// 2 x NJ MFMA 32x32x16 blocks, 128 / 96 accumulator registers), operands HBM -> LDS with global_load_lds_dwordx4
-// into a 2-stage ring consumed behind a counted vmcnt and raw s_barriers, B fragments of a k-step loaded up front,
-// A fragments streamed one k-sub ahead, the next stage's DMA pieces slotted between the MFMAs once the stage's
-// reads have retired.  Epilogue: bias / scale / ReLU in registers, f16 tile through LDS (the ring is free: one
-// tile per workgroup), whole 384 / 512-byte row segments (or whole 512-byte blocks of the blocked layout) to HBM.
-// Workgroups are dealt to XCDs in contiguous runs with n fastest, so an A panel is shared in one private L2.
+// Why a second kernel next to gemm_f16_pp3 (k_gemm.hip): the K loop of both kernels is bound by the per-CU operand
+// path, ~60 GB/s = 25 B/clk through LDS-DMA whatever the source (profiles/round2_gemm_cold_vs_warm.txt: a k-step takes
+// time proportional to its operand bytes — 0.79 us for 48 KB, 0.535 us for 32 KB — on an otherwise idle chip with the
+// operands L2-resident).  A 256 x 128 tile moves 48 KB per 4.2 MFLOP (87 flop/B, ceiling ~5.3 TFLOP/s per CU), a
+// 256 x 256 tile 64 KB per 8.4 MFLOP (131 flop/B, ceiling ~7.9), so the wide projections want the big tile.  A first
+// version (k-steps of 64, two 64 KB stages) had only ONE stage in flight while the other was consumed and ran at
+// 37 GB/s per CU — no faster than the 256 x 128 kernel.  This version: k-steps of 32, a 4-stage ring of 32 KB stages
+// (28 KB for 192-column tiles), THREE stages in flight (96 KB, what gemm_f16_pp3 keeps in flight), one s_barrier per
+// k-step placed in the middle of the step: at mid-step k every wave has its stage-(k+1) pieces landed (counted vmcnt)
+// and all its reads of stage k retired, so after the barrier (a) the first fragments of stage k+1 are read under the
+// second half of step k's MFMAs and (b) slot k % 4 is free for the DMA of stage k+4, whose pieces go out between the
+// MFMAs of the next half-steps.  ONE tile per 512-thread workgroup (8 waves as 4 x 2, wave tile 64 x 128 / 64 x 96 =
+// 2 x NJ MFMA 32x32x16 blocks, 128 / 96 accumulator registers).  64-byte LDS rows are swizzled chunk ^ ((row >> 2) & 3)
+// on the DMA source and on the ds_read_b128 address (conflict-free for the 16-lane read groups).  Epilogue: bias /
+// scale / ReLU in registers, f16 tile through LDS (the ring is free: one tile per workgroup), whole 384 / 512-byte
+// row segments (or whole 512-byte blocks of the blocked layout) to HBM.  Workgroups are dealt to XCDs in contiguous
+// runs with n fastest, so an A panel is shared in one private L2.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 
@@ -37,13 +43,13 @@ struct BigDev {
   int M, N, K, tiles_m, tiles_n;
   int relu, scale_cols, blocked;
   float scale;
-  int abl;   // timing experiments only (PF_BIG_ABL): 1 no steady-state DMA, 2 no MFMA, 4 no result stores, 8 no fragment reads
+  int abl;   // timing experiments only (PF_BIG_ABL): 1 no DMA, 2 no MFMA, 4 no result stores, 8 no fragment reads, 16 no barriers (persistent form)
 };
 
-constexpr int BG_BM = 256, BG_BK = 64, BG_ROWB = BG_BK * 2;
+constexpr int BG_BM = 256, BG_BK = 32, BG_ROWB = BG_BK * 2, BG_S = 4;
 constexpr int bg_stage(int nj) { return (BG_BM + 64 * nj) * BG_ROWB; }          // A tile + W tile of one k-step
 constexpr int bg_xrow(int nj) { return 64 * nj * 2 + 16; }                       // f16 epilogue row + 16-byte skew
-constexpr int bg_lds(int nj) { return 2 * bg_stage(nj) > BG_BM * bg_xrow(nj) ? 2 * bg_stage(nj) : BG_BM * bg_xrow(nj); }
+constexpr int bg_lds(int nj) { return BG_S * bg_stage(nj) > BG_BM * bg_xrow(nj) ? BG_S * bg_stage(nj) : BG_BM * bg_xrow(nj); }
 
 __device__ __forceinline__ void bg_glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -64,12 +70,11 @@ __device__ __forceinline__ void bg_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC
 template <int NJ>
 __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
   constexpr int BN = 64 * NJ, A_BYTES = BG_BM * BG_ROWB, STAGE = bg_stage(NJ), XROW = bg_xrow(NJ);
-  constexpr int A_PW = 4, W_PW = NJ, LPS = A_PW + W_PW;      // 1 KiB DMA pieces per wave per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lh = lane >> 5;
-  auto swz = [](int row) __attribute__((always_inline)) -> int { return (row >> 1) & 7; };
+  auto swz = [](int row) __attribute__((always_inline)) -> int { return (row >> 2) & 3; };   // 64-byte rows
 
   // ---- tile of this workgroup: XCD b % 8 gets a contiguous run of tiles, n fastest
   const int G = gridDim.x, bid = blockIdx.x;
@@ -79,31 +84,36 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
   const int m0 = tm * BG_BM, n0 = tn * BN;
   const int nk = p.K / BG_BK;
 
-  // ---- LDS-DMA source offsets (bytes, per lane)
-  const int srow = lane >> 3, schunk = lane & 7;
-  unsigned a_vo[A_PW], w_vo[W_PW];
+  // ---- LDS-DMA pieces: 1 KiB = 16 rows x 64 bytes.  A: 16 pieces, two per wave.  W: 16 (NJ = 4) or 12 (NJ = 3) pieces:
+  // two per wave, except waves 4-7 of a 192-column tile, which have one (so their vmcnt immediates differ)
+  const bool w2 = NJ == 4 || wave < 4;
+  const int srow = lane >> 2, schunk = lane & 3;
+  unsigned a_vo[2], w_vo[2];
 #pragma unroll
-  for (int i = 0; i < A_PW; ++i) {
-    const int row = (wave + 8 * i) * 8 + srow;
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 8 * i) * 16 + srow;
     a_vo[i] = (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
-  }
-#pragma unroll
-  for (int i = 0; i < W_PW; ++i) {
-    const int row = (wave + 8 * i) * 8 + srow;
     w_vo[i] = (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 3)) * 2u;
   }
   const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
   const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
-  auto issue_piece = [&](int k, int buf, int piece) __attribute__((always_inline)) {
-    char* st = smem + buf * STAGE + wave * 1024;
-    if (piece < A_PW) bg_glds16(a_base + (size_t)k * (BG_BK * 2) + a_vo[piece < A_PW ? piece : 0], st + piece * 8192);
-    else bg_glds16(w_base + (size_t)k * (BG_BK * 2) + w_vo[piece >= A_PW ? piece - A_PW : 0], st + A_BYTES + (piece - A_PW) * 8192);
+  // piece q of stage k: q = 0, 1 -> A; q = 2, 3 -> W (q = 3 only for waves that have a second W piece)
+  auto issue_piece = [&](int k, int q) __attribute__((always_inline)) {
+    if (p.abl & 1) return;
+    char* st = smem + (k & (BG_S - 1)) * STAGE + wave * 1024;
+    if (q < 2) bg_glds16(a_base + (size_t)k * (BG_BK * 2) + a_vo[q & 1], st + (q & 1) * 8192);
+    else if (q == 2 || w2) bg_glds16(w_base + (size_t)k * (BG_BK * 2) + w_vo[q & 1], st + A_BYTES + (q & 1) * 8192);
+  };
+  // wait until at most `stages` of this wave's later stages are still in flight (4 or 3 pieces each)
+  auto wait_allow = [&](int stages) __attribute__((always_inline)) {
+    if (w2) { if (stages >= 2) bg_wait_vmcnt<8>(); else if (stages == 1) bg_wait_vmcnt<4>(); else bg_wait_vmcnt<0>(); }
+    else { if (stages >= 2) bg_wait_vmcnt<6>(); else if (stages == 1) bg_wait_vmcnt<3>(); else bg_wait_vmcnt<0>(); }
   };
 
-  // ---- fragment read offsets inside a stage (bytes)
-  unsigned fa[4][2], fb[4][NJ];
+  // ---- fragment read offsets inside a stage (bytes): sub-step s = 16 k-elements = chunks 2s, 2s+1
+  unsigned fa[2][2], fb[2][NJ];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < 2; ++s) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ra = wm * 64 + i * 32 + (lane & 31);
@@ -124,69 +134,61 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- main loop: 2-stage ring, stage k+1 in flight across the barriers of step k
+  h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
+  auto load = [&](const char* rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
+    if (p.abl & 8) return;
 #pragma unroll
-  for (int q = 0; q < LPS; ++q) issue_piece(0, 0, q);
-  if (nk > 1) {
+    for (int j = 0; j < NJ; ++j) bf[j] = *(const h8*)(rd + fb[s][j]);
 #pragma unroll
-    for (int q = 0; q < LPS; ++q) issue_piece(1, 1, q);
-  }
-  for (int k = 0; k < nk; ++k) {
-    if (k + 1 < nk) bg_wait_vmcnt<LPS>(); else bg_wait_vmcnt<0>();     // this wave's pieces of stage k have landed
-    __builtin_amdgcn_s_barrier();                                       // ... and everybody else's
-    const char* rd = smem + (k & 1) * STAGE;
-    const bool more = k + 2 < nk;
-    // fragments are streamed one k-sub ahead of the MFMAs that use them (two register sets), so the LDS reads of
-    // sub s+1 run under the 2*NJ MFMAs of sub s; the stage is released (barrier) once the reads of the LAST sub have
-    // retired, and the next-but-one stage's DMA pieces go out between the MFMAs of that last sub
-    h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
-    auto load = [&](int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
-      if (p.abl & 8) return;
+    for (int i = 0; i < 2; ++i) af[i] = *(const h8*)(rd + fa[s][i]);
+  };
+  // 2*NJ MFMAs of one sub-step; the pieces [q0, q1) of stage kd go out between them (kd < 0: none)
+  auto mma = [&](h8 (&af)[2], h8 (&bf)[NJ], int kd, int q0, int q1) __attribute__((always_inline)) {
+    int q = q0;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = *(const h8*)(rd + fb[s][j]);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const h8*)(rd + fa[s][i]);
-    };
-    auto mma = [&](h8 (&af)[2], h8 (&bf)[NJ], bool dma) __attribute__((always_inline)) {
-      int piece = 0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (!(p.abl & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-          if (dma && piece < LPS) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (more && !(p.abl & 1)) issue_piece(k + 2, k & 1, piece);
-            ++piece;
-            __builtin_amdgcn_sched_barrier(0);
-          }
+      for (int j = 0; j < NJ; ++j) {
+        if (!(p.abl & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        if (q < q1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kd >= 0) issue_piece(kd, q);
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
         }
-      if (dma) {                                       // NJ = 3: six MFMAs, seven pieces
-#pragma unroll
-        for (; piece < LPS; ++piece)
-          if (more && !(p.abl & 1)) issue_piece(k + 2, k & 1, piece);
       }
-    };
-    load(0, a0, b0);
+  };
+
+  // ---- main loop: 4-stage ring, three stages in flight
+#pragma unroll
+  for (int st = 0; st < BG_S - 1; ++st)
+    if (st < nk) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) issue_piece(st, q);
+    }
+  wait_allow(nk - 1 < 2 ? nk - 1 : 2);                                  // stage 0 of this wave has landed
+  __builtin_amdgcn_s_barrier();                                         // ... and everybody else's
+  load(smem, 0, a0, b0);
+  for (int k = 0; k < nk; ++k) {
+    const char* rd = smem + (k & (BG_S - 1)) * STAGE;
+    const int kd = k + BG_S - 1 < nk ? k + BG_S - 1 : -1;               // stage whose DMA goes out during this step
     __builtin_amdgcn_sched_barrier(0);
-    load(1, a1, b1);
+    load(rd, 1, a1, b1);                                                // second half of stage k, under the first half's MFMAs
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    mma(a0, b0, false);
-    __builtin_amdgcn_sched_barrier(0);
-    load(2, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a1, b1, false);
-    __builtin_amdgcn_sched_barrier(0);
-    load(3, a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a0, b0, false);
+    // slot (k + 3) % 4 held stage k - 1, released by the mid-step barrier of step k - 1
+    mma(a0, b0, kd, 0, 4);
     __builtin_amdgcn_s_setprio(0);
-    bg_wait_lgkm0();                                                    // the last sub's fragments are in registers
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                                       // nobody reads this stage any more
+    const int left = nk - 2 - k;                                        // stages issued beyond k + 1
+    if (k + 1 < nk) wait_allow(left < 2 ? left : 2);                    // stage k + 1 of this wave has landed
+    bg_wait_lgkm0();                                                    // every read of stage k has retired
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (k + 1 < nk) load(smem + ((k + 1) & (BG_S - 1)) * STAGE, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    mma(a1, b1, true);
+    mma(a1, b1, -1, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   }
 
@@ -232,6 +234,234 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
       if (!(p.abl & 4)) bg_store16(p.out + (size_t)(m0 + row) * p.ldc + n0 + ch * 8, v);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form for the blocked-layout result (FFN-up: [M x 512] x [512 x 2048] + bias + ReLU -> the blocked f16
+// hidden): one workgroup per CU walks tiles slot, slot + G, .. with the (tile, k-step) sequence as ONE flat pipeline,
+// so a tile's prologue (three stages of latency) and the next workgroup's launch disappear behind the previous tile's
+// k-steps.  A D^T fragment quad pair IS a 32-row x 8-column block of the blocked layout, so the tile end needs no LDS
+// exchange: bias (from a 1 KiB LDS line fetched with the tile's first stage by a 4-byte LDS-DMA per lane) + scale +
+// ReLU + cvt, then 32 fire-and-forget 512-byte stores per wave straight from the accumulators, which are zeroed and
+// reused at once.  Those stores enter the vmcnt immediates exactly (vmcnt retires in order): the two waits that follow
+// a tile end allow 32 more operations in flight.
+__device__ __forceinline__ void bg_store8(void* p, h4 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void bg_glds4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+constexpr int BGP_NJ = 4, BGP_BN = 64 * BGP_NJ, BGP_STAGE = bg_stage(BGP_NJ), BGP_RING = BG_S * BGP_STAGE;
+constexpr int BGP_LDS = BGP_RING + 2 * BGP_BN * 4;            // ring + two bias lines
+
+__global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
+  constexpr int NJ = BGP_NJ, BN = BGP_BN, A_BYTES = BG_BM * BG_ROWB, STAGE = BGP_STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lh = lane >> 5;
+  auto swz = [](int row) __attribute__((always_inline)) -> int { return (row >> 2) & 3; };
+
+  // ---- tile schedule: persistent block b (on XCD b % 8) takes tiles slot, slot + G, ...; XCDs get contiguous runs
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int total_tiles = p.tiles_m * p.tiles_n;
+  const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
+  const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int n_my = slot < total_tiles ? (total_tiles - slot + G - 1) / G : 0;
+  const int nk = p.K / BG_BK;
+  const int T = n_my * nk;
+  if (T == 0) return;
+  float* const bias_line = reinterpret_cast<float*>(smem + BGP_RING);
+  if (tid < 2 * BN) bias_line[tid] = 0.f;                                // bias == null: the lines stay zero
+
+  // ---- DMA cursor (uniform): stage is_t = k-step is_k of tile is_tile
+  const int srow = lane >> 2, schunk = lane & 3;
+  unsigned a_vo[2], w_vo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 8 * i) * 16 + srow;
+    a_vo[i] = (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
+    w_vo[i] = (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 3)) * 2u;
+  }
+  int is_tile = slot, is_k = 0, is_t = 0, is_round = 0;
+  const char* is_a;
+  const char* is_w;
+  int is_n0 = 0;
+  auto set_issue_tile = [&]() __attribute__((always_inline)) {
+    const int tm = is_tile / p.tiles_n, tn = is_tile - tm * p.tiles_n;
+    is_a = reinterpret_cast<const char*>(p.A + (size_t)tm * BG_BM * p.lda);
+    is_w = reinterpret_cast<const char*>(p.W + (size_t)tn * BN * p.ldw);
+    is_n0 = tn * BN;
+  };
+  set_issue_tile();
+  auto issue_piece = [&](int q) __attribute__((always_inline)) {
+    if (p.abl & 1) return;
+    char* st = smem + (is_t & (BG_S - 1)) * STAGE + wave * 1024;
+    if (q < 2) bg_glds16(is_a + a_vo[q & 1], st + (q & 1) * 8192);
+    else bg_glds16(is_w + w_vo[q & 1], st + A_BYTES + (q & 1) * 8192);
+  };
+  // with a tile's first stage: its bias columns -> the bias line of that round's parity (waves 0-3, 64 floats each);
+  // one more operation in flight than the wait immediates assume only makes a wait stricter
+  auto issue_bias = [&]() __attribute__((always_inline)) {
+    if (is_k == 0 && p.bias && wave < BN / 64) bg_glds4(p.bias + is_n0 + wave * 64 + lane, bias_line + (is_round & 1) * BN + wave * 64);
+  };
+  auto issue_advance = [&]() __attribute__((always_inline)) {
+    ++is_t;
+    is_a += BG_BK * 2; is_w += BG_BK * 2;
+    if (++is_k == nk) {
+      is_k = 0; is_tile += G; ++is_round;
+      if (is_t < T) set_issue_tile();
+    }
+  };
+  auto wait_allow = [&](int stages, bool burst) __attribute__((always_inline)) {
+    if (!burst) { if (stages >= 2) bg_wait_vmcnt<8>(); else if (stages == 1) bg_wait_vmcnt<4>(); else bg_wait_vmcnt<0>(); }
+    else { if (stages >= 2) bg_wait_vmcnt<40>(); else if (stages == 1) bg_wait_vmcnt<36>(); else bg_wait_vmcnt<32>(); }
+  };
+
+  unsigned fa[2][2], fb[2][NJ];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 64 + i * 32 + (lane & 31);
+      fa[s][i] = (unsigned)(ra * BG_ROWB + (((2 * s + lh) ^ swz(ra)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int rb = wn * (32 * NJ) + j * 32 + (lane & 31);
+      fb[s][j] = (unsigned)(A_BYTES + rb * BG_ROWB + (((2 * s + lh) ^ swz(rb)) << 4));
+    }
+  }
+  f16x acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
+  auto load = [&](const char* rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
+    if (p.abl & 8) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bf[j] = *(const h8*)(rd + fb[s][j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[i] = *(const h8*)(rd + fa[s][i]);
+  };
+  auto mma = [&](h8 (&af)[2], h8 (&bf)[NJ], bool dma) __attribute__((always_inline)) {
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (!(p.abl & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        if (q < 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (dma) issue_piece(q);
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  };
+
+  // ---- prologue: three stages in flight
+#pragma unroll
+  for (int st = 0; st < BG_S - 1; ++st)
+    if (st < T) {
+      issue_bias();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) issue_piece(q);
+      issue_advance();
+    }
+  wait_allow(T - 1 < 2 ? T - 1 : 2, false);
+  __builtin_amdgcn_s_barrier();
+  load(smem, 0, a0, b0);
+
+  int tile = slot, k = 0, round = 0, since_burst = 3;
+  for (int t = 0; t < T; ++t) {
+    const char* rd = smem + (t & (BG_S - 1)) * STAGE;
+    const bool dma = t + BG_S - 1 < T;
+    __builtin_amdgcn_sched_barrier(0);
+    load(rd, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma) issue_bias();
+    __builtin_amdgcn_s_setprio(1);
+    mma(a0, b0, dma);
+    __builtin_amdgcn_s_setprio(0);
+    if (dma) issue_advance();
+    __builtin_amdgcn_sched_barrier(0);
+    const int left = T - 2 - t;
+    if (t + 1 < T) wait_allow(left < 2 ? left : 2, since_burst < 2 && !(p.abl & 4));
+    bg_wait_lgkm0();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(p.abl & 16)) __builtin_amdgcn_s_barrier();
+    if (t + 1 < T) load(smem + ((t + 1) & (BG_S - 1)) * STAGE, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma(a1, b1, false);
+    __builtin_amdgcn_s_setprio(0);
+    ++since_burst;
+    if (++k == nk) {
+      // ---- tile end: bias + scale + ReLU + cvt, 2 * NJ * 4 = 32 blocked-layout stores per wave, accumulators reused at once
+      const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+      const int m0 = tm * BG_BM, n0 = tn * BN;
+      const float lo = p.relu ? 0.f : -INFINITY;
+      const float* bl = bias_line + (round & 1) * BN + wn * (32 * NJ) + 4 * lh;
+      char* ob = reinterpret_cast<char*>(p.out) + ((size_t)((m0 >> 5) + wm * 2) * (size_t)(p.N >> 3) + (size_t)((n0 + wn * (32 * NJ)) >> 3)) * 512 +
+                 (lane & 31) * 16 + lh * 8;
+      const size_t rb_stride = (size_t)(p.N >> 3) * 512;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int nc = n0 + wn * (32 * NJ) + j * 32;
+        const float sc = nc < p.scale_cols ? p.scale : 1.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bl + j * 32 + 8 * g);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const h4 hv = {(half_t)fmaxf((acc[i][j][4 * g + 0] + b4.x) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 1] + b4.y) * sc, lo),
+                           (half_t)fmaxf((acc[i][j][4 * g + 2] + b4.z) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 3] + b4.w) * sc, lo)};
+            if (!(p.abl & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
+            acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      k = 0; tile += G; ++round; since_burst = 0;
+    }
+  }
+}
+
+bool gemm_bigp_applicable(const GemmArgs& a) {
+  if (!a.out_f16 || a.out_f32 || a.resid || a.add2 || !a.out_padded || a.a_blocked || !a.out_blocked) return false;
+  if (a.K % 64 != 0 || a.K < 128 || a.lda % 8 != 0 || a.ldw % 8 != 0 || a.scale_cols % 32 != 0 || a.N % BGP_BN != 0) return false;
+  return true;                                               // K >= 128: a bias line is reused two tiles later
+}
+
+void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus) {
+  BigDev d{};
+  d.A = a.A; d.W = a.W; d.bias = a.bias; d.out = a.out_f16;
+  d.lda = a.lda; d.ldw = a.ldw; d.ldc = a.ldc16;
+  d.M = a.M; d.N = a.N; d.K = a.K;
+  d.tiles_m = cdiv(a.M, BG_BM); d.tiles_n = a.N / BGP_BN;
+  d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
+  d.blocked = 1;
+  { static int abl = -1; if (abl < 0) { const char* e = getenv("PF_BIG_ABL"); abl = e ? atoi(e) : 0; } d.abl = abl; }   // timing experiments only
+  static std::mutex init_mu;
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!attr_set[dev & 63]) {
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_bigp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BGP_LDS));
+      attr_set[dev & 63] = true;
+    }
+  }
+  const int total = d.tiles_m * d.tiles_n;
+  if (total == 0) return;
+  hipLaunchKernelGGL(gemm_bigp_kernel, dim3((unsigned)std::min(total, cus)), dim3(512), BGP_LDS, s, d);
+  PF_HIP(hipGetLastError());
 }
 
 bool gemm_big_applicable(const GemmArgs& a, int cus, int* nj_out) {

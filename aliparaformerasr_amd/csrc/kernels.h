@@ -30,7 +30,7 @@ struct GemmArgs {
   int a_blocked;
   float* small_ws;               // scratch of the short-input kernel (k_gemm_small.hip, gemm_small_ws_bytes() bytes, one per
                                  // stream); null = never dispatch to it
-  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 3 = the 256 x {192,256} kernel, 4 = the short-input split-K kernel
+  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 3 = the 256 x {192,256} kernel, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result)
                                  // (stand-alone op tests; 3 fails when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
@@ -38,6 +38,9 @@ void launch_gemm(hipStream_t s, const GemmArgs& a);
 // applicable (f16-only result, N a multiple of 192 / 256, at least one tile per CU) unless force_mi is set
 bool gemm_big_applicable(const GemmArgs& a, int cus, int* nj_out);
 void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj);
+// persistent form of the same tile for the blocked-layout result (FFN-up)
+bool gemm_bigp_applicable(const GemmArgs& a);
+void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus);
 
 // Row-complete GEMM for N = 512 (k_gemm_rc.hip): x = resid + A W^T + bias + FSMN(V); n = LayerNorm(x).
 // One workgroup = 64 complete rows, so the residual add, the FSMN memory and the following LayerNorm are its epilogue.

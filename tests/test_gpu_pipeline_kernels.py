@@ -395,6 +395,26 @@ def test_gemm_big_first_layer_k576_and_wide_n(eng):
         np.testing.assert_allclose(got, _ref(A, Wm, bias), rtol=1.5e-3, atol=1.5e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(16000, 2048, 512), (5000, 512, 576), (300, 256, 128), (40000, 256, 192)])
+def test_gemm_big_persistent_blocked(eng, M, N, K):
+    """The persistent 256 x 256-tile kernel (blocked f16 result, FFN-up): the benchmark's shape (504 tiles on 256 CUs:
+    two tiles per workgroup, the second one's operands and bias prefetched under the first), fewer tiles than CUs, the
+    minimum K, and a run of tiles per workgroup with a k loop of six steps (tile ends inside the ring's depth)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wm += (np.arange(N)[:, None] * 1e-4).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = np.maximum(_ref(A, Wm, bias), 0)
+    got = eng.op_gemm_ex(A, Wm, bias, relu=True, out_kind=2, tile_rows=1024)
+    np.testing.assert_allclose(got, ref, rtol=1.5e-3, atol=1.5e-3)
+    assert np.array_equal(got, eng.op_gemm_ex(A, Wm, bias, relu=True, out_kind=2, tile_rows=1024))
+    nob = eng.op_gemm_ex(A, Wm, None, relu=False, out_kind=2, tile_rows=1024)
+    np.testing.assert_allclose(nob, _ref(A, Wm, 0.0), rtol=1.5e-3, atol=1.5e-3)
+    pp3 = eng.op_gemm_ex(A, Wm, bias, relu=True, out_kind=2, tile_rows=256)
+    np.testing.assert_allclose(got, pp3, rtol=1.5e-3, atol=1.5e-3)
+
+
 def test_gemm_big_refuses_what_it_cannot_do(eng):
     from aliparaformerasr_amd._native import PfError
     rng = np.random.default_rng(603)

@@ -28,6 +28,7 @@ for M in (16000, 64000):
     for tr, nm in ((256, "pp3 256x128"), (512, "big")):
         run("QKV f16 " + nm, M, 1536, 512, out_kind=1, tile_rows=tr, scale_cols=512, scale=0.088)
         run("FFN-up blocked relu " + nm, M, 2048, 512, out_kind=2, relu=True, tile_rows=tr)
+    run("FFN-up blocked relu persistent 256x256", M, 2048, 512, out_kind=2, relu=True, tile_rows=1024)
 run("dec K/V pp3", 16000, 16384, 512, out_kind=1, tile_rows=256, reps=3)
 run("dec K/V big", 16000, 16384, 512, out_kind=1, tile_rows=512, reps=3)
 eng.close()

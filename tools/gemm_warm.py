@@ -23,7 +23,12 @@ def run(name, M, N, K, **kw):
         ms, n, fpl = eng.profile_get(cls)
         res.append(ms / n * 1e3)
     print("%-34s %6d x %5d x %4d   cold %6.1f us   warm %6.1f us" % (name, M, N, K, res[0], res[1]), flush=True)
-for M in (2048, 4096, 16000):
+run("FFN-down f16 256-row tiles (32 tiles)", 2048, 512, 2048, out_kind=1, tile_rows=256)
+run("FFN-down f16 128-row tiles (64 tiles)", 2048, 512, 2048, out_kind=1, tile_rows=128)
+run("FFN-down f16 128-row tiles (32 tiles)", 1024, 512, 2048, out_kind=1, tile_rows=128)
+run("K=8192 256-row tiles (32 tiles)", 2048, 512, 8192, out_kind=1, tile_rows=256)
+run("K=8192 128-row tiles (32 tiles)", 1024, 512, 8192, out_kind=1, tile_rows=128)
+for M in ():
     run("FFN-down shape fp32 out 256-row", M, 512, 2048, out_kind=0, tile_rows=256)
     run("FFN-down shape f16 out 256-row", M, 512, 2048, out_kind=1, tile_rows=256)
     run("FFN-up shape f16 256-row", M, 2048, 512, out_kind=1, tile_rows=256, relu=True)
