@@ -44,7 +44,7 @@ SAMPLES = SECONDS * 16000
 LCAP = 512
 DOMINANT = "gemm_ffn1"
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "round1_f_gemm_ffn1_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round2_pmc.json")
 
 
 def ids_checksum(ids) -> str:
@@ -72,14 +72,27 @@ def respawn_under_torchrun(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2
-    on gfx950 + WRITE_SIZE, separate passes; see the file's notes).  bench.py cannot run a profiler itself."""
+def dominant_kernel_name(rows, cus):
+    """Which kernel launch_gemm picks for the FFN up-projection [rows x 512] x [512 x 2048] (csrc/k_gemm.hip: the
+    persistent 256 x 256-tile kernel when its schedule has fewer idle rounds, else the 256 x 128 persistent kernel)."""
+    cd = lambda a, b: (a + b - 1) // b
+    t_big, t_pp3 = cd(rows, 256) * 8, cd(rows, 256) * 16
+    big = os.environ.get("PF_BIGP", "1") != "0" and t_big >= cus and 1.9 * cd(t_big, cus) <= cd(t_pp3, cus)
+    return "gemm_bigp_kernel" if big else "gemm_f16_pp3<3, 2>"
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of the headline command
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py, notes in the file).  bench.py cannot
+    run a profiler itself."""
     try:
         with open(PMC_FILE) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
+            for k in json.load(f)["kernels"]:
+                if kernel.replace(" ", "") in k["kernel"].replace(" ", "") and k["launches"] >= 50:
+                    return float(k["traffic_bytes_per_launch"])
     except Exception:
-        return None
+        pass
+    return None
 
 
 def ort_reference_baseline(cmvn_unused=None):
@@ -320,6 +333,8 @@ def main():
         value = audio_s / dt
         flops_step = eng.last_flops()
         ach = fpl_dom / ((ms_dom / max(n_dom, 1)) * 1e-3) / 1e12 if n_dom else 0.0
+        dom_rows = B * int(res.L if sv else eng.num_frames(samples))
+        dom_kernel = dominant_kernel_name(dom_rows, torch.cuda.get_device_properties(0).multi_processor_count)
         out = {
             "metric": "RTFx (audio-sec/wall-sec), %s offline, batch %dx%ds per GPU"
                       % ("sensevoice-small" if sv else "paraformer-large", B, seconds),
@@ -340,11 +355,11 @@ def main():
             "host_audio_ms_per_batch": host_ms,     # one GPU's batch incl. H2D of the audio and D2H of the ids
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_pp3<3,2> (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
-                         % (DOMINANT, B * int(res.L if sv else eng.num_frames(samples))), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "%s (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
+                         % (dom_kernel, DOMINANT, dom_rows), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F16_TFLOPS,
-                         "traffic": pmc_traffic() if (not sv and B == BATCH_PER_GPU and seconds == SECONDS) else None,
-                         "traffic_unit": "bytes/launch (PMC, profiles/round1_f_gemm_ffn1_pmc.json)",
+                         "traffic": pmc_traffic(dom_kernel) if (not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS) else None,
+                         "traffic_unit": "bytes/launch (PMC, profiles/round2_pmc.json)",
                          "algorithmic_bytes_per_launch": int(fpl_dom / (2 * 512 * 2048)) * (512 + 2048) * 2 + 2048 * 512 * 2,
                          "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
                          "flops_per_launch": fpl_dom},
