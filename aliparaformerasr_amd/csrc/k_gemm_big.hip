@@ -255,6 +255,8 @@ __device__ __forceinline__ void bg_glds4(const void* g, void* l) {
 constexpr int BGP_NJ = 4, BGP_BN = 64 * BGP_NJ, BGP_STAGE = bg_stage(BGP_NJ), BGP_RING = BG_S * BGP_STAGE;
 constexpr int BGP_LDS = BGP_RING + 2 * BGP_BN * 4;            // ring + two bias lines
 
+// (A variant with the two wave groups — waves 0-3 / 4-7, one of each per SIMD — running the same sequence half a k-step
+// apart, two barriers and two landing waits per step, was built and measured: correct, 265 vs 199 us at M = 64000.)
 __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
   constexpr int NJ = BGP_NJ, BN = BGP_BN, A_BYTES = BG_BM * BG_ROWB, STAGE = BGP_STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -378,6 +380,35 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
   load(smem, 0, a0, b0);
 
   int tile = slot, k = 0, round = 0, since_burst = 3;
+  // ---- tile end: bias + scale + ReLU + cvt, 2 * NJ * 4 = 32 blocked-layout stores per wave, accumulators reused at once
+  auto tile_end = [&]() __attribute__((always_inline)) {
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BG_BM, n0 = tn * BN;
+    const float lo = p.relu ? 0.f : -INFINITY;
+    const float* bl = bias_line + (round & 1) * BN + wn * (32 * NJ) + 4 * lh;
+    char* ob = reinterpret_cast<char*>(p.out) + ((size_t)((m0 >> 5) + wm * 2) * (size_t)(p.N >> 3) + (size_t)((n0 + wn * (32 * NJ)) >> 3)) * 512 +
+               (lane & 31) * 16 + lh * 8;
+    const size_t rb_stride = (size_t)(p.N >> 3) * 512;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nc = n0 + wn * (32 * NJ) + j * 32;
+      const float sc = nc < p.scale_cols ? p.scale : 1.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bl + j * 32 + 8 * g);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const h4 hv = {(half_t)fmaxf((acc[i][j][4 * g + 0] + b4.x) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 1] + b4.y) * sc, lo),
+                         (half_t)fmaxf((acc[i][j][4 * g + 2] + b4.z) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 3] + b4.w) * sc, lo)};
+          if (!(p.abl & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
+          acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    k = 0; tile += G; ++round; since_burst = 0;
+  };
+
   for (int t = 0; t < T; ++t) {
     const char* rd = smem + (t & (BG_S - 1)) * STAGE;
     const bool dma = t + BG_S - 1 < T;
@@ -401,34 +432,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
     mma(a1, b1, false);
     __builtin_amdgcn_s_setprio(0);
     ++since_burst;
-    if (++k == nk) {
-      // ---- tile end: bias + scale + ReLU + cvt, 2 * NJ * 4 = 32 blocked-layout stores per wave, accumulators reused at once
-      const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-      const int m0 = tm * BG_BM, n0 = tn * BN;
-      const float lo = p.relu ? 0.f : -INFINITY;
-      const float* bl = bias_line + (round & 1) * BN + wn * (32 * NJ) + 4 * lh;
-      char* ob = reinterpret_cast<char*>(p.out) + ((size_t)((m0 >> 5) + wm * 2) * (size_t)(p.N >> 3) + (size_t)((n0 + wn * (32 * NJ)) >> 3)) * 512 +
-                 (lane & 31) * 16 + lh * 8;
-      const size_t rb_stride = (size_t)(p.N >> 3) * 512;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int nc = n0 + wn * (32 * NJ) + j * 32;
-        const float sc = nc < p.scale_cols ? p.scale : 1.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bl + j * 32 + 8 * g);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const h4 hv = {(half_t)fmaxf((acc[i][j][4 * g + 0] + b4.x) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 1] + b4.y) * sc, lo),
-                           (half_t)fmaxf((acc[i][j][4 * g + 2] + b4.z) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 3] + b4.w) * sc, lo)};
-            if (!(p.abl & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
-            acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      k = 0; tile += G; ++round; since_burst = 0;
-    }
+    if (++k == nk) tile_end();
   }
 }
 
