@@ -122,6 +122,15 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// A frame's LDS buffers are touched by ONE wavefront only, and a wave's DS operations execute in issue order, so the
+// passes need no s_barrier — only a fence that keeps the compiler from moving LDS accesses across the pass boundary
+// (block-wide barriers made four unrelated frames wait for each other thirteen times per frame).
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // 4 frames per 256-thread block, one wavefront each.  LDS per wave: 2 x 256 complex (4 KiB).
 __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ audio,
                                                     const int64_t* __restrict__ audio_off,
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   const float mean = part / (float)FB_FRAME_LEN;
-  __syncthreads();
+  wave_lds_sync();
   // ---- remove DC, pre-emphasis 0.97 (x[i] -= 0.97 x[i-1]; x[0] -= 0.97 x[0]), window
   float pre[7];
 #pragma unroll
@@ -188,13 +197,13 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
     }
     pre[r] = v;
   }
-  __syncthreads();
+  wave_lds_sync();
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     const int i = lane + 64 * r;
     if (i < FB_FRAME_LEN) fr[i] = pre[r];
   }
-  __syncthreads();
+  wave_lds_sync();
   // fr viewed as float2[256] is z[n] = x[2n] + i x[2n+1]  (bufA).  256-point Stockham radix-2.
   float2* src = bufA;
   float2* dst = bufB;
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
       dst[j0] = make_float2(a.x + t.x, a.y + t.y);
       dst[j0 + ns] = make_float2(a.x - t.x, a.y - t.y);
     }
-    __syncthreads();
+    wave_lds_sync();
     float2* tmp = src; src = dst; dst = tmp;
   }
   // src holds Z[k]; real-input split: X[k] = (Z[k] + conj Z[256-k])/2 - i e^{-2 pi i k/512} (Z[k] - conj Z[256-k])/2
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
     const float re = e.x + t.y, im = e.y - t.x;
     power[k] = re * re + im * im;
   }
-  __syncthreads();
+  wave_lds_sync();
   if (!active) return;
   for (int m = lane; m < n_mels; m += 64) {
     const int s0 = mel_start[m], o0 = mel_off[m], cnt = mel_off[m + 1] - o0;
