@@ -34,13 +34,24 @@ def test_us_cif_peak_matches_oracle(ts_setup):
     # running integrate in [0, 2): compare modulo the reset (a fire one frame early/late shifts it by thr)
     d = np.abs(pk - rp)
     d = np.minimum(d, np.abs(d - 0.9999))
-    assert np.quantile(d, 0.99) < 2e-2, d.max()
+    assert np.quantile(d, 0.99) < 3e-3 and d.max() < 1e-2, (np.quantile(d, 0.99), d.max())      # measured 6e-4 / 7e-4
     # fire frames: same count (= token_num up to the tail), each within one 20 ms upsampled frame
+    thr, margin = 1 - 1e-4, 5e-3
+    n_fire = n_safe = 0
     for b in range(pk.shape[0]):
-        f_dev = np.nonzero(pk[b] > 1 - 1e-4)[0]
-        f_ref = np.nonzero(rp[b] > 1 - 1e-4)[0]
+        f_dev = np.nonzero(pk[b] > thr)[0]
+        f_ref = np.nonzero(rp[b] > thr)[0]
         assert len(f_dev) == len(f_ref)
         assert np.all(np.abs(f_dev - f_ref) <= 1)
+        # a fire whose crossing clears the threshold by more than the peak tolerance on both sides (the integrate one
+        # frame earlier is below thr - margin, at the fire above thr + margin) must land on EXACTLY the oracle's frame
+        prev = np.where(f_ref > 0, rp[b][np.maximum(f_ref - 1, 0)], 0.0)
+        safe = (rp[b][f_ref] > thr + margin) & (prev < thr - margin)
+        assert np.array_equal(f_dev[safe], f_ref[safe])
+        n_fire += len(f_ref)
+        n_safe += int(safe.sum())
+    assert n_safe > 0.8 * n_fire, (n_safe, n_fire)          # the exact check covers most fires, not a corner
+    print("timestamp head: %d fires, %d exact by margin, peak error 99%% %.2e max %.2e" % (n_fire, n_safe, np.quantile(d, 0.99), d.max()))
 
 
 def test_forward_feats_peak_deterministic(ts_setup):
