@@ -240,9 +240,11 @@ typedef struct pf_gemm_desc {
   int32_t out_kind;           /* 0 fp32 result (+ residual / addend), 1 f16 row-major, 2 f16 blocked layout
                                  (32 rows x 8 columns = 512 contiguous bytes; the encoder FFN hidden)         */
   int32_t a_blocked;          /* A is handed to the kernel in the blocked layout (FFN-down's operand)         */
-  int32_t tile_rows;          /* 0 = by shape as the pipeline does (M <= 512 rows: the short-input split-K
-                                 kernel); 128 / 256 = gemm_f16_pp3 tile heights; 512 = the 256 x {192,256} tile
-                                 kernel; 32 = the short-input kernel (error when the named kernel does not apply) */
+  int32_t tile_rows;          /* kernel selector: 0 = by shape as the pipeline does (M <= 512 rows: the short-input
+                                 kernel; blocked results with fewer idle rounds: the persistent 256 x 256 kernel);
+                                 128 / 256 = gemm_f16_pp3 tile heights; 512 = the 256 x {192,256} tile kernel, one tile
+                                 per workgroup; 1024 = its persistent form (blocked result only); 32 = the short-input
+                                 kernel.  PF_ERR_INVALID_ARG when the named kernel does not apply.                  */
   int32_t scale_cols;         /* columns n < scale_cols are multiplied by scale after the bias (q scaling)    */
   float scale;
   const float* bias;          /* [N] or NULL                                                                  */
