@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
   const int T = n_my * nk;
   if (T == 0) return;
   float* const bias_line = reinterpret_cast<float*>(smem + BGP_RING);
-  if (tid < 2 * BN) bias_line[tid] = 0.f;                                // bias == null: the lines stay zero
+  if (!p.bias && tid < 2 * BN) bias_line[tid] = 0.f;                      // bias == null: the lines stay zero
 
   // ---- DMA cursor (uniform): stage is_t = k-step is_k of tile is_tile
   const int srow = lane >> 2, schunk = lane & 3;
@@ -336,12 +336,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
     }
   }
   f16x acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
   auto load = [&](const char* rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
     if (p.abl & 8) return;
@@ -381,34 +375,52 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
 
   int tile = slot, k = 0, round = 0, since_burst = 3;
   // ---- tile end: bias + scale + ReLU + cvt, 2 * NJ * 4 = 32 blocked-layout stores per wave, accumulators reused at once
-  auto tile_end = [&]() __attribute__((always_inline)) {
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * BG_BM, n0 = tn * BN;
-    const float lo = p.relu ? 0.f : -INFINITY;
-    const float* bl = bias_line + (round & 1) * BN + wn * (32 * NJ) + 4 * lh;
-    char* ob = reinterpret_cast<char*>(p.out) + ((size_t)((m0 >> 5) + wm * 2) * (size_t)(p.N >> 3) + (size_t)((n0 + wn * (32 * NJ)) >> 3)) * 512 +
-               (lane & 31) * 16 + lh * 8;
-    const size_t rb_stride = (size_t)(p.N >> 3) * 512;
+  // accumulators START as the bias of their tile (a 16-byte LDS read per register quad), so the tile end is only
+  // [scale] -> cvt -> packed ReLU -> store, and the next tile's bias is loaded in place of the zeroing
+  auto acc_init = [&](int rnd) __attribute__((always_inline)) {
+    const float* bl = bias_line + (rnd & 1) * BN + wn * (32 * NJ) + 4 * lh;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int nc = n0 + wn * (32 * NJ) + j * 32;
-      const float sc = nc < p.scale_cols ? p.scale : 1.f;
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *reinterpret_cast<const float4*>(bl + j * 32 + 8 * g);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const h4 hv = {(half_t)fmaxf((acc[i][j][4 * g + 0] + b4.x) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 1] + b4.y) * sc, lo),
-                         (half_t)fmaxf((acc[i][j][4 * g + 2] + b4.z) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 3] + b4.w) * sc, lo)};
-          if (!(p.abl & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
-          acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+          acc[i][j][4 * g + 0] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w;
         }
       }
+  };
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  auto tile_end = [&]() __attribute__((always_inline)) {
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BG_BM, n0 = tn * BN;
+    char* ob = reinterpret_cast<char*>(p.out) + ((size_t)((m0 >> 5) + wm * 2) * (size_t)(p.N >> 3) + (size_t)((n0 + wn * (32 * NJ)) >> 3)) * 512 +
+               (lane & 31) * 16 + lh * 8;
+    const size_t rb_stride = (size_t)(p.N >> 3) * 512;
+    const h2v zero2 = {(half_t)0.f, (half_t)0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nc = n0 + wn * (32 * NJ) + j * 32;
+      const bool scaled = nc < p.scale_cols;                   // uniform; scale_cols is a multiple of 32
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f2v lo2 = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]}, hi2 = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (scaled) { lo2 *= p.scale; hi2 *= p.scale; }
+          h2v l = __builtin_convertvector(lo2, h2v), h = __builtin_convertvector(hi2, h2v);
+          if (p.relu) { l = __builtin_elementwise_max(l, zero2); h = __builtin_elementwise_max(h, zero2); }
+          const h4 hv = {l[0], l[1], h[0], h[1]};
+          if (!(p.abl & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     k = 0; tile += G; ++round; since_burst = 0;
+    acc_init(round);                                           // landed with the next tile's first stage, three steps ago
   };
 
+  acc_init(0);                                                 // the first tile's bias (or zeros) landed before the barrier above
   for (int t = 0; t < T; ++t) {
     const char* rd = smem + (t & (BG_S - 1)) * STAGE;
     const bool dma = t + BG_S - 1 < T;
