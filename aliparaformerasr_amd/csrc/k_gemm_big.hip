@@ -43,9 +43,15 @@ struct BigDev {
   int M, N, K, tiles_m, tiles_n;
   int relu, scale_cols, blocked;
   float scale;
-  int abl;   // timing experiments only (PF_BIG_ABL): 1 no DMA, 2 no MFMA, 4 no result stores, 8 no fragment reads, 16 no barriers (persistent form)
 };
 
+// compile-time ablation bits for tools/abl_big.sh (timing experiments only; 0 in every shipped build — run-time flags
+// put a branch and a full lgkmcnt(0) in front of every MFMA): 1 no DMA, 2 no MFMA, 4 no result stores, 8 no fragment
+// reads, 16 no barriers (persistent form)
+#ifndef PF_BIG_ABL
+#define PF_BIG_ABL 0
+#endif
+constexpr int BG_ABL = PF_BIG_ABL;
 constexpr int BG_BM = 256, BG_BK = 32, BG_ROWB = BG_BK * 2, BG_S = 4;
 constexpr int bg_stage(int nj) { return (BG_BM + 64 * nj) * BG_ROWB; }          // A tile + W tile of one k-step
 constexpr int bg_xrow(int nj) { return 64 * nj * 2 + 16; }                       // f16 epilogue row + 16-byte skew
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
   const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
   // piece q of stage k: q = 0, 1 -> A; q = 2, 3 -> W (q = 3 only for waves that have a second W piece)
   auto issue_piece = [&](int k, int q) __attribute__((always_inline)) {
-    if (p.abl & 1) return;
+    if (BG_ABL & 1) return;
     char* st = smem + (k & (BG_S - 1)) * STAGE + wave * 1024;
     if (q < 2) bg_glds16(a_base + (size_t)k * (BG_BK * 2) + a_vo[q & 1], st + (q & 1) * 8192);
     else if (q == 2 || w2) bg_glds16(w_base + (size_t)k * (BG_BK * 2) + w_vo[q & 1], st + A_BYTES + (q & 1) * 8192);
@@ -136,20 +142,19 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
 
   h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
   auto load = [&](const char* rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
-    if (p.abl & 8) return;
+    if (BG_ABL & 8) return;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bf[j] = *(const h8*)(rd + fb[s][j]);
 #pragma unroll
     for (int i = 0; i < 2; ++i) af[i] = *(const h8*)(rd + fa[s][i]);
   };
-  // 2*NJ MFMAs of one sub-step; the pieces [q0, q1) of stage kd go out between them (kd < 0: none)
   auto mma = [&](h8 (&af)[2], h8 (&bf)[NJ], int kd, int q0, int q1) __attribute__((always_inline)) {
     int q = q0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if (!(p.abl & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        if (!(BG_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         if (q < q1) {
           __builtin_amdgcn_sched_barrier(0);
           if (kd >= 0) issue_piece(kd, q);
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
     for (int it = 0; it < CPR / 2; ++it) {
       const int cg = 2 * it + lh;
       const h8 v = *reinterpret_cast<const h8a*>(smem + (size_t)(wave * 32 + r) * XROW + cg * 16);
-      if (!(p.abl & 4)) bg_store16(ob + (size_t)cg * 512 + r * 16, v);
+      if (!(BG_ABL & 4)) bg_store16(ob + (size_t)cg * 512 + r * 16, v);
     }
   } else {
     // row-major: wave w owns rows 32w .. 32w+31; consecutive lanes = consecutive 16-byte chunks of a row
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
       const int rl = idx / CPR, ch = idx - rl * CPR;
       const int row = wave * 32 + rl;
       const h8 v = *reinterpret_cast<const h8a*>(smem + (size_t)row * XROW + ch * 16);
-      if (!(p.abl & 4)) bg_store16(p.out + (size_t)(m0 + row) * p.ldc + n0 + ch * 8, v);
+      if (!(BG_ABL & 4)) bg_store16(p.out + (size_t)(m0 + row) * p.ldc + n0 + ch * 8, v);
     }
   }
 }
@@ -275,7 +280,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
   const int T = n_my * nk;
   if (T == 0) return;
   float* const bias_line = reinterpret_cast<float*>(smem + BGP_RING);
-  if (!p.bias && tid < 2 * BN) bias_line[tid] = 0.f;                      // bias == null: the lines stay zero
 
   // ---- DMA cursor (uniform): stage is_t = k-step is_k of tile is_tile
   const int srow = lane >> 2, schunk = lane & 3;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
     a_vo[i] = (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
     w_vo[i] = (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 3)) * 2u;
   }
-  int is_tile = slot, is_k = 0, is_t = 0, is_round = 0;
+  int is_tile = slot, is_k = 0, is_t = 0, is_slot = 0, is_round = 0;
   const char* is_a;
   const char* is_w;
   int is_n0 = 0;
@@ -298,27 +302,33 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
   };
   set_issue_tile();
   auto issue_piece = [&](int q) __attribute__((always_inline)) {
-    if (p.abl & 1) return;
-    char* st = smem + (is_t & (BG_S - 1)) * STAGE + wave * 1024;
+    if (BG_ABL & 1) return;
+    char* st = smem + (is_slot & (BG_S - 1)) * STAGE + wave * 1024;
     if (q < 2) bg_glds16(is_a + a_vo[q & 1], st + (q & 1) * 8192);
     else bg_glds16(is_w + w_vo[q & 1], st + A_BYTES + (q & 1) * 8192);
   };
-  // with a tile's first stage: its bias columns -> the bias line of that round's parity (waves 0-3, 64 floats each);
-  // one more operation in flight than the wait immediates assume only makes a wait stricter
+  // The loop body is BRANCH-FREE (a conditional DMA or wait splits the block, and the compiler then puts a full
+  // lgkmcnt(0) in front of the first MFMA: the fragment reads issued just before it would no longer run under the
+  // MFMAs).  So every step issues exactly five operations per wave — the bias columns of the cursor's tile -> the bias
+  // line of that round's parity (4 bytes per lane; waves 4-7 repeat waves 0-3), then the four pieces of the cursor's
+  // stage — and past the end of the tile list the cursor simply stops advancing (the last stage is re-loaded into a
+  // slot nobody reads again), which makes every vmcnt immediate a compile-time constant.
   auto issue_bias = [&]() __attribute__((always_inline)) {
-    if (is_k == 0 && p.bias && wave < BN / 64) bg_glds4(p.bias + is_n0 + wave * 64 + lane, bias_line + (is_round & 1) * BN + wave * 64);
+    if (BG_ABL & 1) return;
+    bg_glds4(p.bias + is_n0 + (wave & 3) * 64 + lane, bias_line + (is_round & 1) * BN + (wave & 3) * 64);
   };
   auto issue_advance = [&]() __attribute__((always_inline)) {
-    ++is_t;
-    is_a += BG_BK * 2; is_w += BG_BK * 2;
-    if (++is_k == nk) {
-      is_k = 0; is_tile += G; ++is_round;
-      if (is_t < T) set_issue_tile();
+    if (is_t + 1 < T) {
+      ++is_t;
+      is_a += BG_BK * 2; is_w += BG_BK * 2;
+      if (++is_k == nk) { is_k = 0; is_tile += G; ++is_round; set_issue_tile(); }
     }
+    ++is_slot;
   };
-  auto wait_allow = [&](int stages, bool burst) __attribute__((always_inline)) {
-    if (!burst) { if (stages >= 2) bg_wait_vmcnt<8>(); else if (stages == 1) bg_wait_vmcnt<4>(); else bg_wait_vmcnt<0>(); }
-    else { if (stages >= 2) bg_wait_vmcnt<40>(); else if (stages == 1) bg_wait_vmcnt<36>(); else bg_wait_vmcnt<32>(); }
+  // stage t + 1 of this wave has landed: the 2 x 5 operations of stages t + 2, t + 3 (and, for two steps after a tile
+  // end, its 32 stores) may still be in flight
+  auto wait_landed = [&](bool burst) __attribute__((always_inline)) {
+    if (burst) bg_wait_vmcnt<42>(); else bg_wait_vmcnt<10>();
   };
 
   unsigned fa[2][2], fb[2][NJ];
@@ -337,20 +347,32 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
   }
   f16x acc[2][NJ];
   h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
-  auto load = [&](const char* rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
-    if (p.abl & 8) return;
+  // Fragment reads and their waits are inline asm: the compiler's own wait insertion loses count across the loop
+  // back-edge (a full lgkmcnt(0) in front of the first MFMA, so the reads of the second half never ran under the first
+  // half's MFMAs) and answers LDS reads behind in-flight LDS-DMA with vmcnt(0) (at the tile end that drained the three
+  // stages in flight AND the 32 result stores: 5-6 us per tile).  `rd` is the stage's byte offset in LDS.
+  auto load = [&](unsigned rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
+    if (BG_ABL & 8) return;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bf[j] = *(const h8*)(rd + fb[s][j]);
+    for (int j = 0; j < NJ; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bf[j]) : "v"(rd + fb[s][j]) : "memory");
 #pragma unroll
-    for (int i = 0; i < 2; ++i) af[i] = *(const h8*)(rd + fa[s][i]);
+    for (int i = 0; i < 2; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[i]) : "v"(rd + fa[s][i]) : "memory");
   };
+  // wait until at most N LDS reads are outstanding; the fragments are operands so that no use moves above the wait
+  auto frag_wait6 = [&](h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+  };
+  auto frag_wait0 = [&](h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+  };
+  // 2*NJ MFMAs of one sub-step; the pieces [q0, q1) of stage kd go out between them (kd < 0: none)
   auto mma = [&](h8 (&af)[2], h8 (&bf)[NJ], bool dma) __attribute__((always_inline)) {
     int q = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if (!(p.abl & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        if (!(BG_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         if (q < 4) {
           __builtin_amdgcn_sched_barrier(0);
           if (dma) issue_piece(q);
@@ -362,33 +384,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
 
   // ---- prologue: three stages in flight
 #pragma unroll
-  for (int st = 0; st < BG_S - 1; ++st)
-    if (st < T) {
-      issue_bias();
+  for (int st = 0; st < BG_S - 1; ++st) {
+    issue_bias();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) issue_piece(q);
-      issue_advance();
-    }
-  wait_allow(T - 1 < 2 ? T - 1 : 2, false);
+    for (int q = 0; q < 4; ++q) issue_piece(q);
+    issue_advance();
+  }
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;   // LDS byte address of the ring
+  wait_landed(false);                                          // stage 0 (and the first bias line) of this wave
   __builtin_amdgcn_s_barrier();
-  load(smem, 0, a0, b0);
+  load(lds0, 0, a0, b0);
 
   int tile = slot, k = 0, round = 0, since_burst = 3;
   // ---- tile end: bias + scale + ReLU + cvt, 2 * NJ * 4 = 32 blocked-layout stores per wave, accumulators reused at once
   // accumulators START as the bias of their tile (a 16-byte LDS read per register quad), so the tile end is only
   // [scale] -> cvt -> packed ReLU -> store, and the next tile's bias is loaded in place of the zeroing
+  typedef float f4v __attribute__((ext_vector_type(4)));
   auto acc_init = [&](int rnd) __attribute__((always_inline)) {
-    const float* bl = bias_line + (rnd & 1) * BN + wn * (32 * NJ) + 4 * lh;
+    const unsigned bl = lds0 + BGP_RING + ((rnd & 1) * BN + wn * (32 * NJ) + 4 * lh) * 4;
+    f4v b4[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bl + j * 32 + 8 * g);
+      for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(b4[j][g]) : "v"(bl + (j * 32 + 8 * g) * 4) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b4[0][0]), "+v"(b4[0][1]), "+v"(b4[0][2]), "+v"(b4[0][3]), "+v"(b4[1][0]), "+v"(b4[1][1]), "+v"(b4[1][2]), "+v"(b4[1][3]),
+                   "+v"(b4[2][0]), "+v"(b4[2][1]), "+v"(b4[2][2]), "+v"(b4[2][3]), "+v"(b4[3][0]), "+v"(b4[3][1]), "+v"(b4[3][2]), "+v"(b4[3][3]));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          acc[i][j][4 * g + 0] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w;
+          acc[i][j][4 * g + 0] = b4[j][g][0]; acc[i][j][4 * g + 1] = b4[j][g][1]; acc[i][j][4 * g + 2] = b4[j][g][2]; acc[i][j][4 * g + 3] = b4[j][g][3];
         }
-      }
   };
   typedef float f2v __attribute__((ext_vector_type(2)));
   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
           h2v l = __builtin_convertvector(lo2, h2v), h = __builtin_convertvector(hi2, h2v);
           if (p.relu) { l = __builtin_elementwise_max(l, zero2); h = __builtin_elementwise_max(h, zero2); }
           const h4 hv = {l[0], l[1], h[0], h[1]};
-          if (!(p.abl & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
+          if (!(BG_ABL & 4)) bg_store8(ob + i * rb_stride + (size_t)(j * 4 + g) * 512, hv);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -422,23 +451,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
 
   acc_init(0);                                                 // the first tile's bias (or zeros) landed before the barrier above
   for (int t = 0; t < T; ++t) {
-    const char* rd = smem + (t & (BG_S - 1)) * STAGE;
-    const bool dma = t + BG_S - 1 < T;
+    const unsigned rd = lds0 + (t & (BG_S - 1)) * STAGE;
     __builtin_amdgcn_sched_barrier(0);
-    load(rd, 1, a1, b1);
+    load(rd, 1, a1, b1);                                       // second half of stage t, under the first half's MFMAs
     __builtin_amdgcn_sched_barrier(0);
-    if (dma) issue_bias();
+    issue_bias();
+    frag_wait6(a0, b0);                                        // first half (requested behind the last barrier) is in
     __builtin_amdgcn_s_setprio(1);
-    mma(a0, b0, dma);
+    mma(a0, b0, true);                                         // + the four pieces of stage t + 3 (slot freed by the barrier of step t - 1)
     __builtin_amdgcn_s_setprio(0);
-    if (dma) issue_advance();
+    issue_advance();
     __builtin_amdgcn_sched_barrier(0);
-    const int left = T - 2 - t;
-    if (t + 1 < T) wait_allow(left < 2 ? left : 2, since_burst < 2 && !(p.abl & 4));
-    bg_wait_lgkm0();
+    wait_landed(since_burst < 2 && !(BG_ABL & 4));             // stage t + 1 of this wave has landed
+    frag_wait0(a1, b1);                                        // every read of stage t has retired
     __builtin_amdgcn_sched_barrier(0);
-    if (!(p.abl & 16)) __builtin_amdgcn_s_barrier();
-    if (t + 1 < T) load(smem + ((t + 1) & (BG_S - 1)) * STAGE, 0, a0, b0);
+    if (!(BG_ABL & 16)) __builtin_amdgcn_s_barrier();
+    load(lds0 + ((t + 1) & (BG_S - 1)) * STAGE, 0, a0, b0);    // (after the last step: a slot nobody uses)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     mma(a1, b1, false);
@@ -446,11 +474,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bigp_kernel(BigDev p) {
     ++since_burst;
     if (++k == nk) tile_end();
   }
+  bg_wait_vmcnt<0>();                                          // the clamped DMA of the last steps must not outlive the workgroup's LDS
 }
 
 bool gemm_bigp_applicable(const GemmArgs& a) {
   if (!a.out_f16 || a.out_f32 || a.resid || a.add2 || !a.out_padded || a.a_blocked || !a.out_blocked) return false;
-  if (a.K % 64 != 0 || a.K < 128 || a.lda % 8 != 0 || a.ldw % 8 != 0 || a.scale_cols % 32 != 0 || a.N % BGP_BN != 0) return false;
+  if (a.K % 64 != 0 || a.K < 128 || a.lda % 8 != 0 || a.ldw % 8 != 0 || a.scale_cols % 32 != 0 || a.N % BGP_BN != 0 || a.N > 65536) return false;
   return true;                                               // K >= 128: a bias line is reused two tiles later
 }
 
@@ -462,7 +491,15 @@ void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus) {
   d.tiles_m = cdiv(a.M, BG_BM); d.tiles_n = a.N / BGP_BN;
   d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
   d.blocked = 1;
-  { static int abl = -1; if (abl < 0) { const char* e = getenv("PF_BIG_ABL"); abl = e ? atoi(e) : 0; } d.abl = abl; }   // timing experiments only
+  if (!d.bias) {                                             // the kernel always loads a bias line: zeros when there is none
+    static std::mutex zmu;
+    static float* zeros[64] = {nullptr};
+    int zd = 0;
+    PF_HIP(hipGetDevice(&zd));
+    std::lock_guard<std::mutex> lk(zmu);
+    if (!zeros[zd & 63]) { PF_HIP(hipMalloc(&zeros[zd & 63], 65536 * 4)); PF_HIP(hipMemset(zeros[zd & 63], 0, 65536 * 4)); }
+    d.bias = zeros[zd & 63];
+  }
   static std::mutex init_mu;
   static bool attr_set[64] = {false};
   int dev = 0;
@@ -509,7 +546,6 @@ void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj) {
   d.tiles_m = cdiv(a.M, BG_BM); d.tiles_n = a.N / (64 * nj);
   d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
   d.blocked = a.out_blocked;
-  { static int abl = -1; if (abl < 0) { const char* e = getenv("PF_BIG_ABL"); abl = e ? atoi(e) : 0; } d.abl = abl; }
   static std::mutex init_mu;
   static bool attr_set[64] = {false};
   int dev = 0;

@@ -1,4 +1,5 @@
-"""Ablation timing of the persistent 256 x 256 kernel at M = 64000 (8 tiles per workgroup): run with PF_BIG_ABL=bits."""
+"""Timing of the persistent 256 x 256 kernel (FFN-up shape) at ABL_M rows (64000 = 8 tiles per workgroup); the
+ablation bits are compile-time (tools/abl_big.sh rebuilds with -DPF_BIG_ABL=n)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,5 +18,5 @@ for _ in range(4):
     eng.op_gemm_ex(A, Wm, b, relu=True, out_kind=2, tile_rows=1024)
 eng.profile(False)
 ms, n, fpl = eng.profile_get("gemm_op")
-print("M=%d K=%d PF_BIG_ABL=%-3s %7.1f us" % (M, K, os.environ.get("PF_BIG_ABL", "0"), ms / n * 1e3), flush=True)
+print("M=%d K=%d persistent 256x256: %7.1f us  %.0f TF" % (M, K, ms / n * 1e3, fpl / (ms / n * 1e-3) / 1e12), flush=True)
 eng.close()
