@@ -678,8 +678,15 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     PF_CHECK(a.force_mi != 3 || can, PF_ERR_INVALID_ARG, "gemm: the 256 x {192,256} tile kernel does not apply to this problem");
     if (can && (a.force_mi == 3 || (a.force_mi == 0 && use_big))) { launch_gemm_big(s, a, nj); return; }
   }
-  const int mi = a.force_mi ? (a.force_mi == 1 ? 1 : 2)
-                            : (((float)(cdiv(d.M, 256) * cdiv(d.N, GEMM_BN)) < mi_x * cus[dev]) ? 1 : 2);
+  // tile height by rounds: a 128-row tile costs ~0.58 of a 256-row one (half the MFMAs, two thirds of the operand
+  // bytes); whichever schedule has the shorter last round wins (decoder FFN-up, M = 5344: 336 tiles = 2 rounds vs
+  // 672 = 3 x 0.58).  PF_GEMM_ROUNDS=0 keeps the tile-count rule alone.
+  static int by_rounds = -1;
+  if (by_rounds < 0) { const char* e = getenv("PF_GEMM_ROUNDS"); by_rounds = (e && e[0] == '0') ? 0 : 1; }
+  const int t2 = cdiv(d.M, 256) * cdiv(d.N, GEMM_BN), t1 = cdiv(d.M, 128) * cdiv(d.N, GEMM_BN);
+  const bool few = (float)t2 < mi_x * cus[dev];
+  const bool rounds1 = by_rounds && 0.58 * cdiv(t1, cus[dev]) < (double)cdiv(t2, cus[dev]);
+  const int mi = a.force_mi ? (a.force_mi == 1 ? 1 : 2) : ((few || rounds1) ? 1 : 2);
   d.tiles_m = cdiv(d.M, 128 * mi);
   d.tiles_n = cdiv(d.N, GEMM_BN);
   const int total = d.tiles_m * d.tiles_n;
