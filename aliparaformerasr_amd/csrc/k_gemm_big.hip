@@ -497,7 +497,11 @@ void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus) {
     int zd = 0;
     PF_HIP(hipGetDevice(&zd));
     std::lock_guard<std::mutex> lk(zmu);
-    if (!zeros[zd & 63]) { PF_HIP(hipMalloc(&zeros[zd & 63], 65536 * 4)); PF_HIP(hipMemset(zeros[zd & 63], 0, 65536 * 4)); }
+    if (!zeros[zd & 63]) {
+      PF_HIP(hipMalloc(&zeros[zd & 63], 65536 * 4));
+      PF_HIP(hipMemset(zeros[zd & 63], 0, 65536 * 4));
+      PF_HIP(hipDeviceSynchronize());                       // the fill runs on the null stream; the caller's stream does not wait for it
+    }
     d.bias = zeros[zd & 63];
   }
   static std::mutex init_mu;
