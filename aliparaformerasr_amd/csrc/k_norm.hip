@@ -10,6 +10,8 @@
 // into the first layer's norm1; the multiply and the add are kept as two separately
 // rounded fp32 operations (no FMA contraction) to match a Mul node followed by an Add node.
 #include "kernels.h"
+
+#include <cstdlib>
 #include "exact.h"
 
 namespace pf {
@@ -115,11 +117,91 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+// D = 512, many rows (the encoder's post-FFN LayerNorm, 16 000 rows): one wave normalises R consecutive rows with all of
+// their loads requested up front (R = 2: 4 KB in flight per wave instead of 2 KB, half the wave launches: 11.0 -> 9.0 us at
+// 16 000 rows; R = 4 gives nothing more).  Same shifted two-pass form and reduction as layernorm_kernel; the compiler's
+// FMA contraction differs between the two kernels, so results agree to the last bit or two, not bitwise.
+template <int R>
+__global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int64_t rows,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           half_t* __restrict__ out16, int ld16, float* __restrict__ out32, int ld32) {
+  constexpr int D = 512;
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  float4 va[R], vb[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * (int64_t)D);
+    va[r] = xr[lane];
+    vb[r] = xr[lane + 64];
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  const float4 ga = g4[lane], gb = g4[lane + 64], ba = b4[lane], bb = b4[lane + 64];
+  float mean[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float x0 = __shfl(va[r].x, 0, 64);
+    va[r].x = sub_rn(va[r].x, x0); va[r].y = sub_rn(va[r].y, x0); va[r].z = sub_rn(va[r].z, x0); va[r].w = sub_rn(va[r].w, x0);
+    vb[r].x = sub_rn(vb[r].x, x0); vb[r].y = sub_rn(vb[r].y, x0); vb[r].z = sub_rn(vb[r].z, x0); vb[r].w = sub_rn(vb[r].w, x0);
+    float s = 0.f;
+    s += (va[r].x + va[r].y) + (va[r].z + va[r].w);
+    s += (vb[r].x + vb[r].y) + (vb[r].z + vb[r].w);
+    mean[r] = wave_sum(s) / (float)D;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float ss = 0.f;
+    {
+      const float a = va[r].x - mean[r], b = va[r].y - mean[r], c = va[r].z - mean[r], d = va[r].w - mean[r];
+      ss += (a * a + b * b) + (c * c + d * d);
+    }
+    {
+      const float a = vb[r].x - mean[r], b = vb[r].y - mean[r], c = vb[r].z - mean[r], d = vb[r].w - mean[r];
+      ss += (a * a + b * b) + (c * c + d * d);
+    }
+    rstd[r] = 1.0f / sqrtf(wave_sum(ss) / (float)D + LN_EPS);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= rows) break;
+    float4 ya, yb;
+    ya.x = (va[r].x - mean[r]) * rstd[r] * ga.x + ba.x; ya.y = (va[r].y - mean[r]) * rstd[r] * ga.y + ba.y;
+    ya.z = (va[r].z - mean[r]) * rstd[r] * ga.z + ba.z; ya.w = (va[r].w - mean[r]) * rstd[r] * ga.w + ba.w;
+    yb.x = (vb[r].x - mean[r]) * rstd[r] * gb.x + bb.x; yb.y = (vb[r].y - mean[r]) * rstd[r] * gb.y + bb.y;
+    yb.z = (vb[r].z - mean[r]) * rstd[r] * gb.z + bb.z; yb.w = (vb[r].w - mean[r]) * rstd[r] * gb.w + bb.w;
+    if (out32) {
+      reinterpret_cast<float4*>(out32 + row * (int64_t)ld32)[lane] = ya;
+      reinterpret_cast<float4*>(out32 + row * (int64_t)ld32)[lane + 64] = yb;
+    }
+    if (out16) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      reinterpret_cast<h4*>(out16 + row * (int64_t)ld16)[lane] = h4{(half_t)ya.x, (half_t)ya.y, (half_t)ya.z, (half_t)ya.w};
+      reinterpret_cast<h4*>(out16 + row * (int64_t)ld16)[lane + 64] = h4{(half_t)yb.x, (half_t)yb.y, (half_t)yb.z, (half_t)yb.w};
+    }
+  }
+}
+
 template <bool POSENC>
 static void ln_dispatch(hipStream_t s, const float* x, int64_t rows, int D, const float* gamma, const float* beta,
                         half_t* out16, int ld16, float* out32, int ld32, const float* pe, int T, float xscale) {
   PF_CHECK(D % 4 == 0 && D <= 64 * 4 * 8, PF_ERR_INVALID_ARG, "layernorm: unsupported width");
   if (rows == 0) return;
+  if (!POSENC && D == 512 && rows >= 4096 && (!out16 || ld16 == D)) {
+    static int rows_per_wave = -1;                             // PF_LN_ROWS: 1 keeps the one-row kernel (A/B switch)
+    if (rows_per_wave < 0) { const char* e = getenv("PF_LN_ROWS"); rows_per_wave = e ? atoi(e) : 2; }
+    if (rows_per_wave == 2 || rows_per_wave == 4) {
+      const int R = rows_per_wave;
+      const dim3 g2((unsigned)((rows + 4 * R - 1) / (4 * R))), b2(256);
+      if (R == 2) hipLaunchKernelGGL(layernorm512_kernel<2>, g2, b2, 0, s, x, rows, gamma, beta, out16, ld16, out32, ld32);
+      else hipLaunchKernelGGL(layernorm512_kernel<4>, g2, b2, 0, s, x, rows, gamma, beta, out16, ld16, out32, ld32);
+      PF_HIP(hipGetLastError());
+      return;
+    }
+  }
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   const int nv = (D / 4 + 63) / 64;
 #define LN_CASE(N)                                                                                         \
