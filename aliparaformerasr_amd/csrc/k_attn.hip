@@ -21,6 +21,7 @@
 //   V: 16-byte chunk ^= ((key & 3) << 2)    -> the 4 key rows of a tr-read hit 4 bank quarters
 #include "kernels.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace pf {
@@ -61,7 +62,11 @@ __device__ __forceinline__ void att_glds16(const void* g, void* l) {
 // double buffered (tile kt+1 is in flight during tile kt), one workgroup barrier per tile.  (Issuing
 // S(kt+1) ahead of the softmax of S(kt) was tried: +32 VGPRs, no gain — the two workgroups per CU already
 // interleave their phases.)
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
+// NW: wavefronts per workgroup (32 queries each).  4: two workgroups per CU; 8: one workgroup of 256 queries per CU — the
+// K/V tiles of a (batch, head) are then staged by half as many workgroups (half the L2 -> LDS traffic).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
+  constexpr int PPW = 16 / NW;                       // 1 KiB staging pieces (4 key rows) per wave, tile and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
   }
   const int bh = lid / nqt, qt = lid - bh * nqt;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = qt * ATT_BQ + wave * 32;
+  const int q0 = qt * (32 * NW) + wave * 32;
 
   const half_t* qb = p.q + b * p.q_bs + h * ATT_DK;
   const half_t* kb_ = p.k + b * p.k_bs + h * ATT_DK;
@@ -96,10 +101,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
 
   // ---- staging: wave-instruction i of this wave covers tile rows (wave*4+i)*4 .. +3
   const int srow = lane >> 4, schunk = lane & 15;
-  unsigned k_src[4], v_src[4];                     // byte offsets inside a 64-key tile
+  unsigned k_src[PPW], v_src[PPW];                 // byte offsets inside a 64-key tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 4 + srow;
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (wave * PPW + i) * 4 + srow;
     k_src[i] = (unsigned)(row * p.k_rs + ((schunk ^ (row & 15)) << 3)) * 2u;
     v_src[i] = (unsigned)(row * p.v_rs + ((schunk ^ ((row & 3) << 2)) << 3)) * 2u;
   }
@@ -108,15 +113,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
     const char* kg = reinterpret_cast<const char*>(kb_ + (int64_t)kt * ATT_BK * p.k_rs);
     if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) att_glds16(kg + k_src[i], kl + (wave * 4 + i) * 1024);
+      for (int i = 0; i < PPW; ++i) att_glds16(kg + k_src[i], kl + (wave * PPW + i) * 1024);
     } else {
       // tail tile: rows >= Lk are re-reads of row Lk-1.  They are masked out of the softmax anyway, but
       // what lies behind the last key in memory is not ours (another utterance, or stale workspace bytes
       // of another dtype, i.e. possibly NaN/Inf bit patterns) and 0 * NaN would poison the P V product.
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int over = kt * ATT_BK + (wave * 4 + i) * 4 + srow - (p.Lk - 1);     // rows to step back
-        att_glds16(kg + (k_src[i] - (unsigned)((over > 0 ? over : 0) * p.k_rs * 2)), kl + (wave * 4 + i) * 1024);
+      for (int i = 0; i < PPW; ++i) {
+        const int over = kt * ATT_BK + (wave * PPW + i) * 4 + srow - (p.Lk - 1);     // rows to step back
+        att_glds16(kg + (k_src[i] - (unsigned)((over > 0 ? over : 0) * p.k_rs * 2)), kl + (wave * PPW + i) * 1024);
       }
     }
   };
@@ -125,12 +130,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnDev p) {
     const char* vg = reinterpret_cast<const char*>(vb + (int64_t)kt * ATT_BK * p.v_rs);
     if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) att_glds16(vg + v_src[i], vl + (wave * 4 + i) * 1024);
+      for (int i = 0; i < PPW; ++i) att_glds16(vg + v_src[i], vl + (wave * PPW + i) * 1024);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int over = kt * ATT_BK + (wave * 4 + i) * 4 + srow - (p.Lk - 1);
-        att_glds16(vg + (v_src[i] - (unsigned)((over > 0 ? over : 0) * p.v_rs * 2)), vl + (wave * 4 + i) * 1024);
+      for (int i = 0; i < PPW; ++i) {
+        const int over = kt * ATT_BK + (wave * PPW + i) * 4 + srow - (p.Lk - 1);
+        att_glds16(vg + (v_src[i] - (unsigned)((over > 0 ? over : 0) * p.v_rs * 2)), vl + (wave * PPW + i) * 1024);
       }
     }
   };
@@ -337,18 +342,32 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
            PF_ERR_INVALID_ARG, "attention: row strides must keep 16-byte alignment");
   static std::mutex init_mu;                         // engines on different devices launch from different threads
   static bool attr_set[64] = {false};
+  static int cus[64] = {0};
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
   {
     std::lock_guard<std::mutex> lk(init_mu);
     if (!attr_set[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 ATT_LDS_BYTES));
+      PF_HIP(hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
+      PF_HIP(hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
+      hipDeviceProp_t prop;
+      PF_HIP(hipGetDeviceProperties(&prop, dev));
+      cus[dev & 63] = prop.multiProcessorCount;
       attr_set[dev & 63] = true;
     }
   }
-  dim3 grid((a.Lq + ATT_BQ - 1) / ATT_BQ, a.B * a.H);
-  hipLaunchKernelGGL(attn_kernel, grid, dim3(256), ATT_LDS_BYTES, s, d);
+  // 256-query workgroups when they still cover the chip (self-attention at T = 500: 2 x 128 workgroups); PF_ATT_NW forces
+  static int force_nw = -1;
+  if (force_nw < 0) { const char* e = getenv("PF_ATT_NW"); force_nw = e ? atoi(e) : 0; }
+  const int wg8 = ((a.Lq + 255) / 256) * a.B * a.H;
+  const bool nw8 = force_nw ? force_nw == 8 : wg8 >= cus[dev & 63];
+  if (nw8) {
+    dim3 grid((a.Lq + 255) / 256, a.B * a.H);
+    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(512), ATT_LDS_BYTES, s, d);
+  } else {
+    dim3 grid((a.Lq + ATT_BQ - 1) / ATT_BQ, a.B * a.H);
+    hipLaunchKernelGGL(attn_kernel<4>, grid, dim3(256), ATT_LDS_BYTES, s, d);
+  }
   PF_HIP(hipGetLastError());
 }
 
