@@ -305,7 +305,10 @@ void launch_layernorm_f16(hipStream_t s, const half_t* x, int64_t rows, int D, c
 // One wave per FDL_ROWS consecutive positions of one utterance; a lane owns columns 4*lane..+3 and 256+4*lane..+3, the
 // K-1 halo rows are read once per FDL_ROWS outputs (register sliding window, as fsmn_dec_kernel), and the row
 // statistics are the shifted two-pass form of layernorm_kernel.  Saves one launch and one fp32 read of x per layer.
-constexpr int FDL_ROWS = 4;
+#ifndef PF_FDL_ROWS
+#define PF_FDL_ROWS 2
+#endif
+constexpr int FDL_ROWS = PF_FDL_ROWS;   // measured at M = 5344: 2 rows 14.4 us, 4 rows 16.2 us, 8 rows 18.5 us per launch
 template <int K>
 __global__ __launch_bounds__(256) void fsmn_dec_ln_kernel(const float* __restrict__ tn, const float* __restrict__ wT,
                                                           const int32_t* __restrict__ token_num, int B, int L,
