@@ -100,10 +100,13 @@ SIGNATURES = {
     "pf_group_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
     "pf_sync": (C.c_int, [_vp]),
     "pf_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
+    "pf_host_group_sim": (C.c_int, [C.c_int32, C.c_int32, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i64,
+                                    C.c_int32, _i32, _i32]),
     "pf_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "pf_profile_reset": (C.c_int, [_vp]),
     "pf_profile_select": (C.c_int, [_vp, C.c_char_p]),
     "pf_profile_get": (C.c_int, [_vp, C.c_char_p, _P(C.c_double), _i64, _P(C.c_double)]),
+    "pf_profile_kernel": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int32]),
     "pf_last_flops": (C.c_int, [_vp, _P(C.c_double)]),
     "pf_op_lfr_cmvn_pad": (C.c_int, [_vp, _P(_f), _i32, C.c_int32, C.c_int32, _f, C.c_int64, _i32]),
     "pf_op_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _i64]),

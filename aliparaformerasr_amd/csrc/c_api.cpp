@@ -1,5 +1,6 @@
 // c_api.cpp — extern "C" boundary (include/paraformer_hip.h).  Every entry point converts C++
 // exceptions into a negative pf_status + thread-local message; no exception crosses the ABI.
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -279,6 +280,16 @@ int pf_profile_get(pf_engine* h, const char* cls, double* ms, int64_t* launches,
   return PF_OK;
   PF_CATCH
 }
+int pf_profile_kernel(pf_engine* h, const char* cls, char* name_out, int32_t cap) {
+  PF_TRY
+  NEED(cls); NEED(name_out);
+  PF_CHECK(cap > 0, PF_ERR_INVALID_ARG, "pf_profile_kernel: cap <= 0");
+  const std::string k = E(h)->profile_kernel(cls);
+  PF_CHECK((int)k.size() < cap, PF_ERR_CAPACITY, "pf_profile_kernel: name needs " + std::to_string(k.size() + 1) + " bytes");
+  std::memcpy(name_out, k.c_str(), k.size() + 1);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_last_flops(pf_engine* h, double* f) {
   PF_TRY
   NEED(f);
@@ -351,6 +362,84 @@ int pf_group_recognize(pf_group* h, const float* const* samples, const int64_t* 
   std::lock_guard<std::mutex> lk(g->mutex());
   g->recognize(samples, n, B, hotwords, n_hotwords, want_logits(out));
   g->fetch(out);
+  return PF_OK;
+  PF_CATCH
+}
+
+// ---- pf_host_group_sim: the shard runner of pf_group with arithmetic stand-ins for the devices -------------------
+namespace {
+struct SimBackend : pf::ShardBackend {
+  int G, B, has_cif, fixed_L, collective, fail_shard, fail_stage;
+  const int32_t* fire;
+  std::vector<std::vector<char>> send;     // one block per shard
+  std::vector<size_t> sizes;               // the count each shard would hand to ncclAllGather
+  std::vector<char> recv0;                 // shard 0's receive buffer
+  pf::MaxBarrier bar;
+  std::vector<pf::HostBatchOut*> outs;
+  SimBackend(int G_) : G(G_), send((size_t)G_), sizes((size_t)G_, 0), bar(G_), outs((size_t)G_, nullptr) {}
+  void run(int g, int lo, int hi, int /*Tg*/, bool /*want_logits*/, const std::function<int(int)>& l_sync, pf::HostBatchOut& r) override {
+    if (g == fail_shard && fail_stage == 0) throw pf::Error(PF_ERR_DEVICE, "simulated failure before the decoder-length rendez-vous");
+    const int Bg = hi - lo;
+    int own = 0;
+    for (int b = lo; b < hi; ++b) own = std::max(own, fire[b]);
+    const int L = has_cif ? l_sync(own) : fixed_L;
+    if (g == fail_shard && fail_stage == 1) throw pf::Error(PF_ERR_DEVICE, "simulated failure after the decoder-length rendez-vous");
+    r = pf::HostBatchOut();
+    r.B = Bg; r.L = L; r.V = 1;
+    r.ids.resize((size_t)Bg * L);
+    r.token_num.resize((size_t)Bg); r.fire_count.resize((size_t)Bg);
+    for (int b = 0; b < Bg; ++b) {
+      for (int l = 0; l < L; ++l) r.ids[(size_t)b * L + l] = (int64_t)(lo + b) * 100000 + l;
+      r.token_num[(size_t)b] = has_cif ? fire[lo + b] : L;
+      r.fire_count[(size_t)b] = fire[lo + b];
+    }
+    outs[(size_t)g] = &r;
+  }
+  bool has_collective() const override { return collective != 0; }
+  void prepare_gather(int g, int count, int L, const pf::GatherLayout& lay, int) override {
+    if (g == fail_shard && fail_stage == 2) throw pf::Error(PF_ERR_DEVICE, "simulated failure while preparing the gather");
+    sizes[(size_t)g] = lay.block_bytes;
+    send[(size_t)g].assign(lay.block_bytes, (char)0xFF);
+    if (count > 0 && L > 0) {
+      const pf::HostBatchOut& r = *outs[(size_t)g];
+      std::memcpy(send[(size_t)g].data(), r.ids.data(), (size_t)count * L * 8);
+      if (has_cif) std::memcpy(send[(size_t)g].data() + lay.ids_bytes, r.token_num.data(), (size_t)count * 4);
+    }
+  }
+  void gather(int g, const pf::GatherLayout& lay, int) override {
+    bar.arrive_and_max(0);                                       // every block is packed
+    if (g == 0) {
+      for (int i = 0; i < G; ++i)                                // what RCCL requires of its callers
+        PF_CHECK(sizes[(size_t)i] == lay.block_bytes, PF_ERR_DEVICE, "all-gather entered with different counts on different ranks");
+      recv0.resize(lay.block_bytes * (size_t)G);
+      for (int i = 0; i < G; ++i) std::memcpy(recv0.data() + lay.block_bytes * (size_t)i, send[(size_t)i].data(), lay.block_bytes);
+    }
+    bar.arrive_and_max(0);
+  }
+  void read_gathered(std::vector<char>& host, size_t bytes) override {
+    PF_CHECK(bytes == recv0.size(), PF_ERR_DEVICE, "merge expects a different gather size than the collective produced");
+    host = recv0;
+  }
+};
+}  // namespace
+
+int pf_host_group_sim(int32_t G, int32_t B, const int32_t* fire_count, int32_t has_cif, int32_t fixed_L, int32_t collective,
+                      int32_t fail_shard, int32_t fail_stage, int64_t* ids_out, int32_t l_cap, int32_t* token_num_out,
+                      int32_t* L_out) {
+  PF_TRY
+  PF_CHECK(G > 0 && G <= 64 && B >= 0 && (B == 0 || fire_count), PF_ERR_INVALID_ARG, "pf_host_group_sim: bad arguments");
+  SimBackend be(G);
+  be.B = B; be.has_cif = has_cif; be.fixed_L = fixed_L; be.collective = collective; be.fail_shard = fail_shard;
+  be.fail_stage = fail_stage; be.fire = fire_count;
+  pf::ShardRunner runner(G);
+  pf::HostBatchOut m;
+  runner.recognize(be, B, /*Tg=*/1, has_cif != 0, /*V=*/1, false, m);
+  if (L_out) *L_out = m.L;
+  if (ids_out) {
+    PF_CHECK(l_cap >= m.L, PF_ERR_CAPACITY, "pf_host_group_sim: l_cap < L");
+    for (int b = 0; b < B; ++b) std::memcpy(ids_out + (size_t)b * l_cap, m.ids.data() + (size_t)b * m.L, (size_t)m.L * 8);
+  }
+  if (token_num_out && B > 0) std::memcpy(token_num_out, m.token_num.data(), (size_t)B * 4);
   return PF_OK;
   PF_CATCH
 }
@@ -856,6 +945,7 @@ int pf_host_online_lfr(const float* fbank, int32_t t80, int32_t lfr_m, int32_t l
 int pf_host_online_posenc(float* x, int32_t timesteps, int32_t dim, int32_t start_idx) {
   PF_TRY
   NEED(x);
+  PF_CHECK(timesteps >= 0 && dim >= 4 && dim % 2 == 0 && start_idx >= 0, PF_ERR_INVALID_ARG, "online_posenc: bad arguments");
   std::vector<float> v(x, x + (size_t)timesteps * dim);
   online_position_encode(v, timesteps, dim, start_idx);
   std::memcpy(x, v.data(), v.size() * 4);
@@ -865,6 +955,7 @@ int pf_host_online_posenc(float* x, int32_t timesteps, int32_t dim, int32_t star
 int pf_host_online_dynamic_mask(float* alphas, int32_t n) {
   PF_TRY
   NEED(alphas);
+  PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "online_dynamic_mask: negative length");
   std::vector<float> v(alphas, alphas + n);
   online_dynamic_mask(v);
   std::memcpy(alphas, v.data(), v.size() * 4);
@@ -874,7 +965,9 @@ int pf_host_online_dynamic_mask(float* alphas, int32_t n) {
 int pf_host_online_cif(const float* hiddens, const float* alphas, int32_t n, int32_t D, float threshold, float* fired,
                        int32_t fired_cap, int32_t* n_fired, float* carry_alpha, float* carry_hidden) {
   PF_TRY
-  NEED(hiddens); NEED(alphas); NEED(n_fired); NEED(carry_alpha); NEED(carry_hidden);
+  NEED(n_fired); NEED(carry_alpha); NEED(carry_hidden);
+  PF_CHECK(n >= 0 && D > 0 && fired_cap >= 0, PF_ERR_INVALID_ARG, "online_cif: bad sizes");
+  if (n > 0) { NEED(hiddens); NEED(alphas); }
   std::vector<std::vector<float>> h;
   for (int i = 0; i < n; ++i) h.emplace_back(hiddens + (size_t)i * D, hiddens + (size_t)(i + 1) * D);
   std::vector<float> a(alphas, alphas + n), ch;
@@ -883,7 +976,8 @@ int pf_host_online_cif(const float* hiddens, const float* alphas, int32_t n, int
   online_cif(h, a, threshold, f, ca, ch);
   *n_fired = (int32_t)f.size();
   *carry_alpha = ca;
-  std::memcpy(carry_hidden, ch.data(), (size_t)D * 4);
+  std::memset(carry_hidden, 0, (size_t)D * 4);                 // n = 0: nothing was integrated, the carried frame is empty
+  if (!ch.empty()) std::memcpy(carry_hidden, ch.data(), std::min(ch.size(), (size_t)D) * 4);
   PF_CHECK((int32_t)f.size() <= fired_cap, PF_ERR_CAPACITY, "online_cif: fired capacity too small");
   for (size_t l = 0; l < f.size(); ++l) { NEED(fired); std::memcpy(fired + l * D, f[l].data(), (size_t)D * 4); }
   return PF_OK;
@@ -892,8 +986,11 @@ int pf_host_online_cif(const float* hiddens, const float* alphas, int32_t n, int
 int pf_host_online_decode(const char* const* tokens, int32_t n_tokens, const int64_t* ids, int32_t n_ids, char* out, int32_t cap) {
   PF_TRY
   NEED(out);
+  PF_CHECK(n_tokens >= 0 && n_ids >= 0 && cap > 0, PF_ERR_INVALID_ARG, "online_decode: bad sizes");
+  if (n_tokens > 0) NEED(tokens);
+  if (n_ids > 0) NEED(ids);
   std::vector<std::string> tk;
-  for (int i = 0; i < n_tokens; ++i) tk.emplace_back(tokens[i]);
+  for (int i = 0; i < n_tokens; ++i) { PF_CHECK(tokens[i] != nullptr, PF_ERR_INVALID_ARG, "online_decode: null token"); tk.emplace_back(tokens[i]); }
   std::vector<int64_t> idv(ids, ids + n_ids);
   const std::string t = online_decode_text(tk, idv);
   PF_CHECK((int32_t)t.size() + 1 <= cap, PF_ERR_CAPACITY, "online_decode: output capacity too small");

@@ -560,6 +560,11 @@ void Engine::prof_end(const char* cls) {
   if (!prof_only_.empty() && prof_only_ != cls) return;
   ProfClass& pc = prof_[cls];
   PF_HIP(hipEventRecord(pc.ev.back().second, stream_));
+  if (cls[0] == 'g' && cls[1] == 'e') pc.kernel = last_gemm_kernel();   // "gemm_*" classes
+}
+std::string Engine::profile_kernel(const std::string& cls) const {
+  auto it = prof_.find(cls);
+  return it == prof_.end() ? std::string() : it->second.kernel;
 }
 bool Engine::profile_get(const std::string& cls, double* ms, int64_t* launches, double* flops_per_launch) {
   auto it = prof_.find(cls);
@@ -765,7 +770,15 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   // short inputs (M <= 512 rows): every GEMM goes to k_gemm_small.hip, which has no row-complete epilogue and no blocked
   // layout but takes the FSMN memory as an epilogue term and the LayerNorm behind FFN-down in its reduction
   const bool small = M <= gemm_small_max_rows() && small_ws_;
-  if (small && D == 512 && F % 64 == 0 && F > 576 && mc_.kernel == 11 && !no_small_fuse_) {
+  // the split FFN-down form must really apply to (M, F) — e.g. F = 4096 needs 16 splits, whose partials outgrow the
+  // scratch beyond 256 rows: then the regular kernels run instead of failing the utterance
+  auto split_ok = [&](int rows, const Lin& w2, const half_t* Aop) {
+    GemmSmallArgs t{};
+    t.M = rows; t.N = w2.N; t.K = w2.Kpad; t.A = Aop; t.lda = w2.Kpad; t.W = w2.w; t.ldw = w2.Kpad; t.ws = small_ws_;
+    t.post_ln_g = nx.ln.g; t.post_ln_b = nx.ln.b;
+    return gemm_small_applicable(t);
+  };
+  if (small && D == 512 && F % 64 == 0 && F > 576 && mc_.kernel == 11 && !no_small_fuse_ && split_ok(M, L.w2, h16_)) {
     // 7 launches: QKV | attention | out-projection + FSMN memory + residual | norm2 | FFN-up | FFN-down partials | their
     // sum + bias + residual + the LayerNorm behind the block (next norm1 / after_norm)
     gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
@@ -983,7 +996,13 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   // take norm2 (bit 4) and the next block's norm1 (bit 2) as epilogues, but at M = B*L = 5344 it runs on 84 CUs only:
   // measured 47 vs 29.5 + 5.6 us (FFN-down) and 21 vs 16 + 5.6 us (out-projection), so both stay off (PF_DEC_FUSE=7
   // enables them for experiments).
-  const bool dsmall = Md <= gemm_small_max_rows() && small_ws_ && D == 512 && F % 64 == 0 && F > 576 && !no_small_fuse_;
+  bool dsmall = Md <= gemm_small_max_rows() && small_ws_ && D == 512 && F % 64 == 0 && F > 576 && !no_small_fuse_;
+  if (dsmall) {                                        // the split FFN-down form must apply to (Md, F), else the regular kernels
+    GemmSmallArgs t{};
+    t.M = Md; t.N = D; t.K = dec_final_w2_.Kpad; t.A = hd16; t.lda = F; t.W = dec_final_w2_.w; t.ldw = dec_final_w2_.Kpad;
+    t.ws = small_ws_; t.post_ln_g = dec_after_.g; t.post_ln_b = dec_after_.b;
+    dsmall = gemm_small_applicable(t);
+  }
   const bool f_fsmn = (dec_fuse_ & 1) != 0, f_out = (dec_fuse_ & 2) != 0 && !dsmall, f_ffn2 = (dec_fuse_ & 4) != 0;
   bool have_n1 = false;                                // xdn16 already holds norm1(xd) of the coming block
   // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or

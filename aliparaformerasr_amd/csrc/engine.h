@@ -11,6 +11,7 @@
 
 #include "json.h"
 #include "kernels.h"
+#include "shards.h"
 
 namespace pf {
 
@@ -49,17 +50,6 @@ struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; f
 struct DevBuf {       // grow-only device allocation
   void* p = nullptr;
   size_t bytes = 0;
-};
-
-struct HostBatchOut { // results of the last forward, host side
-  int B = 0, L = 0, V = 0, T = 0;
-  std::vector<int64_t> ids;        // [B, L]
-  std::vector<int32_t> token_num;  // [B]
-  std::vector<int32_t> fire_count; // [B]
-  std::vector<float> cif_peak;     // [B, peak_len] us_cif_peak (timestamp models), else empty
-  int peak_len = 0;
-  std::vector<float> logits;       // [B, L, V] host copy (per-thread result slots only)
-  bool has_logits = false;
 };
 
 class Engine {
@@ -129,6 +119,7 @@ class Engine {
   void profile_reset();
   void profile_select(const std::string& cls) { prof_only_ = cls; }
   bool profile_get(const std::string& cls, double* ms, int64_t* launches, double* flops_per_launch);
+  std::string profile_kernel(const std::string& cls) const;   // GEMM classes: the kernel the launcher chose ("" otherwise)
   double last_flops() const { return last_flops_; }
 
   const ModelCfg& model() const { return mc_; }
@@ -139,7 +130,7 @@ class Engine {
 
  private:
   struct Tensor { const float* dev = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
-  struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0; int64_t n = 0; };
+  struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0; int64_t n = 0; std::string kernel; };
 
   void load_weights(const pf_engine_config& cfg);
   const Tensor& tensor(const std::string& name) const;

@@ -50,36 +50,6 @@ struct Rccl {
   }
 };
 
-// ------------------------------------------------------------------ MaxBarrier ------------
-int MaxBarrier::arrive_and_max(int v) {
-  std::unique_lock<std::mutex> lk(mu_);
-  if (broken_) throw Error(PF_ERR_RECOGNITION, "another device of the group failed");
-  const int gen = gen_;
-  cur_ = std::max(cur_, v);
-  if (++count_ == n_) {
-    result_ = cur_;
-    cur_ = 0;
-    count_ = 0;
-    ++gen_;
-    cv_.notify_all();
-    return result_;
-  }
-  cv_.wait(lk, [&] { return gen_ != gen || broken_; });
-  if (gen_ == gen) throw Error(PF_ERR_RECOGNITION, "another device of the group failed");
-  return result_;
-}
-void MaxBarrier::abort() {
-  std::lock_guard<std::mutex> lk(mu_);
-  broken_ = true;
-  cv_.notify_all();
-}
-void MaxBarrier::reset() {
-  std::lock_guard<std::mutex> lk(mu_);
-  broken_ = false;
-  count_ = 0;
-  cur_ = 0;
-}
-
 // ------------------------------------------------------------------ Group ------------------
 Group::Group(const pf_engine_config& cfg, const int32_t* devices, int n) {
   PF_CHECK(devices && n > 0 && n <= 64, PF_ERR_INVALID_ARG, "pf_group: device list must name 1..64 devices");
@@ -163,13 +133,10 @@ Group::Group(const pf_engine_config& cfg, const int32_t* devices, int n) {
       ec.weights_bytes = nbytes;
       eng_.push_back(std::make_shared<Engine>(ec));
     }
-    lbar_.reset(new MaxBarrier(n));
     gsend_.assign((size_t)n, nullptr); grecv_.assign((size_t)n, nullptr);
     gsend_bytes_.assign((size_t)n, 0); grecv_bytes_.assign((size_t)n, 0);
-    for (int i = 0; i < n; ++i) {
-      workers_.emplace_back(new Worker());
-      workers_.back()->th = std::thread([this, i] { worker_loop(i); });
-    }
+    runner_.reset(new ShardRunner(n));
+    runner_->run_on_all([this](int g) { PF_HIP(hipSetDevice(devs_[(size_t)g])); });   // each worker thread binds its device once
   } catch (...) {
     release();
     throw;
@@ -179,12 +146,7 @@ Group::Group(const pf_engine_config& cfg, const int32_t* devices, int n) {
 Group::~Group() { release(); }
 
 void Group::release() {
-  for (auto& w : workers_) {
-    { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
-    w->cv.notify_all();
-    if (w->th.joinable()) w->th.join();
-  }
-  workers_.clear();
+  runner_.reset();                                    // joins the worker threads
   eng_.clear();                                       // engines first: they borrow the images
   for (size_t i = 0; i < gsend_.size(); ++i) {
     hipSetDevice(devs_[i]);
@@ -202,160 +164,76 @@ void Group::release() {
   rccl_.reset();
 }
 
-void Group::worker_loop(int i) {
-  Worker& w = *workers_[(size_t)i];
-  hipSetDevice(devs_[(size_t)i]);
-  for (;;) {
-    std::function<void()> job;
-    {
-      std::unique_lock<std::mutex> lk(w.mu);
-      w.cv.wait(lk, [&] { return w.has_job || w.stop; });
-      if (w.stop) return;
-      job = std::move(w.job);
-      w.has_job = false;
-    }
-    int code = 0;
-    std::string err;
-    try {
-      job();
-    } catch (const Error& ex) {
-      code = ex.code; err = ex.what();
-    } catch (const std::exception& ex) {
-      code = PF_ERR_DEVICE; err = ex.what();
-    }
-    if (code) lbar_->abort();                         // nobody may wait for this device's L any longer
-    {
-      std::lock_guard<std::mutex> lk(w.mu);
-      w.code = code; w.error = err; w.done = true;
-    }
-    w.cv.notify_all();
-  }
-}
-
-void Group::run_on_all(const std::function<void(int)>& fn) {
-  for (size_t i = 0; i < workers_.size(); ++i) {
-    Worker& w = *workers_[i];
-    std::lock_guard<std::mutex> lk(w.mu);
-    const int gi = (int)i;
-    w.job = [fn, gi] { fn(gi); };
-    w.has_job = true; w.done = false; w.code = 0; w.error.clear();
-    w.cv.notify_all();
-  }
-  int code = 0;
-  std::string err;
-  for (auto& wp : workers_) {
-    std::unique_lock<std::mutex> lk(wp->mu);
-    wp->cv.wait(lk, [&] { return wp->done; });
-    // report the root cause, not the "another device failed" echoes
-    if (wp->code && (!code || (code == PF_ERR_RECOGNITION && err.find("another device") != std::string::npos))) {
-      code = wp->code; err = wp->error;
-    }
-  }
-  if (code) throw Error(code, err);
-}
-
 void Group::recognize(const float* const* samples, const int64_t* n, int B, const int32_t* hotwords, int n_hotwords,
                       bool want_logits) {
   PF_CHECK(B >= 0 && (B == 0 || (samples && n)), PF_ERR_INVALID_ARG, "pf_group_recognize: bad arguments");
-  const int G = size();
   merged_ = HostBatchOut();
   merged_logits_ = want_logits;
   if (B == 0) return;
-  const int per = (B + G - 1) / G;                    // contiguous blocks of ceil(B/G)
   int Tg = 0;                                         // the reference pads to the BATCH maximum (PadHelper.cs:25)
   for (int b = 0; b < B; ++b) {
     if (!samples[b] && n[b] > 0) throw Error(PF_ERR_NULL_SAMPLES, "source");
     Tg = std::max(Tg, eng_[0]->num_lfr_frames(n[b]));
   }
-  const bool has_cif = eng_[0]->model().kind != "sensevoicesmall";
-  std::vector<HostBatchOut> part((size_t)G);
-  lbar_->reset();
-  run_on_all([&](int g) {
-    Engine& e = *eng_[(size_t)g];
-    const int lo = std::min(g * per, B), hi = std::min(lo + per, B), Bg = hi - lo;
-    std::lock_guard<std::mutex> lk(e.mutex());
-    HostBatchOut& r = part[(size_t)g];
-    int Lg = 0;
-    if (Bg == 0) {
-      if (has_cif) Lg = lbar_->arrive_and_max(0);
-    } else {
-      if (e.model().seaco) e.set_hotwords(hotwords, hotwords ? n_hotwords : 0);
-      if (has_cif) e.set_l_hook([this](int L) { return lbar_->arrive_and_max(L); });
-      try {
-        e.stage_audio(samples + lo, n + lo, Bg, Tg);
-        e.run_staged(want_logits);
-      } catch (...) {
-        e.set_l_hook(nullptr);
-        throw;
-      }
-      e.set_l_hook(nullptr);
-      e.sync();
-      r = e.last_result();
-      Lg = r.L;
-      if (want_logits && (int64_t)r.B * r.L * r.V > 0) e.copy_logits(r);
-    }
-    // ---- gather of the hypotheses over RCCL: fixed-shape [per, L] int64 ids + [per] int32 token_num
-    if (comms_ready_) {
-      const size_t ids_b = (size_t)per * (size_t)std::max(Lg, 1) * 8, blk = (size_t)round_up((int64_t)(ids_b + (size_t)per * 4), 256);
-      auto grow = [&](void*& p, size_t& have, size_t want) {
-        if (have >= want) return;
-        if (p) { PF_HIP(hipStreamSynchronize(e.stream())); PF_HIP(hipFree(p)); p = nullptr; }
-        PF_HIP(hipMalloc(&p, want));
-        have = want;
-      };
-      grow(gsend_[(size_t)g], gsend_bytes_[(size_t)g], blk);
-      grow(grecv_[(size_t)g], grecv_bytes_[(size_t)g], blk * (size_t)G);
-      char* sb = (char*)gsend_[(size_t)g];
-      PF_HIP(hipMemsetAsync(sb, 0xFF, blk, e.stream()));           // absent rows: id -1, token_num -1
-      if (Bg > 0 && Lg > 0) {
-        PF_HIP(hipMemcpyAsync(sb, e.ids_device(), (size_t)Bg * Lg * 8, hipMemcpyDeviceToDevice, e.stream()));
-        if (has_cif)
-          PF_HIP(hipMemcpyAsync(sb + ids_b, e.token_num_device(), (size_t)Bg * 4, hipMemcpyDeviceToDevice, e.stream()));
-      }
-      rccl_->check(rccl_->AllGather(sb, grecv_[(size_t)g], blk, ncclUint8, (ncclComm_t)comms_[(size_t)g], e.stream()),
-                   "ncclAllGather");
-      PF_HIP(hipStreamSynchronize(e.stream()));
-    }
-  });
-  // ---- merge in the caller's order
-  int L = 0, V = eng_[0]->model().vocab, P = 0;
-  for (auto& r : part) { L = std::max(L, r.L); P = std::max(P, r.peak_len); }
-  merged_.B = B; merged_.L = L; merged_.V = V; merged_.T = Tg; merged_.peak_len = P;
-  merged_.ids.assign((size_t)B * L, 0);
-  merged_.token_num.assign((size_t)B, 0);
-  merged_.fire_count.assign((size_t)B, 0);
-  if (P > 0) merged_.cif_peak.assign((size_t)B * P, 0.f);
-  if (want_logits) merged_.logits.assign((size_t)B * L * V, 0.f);
-  merged_.has_logits = want_logits;
-  std::vector<char> gathered;
-  size_t blk = 0, ids_b = 0;
-  if (comms_ready_ && L > 0) {
-    ids_b = (size_t)per * (size_t)L * 8;
-    blk = (size_t)round_up((int64_t)(ids_b + (size_t)per * 4), 256);
-    gathered.resize(blk * (size_t)G);
-    PF_HIP(hipSetDevice(devs_[0]));
-    PF_HIP(hipMemcpy(gathered.data(), grecv_[0], gathered.size(), hipMemcpyDeviceToHost));   // ONE read-back
+  cur_samples_ = samples; cur_n_ = n; cur_hotwords_ = hotwords; cur_n_hotwords_ = hotwords ? n_hotwords : 0;
+  cur_has_cif_ = eng_[0]->model().kind != "sensevoicesmall";
+  runner_->recognize(*this, B, Tg, cur_has_cif_, eng_[0]->model().vocab, want_logits, merged_);
+  cur_samples_ = nullptr; cur_n_ = nullptr; cur_hotwords_ = nullptr;
+}
+
+// ---- ShardBackend: one shard on its engine (worker thread g, device bound at construction) -------------------
+void Group::run(int g, int lo, int hi, int Tg, bool want_logits, const std::function<int(int)>& l_sync, HostBatchOut& r) {
+  Engine& e = *eng_[(size_t)g];
+  const int Bg = hi - lo;
+  std::lock_guard<std::mutex> lk(e.mutex());
+  if (e.model().seaco) e.set_hotwords(cur_hotwords_, cur_n_hotwords_);
+  if (cur_has_cif_) e.set_l_hook(l_sync);
+  try {
+    e.stage_audio(cur_samples_ + lo, cur_n_ + lo, Bg, Tg);
+    e.run_staged(want_logits);
+  } catch (...) {
+    e.set_l_hook(nullptr);
+    throw;
   }
-  for (int g = 0; g < G; ++g) {
-    const HostBatchOut& r = part[(size_t)g];
-    const int lo = std::min(g * per, B), hi = std::min(lo + per, B), Bg = hi - lo;
-    if (Bg == 0) continue;
-    PF_CHECK(r.L == L || !has_cif, PF_ERR_DEVICE, "pf_group: shards disagree on the decoder length");
-    for (int b = 0; b < Bg; ++b) {
-      if (!gathered.empty()) {
-        std::memcpy(&merged_.ids[(size_t)(lo + b) * L], gathered.data() + blk * (size_t)g + (size_t)b * L * 8, (size_t)L * 8);
-        if (has_cif) std::memcpy(&merged_.token_num[(size_t)(lo + b)], gathered.data() + blk * (size_t)g + ids_b + (size_t)b * 4, 4);
-        else merged_.token_num[(size_t)(lo + b)] = r.token_num[(size_t)b];
-      } else {
-        if (L > 0) std::memcpy(&merged_.ids[(size_t)(lo + b) * L], &r.ids[(size_t)b * r.L], (size_t)L * 8);
-        merged_.token_num[(size_t)(lo + b)] = r.token_num[(size_t)b];
-      }
-      merged_.fire_count[(size_t)(lo + b)] = r.fire_count[(size_t)b];
-      if (P > 0 && r.peak_len == P) std::memcpy(&merged_.cif_peak[(size_t)(lo + b) * P], &r.cif_peak[(size_t)b * P], (size_t)P * 4);
-      if (want_logits && L > 0)
-        std::memcpy(&merged_.logits[(size_t)(lo + b) * L * V], &r.logits[(size_t)b * L * V], (size_t)L * V * 4);
-    }
+  e.set_l_hook(nullptr);
+  e.sync();
+  r = e.last_result();
+  if (want_logits && (int64_t)r.B * r.L * r.V > 0) e.copy_logits(r);
+}
+
+// fixed-shape [per, L] int64 ids + [per] int32 token_num per shard; `lay` is the same on every rank (it is a function
+// of the shard size and the AGREED decoder length, never of a rank's own result)
+void Group::prepare_gather(int g, int count, int L, const GatherLayout& lay, int G) {
+  Engine& e = *eng_[(size_t)g];
+  auto grow = [&](void*& p, size_t& have, size_t want) {
+    if (have >= want) return;
+    if (p) { PF_HIP(hipStreamSynchronize(e.stream())); PF_HIP(hipFree(p)); p = nullptr; have = 0; }
+    PF_HIP(hipMalloc(&p, want));
+    have = want;
+  };
+  grow(gsend_[(size_t)g], gsend_bytes_[(size_t)g], lay.block_bytes);
+  grow(grecv_[(size_t)g], grecv_bytes_[(size_t)g], lay.block_bytes * (size_t)G);
+  char* sb = (char*)gsend_[(size_t)g];
+  PF_HIP(hipMemsetAsync(sb, 0xFF, lay.block_bytes, e.stream()));           // absent rows: id -1, token_num -1
+  if (count > 0 && L > 0) {
+    PF_HIP(hipMemcpyAsync(sb, e.ids_device(), (size_t)count * L * 8, hipMemcpyDeviceToDevice, e.stream()));
+    if (cur_has_cif_)
+      PF_HIP(hipMemcpyAsync(sb + lay.ids_bytes, e.token_num_device(), (size_t)count * 4, hipMemcpyDeviceToDevice, e.stream()));
   }
+}
+
+void Group::gather(int g, const GatherLayout& lay, int /*G*/) {
+  Engine& e = *eng_[(size_t)g];
+  rccl_->check(rccl_->AllGather(gsend_[(size_t)g], grecv_[(size_t)g], lay.block_bytes, ncclUint8, (ncclComm_t)comms_[(size_t)g],
+                                e.stream()),
+               "ncclAllGather");
+  PF_HIP(hipStreamSynchronize(e.stream()));
+}
+
+void Group::read_gathered(std::vector<char>& host, size_t bytes) {
+  host.resize(bytes);
+  PF_HIP(hipSetDevice(devs_[0]));
+  PF_HIP(hipMemcpy(host.data(), grecv_[0], bytes, hipMemcpyDeviceToHost));
 }
 
 void Group::fetch(pf_batch_out* out) {

@@ -598,6 +598,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   wait_vmcnt<0>();                                    // clamped tail DMA must land before LDS is released
 }
 
+static thread_local const char* g_last_gemm_kernel = "";
+const char* last_gemm_kernel() { return g_last_gemm_kernel; }
+void note_gemm_kernel(const char* name) { g_last_gemm_kernel = name; }
+
 void launch_gemm(hipStream_t s, const GemmArgs& a) {
   PF_CHECK(a.K % 64 == 0 && a.K > 0, PF_ERR_INVALID_ARG, "gemm: K must be a multiple of 64");
   PF_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, PF_ERR_INVALID_ARG, "gemm: lda/ldw must be multiples of 8");
@@ -695,6 +699,9 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   if (grid > total) grid = total;
   const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && ((a.ldc16 & 7) == 0 || a.out_blocked);
   const int lds = gemm_lds_bytes(mi);
+  note_gemm_kernel(f16_only && a.out_blocked ? (mi == 2 ? "gemm_f16_pp3<3, 2>" : "gemm_f16_pp3<3, 1>")
+                   : f16_only ? (mi == 2 ? "gemm_f16_pp3<1, 2>" : "gemm_f16_pp3<1, 1>")
+                              : (mi == 2 ? "gemm_f16_pp3<2, 2>" : "gemm_f16_pp3<2, 1>"));
   if (f16_only && a.out_blocked) {
     if (mi == 2) hipLaunchKernelGGL((gemm_f16_pp3<3, 2>), dim3(grid), dim3(512), lds, s, d);
     else hipLaunchKernelGGL((gemm_f16_pp3<3, 1>), dim3(grid), dim3(512), lds, s, d);

@@ -517,6 +517,7 @@ void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus) {
   }
   const int total = d.tiles_m * d.tiles_n;
   if (total == 0) return;
+  note_gemm_kernel("gemm_bigp_kernel");
   hipLaunchKernelGGL(gemm_bigp_kernel, dim3((unsigned)std::min(total, cus)), dim3(512), BGP_LDS, s, d);
   PF_HIP(hipGetLastError());
 }
@@ -563,6 +564,7 @@ void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj) {
     }
   }
   const dim3 grid((unsigned)(d.tiles_m * d.tiles_n));
+  note_gemm_kernel(nj == 4 ? "gemm_big_kernel<4>" : "gemm_big_kernel<3>");
   if (nj == 4) hipLaunchKernelGGL(gemm_big_kernel<4>, grid, dim3(512), bg_lds(4), s, d);
   else hipLaunchKernelGGL(gemm_big_kernel<3>, grid, dim3(512), bg_lds(3), s, d);
   PF_HIP(hipGetLastError());

@@ -371,6 +371,7 @@ void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a) {
     }
   }
   const dim3 grid((unsigned)cdiv(a.M, RC_BM));
+  note_gemm_kernel(a.fsmn_v ? "gemm_rc_kernel<11>" : "gemm_rc_kernel<0>");
   if (a.fsmn_v) hipLaunchKernelGGL(gemm_rc_kernel<11>, grid, dim3(512), RC_LDS, s, d);
   else hipLaunchKernelGGL(gemm_rc_kernel<0>, grid, dim3(512), RC_LDS, s, d);
   PF_HIP(hipGetLastError());

@@ -350,6 +350,7 @@ static void small_launch(hipStream_t s, const SmallDev& d, int rows_alloc) {
     }
   }
   const int lds = (rows_alloc + SM_BN) * CPR * 16;
+  note_gemm_kernel("gemm_small_kernel");
   hipLaunchKernelGGL((gemm_small_kernel<CPR>), dim3((unsigned)(d.tiles_n * d.tiles_m * d.S)), dim3(256), lds, s, d);
   PF_HIP(hipGetLastError());
 }

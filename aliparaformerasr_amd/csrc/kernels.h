@@ -34,6 +34,10 @@ struct GemmArgs {
                                  // (stand-alone op tests; 3 fails when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
+// name of the kernel the calling thread's most recent GEMM launcher chose (bench.py prints it next to the class it
+// reports as `roofline`; the same name appears in the rocprofv3 kernel trace)
+const char* last_gemm_kernel();
+void note_gemm_kernel(const char* name);
 // 256 x {192, 256} tile kernel for wide f16-result GEMMs (k_gemm_big.hip); launch_gemm dispatches to it when
 // applicable (f16-only result, N a multiple of 192 / 256, at least one tile per CU) unless force_mi is set
 bool gemm_big_applicable(const GemmArgs& a, int cus, int* nj_out);

@@ -130,13 +130,17 @@ OnlineStreamM::OnlineStreamM(std::shared_ptr<OnlineRecognizerM> r) : owner(std::
 void OnlineStreamM::AddSamples(const float* samples, int64_t n) {
   if (disposed) throw Error(PF_ERR_DISPOSED, "OnlineStream");
   if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");
-  cache_samples_.insert(cache_samples_.end(), samples, samples + n);
-  const size_t chunk = (size_t)160 * owner->chunk_length();
-  if (cache_samples_.size() > chunk) {                          // ONE chunk per call (:94-102), the rest stays cached
-    std::vector<float> s(cache_samples_.begin(), cache_samples_.begin() + (long)chunk);
-    InputSpeech(s);
-    cache_samples_.erase(cache_samples_.begin(), cache_samples_.begin() + (long)chunk);
+  std::vector<float> s;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cache_samples_.insert(cache_samples_.end(), samples, samples + n);
+    const size_t chunk = (size_t)160 * owner->chunk_length();
+    if (cache_samples_.size() > chunk) {                        // ONE chunk per call (:94-102), the rest stays cached
+      s.assign(cache_samples_.begin(), cache_samples_.begin() + (long)chunk);
+      cache_samples_.erase(cache_samples_.begin(), cache_samples_.begin() + (long)chunk);
+    }
   }
+  if (!s.empty()) InputSpeech(s);
 }
 
 void OnlineStreamM::InputSpeech(const std::vector<float>& samples) {
@@ -148,6 +152,7 @@ void OnlineStreamM::InputSpeech(const std::vector<float>& samples) {
     std::lock_guard<std::mutex> lk(e->mutex());
     e->fbank_host(samples.data(), (int64_t)samples.size(), fb, t80);     // x 32768 + kaldi fbank (:129-130)
   }
+  std::lock_guard<std::mutex> lk(mu);
   if (first_input_ && t80 > 0) {                                          // :131-143: the first frame is repeated once
     Speech.insert(Speech.end(), fb.begin(), fb.begin() + 80);
     first_input_ = false;
@@ -156,6 +161,7 @@ void OnlineStreamM::InputSpeech(const std::vector<float>& samples) {
 }
 
 bool OnlineStreamM::GetDecodeChunk(std::vector<float>& chunk) {
+  std::lock_guard<std::mutex> lk(mu);
   const int F = 80, CL = owner->chunk_length();
   if ((size_t)CL * F > Speech.size()) return false;
   std::vector<float> pad;
@@ -200,9 +206,18 @@ OnlineRecognizerM::OnlineRecognizerM(const std::string& model, const std::string
   ec.fs = conf_.fs; ec.n_mels = conf_.n_mels; ec.lfr_m = conf_.lfr_m; ec.lfr_n = conf_.lfr_n;
   ec.snip_edges = conf_.snip_edges ? 1 : 0;
   ec.dither = conf_.dither;
-  ec.frame_length_ms = conf_.frame_length; ec.frame_shift_ms = conf_.frame_shift;
+  ec.frame_length_ms = 0; ec.frame_shift_ms = 0;     // never forwarded by the reference (OnlineWavFrontend.cs:20-27): kaldi defaults apply
   ec.window = conf_.window.c_str();
   engine_ = std::make_shared<Engine>(ec);
+  // the streaming mirror carries the reference's literal geometry (OnlineStream.cs:44-46,263-278: 10 x 560 feature
+  // cache, 16 x [512, 10] FSMN caches; OnlineWavFrontend.cs:152-188: sqrt(512)); a container of another geometry
+  // would make Forward() index past those buffers, where the reference gets an ORT shape error
+  const ModelCfg& m = engine_->model();
+  PF_CHECK(m.kind_id() != 1, PF_ERR_UNSUPPORTED, "OnlineRecognizer: a SenseVoice container has no streaming graphs");
+  PF_CHECK(m.d_model == 512 && m.feat_dim == 560 && m.kernel == 11, PF_ERR_UNSUPPORTED,
+           "OnlineRecognizer: the streaming path is built for d_model 512, feature dim 560, FSMN kernel 11 (got " +
+               std::to_string(m.d_model) + ", " + std::to_string(m.feat_dim) + ", " + std::to_string(m.kernel) + ")");
+  PF_CHECK(conf_.lfr_m * conf_.n_mels == 560, PF_ERR_UNSUPPORTED, "OnlineRecognizer: lfr_m * n_mels must be 560");
 }
 
 std::shared_ptr<OnlineStreamM> OnlineRecognizerM::CreateOnlineStream() {

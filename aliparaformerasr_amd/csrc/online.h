@@ -48,6 +48,11 @@ class OnlineStreamM {
   std::vector<float> Speech;                                  // OnlineInputEntity.Speech (fbank frames, 80-dim)
   bool disposed = false;
   std::shared_ptr<OnlineRecognizerM> owner;
+  // The reference serialises AddSamples / InputSpeech / GetDecodeChunk with lock(obj) (OnlineStream.cs:30,86,116,174):
+  // a capture thread may add samples while a decode thread runs GetResults on the same stream.  Here the lock is per
+  // stream; it is never held while the engine mutex is taken (AddSamples releases it around the fbank call), so
+  // Forward (engine mutex, then stream state) cannot dead-lock against it.
+  std::mutex mu;
 
  private:
   void InputSpeech(const std::vector<float>& samples);        // :106-160

@@ -268,8 +268,11 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   ec.fs = conf_.fs; ec.n_mels = conf_.n_mels; ec.lfr_m = conf_.lfr_m; ec.lfr_n = conf_.lfr_n;
   ec.snip_edges = conf_.snip_edges ? 1 : 0;
   ec.dither = conf_.dither;
-  ec.frame_length_ms = conf_.frame_length;
-  ec.frame_shift_ms = conf_.frame_shift;
+  // frame_length / frame_shift of the yaml are NOT forwarded: WavFrontend.cs:21-27 builds OnlineFbank from dither,
+  // snip_edges, window, fs and n_mels only, so whatever the file says the reference frames at the kaldi defaults
+  // (25 ms / 10 ms) — a conf with other values must run here exactly as it does there
+  ec.frame_length_ms = 0;
+  ec.frame_shift_ms = 0;
   ec.window = conf_.window.c_str();
   ec.use_itn = conf_.use_itn ? 1 : 0;
   engine_ = std::make_shared<Engine>(ec);

@@ -242,6 +242,11 @@ class Engine:
         N.check(self._lib.pf_profile_get(self._h, cls.encode(), ms, n, fpl))
         return ms.value, n.value, fpl.value
 
+    def profile_kernel(self, cls: str) -> str:
+        buf = C.create_string_buffer(256)
+        N.check(self._lib.pf_profile_kernel(self._h, cls.encode(), buf, 256))
+        return buf.value.decode()
+
     def last_flops(self) -> float:
         f = C.c_double()
         N.check(self._lib.pf_last_flops(self._h, f))

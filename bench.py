@@ -17,9 +17,11 @@ shard (weak scaling, no data-path collective); RCCL is used for the one-off weig
 (rank 0 -> all) and the per-step gather of hypotheses.
 
 The JSON line also carries
-  roofline     — the dominant kernel class (FFN up-projection GEMM) timed live with HIP events
-                 on the engine stream during the timed steps: algorithmic FLOPs / avg duration
-                 against the 2.5 PFLOP/s dense f16 MFMA peak;
+  roofline     — the dominant kernel class = the encoder GEMM class with the largest share of the step
+                 (chosen by an untimed profiling step), timed live with HIP events on the engine stream
+                 during the first timed step: algorithmic FLOPs / avg duration against the 2.5 PFLOP/s
+                 dense f16 MFMA peak;
+  ids_vs_fp32_oracle — the ids of the timed computation against the fp32 CPU oracle's (tests/golden/);
   cpu_baseline — the CPU oracle (a port, NOT onnxruntime: neither ORT nor a model file exists
                  in the image) timed on the host cores on a bounded sample of the same workload.
 """
@@ -42,15 +44,47 @@ BATCH_PER_GPU = 32
 SECONDS = 30
 SAMPLES = SECONDS * 16000
 LCAP = 512
-DOMINANT = "gemm_ffn1"
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = os.path.join(ROOT, "profiles", "round2_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round3_pmc.json")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_MARGIN = 0.1           # = 2 x the 5e-2 log-prob tolerance of tests/test_gpu_full_depth.py
+# kernel classes of Engine::prof_begin (csrc/engine.cpp); the roofline object describes whichever encoder GEMM class
+# takes the most time in a step (found by an untimed profiling step before the timed region)
+CLASSES = ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
+           "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn1", "gemm_dec_ffn2",
+           "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc",
+           "seaco_embed", "gemm_seaco", "attn_seaco", "seaco_merge")
+# (N, K, what) of the encoder GEMM classes: [rows x K] x [K x N]
+GEMM_SHAPES = {"gemm_qkv": (1536, 512, "QKV projection + bias, q scaled"),
+               "gemm_out": (512, 512, "attention out-projection + bias + residual + FSMN memory + LayerNorm"),
+               "gemm_ffn1": (2048, 512, "FFN up-projection + bias + ReLU"),
+               "gemm_ffn2": (512, 2048, "FFN down-projection + bias + residual")}
 
 
 def ids_checksum(ids) -> str:
     """Order-sensitive checksum of the [B, L] arg-max ids of a step (tests/test_gpu_baseline_sizes.py pins it to
     the oracle for a depth-reduced 32 x 30 s run)."""
     return hashlib.sha1(np.ascontiguousarray(ids, dtype=np.int64).tobytes()).hexdigest()
+
+
+def golden_check(tag, ids):
+    """The ids of a step against the fp32 CPU oracle's for the same workload (tests/golden/bench_<tag>.npz, written
+    by tests/golden/make_bench_golden.py; the -m gpu test tests/test_gpu_full_depth.py re-runs that oracle live and
+    cross-checks the file).  ok = identical ids on every position whose oracle top-1/top-2 margin exceeds
+    GOLDEN_MARGIN.  None when there is no golden file for this workload / shape."""
+    path = os.path.join(GOLDEN_DIR, "bench_%s.npz" % tag)
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    gi, gm = g["ids"], g["margin"]
+    ids = np.asarray(ids)
+    if ids.shape != gi.shape:
+        return None
+    firm = gm > GOLDEN_MARGIN
+    same = ids == gi
+    return {"ok": bool(same[firm].all()), "decisive_positions": float(firm.mean()), "decisive_mismatches": int((~same[firm]).sum()),
+            "agree_all_positions": float(same.mean()), "margin": GOLDEN_MARGIN,
+            "oracle": "fp32 CPU oracle, tests/golden/bench_%s.npz" % tag}
 
 
 def respawn_under_torchrun(n: int) -> int:
@@ -70,15 +104,6 @@ def respawn_under_torchrun(n: int) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
-
-
-def dominant_kernel_name(rows, cus):
-    """Which kernel launch_gemm picks for the FFN up-projection [rows x 512] x [512 x 2048] (csrc/k_gemm.hip: the
-    persistent 256 x 256-tile kernel when its schedule has fewer idle rounds, else the 256 x 128 persistent kernel)."""
-    cd = lambda a, b: (a + b - 1) // b
-    t_big, t_pp3 = cd(rows, 256) * 8, cd(rows, 256) * 16
-    big = os.environ.get("PF_BIGP", "1") != "0" and t_big >= cus and 1.9 * cd(t_big, cus) <= cd(t_pp3, cus)
-    return "gemm_bigp_kernel" if big else "gemm_f16_pp3<3, 2>"
 
 
 def pmc_traffic(kernel):
@@ -180,6 +205,53 @@ def cpu_baseline(cfg, weights, cmvn):
             "reference_published": "rtf 0.0371 (RTFx 27) on an i7-10750H, settings unstated (README.EN.md:134-136)"}
 
 
+def group_main(args):
+    """`--group N`: the in-ABI multi-device form.  One call = pf_group_recognize over N x B host utterances (H2D of the
+    audio and D2H of the merged ids INSIDE the timed region: this is the host-inclusive number by construction)."""
+    from aliparaformerasr_amd import weights as W
+    from aliparaformerasr_amd.engine import EngineGroup
+    n = args.group
+    devices = [int(x) for x in args.group_devices.split(",")] if args.group_devices else list(range(n))
+    assert len(devices) == n, "--group-devices must name --group devices"
+    sv = args.model == "sensevoice"
+    seconds = args.seconds or (10 if sv else SECONDS)
+    samples = seconds * 16000
+    B = (args.batch if args.batch > 0 else (64 if sv else BATCH_PER_GPU)) * n
+    cfg = W.sensevoice_small_config(use_itn=True) if sv else (W.seaco_paraformer_config() if args.model == "seaco"
+                                                               else W.paraformer_large_config())
+    blob = W.pack_pfw(cfg, W.synth_weights(cfg, 42))
+    grp = EngineGroup(devices, weights=blob, cmvn=W.synth_cmvn())
+    hw = None
+    if args.model == "seaco":
+        hrng = np.random.default_rng(99)
+        hws = [list(hrng.integers(3, 8000, size=int(hrng.integers(2, 5)))) for _ in range(20)] + [[1]]
+        hw = np.asarray([h[:10] + [0] * (10 - len(h)) for h in hws], np.int32)
+    audio = [W.synth_audio(samples, u) for u in range(B)]
+    for _ in range(args.warmup):
+        res = grp.recognize(audio, hotwords=hw)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = grp.recognize(audio, hotwords=hw)
+    dt = time.perf_counter() - t0
+    assert res.L > 0 and res.token_ids.shape == (B, res.L) and (res.token_num > 0).all()
+    per = B // n
+    chk = golden_check(args.model, res.token_ids[:per]) if seconds == (10 if sv else SECONDS) else None
+    assert chk is None or chk["ok"], chk
+    audio_s = B * seconds * args.steps
+    print(json.dumps({
+        "metric": "RTFx (audio-sec/wall-sec), %s offline, pf_group_recognize over %d device(s), host audio in"
+                  % ("sensevoice-small" if sv else "paraformer-large", n),
+        "value": audio_s / dt, "unit": "audio-sec/wall-sec", "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "%s, %d x %d s per call from host memory, %d engine(s) on devices %s inside one process"
+                               % (args.model, B, seconds, n, devices), "global_batch": B, "L": int(res.L),
+                   "parallelism": "pf_group: %d utterance shards, RCCL %s" % (n, "communicator" if grp.uses_rccl else "not used (repeated device)")},
+        "rtf": dt / audio_s, "utt_per_s": B * args.steps / dt, "rccl_ranks": n if grp.uses_rccl else 0,
+        "group_engines": n, "ids_sha1": ids_checksum(res.token_ids), "ids_vs_fp32_oracle": chk}))
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,15 +261,24 @@ def main():
                     help="utterances per GPU (default: 32 = BASELINE.json configs[1]; 64 for --model sensevoice = configs[2]; "
                          "128 at --gpus 8 = the per-GPU shard of configs[3], 1024 x 30 s over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="extra untimed step with per-class kernel times")
+    ap.add_argument("--breakdown", action="store_true", help="(kept for compatibility: the per-class times of an untimed step are always printed as class_ms_per_step)")
     ap.add_argument("--model", choices=("paraformer", "sensevoice", "seaco"), default="paraformer",
                     help="sensevoice = BASELINE.json configs[2] (sensevoice-small, 64 x 10 s, use_itn on); seaco = configs[4] "
                          "(SeACo bias decoder + 20 hotwords + BiCIF timestamps); neither is the headline config")
     ap.add_argument("--seconds", type=int, default=0, help="utterance length (default 30; 10 for --model sensevoice)")
     ap.add_argument("--timestamp-head", action="store_true",
                     help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="N > 0: ONE process driving pf_group_recognize over N devices (the path a C# caller gets: "
+                         "host audio in, utterance shards, RCCL weight broadcast + all-gather of the ids inside the C ABI) "
+                         "instead of one process per GPU; B = --batch per device x N utterances per call")
+    ap.add_argument("--group-devices", default="",
+                    help="comma-separated device ordinals for --group (default 0..N-1; a repeated ordinal runs several "
+                         "engines on one GPU without a communicator — how the 1-GPU box exercises the sharding)")
     args = ap.parse_args()
 
+    if args.group > 0:
+        return group_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args.gpus))
 
@@ -269,11 +350,32 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.sync()
+    # ---- which kernel class does the roofline object describe?  An UNTIMED profiling step over every class: the
+    # encoder GEMM class with the largest share of the step is the "dominant kernel" (every rank takes the same
+    # decision from its own measurement of the same launches; rank 0's is printed)
+    eng.profile_reset()
+    eng.profile_select("")
+    eng.profile(True)
+    eng.run_staged()
+    eng.sync()
+    eng.profile(False)
+    class_ms = {}
+    for cls in CLASSES:
+        ms, cnt, fpl = eng.profile_get(cls)
+        if cnt:
+            class_ms[cls] = {"ms": round(ms, 4), "launches": cnt, "kernel": eng.profile_kernel(cls) or None,
+                             "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
+    dominant = max(GEMM_SHAPES, key=lambda c: class_ms.get(c, {"ms": 0.0})["ms"])
+    if world > 1:                                             # one decision for the whole job: rank 0's
+        pick = [dominant]
+        dist.broadcast_object_list(pick, src=0)
+        dominant = pick[0]
+    dom_kernel = eng.profile_kernel(dominant)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     eng.profile_reset()
-    eng.profile_select(DOMINANT)
+    eng.profile_select(dominant)
     eng.profile(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -293,7 +395,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     res = eng.fetch()
-    ms_dom, n_dom, fpl_dom = eng.profile_get(DOMINANT)
+    ms_dom, n_dom, fpl_dom = eng.profile_get(dominant)
     # the timed steps must have produced a real transcript-shaped result: every utterance decoded, ids in range
     assert res.L > 0 and res.token_ids.shape == (B, res.L), (res.L, res.token_ids.shape)
     assert (res.token_ids >= 0).all() and (res.token_ids < eng.vocab).all()
@@ -301,40 +403,35 @@ def main():
     if world > 1:
         g = gathered["ids"]
         assert g.shape == (world * B, LCAP) and (g[rank * B:(rank + 1) * B, :res.L] == res.token_ids).all()
+    # ... and the right one: rank 0's ids against the fp32 CPU oracle's for this workload (tests/golden/), wherever
+    # the oracle is decisive.  Only the three BASELINE workloads at their own shapes have a golden file.
+    ids_check = None
+    if rank == 0 and seconds == (10 if sv else SECONDS) and not (args.timestamp_head and args.model == "paraformer"):
+        ids_check = golden_check(args.model, res.token_ids)
+        assert ids_check is None or ids_check["ok"], "ids differ from the fp32 oracle on decisive positions: %r" % (ids_check,)
 
     # PCIe-inclusive rate (never `value`): host float32 audio in, ids back on the host, per batch
     host_ms = None
     if rank == 0:
         eng.recognize(audio)
         t1 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(3):
             eng.recognize(audio)
-        host_ms = (time.perf_counter() - t1) / 2 * 1e3
-
-    breakdown = None
-    if args.breakdown and rank == 0:
-        eng.profile_reset()
-        eng.profile_select("")
-        eng.profile(True)
-        eng.run_staged()
-        eng.sync()
-        eng.profile(False)
-        breakdown = {}
-        for cls in ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
-                    "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn1", "gemm_dec_ffn2",
-                    "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc",
-                    "seaco_embed", "gemm_seaco", "attn_seaco", "seaco_merge"):
-            ms, cnt, fpl = eng.profile_get(cls)
-            breakdown[cls] = {"ms": round(ms, 4), "launches": cnt,
-                              "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
+        host_ms = (time.perf_counter() - t1) / 3 * 1e3
 
     if rank == 0:
         audio_s = world * B * seconds * args.steps
         value = audio_s / dt
         flops_step = eng.last_flops()
-        ach = fpl_dom / ((ms_dom / max(n_dom, 1)) * 1e-3) / 1e12 if n_dom else 0.0
-        dom_rows = B * int(res.L if sv else eng.num_frames(samples))
-        dom_kernel = dominant_kernel_name(dom_rows, torch.cuda.get_device_properties(0).multi_processor_count)
+        avg_s = (ms_dom / max(n_dom, 1)) * 1e-3
+        ach = fpl_dom / avg_s / 1e12 if n_dom else 0.0
+        Nn, Kk, what = GEMM_SHAPES[dominant]
+        dom_rows = int(round(fpl_dom / (2.0 * Nn * Kk)))
+        alg_bytes = {"gemm_qkv": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
+                     "gemm_out": dom_rows * (Kk * 2 + Nn * 2 + Nn * 4 + Nn * 4 + Nn * 2) + Nn * Kk * 2 + Nn * 4,
+                     "gemm_ffn1": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
+                     "gemm_ffn2": dom_rows * (Kk * 2 + Nn * 4 + Nn * 4) + Nn * Kk * 2}[dominant]
+        headline = not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS
         out = {
             "metric": "RTFx (audio-sec/wall-sec), %s offline, batch %dx%ds per GPU"
                       % ("sensevoice-small" if sv else "paraformer-large", B, seconds),
@@ -351,21 +448,24 @@ def main():
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "rccl_ranks": world if world > 1 else 0,
             "ids_sha1": ids_checksum(res.token_ids),   # rank 0's [B, L] ids of the last timed step
+            "ids_vs_fp32_oracle": ids_check,
             "token_num_sum": int(res.token_num.sum()),
             "host_audio_ms_per_batch": host_ms,     # one GPU's batch incl. H2D of the audio and D2H of the ids
+            "host_audio_rtfx": B * seconds / (host_ms * 1e-3) if host_ms else None,
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "%s (class %s: [%d x 512] x [512 x 2048] + bias + ReLU)"
-                         % (dom_kernel, DOMINANT, dom_rows), "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F16_TFLOPS,
-                         "traffic": pmc_traffic(dom_kernel) if (not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS) else None,
-                         "traffic_unit": "bytes/launch (PMC, profiles/round2_pmc.json)",
-                         "algorithmic_bytes_per_launch": int(fpl_dom / (2 * 512 * 2048)) * (512 + 2048) * 2 + 2048 * 512 * 2,
-                         "launches_timed": int(n_dom), "avg_us": ms_dom / max(n_dom, 1) * 1e3,
-                         "flops_per_launch": fpl_dom},
+            "whole_path_frac_of_mfma_peak": flops_step * args.steps / dt / 1e12 / PEAK_F16_TFLOPS,
+            "roofline": {"bound": "mfma",
+                         "kernel": "%s (class %s, the encoder GEMM class with the largest share of the step: [%d x %d] x [%d x %d], %s)"
+                                   % (dom_kernel, dominant, dom_rows, Kk, Kk, Nn, what),
+                         "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
+                         "traffic": pmc_traffic(dom_kernel) if headline else None,
+                         "traffic_unit": "bytes/launch (PMC, %s)" % os.path.relpath(PMC_FILE, ROOT),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches_timed": int(n_dom), "avg_us": avg_s * 1e6, "flops_per_launch": fpl_dom,
+                         "hbm_gbps_algorithmic": alg_bytes / avg_s / 1e9 if n_dom else None},
+            "class_ms_per_step": class_ms,            # untimed profiling step (HIP events around every launch)
         }
-        if breakdown is not None:
-            out["kernel_breakdown_ms_per_step"] = breakdown
         if world == 1 and not args.no_cpu_baseline and not sv and seconds == SECONDS:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, cmvn)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -202,6 +202,18 @@ int pf_group_recognize(pf_group* g, const float* const* samples, const int64_t* 
                        const int32_t* hotwords, int32_t n_hotwords, pf_batch_out* out);
 int pf_group_fetch(pf_group* g, pf_batch_out* out);
 
+/* Host-only rehearsal of pf_group_recognize's control flow (shard plan, the three rendez-vous, the fixed-shape
+   all-gather blocks, failure release, merge in the caller's order) with arithmetic stand-ins for the devices, so
+   that it runs in a CPU test-suite with G up to 64: utterance u "fires" fire_count[u] tokens and decodes to
+   ids[u][l] = u * 100000 + l, token_num[u] = fire_count[u].  has_cif = 0: every non-empty shard reports L = fixed_L
+   on its own (SenseVoice).  collective != 0: the hypotheses travel through the all-gather blocks, and shards entering
+   the collective with different block sizes — which RCCL answers with a hang — are an error.  fail_shard >= 0: that
+   shard throws at fail_stage (0 = in its forward before the decoder-length rendez-vous, 1 = after it, 2 = while
+   preparing the gather); the call must then return an error, never hang. */
+int pf_host_group_sim(int32_t G, int32_t B, const int32_t* fire_count, int32_t has_cif, int32_t fixed_L,
+                      int32_t collective, int32_t fail_shard, int32_t fail_stage, int64_t* ids_out, int32_t l_cap,
+                      int32_t* token_num_out, int32_t* L_out);
+
 /* Per-kernel-class device time, measured with HIP events on the engine stream while
    profiling is enabled (bench.py roofline leg).  class_name e.g. "gemm_ffn1". */
 int pf_profile_enable(pf_engine* e, int32_t on);
@@ -210,6 +222,9 @@ int pf_profile_reset(pf_engine* e);
 int pf_profile_select(pf_engine* e, const char* class_name);
 int pf_profile_get(pf_engine* e, const char* class_name, double* total_ms, int64_t* launches,
                    double* flops_per_launch);
+/* GEMM classes: name of the kernel the launcher chose for the class's last profiled launch (the name the
+   rocprofv3 kernel trace shows), "" for other classes.  cap = bytes available in name_out. */
+int pf_profile_kernel(pf_engine* e, const char* class_name, char* name_out, int32_t cap);
 
 /* Algorithmic FLOPs (2*MAC) of the last forward, SURVEY.md §8(d) formula. */
 int pf_last_flops(pf_engine* e, double* flops);

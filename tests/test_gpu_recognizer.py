@@ -194,3 +194,22 @@ def test_disposed_stream_answers_object_disposed(model_dir):
         t.AddSamples(np.zeros(1600, np.float32))
         r.DisposeOfflineStream(t)
     r.Dispose()
+
+
+def test_conf_frame_length_and_shift_are_ignored_like_the_reference(model_dir, tmp_path):
+    """WavFrontend.cs:21-27 builds OnlineFbank from dither / snip_edges / window / fs / n_mels only: `frame_length` and
+    `frame_shift` of the yaml never reach it, so a conf with other values runs in the reference at the kaldi defaults
+    (25 ms / 10 ms).  The mirror must do the same — not refuse the file — and produce the same features."""
+    from aliparaformerasr_amd.offline_recognizer import OfflineRecognizer
+    d = model_dir[0]
+    odd = tmp_path / "asr_odd.yaml"
+    odd.write_text((d / "asr.yaml").read_text() + "  frame_length: 20\n  frame_shift: 5\n")
+    a = _make(model_dir)
+    b = OfflineRecognizer(modelFilePath=str(d / "model.pfw"), configFilePath=str(odd), mvnFilePath=str(d / "am.mvn"),
+                          tokensFilePath=str(d / "tokens.txt"))
+    x = W.synth_audio(32000, 5)
+    sa, sb = a.CreateOfflineStream(), b.CreateOfflineStream()
+    sa.AddSamples(x)
+    sb.AddSamples(x)
+    assert sa.SpeechLength == sb.SpeechLength == 33 * 560
+    assert a.GetResult(sa).Text == b.GetResult(sb).Text
