@@ -70,6 +70,8 @@ Engine::Engine(const pf_engine_config& cfg) {
   uid_ = register_uid();
   try {
     PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    PF_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
+    PF_HIP(hipEventCreateWithFlags(&ev_scan_, hipEventDisableTiming));
     load_weights(cfg);
     mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
     fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
@@ -94,12 +96,14 @@ void Engine::release() {
   if (uid_) { unregister_uid(uid_); uid_ = 0; }
   hipSetDevice(device_);
   if (stream_) hipStreamSynchronize(stream_);
+  if (aux_stream_) { hipStreamSynchronize(aux_stream_); hipStreamDestroy(aux_stream_); aux_stream_ = nullptr; }
+  if (ev_scan_) { hipEventDestroy(ev_scan_); ev_scan_ = nullptr; }
   if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
   profile_reset();
   if (fb_) { fbank_tables_destroy(fb_); fb_ = nullptr; }
   for (void* p : owned_) hipFree(p);
   owned_.clear();
-  DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_pe_, &ws_tmp_,
+  DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
                     &ws_ts_, &ws_seaco_, &ws_seaco_in_};
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
@@ -129,7 +133,19 @@ void Engine::ensure(DevBuf& b, size_t bytes) {
   b.bytes = want;
 }
 
-void Engine::sync() { PF_HIP(hipStreamSynchronize(stream_)); }
+void Engine::sync() {
+  PF_HIP(hipStreamSynchronize(stream_));
+  check_async_errors();
+}
+
+void Engine::check_async_errors() {
+  if (!lstm_err_) return;                            // the persistent recurrence raises this word when a spin timed out
+  unsigned flag = 0;
+  unsigned* w = lstm_err_;
+  lstm_err_ = nullptr;
+  PF_HIP(hipMemcpy(&flag, w, 4, hipMemcpyDeviceToHost));
+  PF_CHECK(flag == 0, PF_ERR_DEVICE, "timestamp head: the persistent LSTM timed out waiting for a workgroup");
+}
 
 // ------------------------------------------------------------------ weights ---------------
 const Engine::Tensor& Engine::tensor(const std::string& name) const {
@@ -933,23 +949,30 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
   else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
   prof_end("cif_misc");
+  PF_HIP(hipEventRecord(ev_scan_, stream_));
   last_.peak_len = 0;
   last_.cif_peak.clear();
   if (mc_.timestamp_head) timestamp_head(B, T);
-  // the path's only host sync: the decoder length L is data dependent
+  // The cross-attention K/V projections of all decoder layers depend on the encoder output only, not on the decoder
+  // length: they go out BEFORE the length is read back and keep the device busy during the host round trip (and,
+  // in a multi-device group, during the rendez-vous that agrees on the batch-wide length).
+  const int nd = (int)dec_.size();
+  const int64_t Mp = round_up(M, 128) + 128;
+  const int ldkv = std::max(nd, 1) * 2 * D;
+  ensure(ws_kv_, (size_t)Mp * ldkv * 2);
+  half_t* kv16 = (half_t*)ws_kv_.p;
+  if (nd > 0)
+    gemm("gemm_dec_kv", dec_kv_all_, H16_, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  // the path's only host sync: the decoder length L is data dependent.  The read-back rides a side stream that waits
+  // for the CIF scan alone.
   int32_t L = 0;
   last_.fire_count.resize(B);
   last_.token_num.resize(B);
-  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  if (lstm_err_) {                                   // the persistent recurrence raises this word when a spin timed out
-    unsigned flag = 0;
-    PF_HIP(hipMemcpy(&flag, lstm_err_, 4, hipMemcpyDeviceToHost));
-    lstm_err_ = nullptr;
-    PF_CHECK(flag == 0, PF_ERR_DEVICE, "timestamp head: the persistent LSTM timed out waiting for a workgroup");
-  }
+  PF_HIP(hipStreamWaitEvent(aux_stream_, ev_scan_, 0));
+  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, aux_stream_));
+  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
+  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
+  PF_HIP(hipStreamSynchronize(aux_stream_));
   if (l_hook_) L = l_hook_(L);                       // shard of a multi-device batch: the batch-wide maximum
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);
@@ -957,23 +980,19 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
 
   const int Md = B * L;
   const int64_t Mdp = round_up(Md, 128) + 128;
-  const int64_t Mp = round_up(M, 128) + 128;
-  const int nd = (int)dec_.size();
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o_kv = carve((size_t)Mp * std::max(nd, 1) * 2 * D * 2), o_x = carve(Mdp * D * 4), o_xn = carve(Mdp * D * 2);
+  const size_t o_x = carve(Mdp * D * 4), o_xn = carve(Mdp * D * 2);
   const size_t o_h32 = carve(Mdp * F * 4), o_h16 = carve(Mdp * F * 2), o_t = carve(Mdp * D * 4), o_tn = carve(Mdp * D * 4);
   const size_t o_q = carve(Mdp * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * round_up(V, 4) * 4), o_ids = carve((size_t)Md * 8);
   ensure(ws_dec_, off);
   char* base = (char*)ws_dec_.p;
-  half_t* kv16 = (half_t*)(base + o_kv);
   float* xd = (float*)(base + o_x); half_t* xdn16 = (half_t*)(base + o_xn);
   float* hd32 = (float*)(base + o_h32); half_t* hd16 = (half_t*)(base + o_h16);
   float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
   half_t* qd16 = (half_t*)(base + o_q); half_t* ctxd16 = (half_t*)(base + o_ctx);
   logits_ = (float*)(base + o_lg); ids_dev_ = (int64_t*)(base + o_ids);
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
-  const int ldkv = nd * 2 * D;
 
   prof_begin("cif_misc", 0);
   if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
@@ -988,8 +1007,6 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
     hid32 = e0 + (size_t)Mdp * D;
     PF_HIP(hipMemcpyAsync(e0, xd, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
   }
-  if (nd > 0)
-    gemm("gemm_dec_kv", dec_kv_all_, H16_, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
 
   // Decoder layer = 9 launches: norm1 | FFN-up (f16 hidden) | LayerNorm(2048) in place | FFN-down | norm2 | FSMN memory +
   // norm3 (one kernel, dec_fuse_ bit 1) | q | cross attention | out-projection + residual.  The row-complete GEMM can
@@ -1222,7 +1239,6 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   float* e32 = (float*)(base + o_e32); half_t* in16 = (half_t*)(base + o_in16);
   float* xg = (float*)(base + o_xg); float* hout = (float*)(base + o_ho);
   half_t* hs = (half_t*)(base + o_hs); float* cs = (float*)(base + o_cs);
-  half_t* kv16 = (half_t*)(base + o_kv);
   float* xs = (float*)(base + o_x); half_t* xn16 = (half_t*)(base + o_xn);
   float* h32 = (float*)(base + o_h32); half_t* h16 = (half_t*)(base + o_h16);
   float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
@@ -1230,6 +1246,7 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   float* hid = (float*)(base + o_hid); half_t* m16 = (half_t*)(base + o_m16);
   float* dha = (float*)(base + o_dha); int64_t* dha_ids = (int64_t*)(base + o_did);
   int32_t* tn2 = (int32_t*)(base + o_tn2);
+  half_t* kv16 = (half_t*)(base + o_kv);
 
   // ---- hotword embedder: Embedding -> LSTM stack (all J outputs kept), batch-major rows n*J + j
   prof_begin("seaco_embed", 0);
@@ -1610,6 +1627,7 @@ void Engine::unregister_uid(uint64_t id) {
 
 void Engine::publish_thread_result() {
   PF_HIP(hipStreamSynchronize(stream_));
+  check_async_errors();
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     for (auto it = t_slots.begin(); it != t_slots.end();)
@@ -1641,6 +1659,7 @@ void Engine::copy_logits(HostBatchOut& r) {
 void Engine::fetch(pf_batch_out* out) {
   PF_CHECK(out, PF_ERR_INVALID_ARG, "fetch: null out");
   PF_HIP(hipStreamSynchronize(stream_));
+  check_async_errors();
   auto it = t_slots.find(uid_);
   const bool slot = it != t_slots.end();
   const HostBatchOut& r = slot ? it->second : last_;

@@ -167,11 +167,14 @@ class Engine {
   uint32_t next_dither_seed() { return fc_.dither_seed * 2654435761u + (dither_calls_++) * 40503u; }
   int device_ = 0;
   hipStream_t stream_ = nullptr;
+  hipStream_t aux_stream_ = nullptr;   // carries the decoder-length read-back, so stream_ keeps running (K/V projections) meanwhile
+  hipEvent_t ev_scan_ = nullptr;       // CIF scan finished
   bool no_rc_ = false, rc_ffn2_ = false, lstm_steps_ = false;
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)
   int dec_fuse_ = 1;                 // bit 1: FSMN + norm3, bit 2: out-projection + next norm1, bit 4: FFN-down + norm2 (row-complete GEMM)
-  unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next host sync)
+  unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)
+  void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   ModelCfg mc_;
   FrontendCfg fc_;
@@ -213,7 +216,7 @@ class Engine {
   DevBuf ws_f32_;
   float* small_ws_ = nullptr;        // short-input GEMM: split partials
   float* cif_conv_w32_ = nullptr;    // fp32 mode: the CIF conv as a [D][taps*D] GEMM operand
-  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
+  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_kv_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
   int pe_T_ = 0;
   // encoder views (valid after encoder())
   float* x_ = nullptr; half_t* xn16_ = nullptr; half_t* qkv16_ = nullptr; half_t* ctx16_ = nullptr;

@@ -48,6 +48,7 @@ PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 PMC_FILE = os.path.join(ROOT, "profiles", "round3_pmc.json")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_MARGIN = 0.1           # = 2 x the 5e-2 log-prob tolerance of tests/test_gpu_full_depth.py
+ALPHA_NEAR = 0.1              # an oracle sum(alpha) this close to an integer is a near-tie of token_num = floor(sum alpha)
 # kernel classes of Engine::prof_begin (csrc/engine.cpp); the roofline object describes whichever encoder GEMM class
 # takes the most time in a step (found by an untimed profiling step before the timed region)
 CLASSES = ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
@@ -67,24 +68,40 @@ def ids_checksum(ids) -> str:
     return hashlib.sha1(np.ascontiguousarray(ids, dtype=np.int64).tobytes()).hexdigest()
 
 
-def golden_check(tag, ids):
+def golden_check(tag, ids, token_num=None):
     """The ids of a step against the fp32 CPU oracle's for the same workload (tests/golden/bench_<tag>.npz, written
     by tests/golden/make_bench_golden.py; the -m gpu test tests/test_gpu_full_depth.py re-runs that oracle live and
-    cross-checks the file).  ok = identical ids on every position whose oracle top-1/top-2 margin exceeds
-    GOLDEN_MARGIN.  None when there is no golden file for this workload / shape."""
+    cross-checks the file).  None when there is no golden file for this workload / shape.
+
+    ok =  identical ids on every position whose oracle top-1/top-2 margin exceeds GOLDEN_MARGIN, over the utterances
+          whose `token_num` equals the oracle's, AND
+          every other utterance differs from the oracle's token_num = floor(sum alpha) by exactly one with the
+          oracle's sum within ALPHA_NEAR of an integer: 16-bit GEMM operands move that sum by up to ~0.07 at T = 500
+          (measured), so such an utterance is a near-tie of the floor, not an error."""
     path = os.path.join(GOLDEN_DIR, "bench_%s.npz" % tag)
     if not os.path.exists(path):
         return None
     g = np.load(path)
     gi, gm = g["ids"], g["margin"]
     ids = np.asarray(ids)
-    if ids.shape != gi.shape:
+    if ids.ndim != 2 or ids.shape[0] != gi.shape[0] or abs(ids.shape[1] - gi.shape[1]) > 1:
         return None
-    firm = gm > GOLDEN_MARGIN
-    same = ids == gi
-    return {"ok": bool(same[firm].all()), "decisive_positions": float(firm.mean()), "decisive_mismatches": int((~same[firm]).sum()),
-            "agree_all_positions": float(same.mean()), "margin": GOLDEN_MARGIN,
-            "oracle": "fp32 CPU oracle, tests/golden/bench_%s.npz" % tag}
+    B, L = gi.shape[0], min(ids.shape[1], gi.shape[1])
+    rows = np.ones(B, bool)
+    tn_ok, tn_diff = True, 0
+    if token_num is not None and "alpha_sum" in g.files:
+        d = np.asarray(token_num).astype(np.int64) - g["token_num"].astype(np.int64)
+        frac = g["alpha_sum"].astype(np.float64) - np.floor(g["alpha_sum"].astype(np.float64))
+        near = np.minimum(frac, 1.0 - frac) < ALPHA_NEAR
+        tn_diff = int((d != 0).sum())
+        tn_ok = bool((np.abs(d) <= 1).all() and (near | (d == 0)).all())
+        rows = d == 0
+    firm = (gm[:, :L] > GOLDEN_MARGIN) & rows[:, None]
+    same = ids[:, :L] == gi[:, :L]
+    return {"ok": bool(tn_ok and same[firm].all()), "decisive_positions": float(firm.mean()),
+            "decisive_mismatches": int((~same[firm]).sum()), "agree_all_positions": float(same.mean()),
+            "token_num_near_ties_resolved_differently": tn_diff, "L": [int(ids.shape[1]), int(gi.shape[1])],
+            "margin": GOLDEN_MARGIN, "oracle": "fp32 CPU oracle, tests/golden/bench_%s.npz" % tag}
 
 
 def respawn_under_torchrun(n: int) -> int:
@@ -235,7 +252,7 @@ def group_main(args):
     dt = time.perf_counter() - t0
     assert res.L > 0 and res.token_ids.shape == (B, res.L) and (res.token_num > 0).all()
     per = B // n
-    chk = golden_check(args.model, res.token_ids[:per]) if seconds == (10 if sv else SECONDS) else None
+    chk = golden_check(args.model, res.token_ids[:per], res.token_num[:per]) if seconds == (10 if sv else SECONDS) else None
     assert chk is None or chk["ok"], chk
     audio_s = B * seconds * args.steps
     print(json.dumps({
@@ -407,7 +424,7 @@ def main():
     # the oracle is decisive.  Only the three BASELINE workloads at their own shapes have a golden file.
     ids_check = None
     if rank == 0 and seconds == (10 if sv else SECONDS) and not (args.timestamp_head and args.model == "paraformer"):
-        ids_check = golden_check(args.model, res.token_ids)
+        ids_check = golden_check(args.model, res.token_ids, res.token_num)
         assert ids_check is None or ids_check["ok"], "ids differ from the fp32 oracle on decisive positions: %r" % (ids_check,)
 
     # PCIe-inclusive rate (never `value`): host float32 audio in, ids back on the host, per batch

@@ -442,7 +442,7 @@ class Oracle:
         a = self.cif_alphas(H)
         E, counts, tnum = self.cif(H.numpy(), a.numpy())
         logp, hid = self.decoder(E, H, tnum, return_hidden=True)
-        out = {"token_num": tnum, "fire_count": counts, "asr_logits": logp.numpy()}
+        out = {"token_num": tnum, "fire_count": counts, "asr_logits": logp.numpy(), "alphas": a.numpy()}
         hw = np.asarray(hotwords)
         if hw.shape[0] > 0:
             B = H.shape[0]

@@ -14,6 +14,9 @@ Workloads = bench.py's: seeded synthetic weights (weights.synth_weights(cfg, 42)
   top1       [B, L] float32 the top-1 log-prob
   token_num  [B]    int32
   fire_count [B]    int32   (paraformer / seaco)
+  alpha_sum  [B]    float32 (paraformer / seaco) sum of the CIF weights; token_num = floor(alpha_sum): an utterance whose
+                            sum lies within a few 1e-2 of an integer is a near-tie of that floor (16-bit GEMM operands
+                            move the sum by up to ~0.07 at T = 500)
   seaco only: us_fire [B, F] int32 fire frames of us_cif_peak (-1 padded), us_fire_clear [B, F] float32 = by how
   much the oracle's integrator clears the threshold at the fire frame and misses it on the frame before (the smaller
   of the two), hw [21, 10] the PadList'ed hotword ids.
@@ -116,6 +119,8 @@ def run(name):
                token_num=np.asarray(r["token_num"], np.int32))
     if "fire_count" in r:
         out["fire_count"] = np.asarray(r["fire_count"], np.int32)
+    if "alphas" in r:
+        out["alpha_sum"] = r["alphas"].astype(np.float64).sum(axis=1).astype(np.float32)
     path = os.path.join(HERE, "bench_%s.npz" % name)
     np.savez_compressed(path, **out)
     ids = out["ids"]
