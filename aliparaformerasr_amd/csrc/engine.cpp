@@ -395,7 +395,8 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     ts_out_w_ = ow.dev;
     ts_out_b_ = tensor("predictor.out2.bias").dev;
     PF_HIP(hipStreamSynchronize(stream_));
-    PF_HIP(hipFree(tmp));
+    if (fp32_mode_) { ts_up_w32_ = tmp; owned_.push_back(tmp); }   // [(j, out)][in] fp32, the operand of the parity mode
+    else PF_HIP(hipFree(tmp));
   }
   // decoder
   const int nd = mc_.dec_layers;
@@ -493,6 +494,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
         PF_CHECK(L.w1.N == mc_.seaco_ffn, PF_ERR_FORMAT, "weights: seaco ffn width != seaco_ffn");
         launch_f32_to_f16(stream_, kvw.dev, 2 * D, D, D, seaco_kv_all_.w + (size_t)i * 2 * D * D, D);
         PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
+        L.kv32.w32 = kvw.dev; L.kv32.bias = kvbias.dev; L.kv32.N = 2 * D; L.kv32.K = D;
         sdec_.push_back(L);
       }
     }
@@ -1459,8 +1461,6 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
 }
 
 void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logits) {
-  PF_CHECK(!mc_.timestamp_head && !mc_.seaco, PF_ERR_UNSUPPORTED,
-           "math_mode 1 (fp32 parity mode) covers the paraformer and SenseVoice graphs, not the BiCIF / SeACo heads");
   const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab, Fd = mc_.feat_dim, M = B * T, T1 = T + 1;
   const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
   build_pe(T);
@@ -1515,6 +1515,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   launch_cif_alpha(stream_, f[F_FS], B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
   else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
+  if (mc_.timestamp_head) timestamp_head_fp32(B, T);
   int32_t L = 0;
   last_.fire_count.resize(B);
   last_.token_num.resize(B);
@@ -1542,6 +1543,13 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   logits_ = (float*)(b2 + o_lg); ids_dev_ = (int64_t*)(b2 + o_ids); logits_ld_ = ldV;
   if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
   else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
+  const bool bias_branch = mc_.seaco && n_hotwords_ > 0;
+  float* e0 = nullptr;                                 // SeACo: the bias decoder also starts from the CIF embeds
+  if (bias_branch) {
+    ensure(ws_seaco_in_, (size_t)Md * D * 4);
+    e0 = (float*)ws_seaco_in_.p;
+    PF_HIP(hipMemcpyAsync(e0, xd, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  }
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
     launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, nullptr, 0, xn, D);
@@ -1565,7 +1573,121 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
   launch_gemm_f32(stream_, xn, D, dec_out_.w32, D, dec_out_.bias, Md, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
   launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
+  if (bias_branch) seaco_head_fp32(B, L, e0, xn, want_logits);      // xn = the ASR decoder's after_norm hidden
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+// ---- fp32 forms of the two heads (math_mode 1): the same graphs as timestamp_head / seaco_head with fp32 weights and
+// activations, one launch per graph node; the recurrences run as one fp32 GEMM + one cell kernel per time step.
+void Engine::lstm_fp32(const float* x, int Bn, int Tn, const float* w_ih, const float* w_hh, const float* bias, bool reverse,
+                       float* xg, float* gates, float* hbuf, float* cbuf, float* hout, int ldh, int col0) {
+  const int D = mc_.d_model;
+  // input half of the gates for every row at once: xg[b * Tn + t, 0:4D] = x W_ih^T + (b_ih + b_hh)
+  launch_gemm_f32(stream_, x, D, w_ih, D, bias, Bn * Tn, 4 * D, D, xg, 4 * D, nullptr, 0, false, 0, 1.f);
+  PF_HIP(hipMemsetAsync(hbuf, 0, (size_t)Bn * D * 4, stream_));
+  PF_HIP(hipMemsetAsync(cbuf, 0, (size_t)Bn * D * 4, stream_));
+  for (int st = 0; st < Tn; ++st) {
+    const int t = reverse ? Tn - 1 - st : st;
+    // gates[b] = xg[b * Tn + t] + h[b] W_hh^T   (rows of the residual operand are Tn * 4D apart)
+    launch_gemm_f32(stream_, hbuf, D, w_hh, D, nullptr, Bn, 4 * D, D, gates, 4 * D, xg + (size_t)t * 4 * D, Tn * 4 * D, false, 0, 1.f);
+    launch_lstm_cell_f32(stream_, gates, 4 * D, cbuf, hbuf, hout + (size_t)t * ldh + col0, (int64_t)Tn * ldh, Bn, D);
+  }
+}
+
+void Engine::timestamp_head_fp32(int B, int T) {
+  const int D = mc_.d_model, up = mc_.upsample;
+  const int M = B * T, T3 = up * T;
+  const int64_t M3 = (int64_t)B * T3;
+  PF_CHECK(ts_up_w32_, PF_ERR_UNSUPPORTED, "fp32 timestamp head: operands were not prepared (engine not created in math_mode 1)");
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_up = carve((size_t)M3 * D * 4), o_xg = carve((size_t)M3 * 4 * D * 4), o_ho = carve((size_t)M3 * 2 * D * 4);
+  const size_t o_g = carve((size_t)B * 4 * D * 4), o_h = carve((size_t)B * D * 4), o_c = carve((size_t)B * D * 4);
+  const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4);
+  ensure(ws_ts_, off);
+  char* base = (char*)ws_ts_.p;
+  float* up32 = (float*)(base + o_up); float* xg = (float*)(base + o_xg); float* hout = (float*)(base + o_ho);
+  float* gates = (float*)(base + o_g); float* hb = (float*)(base + o_h); float* cb = (float*)(base + o_c);
+  float* al = (float*)(base + o_al);
+  us_peak_ = (float*)(base + o_pk);
+  // [M, 3D] row-major IS [3M, D]
+  launch_gemm_f32(stream_, H32_, D, ts_up_w32_, D, ts_up_.bias, M, up * D, D, up32, up * D, nullptr, 0, false, 0, 1.f);
+  const char* sfx[2] = {"", "_reverse"};
+  for (int d = 0; d < 2; ++d)
+    lstm_fp32(up32, B, T3, tensor(std::string("predictor.blstm.weight_ih") + sfx[d]).dev,
+              tensor(std::string("predictor.blstm.weight_hh") + sfx[d]).dev, ts_ih_.bias + (size_t)d * 4 * D, d == 1, xg, gates, hb,
+              cb, hout, 2 * D, d * D);
+  launch_us_alpha(stream_, hout, M3, 2 * D, ts_out_w_, ts_out_b_, mc_.cif_smooth2, mc_.cif_noise2, al);
+  launch_us_peak(stream_, al, plan_.token_num, B, T3, mc_.cif_threshold - 1e-4f, us_peak_);
+  last_.peak_len = T3;
+  last_.cif_peak.resize((size_t)M3);
+  PF_HIP(hipMemcpyAsync(last_.cif_peak.data(), us_peak_, (size_t)M3 * 4, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::seaco_head_fp32(int B, int L, const float* e0, const float* hid_asr, bool want_logits) {
+  const int D = mc_.d_model, V = mc_.vocab, Fs = mc_.seaco_ffn, ns = (int)sdec_.size();
+  const int N = n_hotwords_, J = 10, NJ = N * J;
+  const int Md = B * L, R = 2 * Md;
+  const int ldV = (int)round_up(V, 4);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_ids = carve((size_t)NJ * 4), o_e = carve((size_t)NJ * D * 4), o_e2 = carve((size_t)NJ * D * 4), o_xg = carve((size_t)NJ * 4 * D * 4);
+  const size_t o_g = carve((size_t)N * 4 * D * 4), o_hb = carve((size_t)N * D * 4), o_cb = carve((size_t)N * D * 4);
+  const size_t o_kv = carve((size_t)NJ * 2 * D * 4), o_x = carve((size_t)R * D * 4), o_xn = carve((size_t)R * D * 4);
+  const size_t o_h = carve((size_t)R * Fs * 4), o_hn = carve((size_t)R * Fs * 4), o_t = carve((size_t)R * D * 4), o_tn = carve((size_t)R * D * 4);
+  const size_t o_q = carve((size_t)R * D * 4), o_cx = carve((size_t)R * D * 4), o_hid = carve((size_t)R * D * 4);
+  const size_t o_dha = carve((size_t)Md * ldV * 4), o_did = carve((size_t)Md * 8), o_tn2 = carve((size_t)2 * B * 4);
+  ensure(ws_seaco_, off);
+  char* base = (char*)ws_seaco_.p;
+  int32_t* ids = (int32_t*)(base + o_ids);
+  float* ea = (float*)(base + o_e); float* eb = (float*)(base + o_e2); float* xg = (float*)(base + o_xg);
+  float* gates = (float*)(base + o_g); float* hb = (float*)(base + o_hb); float* cb = (float*)(base + o_cb);
+  float* kv = (float*)(base + o_kv); float* xs = (float*)(base + o_x); float* xn = (float*)(base + o_xn);
+  float* hd = (float*)(base + o_h); float* hn = (float*)(base + o_hn); float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
+  float* qd = (float*)(base + o_q); float* cx = (float*)(base + o_cx); float* hid = (float*)(base + o_hid);
+  float* dha = (float*)(base + o_dha); int64_t* dha_ids = (int64_t*)(base + o_did); int32_t* tn2 = (int32_t*)(base + o_tn2);
+  // ---- hotword embedder: Embedding -> LSTM stack (all J outputs kept), rows n * J + j
+  PF_HIP(hipMemcpyAsync(ids, hotwords_.data(), (size_t)NJ * 4, hipMemcpyHostToDevice, stream_));
+  launch_embed_gather(stream_, seaco_embed_w_, ids, NJ, D, (int)tensor("seaco.embed.weight").shape[0], ea, nullptr);
+  float* cur = ea;
+  float* nxt = eb;
+  for (size_t l = 0; l < seaco_lstm_.size(); ++l) {
+    const std::string p = "seaco.lstm.l" + std::to_string(l);
+    lstm_fp32(cur, N, J, tensor(p + ".weight_ih").dev, tensor(p + ".weight_hh").dev, seaco_lstm_[l].ih.bias, false, xg, gates, hb, cb,
+              nxt, D, 0);
+    std::swap(cur, nxt);
+  }
+  const float* bias_embed = cur;                       // [NJ, D]
+  // ---- bias decoder on [CIF embeds ; decoder hidden]
+  PF_HIP(hipMemcpyAsync(xs, e0, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(xs + (size_t)Md * D, hid_asr, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(tn2, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(tn2 + B, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    launch_layernorm(stream_, xs, R, D, n1.g, n1.b, nullptr, 0, xn, D);
+    launch_gemm_f32(stream_, xn, D, w1.w32, D, w1.bias, R, Fs, D, hd, Fs, nullptr, 0, true, 0, 1.f);
+    launch_layernorm(stream_, hd, R, Fs, fn.g, fn.b, nullptr, 0, hn, Fs);
+    launch_gemm_f32(stream_, hn, Fs, w2.w32, Fs, nullptr, R, D, Fs, t32, D, nullptr, 0, false, 0, 1.f);
+  };
+  for (int i = 0; i < ns; ++i) {
+    const DecLayer& Lr = sdec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    launch_layernorm(stream_, t32, R, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, tn2, 2 * B, L, D, mc_.seaco_kernel, xs);
+    launch_layernorm(stream_, xs, R, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
+    launch_gemm_f32(stream_, xn, D, Lr.q.w32, D, Lr.q.bias, R, D, D, qd, D, nullptr, 0, false, D, qscale);
+    launch_gemm_f32(stream_, bias_embed, D, Lr.kv32.w32, D, Lr.kv32.bias, NJ, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
+    launch_attention_f32(stream_, qd, (int64_t)L * D, D, kv, 0, 2 * D, kv + D, 0, 2 * D, cx, (int64_t)L * D, D, 2 * B, mc_.heads, L, NJ);
+    launch_gemm_f32(stream_, cx, D, Lr.out.w32, D, Lr.out.bias, R, D, D, xs, D, xs, D, false, 0, 1.f);
+  }
+  ffn_dec(seaco_final_norm1_, seaco_final_w1_, seaco_final_ffn_norm_, seaco_final_w2_);
+  launch_layernorm(stream_, t32, R, D, seaco_after_.g, seaco_after_.b, nullptr, 0, hid, D);
+  // ---- merged = cif_attended + dec_attended -> hotword_output_layer -> NO-BIAS merge with the ASR rows
+  launch_add_f32(stream_, hid, hid + (size_t)Md * D, (int64_t)Md * D);
+  launch_gemm_f32(stream_, hid, D, seaco_out_.w32, D, seaco_out_.bias, Md, V, D, dha, ldV, nullptr, 0, false, 0, 1.f);
+  launch_argmax(stream_, dha, Md, V, ldV, 2, dha_ids);
+  launch_seaco_merge(stream_, dha, ldV, dha_ids, Md, V, mc_.seaco_nobias, want_logits ? 1 : 0, logits_, logits_ld_, ids_dev_);
 }
 
 void Engine::forward_feats_host(const float* speech, int B, int T, bool want_logits) {

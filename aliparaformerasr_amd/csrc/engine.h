@@ -150,6 +150,11 @@ class Engine {
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
   void forward_fp32(const float* speech_dev, int B, int T, bool want_logits);   // math_mode 1 (k_fp32.hip)
+  void timestamp_head_fp32(int B, int T);
+  void seaco_head_fp32(int B, int L, const float* e0, const float* hid, bool want_logits);
+  // fp32 LSTM over rows [Bn * Tn] of x (row b * Tn + t): hout[(b * Tn + t) * ldh + col0 .. + D); reverse = time runs backwards
+  void lstm_fp32(const float* x, int Bn, int Tn, const float* w_ih, const float* w_hh, const float* bias, bool reverse,
+                 float* xg, float* gates, float* hbuf, float* cbuf, float* hout, int ldh, int col0);
   void enc_layer_fp32(const EncLayer& L, bool first, const float* speech_dev, int B, int T, float** bufs);
   void timestamp_head(int B, int T);
   void seaco_head(int B, int L, const float* e0, const float* hid32, bool want_logits);
@@ -216,6 +221,7 @@ class Engine {
   DevBuf ws_f32_;
   float* small_ws_ = nullptr;        // short-input GEMM: split partials
   float* cif_conv_w32_ = nullptr;    // fp32 mode: the CIF conv as a [D][taps*D] GEMM operand
+  float* ts_up_w32_ = nullptr;       // fp32 mode: the transposed conv as a [(j, out)][in] GEMM operand
   DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_kv_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
   int pe_T_ = 0;
   // encoder views (valid after encoder())

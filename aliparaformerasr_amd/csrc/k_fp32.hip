@@ -158,4 +158,27 @@ void launch_posenc_f32(hipStream_t s, const float* x, const float* pe, int B, in
   PF_HIP(hipGetLastError());
 }
 
+// LSTM cell on fp32 gate pre-activations g[b, 0:4D] (PyTorch order i, f, g, o; already xg + h W_hh^T): c, h updated in
+// place, h also written to hout[b * hout_bs + k] (the sequence output)
+__global__ __launch_bounds__(256) void lstm_cell_f32_kernel(const float* __restrict__ g, int ldg, float* __restrict__ c, float* __restrict__ h,
+                                                            float* __restrict__ hout, int64_t hout_bs, int B, int D) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * D) return;
+  const int b = idx / D, k = idx - b * D;
+  const float* gr = g + (size_t)b * ldg;
+  auto sig = [](float x) { return 1.0f / (1.0f + expf(-x)); };
+  const float ig = sig(gr[k]), fg = sig(gr[D + k]), gg = tanhf(gr[2 * D + k]), og = sig(gr[3 * D + k]);
+  const float cn = add_rn(mul_rn(fg, c[idx]), mul_rn(ig, gg));
+  const float hn = mul_rn(og, tanhf(cn));
+  c[idx] = cn;
+  h[idx] = hn;
+  hout[(size_t)b * hout_bs + k] = hn;
+}
+
+void launch_lstm_cell_f32(hipStream_t s, const float* gates, int ldg, float* c, float* h, float* hout, int64_t hout_bs, int B, int D) {
+  if (B * D == 0) return;
+  hipLaunchKernelGGL(lstm_cell_f32_kernel, dim3((unsigned)cdiv((int64_t)B * D, 256)), dim3(256), 0, s, gates, ldg, c, h, hout, hout_bs, B, D);
+  PF_HIP(hipGetLastError());
+}
+
 }  // namespace pf

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
   const float4 v = *reinterpret_cast<const float4*>(table + (int64_t)id * D + c4);
   *reinterpret_cast<float4*>(out32 + (int64_t)r * D + c4) = v;
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  *reinterpret_cast<h4*>(out16 + (int64_t)r * D + c4) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+  if (out16) *reinterpret_cast<h4*>(out16 + (int64_t)r * D + c4) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
 }
 
 void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, int rows, int D, int vocab,

@@ -47,7 +47,7 @@ LCAP = 512
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 PMC_FILE = os.path.join(ROOT, "profiles", "round3_pmc.json")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_MARGIN = 0.1           # = 2 x the 5e-2 log-prob tolerance of tests/test_gpu_full_depth.py
+GOLDEN_MARGIN = 0.05          # = MARGIN of tests/test_gpu_full_depth.py (the two oracles never disagree above 0.02)
 ALPHA_NEAR = 0.1              # an oracle sum(alpha) this close to an integer is a near-tie of token_num = floor(sum alpha)
 # kernel classes of Engine::prof_begin (csrc/engine.cpp); the roofline object describes whichever encoder GEMM class
 # takes the most time in a step (found by an untimed profiling step before the timed region)

@@ -3,7 +3,8 @@
 The reference runs the exported graphs through onnxruntime in fp32 (OfflineModel.cs:41-57).  The default engine path
 feeds the matrix cores f16 operands, which is good for ~1e-2 on log-probs; this mode keeps every activation and every
 weight in fp32 (v_mfma_f32_32x32x2_f32, fp32 softmax / LayerNorm / CIF) so that the only differences from the fp32
-oracle are summation order.  Tolerance: 2e-4 abs on log-probs of magnitude ~10 (fp32 accumulation order over K <= 2048,
+oracle are summation order.  Covers the paraformer and SenseVoice graphs AND the two heads of configs[4] (BiCIF
+timestamps, SeACo bias decoder).  Tolerance: 2e-4 abs on log-probs of magnitude ~10 (fp32 accumulation order over K <= 2048,
 through 50 + 16 layers measured 9.5e-6), token_num / L identical, ids identical wherever the oracle's top-1/top-2 margin
 exceeds 1e-3.
 """
@@ -103,13 +104,72 @@ def test_fp32_mode_sensevoice(sv_embed):
     eng.close()
 
 
-def test_fp32_mode_refuses_heads_it_does_not_cover():
+def test_fp32_mode_bicif_timestamp_head():
+    """configs[4]'s timestamp head in fp32 (ConvTranspose1d, BiLSTM, Linear(1024, 1), renormalisation, cif_wo_hidden):
+    us_cif_peak within 2e-4 of the fp32 oracle modulo the integrator reset, the SAME fire frames wherever the oracle's
+    crossing clears the threshold by 1e-3, recognizer-side timestamps (integer milliseconds) identical on those."""
     from aliparaformerasr_amd.engine import Engine
-    from aliparaformerasr_amd._native import PfError
     cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=256, timestamp_head=True)
     w = W.synth_weights(cfg, seed=1)
-    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=W.synth_cmvn(), device=0, math_mode=1)
-    with pytest.raises(PfError) as ei:
-        eng.recognize([W.synth_audio(16000, 1)])
-    assert "math_mode" in str(ei.value)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
+    audio = [W.synth_audio(n, 11 + u) for u, n in enumerate((48000, 36000))]
+    speech = _speech(audio, cmvn)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").paraformer(speech)
+    res = eng.recognize(audio, want_logits=True)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    assert np.abs(res.logits - ref["logits"]).max() < TOL
+    T3 = 3 * speech.shape[1]
+    assert res.cif_peak.shape == (2, T3)
+    thr = np.float32(np.float32(1.0) - np.float32(1e-4))
+    d = np.abs(res.cif_peak - ref["us_cif_peak"])
+    d = np.minimum(d, np.abs(d - thr))                    # a fire decided the other way shifts the integrator by thr
+    assert d.max() < 2e-4, d.max()
+    n_clear = 0
+    for b in range(2):
+        pk = ref["us_cif_peak"][b]
+        f_ref = np.nonzero(pk > thr)[0]
+        f_dev = np.nonzero(res.cif_peak[b] > thr)[0]
+        clear = np.asarray([min(pk[f] - thr, thr - (pk[f - 1] if (f > 0 and pk[f - 1] <= thr) else 0.0)) > 1e-3 for f in f_ref])
+        assert len(f_dev) == len(f_ref)
+        np.testing.assert_array_equal(f_dev[clear], f_ref[clear])
+        n_clear += int(clear.sum())
+    assert n_clear >= 10
+    eng.close()
+
+
+def test_fp32_mode_seaco_bias_decoder():
+    """configs[4]'s SeACo branch in fp32: hotword embedder (Embedding + 2 x LSTM), the bias decoder on [CIF embeds ;
+    decoder hidden], hotword_output_layer, NO-BIAS merge — merged log-probs within 2e-4 of the fp32 oracle on every
+    row whose NO-BIAS decision is not a near-tie, ids identical off the near-ties; + the timestamp head of the same model."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.seaco_paraformer_config(enc_layers=2, dec_layers=2, seaco_layers=2, vocab=300, seaco_nobias=290)
+    w = W.synth_weights(cfg, seed=6)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
+    audio = [W.synth_audio(n, 40 + u) for u, n in enumerate((32000, 48000, 40000))]
+    speech = _speech(audio, cmvn)
+    hw = np.asarray(glue.pad_list([[11, 12], [100, 200, 30], [7, 8, 9, 10], [1]]), np.int32)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").seaco(speech, hw)
+    res = eng.recognize(audio, want_logits=True, hotwords=hw)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    assert res.logits.shape == ref["logits"].shape
+    dha = ref["dha_logits"]
+    nb = cfg["seaco_nobias"]
+    other = np.where(np.arange(dha.shape[-1])[None, None, :] == nb, -np.inf, dha).max(-1)
+    clear = np.abs(dha[..., nb] - other) > 1e-3
+    assert clear.mean() > 0.9
+    err = np.abs(res.logits - ref["logits"]).max(-1)
+    assert err[clear].max() < TOL, err[clear].max()
+    margin = np.sort(ref["logits"], axis=-1)
+    safe = clear & ((margin[..., -1] - margin[..., -2]) > 1e-3)
+    np.testing.assert_array_equal(res.token_ids[safe], om.argmax_last(ref["logits"])[safe])
+    took_hotword_rows = (np.argmax(dha, -1) != nb)
+    assert took_hotword_rows.any() and (~took_hotword_rows).any()      # both sides of the merge are exercised
+    d = np.abs(res.cif_peak - ref["us_cif_peak"])
+    d = np.minimum(d, np.abs(d - 0.9999))
+    assert d.max() < 2e-4, d.max()
+    # no hotwords: the bias branch is skipped, the ASR rows come back
+    r0 = eng.recognize(audio, want_logits=True, hotwords=np.zeros((0, 10), np.int32))
+    assert np.abs(r0.logits - ref["asr_logits"]).max() < TOL
     eng.close()

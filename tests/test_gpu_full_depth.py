@@ -10,9 +10,9 @@ same batch, twice:
 
   (A) `Oracle(quant="fp16")` — the graph with the engine's 16-bit rounding points (what the kernels are built to
       compute): `token_num`, `L` identical, every log-prob within TOL_Q, ids identical wherever the margin is > 2 x TOL_Q.
-  (B) `Oracle(quant="fp32")` — what onnxruntime computes on the fp32 model: every log-prob within TOL_F, ids identical
-      wherever the oracle's top-1/top-2 margin exceeds 2 x TOL_F and on >= AGREE_ALL of ALL positions — over the
-      utterances whose `token_num` equals the fp32 oracle's.  token_num = floor(sum alpha) is a discontinuous function
+  (B) `Oracle(quant="fp32")` — what onnxruntime computes on the fp32 model: every log-prob within TOL_F (99.9 % of them
+      within TOL_F_P999), ids identical wherever the oracle's top-1/top-2 margin exceeds MARGIN and on >= AGREE_ALL of
+      ALL positions — over the utterances whose `token_num` equals the fp32 oracle's.  token_num = floor(sum alpha) is a discontinuous function
       of 501 CIF weights: 16-bit GEMM operands through 50 layers move the sum by +0.025 on average, up to 0.07
       (a systematic, positive shift: rounding noise in front of the ReLU / sigmoid; measured with the two oracles),
       so an utterance whose fp32 sum lies within ALPHA_NEAR of an integer may resolve to the neighbouring count — by
@@ -25,7 +25,7 @@ the build host) agrees with the live oracle wherever its margin exceeds 1e-3, an
 `bench.py` asserts after its timed steps — accepts the ids of the benchmark call.
 
 The seeded random-weight models predict a narrow set of tokens with a dense field of near-ties behind the winner
-(random logits over 8404 classes: median top-1/top-2 margin 0.11), so "margin > 2 x tol" covers 55-75 % of the
+(random logits over 8404 classes: median top-1/top-2 margin 0.11), so "margin > MARGIN" covers ~75 % of the
 positions; the all-position agreement rate is asserted on top of it.
 """
 import os
@@ -41,9 +41,17 @@ from oracle import model as om
 
 pytestmark = pytest.mark.gpu
 
-TOL_Q = 2e-2          # |log-prob - oracle with the engine's rounding points|
-TOL_F = 5e-2          # |log-prob - fp32 oracle|, f16 operands / fp32 accumulate through 66 (70) layers
-AGREE_ALL = 0.97      # share of ALL positions (decisive or not) whose id equals the oracle's
+# Bars at 30 s are set by the CIF, not by the matrix products: a fire is a threshold decision on a running sum of the
+# weights, and 16-bit GEMM operands move a few per cent of the ~150 fires of a 30 s utterance by one frame (measured
+# between the two oracles: 3-19 per utterance), each of which re-weights two adjacent acoustic embeddings.  Around such
+# positions log-probs move by up to ~0.1 (0.2 behind the SeACo branch); everywhere else by ~1e-3 (10 s SenseVoice,
+# no CIF: max 5e-3).  Hence a maximum AND a 99.9th percentile.
+TOL_Q = 5e-2          # max |log-prob - oracle with the engine's rounding points| (measured 2.3e-2)
+TOL_F = 2e-1          # max |log-prob - fp32 oracle| over utterances with the oracle's token_num (oracle pair: 9.3e-2)
+TOL_F_P999 = 3e-2     # 99.9th percentile of the same (oracle pair: 1.2e-2)
+MARGIN = 5e-2         # ids must equal the fp32 oracle's wherever its top-1/top-2 margin exceeds this (oracle pair:
+                      # every disagreement has a margin below 8e-3 / 1.8e-2 with the SeACo branch)
+AGREE_ALL = 0.985     # share of ALL positions (decisive or not) whose id equals the oracle's (oracle pair: 0.9946)
 ALPHA_NEAR = 0.1      # fp32 sum(alpha) this close to an integer: token_num is a near-tie (bench.ALPHA_NEAR)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -103,20 +111,20 @@ def _compare(tag, res, ids_bench, ref_logits, golden, rows=None, tn_bench=None):
     err = np.abs(dev - ref)
     emax = float(err.max())
     assert emax < TOL_F, emax
+    k = err.size - max(1, err.size // 1000)
+    p999 = float(np.partition(err.reshape(-1), k)[k])
+    assert p999 < TOL_F_P999, p999
     # index work is bit-exact on the device's own numbers, for both kernel variants (log-probs stored / not stored)
     np.testing.assert_array_equal(res.token_ids, om.argmax_last(res.logits))
     np.testing.assert_array_equal(ids_bench, res.token_ids)
     ids_dev = res.token_ids[rows, :L]
     tok_ref = om.argmax_last(ref)
     margin = _top2(ref)
-    safe = margin > 2 * TOL_F
+    safe = margin > MARGIN
+    assert safe.mean() > 0.7, safe.mean()
     np.testing.assert_array_equal(ids_dev[safe], tok_ref[safe])
     agree = float((ids_dev == tok_ref).mean())
     assert agree >= AGREE_ALL, agree
-    # every disagreement sits on a near-tie of the oracle that the measured error explains
-    bad = ids_dev != tok_ref
-    if bad.any():
-        assert margin[bad].max() <= 2 * emax, (margin[bad].max(), emax)
     # the committed golden file is this oracle (another host's BLAS summation order: compare off the near-ties)
     g_ids, g_margin = golden["ids"][rows, :L], golden["margin"][rows, :L]
     firm = g_margin > 1e-3
@@ -124,9 +132,11 @@ def _compare(tag, res, ids_bench, ref_logits, golden, rows=None, tn_bench=None):
     assert np.abs(g_margin - margin).max() < 1e-3
     chk = bench.golden_check(tag, ids_bench, tn_bench)
     assert chk is not None and chk["ok"], chk
-    print("%s: L=%d, %d / %d utterances share the fp32 token_num; max|dlogp|=%.3e (mean %.2e), ids == fp32 oracle on %.4f of "
-          "their positions, %.3f decisive at 2 x %.0e; golden: %s"
-          % (tag, res.L, int(rows.sum()), rows.size, emax, float(err.mean()), agree, float(safe.mean()), TOL_F, chk))
+    bad = ids_dev != tok_ref
+    print("%s: L=%d, %d / %d utterances share the fp32 token_num; |dlogp| max %.3e, 99.9 %% %.3e, mean %.2e; ids == fp32 oracle on "
+          "%.4f of their positions (largest margin among the rest %.1e), %.3f decisive at margin > %.0e; golden: %s"
+          % (tag, res.L, int(rows.sum()), rows.size, emax, p999, float(err.mean()), agree,
+             float(margin[bad].max()) if bad.any() else 0.0, float(safe.mean()), MARGIN, chk))
     return emax, agree
 
 
@@ -213,17 +223,23 @@ def test_seaco_32x30s():
     dha = ref["dha_logits"][rows, :L]
     nb = cfg["seaco_nobias"]
     other = np.where(np.arange(dha.shape[-1])[None, None, :] == nb, -np.inf, dha).max(-1)
-    clear = np.abs(dha[..., nb] - other) > 2 * TOL_F
+    clear = np.abs(dha[..., nb] - other) > 0.1
+    assert clear.mean() > 0.9
     ref_l = ref["logits"][rows, :L]
-    err = np.abs(res.logits[rows, :L] - ref_l).max(-1)
-    assert err[clear].max() < TOL_F, err[clear].max()
+    err = np.abs(res.logits[rows, :L] - ref_l)[clear]            # [rows of clear positions, V]
+    emax = float(err.max())
+    assert emax < 2 * TOL_F, emax                                # oracle pair: 0.18 (bias decoder behind the CIF)
+    k = err.size - max(1, err.size // 1000)
+    p999 = float(np.partition(err.reshape(-1), k)[k])
+    assert p999 < 2 * TOL_F_P999, p999                           # oracle pair: 2.8e-2
     tok_ref = om.argmax_last(ref_l)
     margin = _top2(ref_l)
-    safe = clear & (margin > 2 * TOL_F)
+    safe = clear & (margin > MARGIN)
+    assert safe.mean() > 0.7
     ids_dev = res.token_ids[rows, :L]
     np.testing.assert_array_equal(ids_dev[safe], tok_ref[safe])
     agree = float((ids_dev == tok_ref).mean())
-    assert agree >= AGREE_ALL - 0.02, agree
+    assert agree >= AGREE_ALL - 0.005, agree                     # oracle pair: 0.9928
     # ---- us_cif_peak: fire counts exact, fire frames exact where the oracle is clear
     assert res.cif_peak.shape == (32, 1500)
     thr = np.float32(np.float32(1.0) - np.float32(1e-4))
@@ -243,7 +259,7 @@ def test_seaco_32x30s():
     import bench
     chk = bench.golden_check("seaco", rb.token_ids, rb.token_num)
     assert chk is not None and chk["ok"], chk
-    print("seaco: L=%d, %d / 32 utterances share the fp32 token_num; ids == oracle on %.4f of their positions; %d / %d fires "
-          "decided by > %.0e, all on the oracle's frame; fire counts identical; golden: %s"
-          % (res.L, int(rows.sum()), agree, n_clear, n_all, FIRE_CLEAR, chk))
+    print("seaco: L=%d, %d / 32 utterances share the fp32 token_num; |dlogp| max %.3e, 99.9 %% %.3e; ids == oracle on %.4f of their "
+          "positions; %d / %d fires decided by > %.0e, all on the oracle's frame; fire counts identical; golden: %s"
+          % (res.L, int(rows.sum()), emax, p999, agree, n_clear, n_all, FIRE_CLEAR, chk))
     eng.close()
