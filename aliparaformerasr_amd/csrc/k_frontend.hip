@@ -9,12 +9,16 @@
 //   AliParaformerAsr/Utils/PadHelper.cs:23-65 PadSequence (right pad with 0, then every value
 //                                           == 0.0f becomes float32(-23.025850929940457f*32768))
 //
-// fbank: one wavefront per 25 ms frame.  The 400 samples (mirror-reflected at the utterance
-// edges when snip_edges == false) are staged in LDS, DC-removed, pre-emphasised, windowed,
-// zero-padded to 512 and transformed with a 256-point complex Stockham radix-2 FFT in LDS
-// (real-input split afterwards); the 80 triangular mel filters are stored sparse.
-// HBM-bound: 4 B/sample in (each sample is touched by 2.5 frames, served from L2),
-// 320 B/frame out.
+// fbank: one wavefront per 25 ms frame, four frames per workgroup.  The 400 samples (mirror-reflected at the utterance
+// edges when snip_edges == false; interior frames take a branch-free coalesced path) are staged in LDS; each lane then
+// forms its four complex points z[n] = x[2n] + i x[2n+1] of the 512-point real transform (DC removal, pre-emphasis,
+// window) in registers and runs a 256-point complex Stockham FFT as FOUR radix-4 passes (one in-lane butterfly per
+// pass; twiddles from a workgroup-shared LDS table) instead of eight radix-2 passes, then the real-input split and
+// the power spectrum.  The 80 triangular mel filters are stored sparse and cut into chunks of at most eight bins so
+// that the 64 lanes share the ~500 multiply-adds evenly (a lane per filter leaves the wide high-frequency filters on
+// 16 lanes); chunk sums are combined per filter in a fixed order (deterministic).
+// Instruction-issue bound (round 2: ~1300 instructions per frame, 204 us for 96 000 frames), not HBM-bound:
+// 4 B/sample in (each sample is touched by 2.5 frames, served from L2), 320 B/frame out.
 #include "kernels.h"
 #include "exact.h"
 
@@ -36,7 +40,15 @@ struct FbankTables {
   int* mel_start;   // [n_mels]
   int* mel_off;     // [n_mels + 1] offsets into mel_w
   float* mel_w;     // packed non-zero weights
+  // the same filters cut into chunks of <= 8 consecutive bins: chunk c = (first bin, first weight, count);
+  // filter m owns chunks [mel_chunk_off[m], mel_chunk_off[m + 1])
+  int n_chunks, n_weights;
+  int4* mel_chunk;        // [n_chunks]  (x = first bin, y = offset into mel_w, z = count, w = filter)
+  int* mel_chunk_off;     // [n_mels + 1]
 };
+
+#define FB_MAX_CHUNKS 192      // three rounds of 64 lanes
+#define FB_MAX_WEIGHTS 1024
 
 FbankTables* fbank_tables_create(int n_mels, int fs, const char* window) {
   PF_CHECK(n_mels > 0 && n_mels <= FB_MAX_BINS, PF_ERR_INVALID_ARG, "fbank: n_mels out of range");
@@ -92,12 +104,30 @@ FbankTables* fbank_tables_create(int n_mels, int fs, const char* window) {
   PF_HIP(hipMemcpy(t->mel_start, start.data(), sizeof(int) * n_mels, hipMemcpyHostToDevice));
   PF_HIP(hipMemcpy(t->mel_off, off.data(), sizeof(int) * (n_mels + 1), hipMemcpyHostToDevice));
   PF_HIP(hipMemcpy(t->mel_w, wts.data(), sizeof(float) * wts.size(), hipMemcpyHostToDevice));
+  std::vector<int> choff(n_mels + 1, 0);
+  std::vector<int> chunks;                                   // 4 ints per chunk
+  for (int b = 0; b < n_mels; ++b) {
+    const int cnt = off[b + 1] - off[b];
+    for (int c0 = 0; c0 < cnt; c0 += 8) {
+      chunks.push_back(start[b] + c0); chunks.push_back(off[b] + c0); chunks.push_back(std::min(8, cnt - c0)); chunks.push_back(b);
+    }
+    choff[b + 1] = (int)chunks.size() / 4;
+  }
+  t->n_chunks = (int)chunks.size() / 4;
+  t->n_weights = (int)wts.size();
+  PF_CHECK(t->n_chunks <= FB_MAX_CHUNKS && t->n_weights <= FB_MAX_WEIGHTS, PF_ERR_UNSUPPORTED, "fbank: mel filter bank too dense for the kernel's tables");
+  if (chunks.empty()) chunks.assign(4, 0);
+  PF_HIP(hipMalloc(&t->mel_chunk, sizeof(int) * chunks.size()));
+  PF_HIP(hipMalloc(&t->mel_chunk_off, sizeof(int) * (n_mels + 1)));
+  PF_HIP(hipMemcpy(t->mel_chunk, chunks.data(), sizeof(int) * chunks.size(), hipMemcpyHostToDevice));
+  PF_HIP(hipMemcpy(t->mel_chunk_off, choff.data(), sizeof(int) * (n_mels + 1), hipMemcpyHostToDevice));
   return t;
 }
 
 void fbank_tables_destroy(FbankTables* t) {
   if (!t) return;
   hipFree(t->window); hipFree(t->tw512); hipFree(t->mel_start); hipFree(t->mel_off); hipFree(t->mel_w);
+  hipFree(t->mel_chunk); hipFree(t->mel_chunk_off);
   delete t;
 }
 
@@ -131,95 +161,121 @@ __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("" ::: "memory");
 }
 
-// 4 frames per 256-thread block, one wavefront each.  LDS per wave: 2 x 256 complex (4 KiB).
-__global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ audio,
-                                                    const int64_t* __restrict__ audio_off,
-                                                    const int64_t* __restrict__ n_samples,
-                                                    const int64_t* __restrict__ frame_off, int B,
-                                                    int64_t total_frames, int snip_edges, int n_mels,
-                                                    const float* __restrict__ window,
-                                                    const float2* __restrict__ tw512,
-                                                    const int* __restrict__ mel_start,
-                                                    const int* __restrict__ mel_off,
-                                                    const float* __restrict__ mel_w, float dither,
-                                                    uint32_t dither_seed, float* __restrict__ out) {
+struct FbankDev {
+  const float* audio; const int64_t* audio_off; const int64_t* n_samples; const int64_t* frame_off;
+  int B; int64_t total_frames; int snip_edges, n_mels;
+  const float* window; const float2* tw512; const float* mel_w; const int4* mel_chunk; const int* mel_chunk_off;
+  int n_chunks, n_weights;
+  float dither; uint32_t dither_seed;
+  float* out;
+};
+
+// 4 frames per 256-thread block, one wavefront each.  LDS: per wave 2 x 256 complex (4 KiB) + shared tables
+// (twiddles 2 x 2 KiB, window 1.6 KiB, mel weights <= 4 KiB, chunk table <= 3 KiB).
+__global__ __launch_bounds__(256) void fbank_kernel(FbankDev p) {
   __shared__ float2 lds[4][2][256];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ float2 tw256_s[256];        // e^{-2 pi i t / 256}
+  __shared__ float2 tw512_s[256];        // e^{-2 pi i t / 512}
+  __shared__ float win_s[FB_NFFT];       // window, zero beyond 400
+  __shared__ float melw_s[FB_MAX_WEIGHTS];
+  __shared__ int4 chunk_s[FB_MAX_CHUNKS];
+  __shared__ float part_s[4][FB_MAX_CHUNKS];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  {                                                     // workgroup-shared tables
+    const float2 w = p.tw512[tid];
+    tw512_s[tid] = w;
+    const float2 w2 = p.tw512[(2 * tid) & 255];         // e^{-2 pi i t / 256} = +-tw512[2t mod 256]
+    tw256_s[tid] = tid < 128 ? w2 : make_float2(-w2.x, -w2.y);
+    win_s[tid] = p.window[tid];
+    win_s[tid + 256] = tid + 256 < FB_FRAME_LEN ? p.window[tid + 256] : 0.f;
+    for (int i = tid; i < p.n_weights; i += 256) melw_s[i] = p.mel_w[i];
+    for (int i = tid; i < p.n_chunks; i += 256) chunk_s[i] = p.mel_chunk[i];
+  }
+  __syncthreads();
   const int64_t gf = (int64_t)blockIdx.x * 4 + wv;       // global frame index
-  const bool active = gf < total_frames;
+  if (gf >= p.total_frames) return;                      // whole wave; no block-wide barrier follows
   float2* bufA = lds[wv][0];
   float2* bufB = lds[wv][1];
-  float* fr = reinterpret_cast<float*>(bufA);             // 512 floats: the real frame, later z[n]
+  float* raw = reinterpret_cast<float*>(bufB);           // 512 floats: the raw frame
 
-  int b = 0;
-  int64_t f = 0, n = 0;
-  const float* wav = audio;
-  if (active) {
-    int lo = 0, hi = B;                                   // largest b with frame_off[b] <= gf
+  int b;
+  {
+    int lo = 0, hi = p.B;                                // largest b with frame_off[b] <= gf
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (frame_off[mid] <= gf) lo = mid; else hi = mid;
+      if (p.frame_off[mid] <= gf) lo = mid; else hi = mid;
     }
     b = lo;
-    f = gf - frame_off[b];
-    n = n_samples[b];
-    wav = audio + audio_off[b];
   }
-  const int64_t start = snip_edges ? f * FB_SHIFT : f * FB_SHIFT + FB_SHIFT / 2 - FB_FRAME_LEN / 2;
+  const int64_t f = gf - p.frame_off[b];
+  const int64_t n = p.n_samples[b];
+  const float* wav = p.audio + p.audio_off[b];
+  const int64_t start = p.snip_edges ? f * FB_SHIFT : f * FB_SHIFT + FB_SHIFT / 2 - FB_FRAME_LEN / 2;
+  const bool interior = start >= 0 && start + FB_FRAME_LEN <= n;      // wave-uniform
 
   // ---- load (x * 32768), reflect at the edges, partial sums for the DC offset
   float part = 0.f;
-  for (int i = lane; i < FB_NFFT; i += 64) {
-    float v = 0.f;
-    if (active && i < FB_FRAME_LEN) {
-      int64_t sidx = start + i;
-      while (sidx < 0 || sidx >= n) sidx = sidx < 0 ? -sidx - 1 : 2 * n - 1 - sidx;
-      v = wav[sidx] * 32768.0f;
-      if (dither != 0.f) v = add_rn(v, mul_rn(gauss_at(dither_seed, (uint64_t)gf, (uint32_t)i), dither));
-      part += v;
-    }
-    fr[i] = v;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-  const float mean = part / (float)FB_FRAME_LEN;
-  wave_lds_sync();
-  // ---- remove DC, pre-emphasis 0.97 (x[i] -= 0.97 x[i-1]; x[0] -= 0.97 x[0]), window
-  float pre[7];
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     const int i = lane + 64 * r;
     float v = 0.f;
     if (i < FB_FRAME_LEN) {
-      const float cur = fr[i] - mean;
-      const float prev = fr[i > 0 ? i - 1 : 0] - mean;
-      v = sub_rn(cur, mul_rn(0.97f, prev)) * window[i];
+      int64_t sidx = start + i;
+      if (!interior)
+        while (sidx < 0 || sidx >= n) sidx = sidx < 0 ? -sidx - 1 : 2 * n - 1 - sidx;
+      v = wav[sidx] * 32768.0f;
+      if (p.dither != 0.f) v = add_rn(v, mul_rn(gauss_at(p.dither_seed, (uint64_t)gf, (uint32_t)i), p.dither));
+      part += v;
     }
-    pre[r] = v;
+    raw[i] = v;
   }
-  wave_lds_sync();
+  raw[lane + 448] = 0.f;
 #pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    const int i = lane + 64 * r;
-    if (i < FB_FRAME_LEN) fr[i] = pre[r];
-  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const float mean = part / (float)FB_FRAME_LEN;
   wave_lds_sync();
-  // fr viewed as float2[256] is z[n] = x[2n] + i x[2n+1]  (bufA).  256-point Stockham radix-2.
+  // ---- this lane's four points z[n] = x[2n] + i x[2n+1], n = lane + 64 m: remove DC, pre-emphasis 0.97
+  //      (x[i] -= 0.97 x[i-1]; x[0] -= 0.97 x[0]), window; zero beyond sample 399
+  float2 u[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i0 = 2 * (lane + 64 * m);
+    float2 z = make_float2(0.f, 0.f);
+    if (i0 < FB_FRAME_LEN) {
+      const float xm = raw[i0 > 0 ? i0 - 1 : 0] - mean, x0 = raw[i0] - mean, x1 = raw[i0 + 1] - mean;
+      z.x = sub_rn(x0, mul_rn(0.97f, xm)) * win_s[i0];
+      z.y = sub_rn(x1, mul_rn(0.97f, x0)) * win_s[i0 + 1];
+    }
+    u[m] = z;
+  }
+  wave_lds_sync();                                       // every read of the raw frame is done: bufB may be overwritten later
+  // ---- 256-point complex FFT, Stockham autosort, radix 4: pass Ns takes u_m = src[j + 64 m] * w^(k m),
+  //      w = e^{-2 pi i / (4 Ns)}, k = j mod Ns, and writes the butterfly to dst[(j - k) 4 + k + m Ns]
+  auto butterfly_store = [&](float2* dst, int Ns, int k) __attribute__((always_inline)) {
+    const float2 v0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y), v1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+    const float2 v2 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
+    const float2 d = make_float2(u[1].x - u[3].x, u[1].y - u[3].y);
+    const float2 v3 = make_float2(d.y, -d.x);            // -i (u1 - u3)
+    const int j0 = ((lane - k) << 2) + k;
+    dst[j0] = make_float2(v0.x + v2.x, v0.y + v2.y);
+    dst[j0 + Ns] = make_float2(v1.x + v3.x, v1.y + v3.y);
+    dst[j0 + 2 * Ns] = make_float2(v0.x - v2.x, v0.y - v2.y);
+    dst[j0 + 3 * Ns] = make_float2(v1.x - v3.x, v1.y - v3.y);
+  };
+  butterfly_store(bufA, 1, 0);                           // Ns = 1: no twiddles
+  wave_lds_sync();
   float2* src = bufA;
   float2* dst = bufB;
 #pragma unroll
-  for (int ns = 1; ns < 256; ns <<= 1) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = lane + 64 * r;                 // 0..127
-      const int k = j & (ns - 1);
-      const float2 w = tw512[2 * k * (128 / ns)];  // e^{-2 pi i k / (2 ns)}
-      const float2 a = src[j];
-      const float2 t = cmul(src[j + 128], w);
-      const int j0 = ((j - k) << 1) + k;           // (j / ns) * 2ns + k
-      dst[j0] = make_float2(a.x + t.x, a.y + t.y);
-      dst[j0 + ns] = make_float2(a.x - t.x, a.y - t.y);
-    }
+  for (int Ns = 4; Ns < 256; Ns <<= 2) {
+    const int k = lane & (Ns - 1);
+    const int t = k * (64 / Ns);                         // w^(k m) = tw256[t m], t m <= 189
+    u[0] = src[lane];
+    u[1] = cmul(src[lane + 64], tw256_s[t]);
+    u[2] = cmul(src[lane + 128], tw256_s[2 * t]);
+    u[3] = cmul(src[lane + 192], tw256_s[3 * t]);
+    wave_lds_sync();
+    butterfly_store(dst, Ns, k);
     wave_lds_sync();
     float2* tmp = src; src = dst; dst = tmp;
   }
@@ -232,19 +288,27 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ au
     const float2 zc = src[(256 - k) & 255];
     const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));   // even part
     const float2 o = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));   // (Z - conj Z')/2
-    const float2 t = cmul(o, tw512[k]);
+    const float2 t = cmul(o, tw512_s[k]);
     // X = e - i*t = (e.x + t.y, e.y - t.x)
     const float re = e.x + t.y, im = e.y - t.x;
     power[k] = re * re + im * im;
   }
   wave_lds_sync();
-  if (!active) return;
-  for (int m = lane; m < n_mels; m += 64) {
-    const int s0 = mel_start[m], o0 = mel_off[m], cnt = mel_off[m + 1] - o0;
+  // ---- mel energies: chunk sums (<= 8 bins each), then per filter the sum of its chunks in order
+  float* parts = part_s[wv];
+  for (int c = lane; c < p.n_chunks; c += 64) {
+    const int4 ch = chunk_s[c];
     float acc = 0.f;
-    for (int i = 0; i < cnt; ++i) acc += mel_w[o0 + i] * power[s0 + i];
+    for (int i = 0; i < ch.z; ++i) acc += melw_s[ch.y + i] * power[ch.x + i];
+    parts[c] = acc;
+  }
+  wave_lds_sync();
+  for (int m = lane; m < p.n_mels; m += 64) {
+    const int c0 = p.mel_chunk_off[m], c1 = p.mel_chunk_off[m + 1];
+    float acc = 0.f;
+    for (int c = c0; c < c1; ++c) acc += parts[c];
     acc = fmaxf(acc, 1.1920929e-07f);
-    out[gf * n_mels + m] = logf(acc);
+    p.out[gf * p.n_mels + m] = logf(acc);
   }
 }
 
@@ -252,9 +316,13 @@ void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, cons
                   const int64_t* n_samples, const int64_t* frame_off, int B, int64_t total_frames,
                   int snip_edges, float* fbank, float dither, uint32_t dither_seed) {
   if (total_frames <= 0) return;
-  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total_frames + 3) / 4)), dim3(256), 0, s, audio, audio_off,
-                     n_samples, frame_off, B, total_frames, snip_edges, tb->n_mels, tb->window, tb->tw512,
-                     tb->mel_start, tb->mel_off, tb->mel_w, dither, dither_seed, fbank);
+  FbankDev p;
+  p.audio = audio; p.audio_off = audio_off; p.n_samples = n_samples; p.frame_off = frame_off; p.B = B;
+  p.total_frames = total_frames; p.snip_edges = snip_edges; p.n_mels = tb->n_mels;
+  p.window = tb->window; p.tw512 = tb->tw512; p.mel_w = tb->mel_w; p.mel_chunk = tb->mel_chunk; p.mel_chunk_off = tb->mel_chunk_off;
+  p.n_chunks = tb->n_chunks; p.n_weights = tb->n_weights;
+  p.dither = dither; p.dither_seed = dither_seed; p.out = fbank;
+  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total_frames + 3) / 4)), dim3(256), 0, s, p);
   PF_HIP(hipGetLastError());
 }
 

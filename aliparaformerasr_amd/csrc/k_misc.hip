@@ -419,19 +419,95 @@ void launch_cif_scan(hipStream_t s, const float* alphas, int B, int T1, float th
 
 // ---- the prefix-sum formulation (FunASR cif_v1_export; container key cif_variant = "cumsum") ----------------
 // prefix = float32(cumsum_float64(alpha)); fire at t <=> floor(prefix[t]) > floor(prefix[t-1]);
-// remain[t] = (1 + (prefix[t] - floor(prefix[t]))) - 1.  One lane per utterance (T+1 dependent double adds).
+// remain[t] = (1 + (prefix[t] - floor(prefix[t]))) - 1.
+// A WAVE per utterance: lane i owns the contiguous chunk [i c, (i + 1) c) of the T + 1 weights, sums it in double, the
+// 64 chunk totals go through a wave prefix scan, and every lane rebuilds its own prefixes from its offset.  Double
+// additions of fp32 weights are exact here except in contrived cases (a sum needs more than 53 bits only when weights
+// 2^30 apart in magnitude meet), and a re-associated sum equals the sequential ONNX CumSum bit for bit whenever every
+// addition was exact — which each addition checks (Knuth's TwoSum); an utterance with ANY inexact addition is redone
+// sequentially by lane 0, so the result is the sequential one by construction.  token_num = floor(fp32 sequential sum)
+// is an order-dependent fp32 chain and stays one (lane 0, ~T dependent adds).
+__device__ __forceinline__ double two_sum(double a, double b, bool& inexact) {
+#pragma clang fp contract(off)
+  const double s = a + b;
+  const double bb = s - a;
+  const double err = (a - (s - bb)) + (b - bb);
+  inexact |= err != 0.0;
+  return s;
+}
+
 __global__ __launch_bounds__(64) void cif_scan_cumsum_kernel(const float* __restrict__ alphas, int B, int T1, CifPlan plan) {
   extern __shared__ float sa[];
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* a = alphas + (int64_t)b * T1;
   for (int t = lane; t < T1; t += 64) sa[t] = a[t];
   __syncthreads();
-  if (lane != 0) return;
-  double dsum = 0.0;
-  float sum = 0.f, prev_floor = 0.f;
-  int count = 0;
   int32_t* ff = plan.fire_frame + (int64_t)b * T1;
   float* wr = plan.w_rem + (int64_t)b * T1;
+  const int c = (T1 + 63) / 64;                         // chunk length
+  const int t0 = min(lane * c, T1), t1 = min(t0 + c, T1);
+  bool inexact = false;
+  double tot = 0.0;
+  for (int t = t0; t < t1; ++t) tot = two_sum(tot, (double)sa[t], inexact);
+  // inclusive wave scan of the chunk totals (Hillis-Steele over 64 lanes), then exclusive offset
+  double inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc = two_sum(up, inc, inexact);
+  }
+  double off = __shfl_up(inc, 1, 64);
+  if (lane == 0) off = 0.0;
+  // floor of the prefix just before this chunk (the last element of the previous non-empty chunk)
+  float prev_floor = floorf((float)off);
+  if (t0 == 0) prev_floor = 0.f;
+  int nfire = 0;
+  double run = off;
+  for (int t = t0; t < t1; ++t) {
+    run = two_sum(run, (double)sa[t], inexact);
+    const float fl = floorf((float)run);
+    nfire += sub_rn(fl, prev_floor) > 0.f ? 1 : 0;
+    prev_floor = fl;
+  }
+  const bool any_inexact = __any(inexact);
+  if (!any_inexact) {
+    int pos = nfire;                                    // exclusive scan of the fire counts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(pos, o, 64);
+      if (lane >= o) pos += up;
+    }
+    const int total = __shfl(pos, 63, 64);
+    pos -= nfire;
+    run = off;
+    prev_floor = t0 == 0 ? 0.f : floorf((float)off);
+    for (int t = t0; t < t1; ++t) {
+      run += (double)sa[t];                             // exact (checked above): same value as in the first walk
+      const float prefix = (float)run;
+      const float fl = floorf(prefix);
+      if (sub_rn(fl, prev_floor) > 0.f) {
+        const float fires = add_rn(1.0f, sub_rn(prefix, fl));
+        wr[t] = sub_rn(fires, floorf(fires));
+        ff[pos++] = t;
+      } else {
+        wr[t] = 0.f;
+      }
+      prev_floor = fl;
+    }
+    if (lane == 0) {
+      float sum = 0.f;
+      for (int t = 0; t < T1; ++t) sum = add_rn(sum, sa[t]);
+      plan.fire_count[b] = total;
+      plan.token_num[b] = (int32_t)floorf(sum);
+      atomicMax(plan.max_count, total);
+    }
+    return;
+  }
+  if (lane != 0) return;                                // some addition was inexact: the sequential definition, verbatim
+  double dsum = 0.0;
+  float sum = 0.f;
+  prev_floor = 0.f;
+  int count = 0;
   for (int t = 0; t < T1; ++t) {
     const float alpha = sa[t];
     sum = add_rn(sum, alpha);

@@ -145,6 +145,7 @@ def test_fp32_mode_seaco_bias_decoder():
     from aliparaformerasr_amd.engine import Engine
     cfg = W.seaco_paraformer_config(enc_layers=2, dec_layers=2, seaco_layers=2, vocab=300, seaco_nobias=290)
     w = W.synth_weights(cfg, seed=6)
+    w["seaco.output.bias"][290] += 2.6          # random heads never pick NO-BIAS: lift it so that both sides of the merge occur
     cmvn = W.synth_cmvn()
     eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
     audio = [W.synth_audio(n, 40 + u) for u, n in enumerate((32000, 48000, 40000))]
@@ -165,7 +166,7 @@ def test_fp32_mode_seaco_bias_decoder():
     safe = clear & ((margin[..., -1] - margin[..., -2]) > 1e-3)
     np.testing.assert_array_equal(res.token_ids[safe], om.argmax_last(ref["logits"])[safe])
     took_hotword_rows = (np.argmax(dha, -1) != nb)
-    assert took_hotword_rows.any() and (~took_hotword_rows).any()      # both sides of the merge are exercised
+    assert 0.1 < took_hotword_rows.mean() < 0.9, took_hotword_rows.mean()      # both sides of the merge are exercised
     d = np.abs(res.cif_peak - ref["us_cif_peak"])
     d = np.minimum(d, np.abs(d - 0.9999))
     assert d.max() < 2e-4, d.max()

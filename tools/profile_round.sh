@@ -1,14 +1,15 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun): bench lines of every config, rocprofv3 kernel stats of the headline
 # command, PMC traffic (separate passes, per the MI355X guide) of the dominant kernels.  Everything lands in gpurun_out/$TAG.
-TAG=${1:-round2}
+TAG=${1:-round3}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 --breakdown > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --model sensevoice > $OUT/bench_sensevoice.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --model seaco > $OUT/bench_seaco.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --batch 128 > $OUT/bench_batch128.json 2>> $OUT/bench.err
+python bench.py --group 4 --group-devices 0,0,0,0 --batch 32 --steps 5 --warmup 2 > $OUT/bench_group4x32.json 2>> $OUT/bench.err
 python tools/latency.py > $OUT/latency.txt 2>> $OUT/bench.err
 python tools/bench_online.py > $OUT/online.txt 2>> $OUT/bench.err
 CMD="python bench.py --no-cpu-baseline --steps 5 --warmup 2"

@@ -1,6 +1,6 @@
 """Per-kernel roofline table for BASELINE.json configs[1] (32 x 30 s) from a rocprofv3 kernel trace
 (`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...`) and the event-timed GEMM /
-attention classes of `bench.py --breakdown`.  Algorithmic bytes / FLOPs are the config-2 figures of DESIGN.md §4.
+attention classes of `bench.py` (`class_ms_per_step`).  Algorithmic bytes / FLOPs are the config-2 figures of DESIGN.md §4.
 
 usage: roofline_table.py <kernel_trace.csv> <bench_breakdown.json> > profiles/<name>.md"""
 import collections, csv, json, sys
@@ -33,11 +33,11 @@ def main():
         ("CIF im2col", "cif_im2col_kernel", None, (M * D * 2 + M * 3 * D * 2) / 1e6),
         ("CIF weighted gather", "cif_gather_kernel", None, (M * D * 4 + Md * D * 4) / 1e6),
     ]
-    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 2)\n")
+    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 3)\n")
     print("Source: `%s` (rocprofv3 --kernel-trace, average kernel duration) and the HIP-event class times of "
-          "`bench.py --breakdown`.  L = %d.  Peaks: HBM 8 TB/s spec (6.3 TB/s achievable), dense f16 MFMA 2.5 PFLOP/s.\n" % (trace.split("/")[-1], L))
+          "`bench.py` (`class_ms_per_step`).  L = %d.  Peaks: HBM 8 TB/s spec (6.3 TB/s achievable), dense f16 MFMA 2.5 PFLOP/s.\n" % (trace.split("/")[-1], L))
     print("## HBM-bound kernels\n\n| kernel | avg µs | launches/step | algorithmic MB | achieved TB/s | of 8 TB/s | of 6.3 TB/s |\n|---|---|---|---|---|---|---|")
-    steps = 7
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 11     # forward passes in the traced command: warmup 2 + 1 profiling + 5 timed + 3 host-audio calls
     for label, sub, grid, mb in mem:
         us, n = find(sub, grid)
         if us is None:
@@ -49,7 +49,7 @@ def main():
         print("| CIF integrate-and-fire scan (sequential, latency bound) | %.1f | %d | – | – | – | – |" % (us, round(n / steps)))
     print("\n## MFMA-bound kernel classes (HIP events around each launch; include ~3-4 µs of event overhead per launch)\n")
     print("| class | launches/step | ms/step | TFLOP/s | of 2.5 PFLOP/s |\n|---|---|---|---|---|")
-    for cls, v in bench["kernel_breakdown_ms_per_step"].items():
+    for cls, v in bench.get("class_ms_per_step", bench.get("kernel_breakdown_ms_per_step", {})).items():
         if v.get("tflops"):
             print("| %s | %d | %.3f | %.0f | %.0f %% |" % (cls, v["launches"], v["ms"], v["tflops"], 100 * v["tflops"] / MFMA_PEAK))
     r = bench["roofline"]
