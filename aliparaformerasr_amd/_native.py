@@ -109,6 +109,8 @@ SIGNATURES = {
     "pf_profile_kernel": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int32]),
     "pf_last_flops": (C.c_int, [_vp, _P(C.c_double)]),
     "pf_op_lfr_cmvn_pad": (C.c_int, [_vp, _P(_f), _i32, C.c_int32, C.c_int32, _f, C.c_int64, _i32]),
+    "pf_op_qlinear": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f, _P(C.c_uint8), _f,
+                                _P(C.c_uint8), _f, _i32]),
     "pf_op_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _i64]),
     "pf_op_gemm": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_gemm_ex": (C.c_int, [_vp, _P(PfGemmDesc), _f, _f, _f]),

@@ -486,6 +486,18 @@ int pf_op_gemm(pf_engine* h, const float* A, const float* W, const float* bias, 
   return PF_OK;
   PF_CATCH
 }
+int pf_op_qlinear(pf_engine* h, const float* x, const float* W, const float* bias, int32_t M, int32_t N, int32_t K, int32_t relu,
+                  int32_t x_is_f16, float* y, uint8_t* xq_out, float* aparams_out, uint8_t* wq_out, float* wscale_out,
+                  int32_t* wzp_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(x); NEED(W); NEED(y);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_qlinear(x, W, bias, M, N, K, relu, x_is_f16, y, xq_out, aparams_out, wq_out, wscale_out, wzp_out);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_gemm_ex(pf_engine* h, const pf_gemm_desc* d, const float* A, const float* W, float* C) {
   PF_TRY
   std::shared_ptr<Engine> eh_ = E(h);

@@ -45,8 +45,10 @@ Engine::Engine(const pf_engine_config& cfg) {
   // the configuration must be refused, not silently ignored
   PF_CHECK((cfg.frame_length_ms == 0 || cfg.frame_length_ms == 25) && (cfg.frame_shift_ms == 0 || cfg.frame_shift_ms == 10),
            PF_ERR_UNSUPPORTED, "only frame_length = 25 ms and frame_shift = 10 ms are supported");
-  PF_CHECK(cfg.math_mode == 0 || cfg.math_mode == 1, PF_ERR_INVALID_ARG, "math_mode must be 0 (f16 MFMA) or 1 (fp32 MFMA)");
+  PF_CHECK(cfg.math_mode >= 0 && cfg.math_mode <= 2, PF_ERR_INVALID_ARG,
+           "math_mode must be 0 (f16 MFMA), 1 (fp32 MFMA) or 2 (dynamic int8 as model.int8.onnx, int8 MFMA)");
   fp32_mode_ = cfg.math_mode == 1;
+  int8_mode_ = cfg.math_mode == 2;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_DEC_FUSE"); if (e && e[0]) dec_fuse_ = atoi(e) & 7; }
@@ -104,7 +106,7 @@ void Engine::release() {
   for (void* p : owned_) hipFree(p);
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
-                    &ws_ts_, &ws_seaco_, &ws_seaco_in_};
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_q_};
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
   if (blob_owned_ && blob_dev_) hipFree(blob_dev_);
@@ -1409,6 +1411,7 @@ void Engine::forward_device(const float* speech_dev, int B, int T, bool want_log
   PF_CHECK(B > 0 && T > 0, PF_ERR_INVALID_ARG, "forward: empty batch");
   last_logits_ = want_logits;
   if (fp32_mode_) { forward_fp32(speech_dev, B, T, want_logits); return; }
+  if (int8_mode_) { forward_int8(speech_dev, B, T, want_logits); return; }
   encoder(speech_dev, B, T);
   if (mc_.kind == "sensevoicesmall") sensevoice_head(B, T, want_logits);
   else predictor_and_decoder(B, T, want_logits);

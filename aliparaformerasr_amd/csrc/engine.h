@@ -44,6 +44,15 @@ struct Lin {          // y = x W^T + b ; W stored f16 [Npad][Kpad]
   const float* w32 = nullptr;         // the fp32 tensor [N][K] as stored in the container (fp32 parity mode)
 };
 struct LNp { const float* g = nullptr; const float* b = nullptr; int D = 0; };
+// a Linear as onnxruntime's quantize_dynamic stores it (math_mode 2): w' = w_q - 128 as signed bytes [Npad][Kpad], K-contiguous
+struct QLin {
+  int8_t* w = nullptr;
+  int32_t* colsum = nullptr;      // [N] sum_k w'
+  int32_t* wzp = nullptr;         // [N] w_zp - 128
+  float* wscale = nullptr;        // [N]
+  const float* bias = nullptr;
+  int N = 0, K = 0, Kpad = 0;
+};
 struct EncLayer { LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512; };
 struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
 
@@ -102,6 +111,10 @@ class Engine {
   void op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C);
   void op_gemm_ex(const pf_gemm_desc& d, const float* A, const float* W, float* C);
   void op_gemm_rc(const pf_gemm_rc_desc& d, const float* A, const float* W, float* x_out, float* n16_out, float* n32_out);
+  // DynamicQuantizeLinear(x) + MatMulInteger + rescale (+ bias) (+ ReLU) on the int8 MFMA; optional outputs: the uint8
+  // activations [M, K], {a_scale, a_zp}, the uint8 weights [N, K] and their per-channel scale / zero point
+  void op_qlinear(const float* x, const float* W, const float* bias, int M, int N, int K, int relu, int x_is_f16, float* y,
+                  uint8_t* xq_out, float* aparams_out, uint8_t* wq_out, float* wscale_out, int32_t* wzp_out);
   void op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
               int M, int D, int F, float* y);
   void op_fsmn_enc(const float* v, const float* w, int B, int T, int D, int k, float* y);
@@ -150,6 +163,13 @@ class Engine {
   void predictor_and_decoder(int B, int T, bool want_logits);
   void sensevoice_head(int B, int T, bool want_logits);
   void forward_fp32(const float* speech_dev, int B, int T, bool want_logits);   // math_mode 1 (k_fp32.hip)
+  // math_mode 2 (engine_int8.cpp): every Linear as DynamicQuantizeLinear + MatMulInteger on v_mfma_i32_32x32x32_i8
+  void forward_int8(const float* speech_dev, int B, int T, bool want_logits);
+  const QLin& qlin(const Lin& l, bool bias = true);
+  const QLin& qlin_raw(const float* w32, const float* bias, int N, int K);
+  // y = dequant(quant(x) w_q^T) + bias [* scale on the first scale_cols columns] [+ add2] [+ resid] [ReLU]; x fp32 [M, ldx] or f16
+  void qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32, half_t* out16,
+             int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols, float scale);
   void timestamp_head_fp32(int B, int T);
   void seaco_head_fp32(int B, int L, const float* e0, const float* hid, bool want_logits);
   // fp32 LSTM over rows [Bn * Tn] of x (row b * Tn + t): hout[(b * Tn + t) * ldh + col0 .. + D); reverse = time runs backwards
@@ -181,6 +201,12 @@ class Engine {
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
+  bool int8_mode_ = false;           // math_mode 2: Linear layers dynamically quantised to uint8, products on the int8 MFMA
+  std::map<const float*, QLin> qlins_;
+  DevBuf ws_q_;                      // quantised activations: a' [Mp, Kpad], row sums, {scale, zp}, min / max scratch
+  int8_t* q_a_ = nullptr; int32_t* q_rowsum_ = nullptr; float* q_params_ = nullptr; unsigned* q_scratch_ = nullptr;
+  int64_t q_rows_ = 0; int q_kpad_ = 0;
+  void ensure_q(int64_t rows, int kpad);
   ModelCfg mc_;
   FrontendCfg fc_;
   std::mutex mu_;

@@ -1,0 +1,325 @@
+// engine_int8.cpp — pf_engine_config.math_mode = 2: the graph as the reference's DEFAULT model files compute it.
+//
+// `-accuracy int8` is the reference CLI's default (AliParaformerAsr.Examples/Program.cs:98-101 -> model.int8.onnx,
+// Examples/OfflineAliParaformerAsrRecognizer.cs:17-22): FunASR exports passed through onnxruntime's quantize_dynamic,
+// in which every MatMul with a constant weight runs as DynamicQuantizeLinear (per-tensor uint8 activations, computed at
+// run time) + MatMulInteger (uint8 weights, per output channel) + a float rescale (k_quant.hip restates the operator
+// arithmetic; oracle/int8.py is its numpy twin).  Here those products run on v_mfma_i32_32x32x32_i8 with exact int32
+// accumulation (k_gemm.hip gemm_i8_pp3); everything else — LayerNorm, FSMN, attention (f16 MFMA), CIF, soft-max, arg-max
+// — is the f16 path's kernels.  What is NOT quantised, as in the export: the depthwise FSMN convolutions, the CIF
+// Conv1d (Conv nodes) and the N = 1 predictor output (kept fp32 here).
+// Weights: the container carries fp32 tensors; they are quantised at first use on the device with quantize_dynamic's
+// per-channel algorithm (a real model.int8.onnx is de-quantised by the converter and re-quantised here, which recovers
+// the stored bytes; carrying the bytes through the container is the remaining step).
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace pf {
+
+static const size_t kAlignQ = 256;
+
+void Engine::ensure_q(int64_t rows, int kpad) {
+  const int64_t rp = round_up(rows, 256) + 256;
+  const size_t need = (size_t)rp * kpad + (size_t)rp * 4 + 1024;
+  if (!ws_q_.p || ws_q_.bytes < need || q_kpad_ < kpad || q_rows_ < rp) {
+    const int64_t r2 = std::max(rp, q_rows_);
+    const int k2 = std::max(kpad, q_kpad_);
+    ensure(ws_q_, (size_t)r2 * k2 + (size_t)r2 * 4 + 1024);
+    q_rows_ = r2; q_kpad_ = k2;
+    char* b = (char*)ws_q_.p;
+    q_a_ = (int8_t*)b;
+    q_rowsum_ = (int32_t*)(b + round_up((int64_t)r2 * k2, (int64_t)kAlignQ));
+    q_params_ = (float*)((char*)q_rowsum_ + (size_t)r2 * 4);
+    q_scratch_ = (unsigned*)(q_params_ + 8);
+  }
+}
+
+const QLin& Engine::qlin_raw(const float* w32, const float* bias, int N, int K) {
+  auto it = qlins_.find(w32);
+  if (it != qlins_.end()) return it->second;
+  QLin q;
+  q.N = N; q.K = K; q.Kpad = (int)round_up(K, 128);
+  const size_t npad = (size_t)round_up(N, 128);
+  q.w = (int8_t*)dalloc(npad * q.Kpad);
+  PF_HIP(hipMemsetAsync(q.w, 0, npad * q.Kpad, stream_));
+  q.colsum = (int32_t*)dalloc((size_t)(N + 8) * 4);
+  q.wzp = (int32_t*)dalloc((size_t)(N + 8) * 4);
+  q.wscale = (float*)dalloc((size_t)(N + 8) * 4);
+  PF_HIP(hipMemsetAsync(q.colsum, 0, (size_t)(N + 8) * 4, stream_));
+  PF_HIP(hipMemsetAsync(q.wzp, 0, (size_t)(N + 8) * 4, stream_));
+  PF_HIP(hipMemsetAsync(q.wscale, 0, (size_t)(N + 8) * 4, stream_));
+  launch_quantize_weight(stream_, w32, N, K, q.w, q.Kpad, q.colsum, q.wzp, q.wscale);
+  q.bias = bias;
+  return qlins_.emplace(w32, q).first->second;
+}
+
+const QLin& Engine::qlin(const Lin& l, bool bias) {
+  PF_CHECK(l.w32, PF_ERR_UNSUPPORTED, "int8 mode: a Linear without its fp32 tensor");
+  return qlin_raw(l.w32, bias ? l.bias : nullptr, l.N, l.K);
+}
+
+void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
+                   half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols,
+                   float scale) {
+  if (M == 0) return;
+  prof_begin(cls, 2.0 * M * (double)w.N * w.K);
+  if (x32 || x16) {                                    // null / null: the tensor quantised by the previous call is reused
+    ensure_q(M, w.Kpad);
+    launch_quantize_rows(stream_, x32, x16, M, w.K, ldx, q_a_, q_kpad_, q_rowsum_, q_params_, q_scratch_);
+  }
+  GemmI8Args g{};
+  g.A = q_a_; g.lda = q_kpad_; g.W = w.w; g.ldw = w.Kpad;
+  g.rowsum = q_rowsum_; g.colsum = w.colsum; g.wzp = w.wzp; g.wscale = w.wscale; g.aparams = q_params_;
+  g.bias = w.bias; g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad;
+  g.out_f32 = out32; g.ldc32 = ld32; g.out_f16 = out16; g.ldc16 = ld16;
+  g.resid = resid; g.ldr = ldr; g.add2 = add2; g.ld2 = ld2;
+  g.relu = relu ? 1 : 0; g.scale_cols = scale_cols; g.scale = scale;
+  launch_gemm_i8(stream_, g);
+  prof_end(cls);
+}
+
+void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logits) {
+  PF_CHECK(!mc_.timestamp_head && !mc_.seaco, PF_ERR_UNSUPPORTED,
+           "math_mode 2 (int8) covers the paraformer and SenseVoice graphs, not the BiCIF / SeACo heads");
+  const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab, Fd = mc_.feat_dim, T1 = T + 1;
+  const int64_t M = (int64_t)B * T, Mp = round_up(M, 128) + 128;
+  const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  build_pe(T);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
+  const size_t o_x = carve(Mp * D * 4), o_xn = carve(Mp * std::max(Fd, D) * 4), o_t = carve(Mp * std::max(Fd, D) * 4);
+  const size_t o_qkv = carve(Mp * 3 * D * 2), o_ctx = carve(Mp * D * 2), o_fsm = carve(Mp * D * 4);
+  const size_t o_h = carve(Mp * std::max(F, taps * D) * 2), o_H32 = carve(Mp * D * 4), o_H16 = carve(Mp * D * 2);
+  const size_t o_al = carve((size_t)B * T1 * 4), o_fc = carve((size_t)B * 4), o_tn = carve((size_t)B * 4);
+  const size_t o_ff = carve((size_t)B * T1 * 4), o_wc = carve((size_t)B * T1 * 4), o_wr = carve((size_t)B * T1 * 4), o_mx = carve(256);
+  ensure(ws_enc_, off);
+  char* base = (char*)ws_enc_.p;
+  x_ = (float*)(base + o_x);
+  float* xn32 = (float*)(base + o_xn);
+  float* t32e = (float*)(base + o_t);
+  qkv16_ = (half_t*)(base + o_qkv); ctx16_ = (half_t*)(base + o_ctx); fsm_ = (float*)(base + o_fsm); h16_ = (half_t*)(base + o_h);
+  H32_ = (float*)(base + o_H32); H16_ = (half_t*)(base + o_H16); alphas_ = (float*)(base + o_al);
+  plan_.fire_count = (int32_t*)(base + o_fc); plan_.token_num = (int32_t*)(base + o_tn);
+  plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
+  plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
+
+  // ---- encoder: LayerNorm (fp32) -> quantise -> QKV (f16 out, q scaled) -> attention (f16) | FSMN(V) -> quantise(ctx) ->
+  //      out-projection (+ FSMN memory + residual, fp32) -> LayerNorm -> quantise -> FFN-up + ReLU (f16) -> quantise -> FFN-down + residual
+  auto layer = [&](const EncLayer& L, bool first) {
+    const int din = first ? Fd : D;
+    if (first) {
+      launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), t32e);
+      prof_begin("layernorm", 0);
+      launch_layernorm(stream_, t32e, M, Fd, L.norm1.g, L.norm1.b, nullptr, 0, xn32, Fd);
+      prof_end("layernorm");
+    } else {
+      prof_begin("layernorm", 0);
+      launch_layernorm(stream_, x_, M, D, L.norm1.g, L.norm1.b, nullptr, 0, xn32, D);
+      prof_end("layernorm");
+    }
+    qgemm("gemm_qkv", qlin(L.qkv), xn32, nullptr, din, (int)M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
+    AttnArgs a{};
+    a.q = qkv16_; a.k = qkv16_ + D; a.v = qkv16_ + 2 * D; a.o = ctx16_;
+    a.q_bstride = a.k_bstride = a.v_bstride = (int64_t)T * 3 * D;
+    a.q_rstride = a.k_rstride = a.v_rstride = 3 * D;
+    a.o_bstride = (int64_t)T * D; a.o_rstride = D;
+    a.B = B; a.H = mc_.heads; a.Lq = T; a.Lk = T;
+    prof_begin("attn_self", 4.0 * B * (double)T * T * D);
+    launch_attention(stream_, a);
+    prof_end("attn_self");
+    prof_begin("fsmn", 0);
+    launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
+    prof_end("fsmn");
+    qgemm("gemm_out", qlin(L.out), nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, nullptr, 0, xn32, D);
+    prof_end("layernorm");
+    qgemm("gemm_ffn1", qlin(L.w1), xn32, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    qgemm("gemm_ffn2", qlin(L.w2), nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f);
+  };
+  for (size_t i = 0; i < enc_.size(); ++i) layer(enc_[i], i == 0);
+  prof_begin("layernorm", 0);
+  if (tp_.empty()) {
+    launch_layernorm(stream_, x_, M, D, enc_after_.g, enc_after_.b, H16_, D, H32_, D);
+  } else {
+    launch_layernorm(stream_, x_, M, D, enc_after_.g, enc_after_.b, nullptr, 0, x_, D);
+  }
+  prof_end("layernorm");
+  if (!tp_.empty()) {
+    for (size_t i = 0; i < tp_.size(); ++i) layer(tp_[i], false);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, x_, M, D, tp_norm_.g, tp_norm_.b, H16_, D, H32_, D);
+    prof_end("layernorm");
+  }
+  const int ldV = (int)round_up(V, 4);
+  last_.peak_len = 0;
+  last_.cif_peak.clear();
+  last_flops_ = 0;
+  if (mc_.kind == "sensevoicesmall") {
+    size_t o2 = 0;
+    auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
+    const size_t o_lg = c2((size_t)Mp * ldV * 4), o_ids = c2((size_t)M * 8);
+    ensure(ws_dec_, o2);
+    logits_ = (float*)((char*)ws_dec_.p + o_lg); ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids); logits_ld_ = ldV;
+    qgemm("gemm_vocab", qlin(ctc_), H32_, nullptr, D, (int)M, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+    prof_begin("argmax", 0);
+    launch_argmax(stream_, logits_, M, V, ldV, want_logits ? 2 : 1, ids_dev_);
+    prof_end("argmax");
+    last_.B = B; last_.L = T; last_.V = V; last_.T = T;
+    last_.ids.assign((size_t)M, 0);
+    last_.token_num.assign(B, T);
+    last_.fire_count.assign(B, T);
+    PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)M * 8, hipMemcpyDeviceToHost, stream_));
+    return;
+  }
+  // ---- CIF predictor: the Conv1d is a Conv node (not quantised by quantize_dynamic): the f16 path's im2col GEMM
+  {
+    half_t* col16 = h16_;
+    float* conv32 = fsm_;
+    prof_begin("cif_misc", 0);
+    launch_cif_im2col(stream_, H16_, B, T, D, mc_.cif_l_order, mc_.cif_r_order, col16);
+    prof_end("cif_misc");
+    gemm("gemm_cif", cif_conv_, col16, taps * D, (int)M, conv32, D, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    prof_begin("cif_misc", 0);
+    launch_cif_alpha(stream_, conv32, B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
+    if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
+    else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
+    prof_end("cif_misc");
+  }
+  int32_t L = 0;
+  last_.fire_count.resize(B);
+  last_.token_num.resize(B);
+  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  if (l_hook_) L = l_hook_(L);
+  last_.B = B; last_.L = L; last_.V = V; last_.T = T;
+  last_.ids.assign((size_t)B * L, 0);
+  if (L == 0) return;
+  // ---- decoder
+  const int Md = B * L;
+  const int64_t Mdp = round_up(Md, 128) + 128;
+  size_t o2 = 0;
+  auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
+  const size_t o_xd = c2(Mdp * D * 4), o_xdn = c2(Mdp * D * 4), o_hd = c2(Mdp * F * 4), o_hn = c2(Mdp * F * 4);
+  const size_t o_td = c2(Mdp * D * 4), o_tn2 = c2(Mdp * D * 4), o_q = c2(Mdp * D * 2), o_cx = c2(Mdp * D * 2);
+  const size_t o_kv = c2((size_t)Mp * 2 * D * 2), o_lg = c2((size_t)Mdp * ldV * 4), o_ids = c2((size_t)Md * 8);
+  ensure(ws_dec_, o2);
+  char* b2 = (char*)ws_dec_.p;
+  float* xd = (float*)(b2 + o_xd); float* xn = (float*)(b2 + o_xdn); float* hd = (float*)(b2 + o_hd); float* hn = (float*)(b2 + o_hn);
+  float* t32 = (float*)(b2 + o_td); float* tn32 = (float*)(b2 + o_tn2);
+  half_t* qd16 = (half_t*)(b2 + o_q); half_t* cx16 = (half_t*)(b2 + o_cx); half_t* kv16 = (half_t*)(b2 + o_kv);
+  logits_ = (float*)(b2 + o_lg); ids_dev_ = (int64_t*)(b2 + o_ids); logits_ld_ = ldV;
+  prof_begin("cif_misc", 0);
+  if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
+  else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
+  prof_end("cif_misc");
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, nullptr, 0, xn, D);
+    prof_end("layernorm");
+    qgemm("gemm_dec_ffn1", qlin(w1), xn, nullptr, D, Md, hd, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, hd, Md, F, fn.g, fn.b, nullptr, 0, hn, F);
+    prof_end("layernorm");
+    qgemm("gemm_dec_ffn2", qlin(w2, false), hn, nullptr, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  };
+  bool memory_quantised = false;
+  for (size_t i = 0; i < dec_.size(); ++i) {
+    const DecLayer& Lr = dec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    prof_end("layernorm");
+    prof_begin("fsmn", 0);
+    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
+    prof_end("fsmn");
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
+    prof_end("layernorm");
+    qgemm("gemm_dec_q", qlin(Lr.q), xn, nullptr, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
+    // K / V of the encoder memory: every layer's MatMul quantises the SAME tensor (one DynamicQuantizeLinear result)
+    (void)memory_quantised;
+    qgemm("gemm_dec_kv", qlin_raw(Lr.kv32.w32, Lr.kv32.bias, 2 * D, D), H32_, nullptr, D, (int)M, nullptr, 0, kv16, 2 * D, nullptr, 0,
+          nullptr, 0, false, 0, 1.f);
+    AttnArgs a{};
+    a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
+    a.k = kv16; a.v = kv16 + D; a.k_bstride = a.v_bstride = (int64_t)T * 2 * D; a.k_rstride = a.v_rstride = 2 * D;
+    a.o = cx16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
+    a.B = B; a.H = mc_.heads; a.Lq = L; a.Lk = T;
+    prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
+    launch_attention(stream_, a);
+    prof_end("attn_cross");
+    qgemm("gemm_dec_out", qlin(Lr.out), nullptr, cx16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
+  }
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
+  prof_begin("layernorm", 0);
+  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
+  prof_end("layernorm");
+  qgemm("gemm_vocab", qlin(dec_out_), xn, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  prof_begin("argmax", 0);
+  launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
+  prof_end("argmax");
+  PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+// stand-alone operator (parity tests): one dynamically quantised Linear, nothing cached
+void Engine::op_qlinear(const float* x, const float* W, const float* bias, int M, int N, int K, int relu, int x_is_f16, float* y,
+                        uint8_t* xq_out, float* aparams_out, uint8_t* wq_out, float* wscale_out, int32_t* wzp_out) {
+  PF_HIP(hipSetDevice(device_));
+  PF_CHECK(x && W && y && M > 0 && N > 0 && K > 0 && K % 4 == 0, PF_ERR_INVALID_ARG, "op_qlinear: bad arguments (K must be a multiple of 4)");
+  const int Kp = (int)round_up(K, 128), ldy = (int)round_up(N, 4);
+  const int64_t Mp = round_up(M, 256) + 256, Np = round_up(N, 128);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
+  const size_t ox = carve((size_t)M * K * 4), ox16 = carve((size_t)M * K * 2), oW = carve((size_t)N * K * 4), ob = carve((size_t)(N + 8) * 4);
+  const size_t oa = carve((size_t)Mp * Kp), ors = carve((size_t)Mp * 4), opar = carve(64), osc = carve(64);
+  const size_t ow = carve((size_t)Np * Kp), ocs = carve((size_t)(N + 8) * 4), ozp = carve((size_t)(N + 8) * 4), ows = carve((size_t)(N + 8) * 4);
+  const size_t oy = carve((size_t)Mp * ldy * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
+  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemsetAsync(base + ow, 0, (size_t)Np * Kp, stream_));
+  PF_HIP(hipMemsetAsync(base + oa, 0, (size_t)Mp * Kp, stream_));
+  launch_quantize_weight(stream_, (const float*)(base + oW), N, K, (int8_t*)(base + ow), Kp, (int32_t*)(base + ocs), (int32_t*)(base + ozp),
+                         (float*)(base + ows));
+  if (x_is_f16) {                                      // the activation arrives as f16 (attention context, FFN hidden): exact widening
+    launch_f32_to_f16(stream_, (const float*)(base + ox), M, K, K, (half_t*)(base + ox16), K);
+    launch_quantize_rows(stream_, nullptr, (const half_t*)(base + ox16), M, K, K, (int8_t*)(base + oa), Kp, (int32_t*)(base + ors),
+                         (float*)(base + opar), (unsigned*)(base + osc));
+  } else {
+    launch_quantize_rows(stream_, (const float*)(base + ox), nullptr, M, K, K, (int8_t*)(base + oa), Kp, (int32_t*)(base + ors),
+                         (float*)(base + opar), (unsigned*)(base + osc));
+  }
+  GemmI8Args g{};
+  g.A = (int8_t*)(base + oa); g.lda = Kp; g.W = (int8_t*)(base + ow); g.ldw = Kp;
+  g.rowsum = (int32_t*)(base + ors); g.colsum = (int32_t*)(base + ocs); g.wzp = (int32_t*)(base + ozp); g.wscale = (float*)(base + ows);
+  g.aparams = (float*)(base + opar); g.bias = bias ? (const float*)(base + ob) : nullptr;
+  g.M = M; g.N = N; g.K = K; g.Kpad = Kp; g.out_f32 = (float*)(base + oy); g.ldc32 = ldy; g.relu = relu;
+  launch_gemm_i8(stream_, g);
+  PF_HIP(hipMemcpy2DAsync(y, (size_t)N * 4, base + oy, (size_t)ldy * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
+  std::vector<int8_t> aq, wq;
+  std::vector<int32_t> zp((size_t)N);
+  if (xq_out) { aq.resize((size_t)M * Kp); PF_HIP(hipMemcpyAsync(aq.data(), base + oa, aq.size(), hipMemcpyDeviceToHost, stream_)); }
+  if (wq_out) { wq.resize((size_t)N * Kp); PF_HIP(hipMemcpyAsync(wq.data(), base + ow, wq.size(), hipMemcpyDeviceToHost, stream_)); }
+  if (aparams_out) PF_HIP(hipMemcpyAsync(aparams_out, base + opar, 8, hipMemcpyDeviceToHost, stream_));
+  if (wscale_out) PF_HIP(hipMemcpyAsync(wscale_out, base + ows, (size_t)N * 4, hipMemcpyDeviceToHost, stream_));
+  if (wzp_out) PF_HIP(hipMemcpyAsync(zp.data(), base + ozp, (size_t)N * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  if (xq_out)
+    for (int m = 0; m < M; ++m)
+      for (int k = 0; k < K; ++k) xq_out[(size_t)m * K + k] = (uint8_t)((int)aq[(size_t)m * Kp + k] + 128);
+  if (wq_out)
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) wq_out[(size_t)n * K + k] = (uint8_t)((int)wq[(size_t)n * Kp + k] + 128);
+  if (wzp_out)
+    for (int n = 0; n < N; ++n) wzp_out[n] = zp[(size_t)n] + 128;
+}
+
+}  // namespace pf

@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "exact.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -192,38 +193,73 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankDev p) {
     for (int i = tid; i < p.n_chunks; i += 256) chunk_s[i] = p.mel_chunk[i];
   }
   __syncthreads();
-  const int64_t gf = (int64_t)blockIdx.x * 4 + wv;       // global frame index
-  if (gf >= p.total_frames) return;                      // whole wave; no block-wide barrier follows
   float2* bufA = lds[wv][0];
   float2* bufB = lds[wv][1];
   float* raw = reinterpret_cast<float*>(bufB);           // 512 floats: the raw frame
-
-  int b;
-  {
-    int lo = 0, hi = p.B;                                // largest b with frame_off[b] <= gf
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (p.frame_off[mid] <= gf) lo = mid; else hi = mid;
+  // Persistent: a wave walks frames gf, gf + 4 G, ... so that the tables above are filled once per workgroup and the
+  // samples of the NEXT frame are requested before the current one is transformed (the kernel was bound by the chain
+  // of dependent global loads in front of every frame — five for the utterance search alone — at 20-40 waves per CU,
+  // not by instruction issue).  The utterance table lives in registers (lane b holds utterance b) when B <= 64.
+  const bool small_b = p.B <= 64;
+  const int64_t my_foff = (small_b && lane < p.B) ? p.frame_off[lane] : INT64_MAX;
+  const int64_t my_n = (small_b && lane < p.B) ? p.n_samples[lane] : 0;
+  const int64_t my_aoff = (small_b && lane < p.B) ? p.audio_off[lane] : 0;
+  struct Frame { int64_t n, start; const float* wav; bool interior; };
+  auto locate = [&](int64_t gf) __attribute__((always_inline)) -> Frame {
+    int b;
+    int64_t foff, n, aoff;
+    if (small_b) {
+      const unsigned long long m = __ballot(my_foff <= gf);           // frame_off ascends from 0: bits 0..b set
+      b = 63 - __builtin_clzll(m);
+      foff = __shfl(my_foff, b, 64); n = __shfl(my_n, b, 64); aoff = __shfl(my_aoff, b, 64);
+    } else {
+      int lo = 0, hi = p.B;                              // largest b with frame_off[b] <= gf
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p.frame_off[mid] <= gf) lo = mid; else hi = mid;
+      }
+      b = lo;
+      foff = p.frame_off[b]; n = p.n_samples[b]; aoff = p.audio_off[b];
     }
-    b = lo;
-  }
-  const int64_t f = gf - p.frame_off[b];
-  const int64_t n = p.n_samples[b];
-  const float* wav = p.audio + p.audio_off[b];
-  const int64_t start = p.snip_edges ? f * FB_SHIFT : f * FB_SHIFT + FB_SHIFT / 2 - FB_FRAME_LEN / 2;
-  const bool interior = start >= 0 && start + FB_FRAME_LEN <= n;      // wave-uniform
+    Frame fr;
+    const int64_t f = gf - foff;
+    fr.n = n;
+    fr.wav = p.audio + aoff;
+    fr.start = p.snip_edges ? f * FB_SHIFT : f * FB_SHIFT + FB_SHIFT / 2 - FB_FRAME_LEN / 2;
+    fr.interior = fr.start >= 0 && fr.start + FB_FRAME_LEN <= n;      // wave-uniform
+    return fr;
+  };
+  // raw samples of a frame: lane's elements i = lane + 64 r (x 32768 and dither are applied when they are consumed)
+  auto fetch = [&](const Frame& fr, float (&v)[7]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int i = lane + 64 * r;
+      v[r] = 0.f;
+      if (i < FB_FRAME_LEN) {
+        int64_t sidx = fr.start + i;
+        if (!fr.interior)
+          while (sidx < 0 || sidx >= fr.n) sidx = sidx < 0 ? -sidx - 1 : 2 * fr.n - 1 - sidx;
+        v[r] = fr.wav[sidx];
+      }
+    }
+  };
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t gf = (int64_t)blockIdx.x * 4 + wv;               // global frame index
+  if (gf >= p.total_frames) return;                        // whole wave; no block-wide barrier follows
+  float cur[7], nxt[7];
+  fetch(locate(gf), cur);
+  for (; gf < p.total_frames; gf += stride) {
+  const bool more = gf + stride < p.total_frames;
+  if (more) fetch(locate(gf + stride), nxt);               // in flight under this frame's transform
 
-  // ---- load (x * 32768), reflect at the edges, partial sums for the DC offset
+  // ---- x * 32768 (+ dither), partial sums for the DC offset
   float part = 0.f;
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
     const int i = lane + 64 * r;
     float v = 0.f;
     if (i < FB_FRAME_LEN) {
-      int64_t sidx = start + i;
-      if (!interior)
-        while (sidx < 0 || sidx >= n) sidx = sidx < 0 ? -sidx - 1 : 2 * n - 1 - sidx;
-      v = wav[sidx] * 32768.0f;
+      v = cur[r] * 32768.0f;
       if (p.dither != 0.f) v = add_rn(v, mul_rn(gauss_at(p.dither_seed, (uint64_t)gf, (uint32_t)i), p.dither));
       part += v;
     }
@@ -310,6 +346,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankDev p) {
     acc = fmaxf(acc, 1.1920929e-07f);
     p.out[gf * p.n_mels + m] = logf(acc);
   }
+  wave_lds_sync();                                       // the next frame overwrites this wave's buffers
+#pragma unroll
+  for (int r = 0; r < 7; ++r) cur[r] = nxt[r];
+  }
 }
 
 void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, const int64_t* audio_off,
@@ -322,7 +362,16 @@ void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, cons
   p.window = tb->window; p.tw512 = tb->tw512; p.mel_w = tb->mel_w; p.mel_chunk = tb->mel_chunk; p.mel_chunk_off = tb->mel_chunk_off;
   p.n_chunks = tb->n_chunks; p.n_weights = tb->n_weights;
   p.dither = dither; p.dither_seed = dither_seed; p.out = fbank;
-  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)((total_frames + 3) / 4)), dim3(256), 0, s, p);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    PF_HIP(hipGetDevice(&dev));
+    PF_HIP(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount;
+  }
+  const int64_t blocks = (total_frames + 3) / 4;
+  hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)std::min<int64_t>(blocks, (int64_t)cus * 5)), dim3(256), 0, s, p);
   PF_HIP(hipGetLastError());
 }
 

@@ -41,6 +41,7 @@
 //    residual loads and stores are whole row segments (lds_epilogue32); edge tiles use direct 16-byte I/O.
 //  * Two kernel kinds (f16-only / fp32) x two tile heights (256 / 128 rows, MI = 2 / 1) are instantiated.
 #include "kernels.h"
+#include "exact.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -67,6 +68,14 @@ struct GemmDev {
   int relu, scale_cols; float scale;
   int out_padded;
   int out_blocked, a_blocked;
+  // int8 variant (gemm_i8_pp3): A / W hold SIGNED bytes a' = a_q - 128, w' = w_q - 128 (K counted in bytes);
+  // acc = sum a' w' is corrected to sum (a_q - a_zp)(w_q - w_zp[n]) with the row / column sums and dequantised
+  const int32_t* q_rowsum;   // [M]  sum_k a'[m,k]
+  const int32_t* q_colsum;   // [N]  sum_k w'[n,k]
+  const int32_t* q_wzp;      // [N]  w_zp[n] - 128
+  const float* q_wscale;     // [N]
+  const float* q_aparams;    // [2]  {a_scale, a_zp} of the dynamically quantised activation tensor (device, written by the quantise kernels)
+  int q_k;                   // true K (before padding)
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -124,8 +133,17 @@ constexpr int gemm_lds_bytes(int mi) { return GEMM_S * (128 * mi + GEMM_BN) * GE
 // KIND 3: f16-only results in the blocked activation layout (kernels.h): fragments stored as whole lines, no transposition
 // MI: 32-row MFMA blocks per wave (2 -> 256-row tiles; 1 -> 128-row tiles for GEMMs whose 256-row
 //     tile count would leave most CUs idle, i.e. the decoder's M = B*L rows)
-template <int KIND, int MI>
-__global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
+typedef int i16x __attribute__((ext_vector_type(16)));
+typedef int i4x __attribute__((ext_vector_type(4)));
+typedef i4x __attribute__((may_alias)) i4xa;
+
+// I8: the same pipeline on v_mfma_i32_32x32x32_i8 — a k-step is still 128 bytes per row (128 int8 instead of 64 f16),
+// fragments are still 16 bytes per lane, so staging, swizzle and fragment reads are unchanged; the accumulators are
+// int32 and the (KIND 2) epilogues dequantise: y = float(acc - corr) * (a_scale * w_scale[n]) + bias[n], exact integers.
+template <int KIND, int MI, bool I8>
+__device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
+  static_assert(!I8 || KIND == 2, "the int8 variant uses the fp32-result epilogues");
+  using acc_t = std::conditional_t<I8, i16x, f16x>;
   constexpr int BK = GEMM_BK, S = GEMM_S, BM = 128 * MI, BN = GEMM_BN, WM = 32 * MI;
   constexpr int WN = 2, NW = 8;
   constexpr int ROWB = BK * 2, CPR = ROWB / 16, RPI = 64 / CPR;
@@ -148,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
   const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int n_my = slot < total_tiles ? (total_tiles - slot + G - 1) / G : 0;
-  const int nk = p.K / BK;
+  const int nk = I8 ? p.K / (2 * BK) : p.K / BK;      // int8: K is in bytes, a k-step is 128 of them
   const int T = n_my * nk;
   if (T == 0) return;
 
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
     const int row = (wave + NW * i) * RPI + srow;
-    a_vo[i] = (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
+    a_vo[i] = I8 ? (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 4)) : (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
     if (p.a_blocked) {                               // piece pi = 1 KiB = 2 column groups of one 32-row block
       const int pi = wave + NW * i;
       a_vo[i] = (unsigned)((pi >> 2) * (p.K >> 3) * 512 + (pi & 3) * 1024 + lane * 16);
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 #pragma unroll
   for (int i = 0; i < B_PW; ++i) {
     const int row = (wave + NW * i) * RPI + srow;
-    w_vo[i] = (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 3)) * 2u;
+    w_vo[i] = I8 ? (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 4)) : (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 3)) * 2u;
   }
   int is_tile = slot, is_kt = 0, is_left = T;        // DMA cursor (uniform); clamps at the last step
   char* is_lds = smem + wave * 1024;
@@ -178,8 +196,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   auto set_issue_tile = [&]() __attribute__((always_inline)) {
     const int tm = is_tile / p.tiles_n, tn = is_tile - tm * p.tiles_n;
     is_a = p.a_blocked ? reinterpret_cast<const char*>(p.A) + (size_t)tm * (BM / 32) * (size_t)(p.K >> 3) * 512
-                       : reinterpret_cast<const char*>(p.A + (size_t)tm * BM * p.lda);
-    is_w = reinterpret_cast<const char*>(p.W + (size_t)tn * BN * p.ldw);
+                       : reinterpret_cast<const char*>(p.A) + (size_t)tm * BM * p.lda * (I8 ? 1 : 2);
+    is_w = reinterpret_cast<const char*>(p.W) + (size_t)tn * BN * p.ldw * (I8 ? 1 : 2);
   };
   set_issue_tile();
   auto issue_piece = [&](int i) __attribute__((always_inline)) {
@@ -229,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   };
 
   // ---- accumulators + packed copy of the previous tile
-  f16x acc[MI][2];
+  acc_t acc[MI][2];
   h4 hq[MI][2][4];                                      // finished tile, packed f16, awaiting its passes
 
   // ---- deferred f16 epilogue state
@@ -332,6 +350,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     }
   };
 
+  // int8: exact integer correction + dequantisation of one accumulator value (row m, column n)
+  //   sum (a_q - a_zp)(w_q - w_zp) = acc - w_zp' rowsum[m] - a_zp' colsum[n] + K a_zp' w_zp'   (primes: minus 128)
+  //   y = float(that) * (a_scale * w_scale[n])            [two roundings; bias / residual follow as separate adds]
+  float q_ascale = 1.f;
+  int q_azp = 0;
+  if constexpr (I8) { q_ascale = p.q_aparams[0]; q_azp = (int)p.q_aparams[1] - 128; }
+  auto dequant = [&](int a, int rowsum, int n) __attribute__((always_inline)) -> float {
+    const int wz = p.q_wzp[n];
+    const int v = a - wz * rowsum - q_azp * p.q_colsum[n] + p.q_k * q_azp * wz;
+    return mul_rn((float)v, mul_rn(q_ascale, p.q_wscale[n]));
+  };
+
   // direct epilogue (fp32 results, residual / FSMN add, or a wave tile that straddles N)
   auto direct_epilogue = [&](int tile) __attribute__((always_inline)) {
     if constexpr (ABL & 16) return;
@@ -352,8 +382,16 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
         for (int g = 0; g < 4; ++g) {
           const int dn = j * 32 + 8 * g;
           const int n = nb + dn;
-          float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+          float v[4];
+          if constexpr (I8) {
+            const int rs = m < p.M ? p.q_rowsum[m] : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = n + e < p.N ? dequant(acc[i][j][4 * g + e], rs, n + e) : 0.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          }
+          acc[i][j][4 * g + 0] = 0; acc[i][j][4 * g + 1] = 0; acc[i][j][4 * g + 2] = 0; acc[i][j][4 * g + 3] = 0;
           if (!interior && (m >= p.M || n >= p.N)) continue;
           if (interior || n + 3 < p.N) {
             if (p.bias) {
@@ -407,6 +445,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + n);
     const float sc = (n < p.scale_cols) ? p.scale : 1.f;
+    // int8: the four columns' correction terms and scales, fixed for this lane
+    i4x q_wz = {0, 0, 0, 0}, q_cs = {0, 0, 0, 0};
+    float4 q_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (I8) {
+      q_wz = *reinterpret_cast<const i4x*>(p.q_wzp + n);
+      q_cs = *reinterpret_cast<const i4x*>(p.q_colsum + n);
+      const float4 ws = *reinterpret_cast<const float4*>(p.q_wscale + n);
+      q_sc = make_float4(mul_rn(q_ascale, ws.x), mul_rn(q_ascale, ws.y), mul_rn(q_ascale, ws.z), mul_rn(q_ascale, ws.w));
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -415,17 +462,33 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), a4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.resid) r4 = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
         if (p.add2) a4 = *reinterpret_cast<const float4*>(p.add2 + (size_t)m * p.ld2 + n);
+        int q_rs = 0;
+        if constexpr (I8) q_rs = p.q_rowsum[m];
         if ((lc >> 2) == c) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              *reinterpret_cast<float4a*>(wq + (j * 32 + 8 * g) * 4) =
-                  make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+              if constexpr (I8)
+                *reinterpret_cast<i4xa*>(wq + (j * 32 + 8 * g) * 4) =
+                    i4x{acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              else
+                *reinterpret_cast<float4a*>(wq + (j * 32 + 8 * g) * 4) =
+                    make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
             }
         }
         asm volatile("" ::: "memory");
-        float4 v = *reinterpret_cast<const float4a*>(rq);
+        float4 v;
+        if constexpr (I8) {
+          const i4x a = *reinterpret_cast<const i4xa*>(rq);
+          const int kz = p.q_k * q_azp;
+          v.x = mul_rn((float)(a[0] - q_wz[0] * q_rs - q_azp * q_cs[0] + kz * q_wz[0]), q_sc.x);
+          v.y = mul_rn((float)(a[1] - q_wz[1] * q_rs - q_azp * q_cs[1] + kz * q_wz[1]), q_sc.y);
+          v.z = mul_rn((float)(a[2] - q_wz[2] * q_rs - q_azp * q_cs[2] + kz * q_wz[2]), q_sc.z);
+          v.w = mul_rn((float)(a[3] - q_wz[3] * q_rs - q_azp * q_cs[3] + kz * q_wz[3]), q_sc.w);
+        } else {
+          v = *reinterpret_cast<const float4a*>(rq);
+        }
         asm volatile("" ::: "memory");
         v.x = (v.x + b4.x) * sc; v.y = (v.y + b4.y) * sc; v.z = (v.z + b4.z) * sc; v.w = (v.w + b4.w) * sc;
         v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
@@ -442,7 +505,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
   };
 
   // tile end: pack the finished tile (fast path) or run the direct epilogue, then re-arm the
@@ -514,8 +577,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
         }
         if constexpr (!(ABL & 4))
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (I8)
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i4x, bf[s][j]), __builtin_bit_cast(i4x, af[s][i]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+        }
         // all LPS pieces go out in the KSUB*MI - 2 iterations before `mid` (which advances the cursor)
         constexpr int PPI = (LPS + KSUB * MI - 3) / (KSUB * MI - 2);
 #pragma unroll
@@ -597,6 +664,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) {
   flush();                                            // the last tile's passes
   wait_vmcnt<0>();                                    // clamped tail DMA must land before LDS is released
 }
+
+template <int KIND, int MI>
+__global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) { gemm_pp3_impl<KIND, MI, false>(p); }
+template <int MI>
+__global__ __launch_bounds__(512, 1) void gemm_i8_pp3(GemmDev p) { gemm_pp3_impl<2, MI, true>(p); }
 
 static thread_local const char* g_last_gemm_kernel = "";
 const char* last_gemm_kernel() { return g_last_gemm_kernel; }
@@ -712,6 +784,51 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     if (mi == 2) hipLaunchKernelGGL((gemm_f16_pp3<2, 2>), dim3(grid), dim3(512), lds, s, d);
     else hipLaunchKernelGGL((gemm_f16_pp3<2, 1>), dim3(grid), dim3(512), lds, s, d);
   }
+  PF_HIP(hipGetLastError());
+}
+
+void launch_gemm_i8(hipStream_t s, const GemmI8Args& a) {
+  PF_CHECK(a.Kpad % 128 == 0 && a.Kpad > 0 && a.K > 0 && a.K <= a.Kpad, PF_ERR_INVALID_ARG, "gemm_i8: Kpad must be a multiple of 128 covering K");
+  PF_CHECK(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.lda >= a.Kpad && a.ldw >= a.Kpad, PF_ERR_INVALID_ARG, "gemm_i8: lda / ldw must be multiples of 16 >= Kpad");
+  PF_CHECK((!a.out_f32 || a.ldc32 % 4 == 0) && (!a.out_f16 || a.ldc16 % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&
+               (!a.add2 || a.ld2 % 4 == 0) && a.scale_cols % 64 == 0,
+           PF_ERR_INVALID_ARG, "gemm_i8: output leading dimensions must keep 16-byte row alignment");
+  PF_CHECK(a.rowsum && a.colsum && a.wzp && a.wscale && a.aparams && (a.out_f32 || a.out_f16), PF_ERR_INVALID_ARG, "gemm_i8: missing operand");
+  GemmDev d{};
+  d.A = reinterpret_cast<const half_t*>(a.A); d.W = reinterpret_cast<const half_t*>(a.W); d.bias = a.bias;
+  d.out_f32 = a.out_f32; d.out_f16 = a.out_f16; d.resid = a.resid; d.add2 = a.add2;
+  d.lda = a.lda; d.ldw = a.ldw; d.ldc32 = a.ldc32; d.ldc16 = a.ldc16; d.ldr = a.ldr; d.ld2 = a.ld2;
+  d.M = a.M; d.N = a.N; d.K = a.Kpad;
+  d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
+  d.out_padded = 0; d.out_blocked = 0; d.a_blocked = 0;
+  d.q_rowsum = a.rowsum; d.q_colsum = a.colsum; d.q_wzp = a.wzp; d.q_wscale = a.wscale; d.q_aparams = a.aparams; d.q_k = a.K;
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  dev &= 63;
+  static std::mutex init_mu;
+  static int cus[64] = {0};
+  {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!cus[dev]) {
+      hipDeviceProp_t prop;
+      PF_HIP(hipGetDeviceProperties(&prop, dev));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_i8_pp3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_i8_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+      cus[dev] = prop.multiProcessorCount;
+    }
+  }
+  const int t2 = cdiv(d.M, 256) * cdiv(d.N, GEMM_BN), t1 = cdiv(d.M, 128) * cdiv(d.N, GEMM_BN);
+  const bool few = (float)t2 < 0.9f * cus[dev];
+  const bool rounds1 = 0.58 * cdiv(t1, cus[dev]) < (double)cdiv(t2, cus[dev]);
+  const int mi = (few || rounds1) ? 1 : 2;
+  d.tiles_m = cdiv(d.M, 128 * mi);
+  d.tiles_n = cdiv(d.N, GEMM_BN);
+  const int total = d.tiles_m * d.tiles_n;
+  if (total == 0) return;
+  const int grid = std::min(cus[dev], total);
+  note_gemm_kernel(mi == 2 ? "gemm_i8_pp3<2>" : "gemm_i8_pp3<1>");
+  if (mi == 2) hipLaunchKernelGGL((gemm_i8_pp3<2>), dim3(grid), dim3(512), gemm_lds_bytes(2), s, d);
+  else hipLaunchKernelGGL((gemm_i8_pp3<1>), dim3(grid), dim3(512), gemm_lds_bytes(1), s, d);
   PF_HIP(hipGetLastError());
 }
 

@@ -46,6 +46,36 @@ void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj);
 bool gemm_bigp_applicable(const GemmArgs& a);
 void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus);
 
+// ---- int8 (u8 x u8 dynamic quantisation as onnxruntime's quantize_dynamic emits it; k_gemm.hip gemm_i8_pp3 + k_quant.hip)
+//   y[m,n] = float( sum_k (a_q[m,k] - a_zp)(w_q[n,k] - w_zp[n]) ) * (a_scale * w_scale[n]) + bias[n]  [+ add2 + resid] [ReLU]
+// The device keeps SIGNED bytes a' = a_q - 128, w' = w_q - 128 (the matrix cores multiply signed int8) plus the row /
+// column sums that turn sum a' w' back into the exact integer above.
+struct GemmI8Args {
+  const int8_t* A; int lda;            // [M, Kpad] a', rows readable up to round_up(M, 256); lda (bytes) % 16 == 0
+  const int8_t* W; int ldw;            // [round_up(N,128), Kpad] w', K-contiguous; pad columns of A and W hold 0
+  const int32_t* rowsum;               // [M] sum_k a'
+  const int32_t* colsum;               // [N] sum_k w'
+  const int32_t* wzp;                  // [N] w_zp - 128
+  const float* wscale;                 // [N]
+  const float* aparams;                // device [2]: a_scale, a_zp (written by launch_quantize_rows)
+  const float* bias;                   // [N] or null
+  int M, N, K, Kpad;                   // K = true depth, Kpad = multiple of 128
+  float* out_f32; int ldc32; half_t* out_f16; int ldc16;
+  const float* resid; int ldr; const float* add2; int ld2;
+  int relu; int scale_cols; float scale;
+};
+void launch_gemm_i8(hipStream_t s, const GemmI8Args& a);
+// DynamicQuantizeLinear over the WHOLE tensor x [rows, cols] (fp32, or f16 when x16 is given): min / max (including 0)
+// -> a_scale = (max - min) / 255, a_zp = rne(clamp(-min / a_scale, 0, 255)); q = clamp(rne(x / a_scale) + a_zp, 0, 255);
+// writes a' = q - 128 into out [rows, ld] (pad columns 0), the row sums of a', and {a_scale, a_zp} into params[2].
+// scratch: >= 16 bytes of device memory (min / max accumulators).
+void launch_quantize_rows(hipStream_t s, const float* x32, const half_t* x16, int64_t rows, int cols, int ldx, int8_t* out, int ld,
+                          int32_t* rowsum, float* params, unsigned* scratch);
+// per-output-channel weight quantisation as onnxruntime.quantization quantize_dynamic(per_channel=True, weight_type=QUInt8)
+// does it: row n of W [N, K] (fp32): rmin = min(0, min), rmax = max(0, max), scale = (rmax - rmin) / 255,
+// zp = rne(-rmin / scale) clamped to [0, 255], q = clamp(rne(w / scale) + zp, 0, 255) -> w' = q - 128 [N, ld], colsum, wzp = zp - 128, wscale
+void launch_quantize_weight(hipStream_t s, const float* W, int N, int K, int8_t* out, int ld, int32_t* colsum, int32_t* wzp, float* wscale);
+
 // Row-complete GEMM for N = 512 (k_gemm_rc.hip): x = resid + A W^T + bias + FSMN(V); n = LayerNorm(x).
 // One workgroup = 64 complete rows, so the residual add, the FSMN memory and the following LayerNorm are its epilogue.
 struct GemmRcArgs {

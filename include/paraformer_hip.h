@@ -94,7 +94,10 @@ typedef struct pf_engine_config {
   int32_t frame_shift_ms;     /* 0 = 10; anything but 10 -> PF_ERR_UNSUPPORTED                 */
   int32_t dither_seed;        /* seed of the dither stream (same seed + same audio = same features) */
   int32_t math_mode;          /* 0 = f16 operands on the MFMA (default); 1 = fp32 MFMA parity mode
-                                 (v_mfma_f32_32x32x2_f32: exact fp32 products, ~1/16 of the speed) */
+                                 (v_mfma_f32_32x32x2_f32: exact fp32 products, ~1/16 of the speed); 2 = the arithmetic
+                                 of the reference's default model.int8.onnx (Examples/Program.cs:98-101): every
+                                 Linear as DynamicQuantizeLinear + MatMulInteger on v_mfma_i32_32x32x32_i8, weights
+                                 quantised per output channel as onnxruntime's quantize_dynamic does */
   int32_t reserved[3];
 } pf_engine_config;
 
@@ -245,6 +248,15 @@ int pf_op_lfr_cmvn_pad(pf_engine* e, const float* const* fbank, const int32_t* t
 int pf_op_argmax(pf_engine* e, const float* x, int64_t rows, int32_t V, int64_t* ids_out);
 /* C = A[M,K] * W[N,K]^T + bias, f16 operands / f32 accumulate; epilogue 0 none, 1 relu,
    2 = f16 result store (the path the pipeline uses), returned widened to fp32. */
+/* One dynamically quantised Linear, the building block of math_mode 2 (the reference's default model.int8.onnx:
+   DynamicQuantizeLinear + MatMulInteger + rescale, as onnxruntime's quantize_dynamic emits them for every MatMul with a
+   constant weight).  x [M, K] fp32 (x_is_f16: first rounded to f16, as the engine's f16-stored activations are),
+   W [N, K] fp32 (quantised per output channel to uint8 here), y [M, N] = float(sum (x_q - x_zp)(w_q - w_zp[n])) *
+   (x_scale * w_scale[n]) + bias[n] [ReLU]; the integer sum runs on v_mfma_i32_32x32x32_i8 and is exact.  Optional outputs
+   (NULL = skip): the uint8 activations [M, K], {x_scale, x_zp}, the uint8 weights [N, K], w_scale [N], w_zp [N]. */
+int pf_op_qlinear(pf_engine* e, const float* x, const float* W, const float* bias, int32_t M, int32_t N, int32_t K,
+                  int32_t relu, int32_t x_is_f16, float* y, uint8_t* xq_out, float* aparams_out, uint8_t* wq_out,
+                  float* wscale_out, int32_t* wzp_out);
 int pf_op_gemm(pf_engine* e, const float* A, const float* W, const float* bias,
                int32_t M, int32_t N, int32_t K, int32_t epilogue, float* C);
 /* The GEMM as the pipeline launches it, every variant selectable. */

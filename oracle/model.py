@@ -150,11 +150,21 @@ class Oracle:
         self.cfg = cfg
         self.w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()
                   if isinstance(v, np.ndarray) and v.dtype == np.float32}
-        self.q = quantizer(quant)
+        # "int8": the graph of the reference's default model.int8.onnx (every Linear = DynamicQuantizeLinear +
+        # MatMulInteger, oracle/int8.py) with the engine's 16-bit storage points (q / k / v, attention context, encoder
+        # FFN hidden); "int8_ref": the same graph without any 16-bit rounding = what onnxruntime computes.
+        self.int8 = quant in ("int8", "int8_ref")
+        self.q = quantizer("fp16" if quant == "int8" else ("fp32" if quant == "int8_ref" else quant))
         self.quant = quant
+        if self.int8:
+            from .int8 import QuantizedLinears
+            self.qlin = QuantizedLinears({k: np.ascontiguousarray(v) for k, v in weights.items()
+                                          if isinstance(v, np.ndarray) and v.dtype == np.float32})
 
     # -- helpers -----------------------------------------------------------
     def lin(self, x, name, bias=True):
+        if self.int8:
+            return torch.from_numpy(self.qlin(np.ascontiguousarray(x.detach().numpy(), dtype=np.float32), name, bias))
         w = self.q(self.w[name + ".weight"])
         y = torch.matmul(self.q(x), w.t())
         if bias:
@@ -187,10 +197,14 @@ class Oracle:
         f = fsmn(vq, self.w[p + ".attn.fsmn.weight"], c.kernel)
         dk = c.d_model // c.heads
         ctx = self.mha(q(qh * (dk ** -0.5)), q(kh), vq)
+        if self.int8:
+            ctx = q(ctx)                             # the engine's attention writes f16; it is quantised from there
         att = self.lin(ctx, p + ".attn.out") + f
         x = att if first else x + att
         xn = self.ln(x, p + ".norm2")
         h = torch.relu(self.lin(xn, p + ".ffn.w1"))
+        if self.int8:
+            h = q(h)                                 # f16 FFN hidden in the engine
         return x + self.lin(h, p + ".ffn.w2")
 
     def encoder(self, speech):
@@ -366,7 +380,9 @@ class Oracle:
 
     # -- decoder -----------------------------------------------------------
     def ffn_dec(self, x, p):
-        h = self.q(torch.relu(self.lin(x, p + ".ffn.w1")))     # 16-bit modes: the engine stores this hidden as f16
+        h = torch.relu(self.lin(x, p + ".ffn.w1"))
+        if not self.int8:
+            h = self.q(h)                                     # 16-bit modes: the engine stores this hidden as f16 (fp32 in int8 mode)
         h = self.ln(h, p + ".ffn.norm")
         return self.lin(h, p + ".ffn.w2", bias=False)
 
@@ -394,6 +410,8 @@ class Oracle:
             kv = self.lin(memory, p + ".src.kv")
             k, v = torch.split(kv, D, dim=-1)
             ctx = self.mha(q(qq * (dk ** -0.5)), q(k), q(v))
+            if self.int8:
+                ctx = q(ctx)
             x = x + self.lin(ctx, p + ".src.out")
         x = self.ffn_dec(self.ln(x, prefix + ".final.norm1"), prefix + ".final")
         return self.ln(x, prefix + ".after_norm")

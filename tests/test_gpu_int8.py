@@ -1,0 +1,143 @@
+"""GPU: math_mode 2 — the arithmetic of the reference's default `model.int8.onnx` (Examples/Program.cs:98-101) on the
+int8 matrix cores.
+
+Operator level (BIT-EXACT): `pf_op_qlinear` = DynamicQuantizeLinear(x) + MatMulInteger + rescale (+ bias) against
+oracle/int8.py — the uint8 activations, their scale / zero point, the per-channel uint8 weights and the float results
+must be identical bit for bit (the integer accumulators are exact by construction: v_mfma_i32_32x32x32_i8 + exact int32
+correction terms; a single differing accumulator would change y).
+
+Model level: the engine in math_mode 2 against `Oracle(quant="int8")` (same graph, same 16-bit storage points).  A uint8
+activation that sits on a rounding boundary may land on the neighbouring code when LayerNorm / attention differ in the
+last bits, which moves one product by one quantisation step — so log-probs are compared with a tolerance, not bit for bit.
+"""
+import numpy as np
+import pytest
+
+from aliparaformerasr_amd import weights as W
+from oracle import frontend as fe
+from oracle import glue
+from oracle import int8 as q8
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=64)
+    e = Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, 3)), cmvn=W.synth_cmvn(), device=0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 512), (1000, 1536, 560), (16000, 512, 2048), (257, 8404, 512), (64, 25055, 512),
+                                   (5, 128, 4), (4096, 2048, 512)])
+def test_qlinear_bit_exact(eng, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0)).astype(np.float32)
+    x[rng.integers(0, M), rng.integers(0, K)] = 11.5                      # an outlier sets the dynamic range
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wm[:, 0] += 0.3 * rng.standard_normal(N).astype(np.float32)           # channels with different ranges
+    bias = rng.standard_normal(N).astype(np.float32)
+    y, xq, (xs, xz), wq, ws, wz = eng.op_qlinear(x, Wm, bias, details=True)
+    rq, rs, rz = q8.quantize_activation(x)
+    assert xs == float(rs) and xz == rz
+    np.testing.assert_array_equal(xq, rq.astype(np.uint8))
+    gq, gs, gz = q8.quantize_weight(Wm)
+    np.testing.assert_array_equal(ws, gs)
+    np.testing.assert_array_equal(wz, gz)
+    np.testing.assert_array_equal(wq, gq.astype(np.uint8))
+    ref = q8.qlinear(x, gq, gs, gz, bias)
+    np.testing.assert_array_equal(y, ref)                                 # bit for bit
+    # and it is a faithful Linear: within the quantisation noise of the float product
+    full = x.astype(np.float64) @ Wm.astype(np.float64).T + bias
+    assert np.abs(y - full).max() < 0.05 * np.abs(full).max() + 0.2
+
+
+def test_qlinear_relu_f16_input_and_degenerate_ranges(eng):
+    rng = np.random.default_rng(7)
+    x = np.abs(rng.standard_normal((130, 256))).astype(np.float32)        # non-negative input (post-ReLU hidden): zero point 0
+    Wm = rng.standard_normal((192, 256)).astype(np.float32)
+    y, xq, (xs, xz), *_ = eng.op_qlinear(x, Wm, None, relu=True, x_is_f16=True, details=True)
+    x16 = x.astype(np.float16).astype(np.float32)
+    assert xz == 0
+    gq, gs, gz = q8.quantize_weight(Wm)
+    np.testing.assert_array_equal(y, np.maximum(q8.qlinear(x16, gq, gs, gz, None), 0))
+    # all-zero activation tensor: scale 1, zero point 0 (MLAS), result = bias
+    z, _, (zs, zz), *_ = eng.op_qlinear(np.zeros((8, 256), np.float32), Wm, np.arange(192, dtype=np.float32), details=True)
+    assert zs == 1.0 and zz == 0
+    np.testing.assert_array_equal(z, np.tile(np.arange(192, dtype=np.float32), (8, 1)))
+    # an all-zero weight channel and a constant one
+    Wm[3] = 0.0
+    Wm[4] = 0.25
+    y2 = eng.op_qlinear(x, Wm, None)
+    gq, gs, gz = q8.quantize_weight(Wm)
+    np.testing.assert_array_equal(y2, q8.qlinear(x, gq, gs, gz, None))
+    assert np.all(y2[:, 3] == 0)
+
+
+def _speech(audio, cmvn, prep=None):
+    conf = fe.FrontendConf(dither=0.0)
+    feats = [fe.wav_frontend(a, conf, cmvn[0], cmvn[1]) for a in audio]
+    if prep is not None:
+        feats = [prep(f) for f in feats]
+    T = max(f.shape[0] for f in feats)
+    return fe.pad_sequence(feats).reshape(len(audio), T, 560)
+
+
+def test_int8_paraformer_vs_oracle():
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=3, dec_layers=2, vocab=515)
+    w = W.synth_weights(cfg, seed=33)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=2)
+    audio = [W.synth_audio(n, 5 + u) for u, n in enumerate((48000, 30000, 41000))]
+    speech = _speech(audio, cmvn)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="int8").paraformer(speech)
+    res = eng.recognize(audio, want_logits=True)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    assert res.logits.shape == ref["logits"].shape
+    err = np.abs(res.logits - ref["logits"])
+    print("int8 paraformer: max|dlogp| %.3e mean %.2e" % (err.max(), err.mean()))
+    assert err.max() < 5e-2 and err.mean() < 3e-3
+    srt = np.sort(ref["logits"], axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 0.1
+    np.testing.assert_array_equal(res.token_ids[safe], om.argmax_last(ref["logits"])[safe])
+    np.testing.assert_array_equal(res.token_ids, om.argmax_last(res.logits))
+    # against the fp32 graph the int8 model is a different (coarser) model: close, not equal
+    f32 = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").paraformer(speech)
+    if f32["logits"].shape == res.logits.shape:
+        print("int8 vs fp32 graph: max|dlogp| %.3e" % np.abs(res.logits - f32["logits"]).max())
+    ids_only = eng.recognize(audio)
+    np.testing.assert_array_equal(ids_only.token_ids, res.token_ids)
+    eng.close()
+
+
+def test_int8_sensevoice_vs_oracle(sv_embed):
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.sensevoice_small_config(enc_layers=2, tp_layers=1, vocab=403, use_itn=True)
+    w = W.synth_weights(cfg, seed=9)
+    w["embed.weight"] = sv_embed.astype(np.float32)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=2)
+    audio = [W.synth_audio(n, 70 + u) for u, n in enumerate((32000, 24000))]
+    speech = _speech(audio, cmvn, prep=lambda f: glue.sensevoice_prepend(f, sv_embed, use_itn=True))
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="int8").sensevoice(speech)
+    res = eng.recognize(audio, want_logits=True)
+    assert res.logits.shape == ref["logits"].shape
+    err = np.abs(res.logits - ref["logits"])
+    print("int8 sensevoice: max|dlogp| %.3e mean %.2e" % (err.max(), err.mean()))
+    assert err.max() < 5e-2 and err.mean() < 3e-3
+    eng.close()
+
+
+def test_int8_mode_refuses_heads_it_does_not_cover():
+    from aliparaformerasr_amd.engine import Engine
+    from aliparaformerasr_amd._native import PfError
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=256, timestamp_head=True)
+    eng = Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, 1)), cmvn=W.synth_cmvn(), device=0, math_mode=2)
+    with pytest.raises(PfError) as ei:
+        eng.recognize([W.synth_audio(16000, 1)])
+    assert "math_mode 2" in str(ei.value)
+    eng.close()
