@@ -1952,7 +1952,7 @@ void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, 
   g.scale_cols = ds.scale_cols; g.scale = ds.scale;
   g.out_padded = 1;
   g.a_blocked = ds.a_blocked ? 1 : 0;
-  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 512 ? 3 : (ds.tile_rows == 32 ? 4 : (ds.tile_rows == 1024 ? 5 : 0))));
+  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 32 ? 4 : (ds.tile_rows == 1024 ? 5 : 0)));
   g.small_ws = small_ws_;
   if (ds.out_kind == 0) {
     g.out_f32 = (float*)(base + oC); g.ldc32 = ld32;

@@ -64,13 +64,15 @@ void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_
                    half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols,
                    float scale) {
   if (M == 0) return;
-  prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   if (x32 || x16) {                                    // null / null: the tensor quantised by the previous call is reused
     ensure_q(M, w.Kpad);
-    launch_quantize_rows(stream_, x32, x16, M, w.K, ldx, q_a_, q_kpad_, q_rowsum_, q_params_, q_scratch_);
+    prof_begin("quantize", 0);
+    launch_quantize_rows(stream_, x32, x16, M, w.K, ldx, q_a_, w.Kpad, q_rowsum_, q_params_, q_scratch_);   // rows packed at this GEMM's Kpad
+    prof_end("quantize");
   }
+  prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   GemmI8Args g{};
-  g.A = q_a_; g.lda = q_kpad_; g.W = w.w; g.ldw = w.Kpad;
+  g.A = q_a_; g.lda = w.Kpad; g.W = w.w; g.ldw = w.Kpad;
   g.rowsum = q_rowsum_; g.colsum = w.colsum; g.wzp = w.wzp; g.wscale = w.wscale; g.aparams = q_params_;
   g.bias = w.bias; g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad;
   g.out_f32 = out32; g.ldc32 = ld32; g.out_f16 = out16; g.ldc16 = ld16;

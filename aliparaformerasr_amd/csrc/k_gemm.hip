@@ -742,18 +742,6 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
       return;
     }
   }
-  {
-    // the 256 x {192,256} one-tile-per-workgroup kernel (k_gemm_big.hip) is OPT-IN (PF_BIG=1 or force_mi = 3): its
-    // main loop runs at 0.9 us per k-step, but every tile pays ~9 us of un-overlapped prologue + epilogue, which at
-    // K = 512 (8 k-steps per tile) cancels the gain — measured equal to this kernel within +-4 % on every shape
-    // (tools/bench_gemm.py, tools/abl_big.sh)
-    static int use_big = -1;
-    if (use_big < 0) { const char* e = getenv("PF_BIG"); use_big = (e && e[0] == '1') ? 1 : 0; }
-    int nj = 0;
-    const bool can = gemm_big_applicable(a, cus[dev], &nj);
-    PF_CHECK(a.force_mi != 3 || can, PF_ERR_INVALID_ARG, "gemm: the 256 x {192,256} tile kernel does not apply to this problem");
-    if (can && (a.force_mi == 3 || (a.force_mi == 0 && use_big))) { launch_gemm_big(s, a, nj); return; }
-  }
   // tile height by rounds: a 128-row tile costs ~0.58 of a 256-row one (half the MFMAs, two thirds of the operand
   // bytes); whichever schedule has the shorter last round wins (decoder FFN-up, M = 5344: 336 tiles = 2 rounds vs
   // 672 = 3 x 0.58).  PF_GEMM_ROUNDS=0 keeps the tile-count rule alone.

@@ -1,28 +1,24 @@
-// k_gemm_big.hip — 256 x {192, 256} tile GEMM for the wide projections with f16 results (QKV: N = 1536, FFN-up:
-// N = 2048, the 16 decoder K/V projections: N = 16384), K = 512..576:
+// k_gemm_big.hip — persistent 256 x 256 tile GEMM for the FFN up-projection, f16 result in the blocked layout:
 //
-//   C[M,N] = A[M,K] * W[N,K]^T + bias  [* q-scale on the first columns] [ReLU]  -> f16 (row-major or blocked layout)
+//   C[M,N] = relu(A[M,K] * W[N,K]^T + bias)  [* scale on the first columns]  -> blocked f16 (kernels.h)
 //
-// (the MatMul + Add [+ Mul] [+ Relu] nodes of the graph InferenceSession.Run executes,
-// AliParaformerAsr/OfflineProjOfParaformer.cs:68).
+// (the MatMul + Add + Relu nodes of the graph InferenceSession.Run executes, AliParaformerAsr/OfflineProjOfParaformer.cs:68).
 //
 // Why a second kernel next to gemm_f16_pp3 (k_gemm.hip): the K loop of both kernels is bound by the per-CU operand
 // path, ~60 GB/s = 25 B/clk through LDS-DMA whatever the source (profiles/round2_gemm_cold_vs_warm.txt: a k-step takes
 // time proportional to its operand bytes — 0.79 us for 48 KB, 0.535 us for 32 KB — on an otherwise idle chip with the
 // operands L2-resident).  A 256 x 128 tile moves 48 KB per 4.2 MFLOP (87 flop/B, ceiling ~5.3 TFLOP/s per CU), a
-// 256 x 256 tile 64 KB per 8.4 MFLOP (131 flop/B, ceiling ~7.9), so the wide projections want the big tile.  A first
-// version (k-steps of 64, two 64 KB stages) had only ONE stage in flight while the other was consumed and ran at
-// 37 GB/s per CU — no faster than the 256 x 128 kernel.  This version: k-steps of 32, a 4-stage ring of 32 KB stages
-// (28 KB for 192-column tiles), THREE stages in flight (96 KB, what gemm_f16_pp3 keeps in flight), one s_barrier per
-// k-step placed in the middle of the step: at mid-step k every wave has its stage-(k+1) pieces landed (counted vmcnt)
-// and all its reads of stage k retired, so after the barrier (a) the first fragments of stage k+1 are read under the
-// second half of step k's MFMAs and (b) slot k % 4 is free for the DMA of stage k+4, whose pieces go out between the
-// MFMAs of the next half-steps.  ONE tile per 512-thread workgroup (8 waves as 4 x 2, wave tile 64 x 128 / 64 x 96 =
-// 2 x NJ MFMA 32x32x16 blocks, 128 / 96 accumulator registers).  64-byte LDS rows are swizzled chunk ^ ((row >> 2) & 3)
-// on the DMA source and on the ds_read_b128 address (conflict-free for the 16-lane read groups).  Epilogue: bias /
-// scale / ReLU in registers, f16 tile through LDS (the ring is free: one tile per workgroup), whole 384 / 512-byte
-// row segments (or whole 512-byte blocks of the blocked layout) to HBM.  Workgroups are dealt to XCDs in contiguous
-// runs with n fastest, so an A panel is shared in one private L2.
+// 256 x 256 tile 64 KB per 8.4 MFLOP (131 flop/B, ceiling ~7.9), so the wide projections want the big tile.  k-steps of
+// 32, a 4-stage ring of 32 KB stages, THREE stages in flight, one s_barrier per k-step placed in the middle of the
+// step: at mid-step k every wave has its stage-(k+1) pieces landed (counted vmcnt) and all its reads of stage k
+// retired, so after the barrier (a) the first fragments of stage k+1 are read under the second half of step k's MFMAs
+// and (b) slot k % 4 is free for the DMA of stage k+4, whose pieces go out between the MFMAs of the next half-steps.
+// 8 waves as 4 x 2, wave tile 64 x 128 = 2 x 4 MFMA 32x32x16 blocks (128 accumulator registers).  64-byte LDS rows are
+// swizzled chunk ^ ((row >> 2) & 3) on the DMA source and on the ds_read_b128 address (conflict-free for the 16-lane
+// read groups).  Workgroups are dealt to XCDs in contiguous runs with n fastest, so an A panel is shared in one private
+// L2.  (Rounds 1-2 also carried a one-tile-per-workgroup 256 x {192, 256} form with an LDS-transposed row-major
+// epilogue; it measured equal to gemm_f16_pp3 on every shape — its per-tile prologue / epilogue is not overlapped at
+// K = 512 — and was removed in round 3: profiles/round2_gemm_big_ablation.txt keeps the numbers.)
 #include "kernels.h"
 
 #include <algorithm>
@@ -71,175 +67,6 @@ __device__ __forceinline__ void bg_store16(void* p, h8 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void bg_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
-
-// NJ: 32-column MFMA blocks per wave (4 -> 256-column tiles, 3 -> 192-column tiles)
-template <int NJ>
-__global__ __launch_bounds__(512, 1) void gemm_big_kernel(BigDev p) {
-  constexpr int BN = 64 * NJ, A_BYTES = BG_BM * BG_ROWB, STAGE = bg_stage(NJ), XROW = bg_xrow(NJ);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, lh = lane >> 5;
-  auto swz = [](int row) __attribute__((always_inline)) -> int { return (row >> 2) & 3; };   // 64-byte rows
-
-  // ---- tile of this workgroup: XCD b % 8 gets a contiguous run of tiles, n fastest
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = G >> 3, r8 = G & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  const int m0 = tm * BG_BM, n0 = tn * BN;
-  const int nk = p.K / BG_BK;
-
-  // ---- LDS-DMA pieces: 1 KiB = 16 rows x 64 bytes.  A: 16 pieces, two per wave.  W: 16 (NJ = 4) or 12 (NJ = 3) pieces:
-  // two per wave, except waves 4-7 of a 192-column tile, which have one (so their vmcnt immediates differ)
-  const bool w2 = NJ == 4 || wave < 4;
-  const int srow = lane >> 2, schunk = lane & 3;
-  unsigned a_vo[2], w_vo[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave + 8 * i) * 16 + srow;
-    a_vo[i] = (unsigned)(row * p.lda + ((schunk ^ swz(row)) << 3)) * 2u;
-    w_vo[i] = (unsigned)(row * p.ldw + ((schunk ^ swz(row)) << 3)) * 2u;
-  }
-  const char* a_base = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
-  const char* w_base = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
-  // piece q of stage k: q = 0, 1 -> A; q = 2, 3 -> W (q = 3 only for waves that have a second W piece)
-  auto issue_piece = [&](int k, int q) __attribute__((always_inline)) {
-    if (BG_ABL & 1) return;
-    char* st = smem + (k & (BG_S - 1)) * STAGE + wave * 1024;
-    if (q < 2) bg_glds16(a_base + (size_t)k * (BG_BK * 2) + a_vo[q & 1], st + (q & 1) * 8192);
-    else if (q == 2 || w2) bg_glds16(w_base + (size_t)k * (BG_BK * 2) + w_vo[q & 1], st + A_BYTES + (q & 1) * 8192);
-  };
-  // wait until at most `stages` of this wave's later stages are still in flight (4 or 3 pieces each)
-  auto wait_allow = [&](int stages) __attribute__((always_inline)) {
-    if (w2) { if (stages >= 2) bg_wait_vmcnt<8>(); else if (stages == 1) bg_wait_vmcnt<4>(); else bg_wait_vmcnt<0>(); }
-    else { if (stages >= 2) bg_wait_vmcnt<6>(); else if (stages == 1) bg_wait_vmcnt<3>(); else bg_wait_vmcnt<0>(); }
-  };
-
-  // ---- fragment read offsets inside a stage (bytes): sub-step s = 16 k-elements = chunks 2s, 2s+1
-  unsigned fa[2][2], fb[2][NJ];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ra = wm * 64 + i * 32 + (lane & 31);
-      fa[s][i] = (unsigned)(ra * BG_ROWB + (((2 * s + lh) ^ swz(ra)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int rb = wn * (32 * NJ) + j * 32 + (lane & 31);
-      fb[s][j] = (unsigned)(A_BYTES + rb * BG_ROWB + (((2 * s + lh) ^ swz(rb)) << 4));
-    }
-  }
-
-  f16x acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  h8 a0[2] = {}, b0[NJ] = {}, a1[2] = {}, b1[NJ] = {};
-  auto load = [&](const char* rd, int s, h8 (&af)[2], h8 (&bf)[NJ]) __attribute__((always_inline)) {
-    if (BG_ABL & 8) return;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bf[j] = *(const h8*)(rd + fb[s][j]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[i] = *(const h8*)(rd + fa[s][i]);
-  };
-  auto mma = [&](h8 (&af)[2], h8 (&bf)[NJ], int kd, int q0, int q1) __attribute__((always_inline)) {
-    int q = q0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (!(BG_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        if (q < q1) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (kd >= 0) issue_piece(kd, q);
-          ++q;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-  };
-
-  // ---- main loop: 4-stage ring, three stages in flight
-#pragma unroll
-  for (int st = 0; st < BG_S - 1; ++st)
-    if (st < nk) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_piece(st, q);
-    }
-  wait_allow(nk - 1 < 2 ? nk - 1 : 2);                                  // stage 0 of this wave has landed
-  __builtin_amdgcn_s_barrier();                                         // ... and everybody else's
-  load(smem, 0, a0, b0);
-  for (int k = 0; k < nk; ++k) {
-    const char* rd = smem + (k & (BG_S - 1)) * STAGE;
-    const int kd = k + BG_S - 1 < nk ? k + BG_S - 1 : -1;               // stage whose DMA goes out during this step
-    __builtin_amdgcn_sched_barrier(0);
-    load(rd, 1, a1, b1);                                                // second half of stage k, under the first half's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    // slot (k + 3) % 4 held stage k - 1, released by the mid-step barrier of step k - 1
-    mma(a0, b0, kd, 0, 4);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int left = nk - 2 - k;                                        // stages issued beyond k + 1
-    if (k + 1 < nk) wait_allow(left < 2 ? left : 2);                    // stage k + 1 of this wave has landed
-    bg_wait_lgkm0();                                                    // every read of stage k has retired
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    if (k + 1 < nk) load(smem + ((k + 1) & (BG_S - 1)) * STAGE, 0, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mma(a1, b1, -1, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-
-  // ---- epilogue: bias / scale / ReLU -> f16 -> LDS row-major (16-byte skew per row), then whole row segments
-  const float lo = p.relu ? 0.f : -INFINITY;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int nc = n0 + wn * (32 * NJ) + j * 32;               // first column of this 32-column block
-    const float sc = nc < p.scale_cols ? p.scale : 1.f;        // scale_cols is a multiple of 32
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + nc + 8 * g + 4 * lh);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + (lane & 31);
-        const h4 hv = {(half_t)fmaxf((acc[i][j][4 * g + 0] + b4.x) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 1] + b4.y) * sc, lo),
-                       (half_t)fmaxf((acc[i][j][4 * g + 2] + b4.z) * sc, lo), (half_t)fmaxf((acc[i][j][4 * g + 3] + b4.w) * sc, lo)};
-        *reinterpret_cast<h4a*>(smem + (size_t)row * XROW + (wn * (32 * NJ) + j * 32 + 8 * g + 4 * lh) * 2) = hv;
-      }
-    }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;                                   // 16-byte chunks per tile row
-  if (p.blocked) {
-    // blocked activation layout (kernels.h): 32 rows x 8 columns = 512 contiguous bytes; wave w writes row block w
-    char* ob = reinterpret_cast<char*>(p.out) + ((size_t)((m0 >> 5) + wave) * (size_t)(p.N >> 3) + (size_t)(n0 >> 3)) * 512;
-    const int r = lane & 31;
-#pragma unroll 4
-    for (int it = 0; it < CPR / 2; ++it) {
-      const int cg = 2 * it + lh;
-      const h8 v = *reinterpret_cast<const h8a*>(smem + (size_t)(wave * 32 + r) * XROW + cg * 16);
-      if (!(BG_ABL & 4)) bg_store16(ob + (size_t)cg * 512 + r * 16, v);
-    }
-  } else {
-    // row-major: wave w owns rows 32w .. 32w+31; consecutive lanes = consecutive 16-byte chunks of a row
-#pragma unroll 4
-    for (int it = 0; it < 32 * CPR / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int rl = idx / CPR, ch = idx - rl * CPR;
-      const int row = wave * 32 + rl;
-      const h8 v = *reinterpret_cast<const h8a*>(smem + (size_t)row * XROW + ch * 16);
-      if (!(BG_ABL & 4)) bg_store16(p.out + (size_t)(m0 + row) * p.ldc + n0 + ch * 8, v);
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent form for the blocked-layout result (FFN-up: [M x 512] x [512 x 2048] + bias + ReLU -> the blocked f16
@@ -519,54 +346,6 @@ void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus) {
   if (total == 0) return;
   note_gemm_kernel("gemm_bigp_kernel");
   hipLaunchKernelGGL(gemm_bigp_kernel, dim3((unsigned)std::min(total, cus)), dim3(512), BGP_LDS, s, d);
-  PF_HIP(hipGetLastError());
-}
-
-bool gemm_big_applicable(const GemmArgs& a, int cus, int* nj_out) {
-  if (!a.out_f16 || a.out_f32 || a.resid || a.add2 || !a.out_padded || a.a_blocked) return false;
-  if (a.K % 64 != 0 || a.lda % 8 != 0 || a.ldw % 8 != 0 || a.scale_cols % 32 != 0) return false;
-  if (!a.out_blocked && a.ldc16 % 8 != 0) return false;
-  if (a.out_blocked && a.N % 64 != 0) return false;
-  const int tm = cdiv(a.M, BG_BM);
-  int best = 0;
-  double best_cost = 0;
-  for (int nj = 4; nj >= 3; --nj) {
-    const int bn = 64 * nj;
-    if (a.N % bn != 0) continue;
-    const int tiles = tm * (a.N / bn);
-    if (tiles < cus) continue;                         // fewer tiles than CUs: the 128-row tiles of gemm_f16_pp3 fill the chip better
-    const double cost = (double)cdiv(tiles, cus) * bn; // rounds x tile width
-    if (!best || cost < best_cost) { best = nj; best_cost = cost; }
-  }
-  if (!best) return false;
-  *nj_out = best;
-  return true;
-}
-
-void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj) {
-  BigDev d;
-  d.A = a.A; d.W = a.W; d.bias = a.bias; d.out = a.out_f16;
-  d.lda = a.lda; d.ldw = a.ldw; d.ldc = a.ldc16;
-  d.M = a.M; d.N = a.N; d.K = a.K;
-  d.tiles_m = cdiv(a.M, BG_BM); d.tiles_n = a.N / (64 * nj);
-  d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
-  d.blocked = a.out_blocked;
-  static std::mutex init_mu;
-  static bool attr_set[64] = {false};
-  int dev = 0;
-  PF_HIP(hipGetDevice(&dev));
-  {
-    std::lock_guard<std::mutex> lk(init_mu);
-    if (!attr_set[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bg_lds(4)));
-      PF_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, bg_lds(3)));
-      attr_set[dev & 63] = true;
-    }
-  }
-  const dim3 grid((unsigned)(d.tiles_m * d.tiles_n));
-  note_gemm_kernel(nj == 4 ? "gemm_big_kernel<4>" : "gemm_big_kernel<3>");
-  if (nj == 4) hipLaunchKernelGGL(gemm_big_kernel<4>, grid, dim3(512), bg_lds(4), s, d);
-  else hipLaunchKernelGGL(gemm_big_kernel<3>, grid, dim3(512), bg_lds(3), s, d);
   PF_HIP(hipGetLastError());
 }
 

@@ -30,19 +30,15 @@ struct GemmArgs {
   int a_blocked;
   float* small_ws;               // scratch of the short-input kernel (k_gemm_small.hip, gemm_small_ws_bytes() bytes, one per
                                  // stream); null = never dispatch to it
-  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 3 = the 256 x {192,256} kernel, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result)
-                                 // (stand-alone op tests; 3 fails when that kernel does not apply)
+  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result)
+                                 // (stand-alone op tests; 4 / 5 fail when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
 // name of the kernel the calling thread's most recent GEMM launcher chose (bench.py prints it next to the class it
 // reports as `roofline`; the same name appears in the rocprofv3 kernel trace)
 const char* last_gemm_kernel();
 void note_gemm_kernel(const char* name);
-// 256 x {192, 256} tile kernel for wide f16-result GEMMs (k_gemm_big.hip); launch_gemm dispatches to it when
-// applicable (f16-only result, N a multiple of 192 / 256, at least one tile per CU) unless force_mi is set
-bool gemm_big_applicable(const GemmArgs& a, int cus, int* nj_out);
-void launch_gemm_big(hipStream_t s, const GemmArgs& a, int nj);
-// persistent form of the same tile for the blocked-layout result (FFN-up)
+// persistent 256 x 256 tile kernel for the blocked-layout result (FFN-up; k_gemm_big.hip)
 bool gemm_bigp_applicable(const GemmArgs& a);
 void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus);
 

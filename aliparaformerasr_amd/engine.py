@@ -268,19 +268,19 @@ class Engine:
         """One dynamically quantised Linear on the int8 MFMA (pf_op_qlinear).  details=True also returns the uint8
         activations, (x_scale, x_zp), the uint8 weights, w_scale and w_zp."""
         x, W = _f32(x), _f32(W)
-        M, K = x.shape
-        N = W.shape[0]
-        y = np.zeros((M, N), np.float32)
+        rows, depth = x.shape
+        cols = W.shape[0]
+        y = np.zeros((rows, cols), np.float32)
         b = _f32(bias) if bias is not None else None
-        xq = np.zeros((M, K), np.uint8)
-        wq = np.zeros((N, K), np.uint8)
+        xq = np.zeros((rows, depth), np.uint8)
+        wq = np.zeros((cols, depth), np.uint8)
         ap = np.zeros(2, np.float32)
-        ws = np.zeros(N, np.float32)
-        wz = np.zeros(N, np.int32)
+        ws = np.zeros(cols, np.float32)
+        wz = np.zeros(cols, np.int32)
         u8 = C.POINTER(C.c_uint8)
-        N.check(self._lib.pf_op_qlinear(self._h, _fp(x), _fp(W), _fp(b) if b is not None else None, M, N, K, 1 if relu else 0,
-                                        1 if x_is_f16 else 0, _fp(y), xq.ctypes.data_as(u8), _fp(ap), wq.ctypes.data_as(u8), _fp(ws),
-                                        wz.ctypes.data_as(C.POINTER(C.c_int32))))
+        N.check(self._lib.pf_op_qlinear(self._h, _fp(x), _fp(W), _fp(b) if b is not None else None, rows, cols, depth,
+                                        1 if relu else 0, 1 if x_is_f16 else 0, _fp(y), xq.ctypes.data_as(u8), _fp(ap),
+                                        wq.ctypes.data_as(u8), _fp(ws), wz.ctypes.data_as(C.POINTER(C.c_int32))))
         return (y, xq, (float(ap[0]), int(ap[1])), wq, ws, wz) if details else y
 
     def op_argmax(self, x) -> np.ndarray:
