@@ -6,9 +6,12 @@ oracle/int8.py — the uint8 activations, their scale / zero point, the per-chan
 must be identical bit for bit (the integer accumulators are exact by construction: v_mfma_i32_32x32x32_i8 + exact int32
 correction terms; a single differing accumulator would change y).
 
-Model level: the engine in math_mode 2 against `Oracle(quant="int8")` (same graph, same 16-bit storage points).  A uint8
-activation that sits on a rounding boundary may land on the neighbouring code when LayerNorm / attention differ in the
-last bits, which moves one product by one quantisation step — so log-probs are compared with a tolerance, not bit for bit.
+Model level: the engine in math_mode 2 against `Oracle(quant="int8")` (same graph, same 16-bit storage points).  The
+products are exact, but the engine's attention (f16 MFMA soft-max) and LayerNorm differ from the oracle's by ~1e-3
+relative, and an activation within that distance of a rounding boundary lands on the neighbouring uint8 code: a few per
+cent of the codes move by one step (range / 255), i.e. ~0.5 % noise per quantised product, a few 1e-2 on the log-probs
+after ~200 of them (the two oracles `int8` and `int8_ref`, which differ only in their 16-bit storage points, are 6e-2
+apart themselves).  Hence a tolerance here and bit-exactness at the operator level.
 """
 import numpy as np
 import pytest
@@ -100,7 +103,7 @@ def test_int8_paraformer_vs_oracle():
     assert res.logits.shape == ref["logits"].shape
     err = np.abs(res.logits - ref["logits"])
     print("int8 paraformer: max|dlogp| %.3e mean %.2e" % (err.max(), err.mean()))
-    assert err.max() < 0.3 and err.mean() < 3e-2          # TODO tighten once the op-level tests are green
+    assert err.max() < 0.3 and err.mean() < 3e-2          # measured 1.3e-1 / 2.1e-2: see the module docstring (code flips, not products)
     srt = np.sort(ref["logits"], axis=-1)
     safe = (srt[..., -1] - srt[..., -2]) > 0.3
     np.testing.assert_array_equal(res.token_ids[safe], om.argmax_last(ref["logits"])[safe])
