@@ -73,10 +73,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   try {
     PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     PF_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
-    PF_HIP(hipStreamCreateWithFlags(&dec_stream2_, hipStreamNonBlocking));
     PF_HIP(hipEventCreateWithFlags(&ev_scan_, hipEventDisableTiming));
-    PF_HIP(hipEventCreateWithFlags(&ev_dec_a_, hipEventDisableTiming));
-    PF_HIP(hipEventCreateWithFlags(&ev_dec_b_, hipEventDisableTiming));
     load_weights(cfg);
     mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
     fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
@@ -102,10 +99,7 @@ void Engine::release() {
   hipSetDevice(device_);
   if (stream_) hipStreamSynchronize(stream_);
   if (aux_stream_) { hipStreamSynchronize(aux_stream_); hipStreamDestroy(aux_stream_); aux_stream_ = nullptr; }
-  if (dec_stream2_) { hipStreamSynchronize(dec_stream2_); hipStreamDestroy(dec_stream2_); dec_stream2_ = nullptr; }
   if (ev_scan_) { hipEventDestroy(ev_scan_); ev_scan_ = nullptr; }
-  if (ev_dec_a_) { hipEventDestroy(ev_dec_a_); ev_dec_a_ = nullptr; }
-  if (ev_dec_b_) { hipEventDestroy(ev_dec_b_); ev_dec_b_ = nullptr; }
   if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
   profile_reset();
   if (fb_) { fbank_tables_destroy(fb_); fb_ = nullptr; }
@@ -993,9 +987,8 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
   const size_t o_x = carve(Mdp * D * 4), o_xn = carve(Mdp * D * 2);
-  const int64_t Mdp2 = Mdp + 768;                      // f16-result GEMM outputs: the second half starts at a padded row (decoder split)
-  const size_t o_h32 = carve(Mdp * F * 4), o_h16 = carve(Mdp2 * F * 2), o_t = carve(Mdp * D * 4), o_tn = carve(Mdp * D * 4);
-  const size_t o_q = carve(Mdp2 * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * round_up(V, 4) * 4), o_ids = carve((size_t)Md * 8);
+  const size_t o_h32 = carve(Mdp * F * 4), o_h16 = carve(Mdp * F * 2), o_t = carve(Mdp * D * 4), o_tn = carve(Mdp * D * 4);
+  const size_t o_q = carve(Mdp * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * round_up(V, 4) * 4), o_ids = carve((size_t)Md * 8);
   ensure(ws_dec_, off);
   char* base = (char*)ws_dec_.p;
   float* xd = (float*)(base + o_x); half_t* xdn16 = (half_t*)(base + o_xn);
@@ -1032,133 +1025,93 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
     dsmall = gemm_small_applicable(t);
   }
   const bool f_fsmn = (dec_fuse_ & 1) != 0, f_out = (dec_fuse_ & 2) != 0 && !dsmall, f_ffn2 = (dec_fuse_ & 4) != 0;
-  // The decoder's launches underfill the chip (M = B*L = 5344 rows: 84-336 tiles on 256 CUs, 2.3 ms for 12 % of the
-  // FLOPs) and utterances are independent, so the batch is cut in two halves of utterances whose layers are enqueued
-  // alternately on two streams: the kernels of one half run on the CUs the other half leaves idle.  (The encoder's
-  // kernels fill every CU; two engines on one GPU gain nothing there — measured)  Buffers are shared:
-  // every kernel writes exactly its own rows, except the f16-result GEMMs (whole-tile stores into row padding), whose
-  // outputs hd16 / qd16 therefore start at a padded row offset for the second half.  PF_DEC_SPLIT=0 disables.
-  static const bool split_env = [] { const char* e = getenv("PF_DEC_SPLIT"); return !(e && e[0] == '0'); }();
-  const bool split = split_env && !dsmall && B >= 2 && Md >= 2048 && (Md - Md / 2) * 1 > 0 && dec_stream2_ != nullptr;
-  struct Half { int b0, Bh, r0, rows; int64_t pad0; bool have_n1; hipStream_t s; };
-  Half hv[2];
-  const int nh = split ? 2 : 1;
-  const int B0 = split ? B / 2 : B;
-  hv[0] = Half{0, B0, 0, B0 * L, 0, false, stream_};
-  hv[1] = Half{B0, B - B0, B0 * L, (B - B0) * L, round_up((int64_t)B0 * L, 256) + 256, false, dec_stream2_};
-  hipStream_t const main_stream = stream_;
-  if (split) {
-    PF_HIP(hipEventRecord(ev_dec_a_, main_stream));
-    PF_HIP(hipStreamWaitEvent(dec_stream2_, ev_dec_a_, 0));
-  }
+  bool have_n1 = false;                                // xdn16 already holds norm1(xd) of the coming block
   // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or
-  // post(t) in n32 / n16 (row pointers of the half)
-  auto ffn_dec = [&](Half& H, const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const LNp& post, float* n32, half_t* n16) {
-    float* xd_h = xd + (size_t)H.r0 * D; half_t* xdn_h = xdn16 + (size_t)H.r0 * D;
-    float* hd32_h = hd32 + (size_t)H.r0 * F; half_t* hd16_h = hd16 + (size_t)H.pad0 * F;
-    float* t32_h = t32 + (size_t)H.r0 * D;
-    const int Mh = H.rows;
+  // post(t) in n32 / n16
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const LNp& post, float* n32, half_t* n16) {
     if (dsmall) {
       // short inputs: norm1 | FFN-up | LayerNorm(2048) in place | FFN-down partials | their sum + the LayerNorm behind it
       prof_begin("layernorm", 0);
-      launch_layernorm(stream_, xd_h, Mh, D, n1.g, n1.b, xdn_h, D, nullptr, 0);
+      launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
       prof_end("layernorm");
-      dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn_h, D, Mh, hd32_h, hd16_h);
+      dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn16, D, Md, hd32, hd16);
       GemmSmallArgs dn{};
-      dn.M = Mh; dn.A = hd16_h; dn.lda = F;
+      dn.M = Md; dn.A = hd16; dn.lda = F;
       dn.post_ln_g = post.g; dn.post_ln_b = post.b; dn.post_n16 = n16; dn.ldn16 = D; dn.post_n32 = n32; dn.ldn32 = D;
       gemm_small_call("gemm_dec_ffn2", w2, dn, false);
-      H.have_n1 = false;
+      have_n1 = false;
       return;
     }
-    if (!H.have_n1) {
+    if (!have_n1) {
       prof_begin("layernorm", 0);
-      launch_layernorm(stream_, xd_h, Mh, D, n1.g, n1.b, xdn_h, D, nullptr, 0);
+      launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
       prof_end("layernorm");
     }
-    H.have_n1 = false;
-    dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn_h, D, Mh, hd32_h, hd16_h);
+    have_n1 = false;
+    dec_ffn_hidden("gemm_dec_ffn1", w1, fn, xdn16, D, Md, hd32, hd16);
     if (f_ffn2) {
       GemmRcArgs g{};
-      g.A = hd16_h; g.lda = F; g.W = w2.w; g.ldw = w2.Kpad; g.bias = nullptr; g.M = Mh; g.K = w2.Kpad;
+      g.A = hd16; g.lda = F; g.W = w2.w; g.ldw = w2.Kpad; g.bias = nullptr; g.M = Md; g.K = w2.Kpad;
       g.ln_g = post.g; g.ln_b = post.b; g.eps = 1e-12f;
       g.out_n32 = n32; g.ldn32 = D; g.out_n16 = n16; g.ldn16 = D;
-      prof_begin("gemm_dec_ffn2", 2.0 * Mh * (double)D * F);
+      prof_begin("gemm_dec_ffn2", 2.0 * Md * (double)D * F);
       launch_gemm_rc(stream_, g);
       prof_end("gemm_dec_ffn2");
     } else {
-      gemm("gemm_dec_ffn2", w2, hd16_h, F, Mh, t32_h, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
+      gemm("gemm_dec_ffn2", w2, hd16, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, false);
       prof_begin("layernorm", 0);
-      launch_layernorm(stream_, t32_h, Mh, D, post.g, post.b, n16, D, n32, n32 ? D : 0);
+      launch_layernorm(stream_, t32, Md, D, post.g, post.b, n16, D, n32, n32 ? D : 0);
       prof_end("layernorm");
     }
   };
-  auto layer = [&](Half& H, int i) {
+
+  for (int i = 0; i < nd; ++i) {
     const DecLayer& Lr = dec_[i];
-    float* xd_h = xd + (size_t)H.r0 * D; half_t* xdn_h = xdn16 + (size_t)H.r0 * D;
-    float* tn32_h = tn32 + (size_t)H.r0 * D;
-    half_t* qd_h = qd16 + (size_t)H.pad0 * D; half_t* ctx_h = ctxd16 + (size_t)H.r0 * D;
-    const int32_t* tnum = plan_.token_num + H.b0;
-    const int Mh = H.rows;
-    ffn_dec(H, Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2, Lr.norm2, tn32_h, nullptr);
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2, Lr.norm2, tn32, nullptr);
     bool fused = false;
     if (f_fsmn) {
       prof_begin("fsmn", 0);
-      fused = launch_fsmn_dec_ln(stream_, tn32_h, Lr.fsmn_wT, tnum, H.Bh, L, D, mc_.kernel, xd_h, Lr.norm3.g, Lr.norm3.b, xdn_h);
+      fused = launch_fsmn_dec_ln(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd, Lr.norm3.g, Lr.norm3.b, xdn16);
       prof_end("fsmn");
     }
     if (!fused) {
       prof_begin("fsmn", 0);
-      launch_fsmn_dec(stream_, tn32_h, Lr.fsmn_wT, tnum, H.Bh, L, D, mc_.kernel, xd_h);
+      launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
       prof_end("fsmn");
       prof_begin("layernorm", 0);
-      launch_layernorm(stream_, xd_h, Mh, D, Lr.norm3.g, Lr.norm3.b, xdn_h, D, nullptr, 0);
+      launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, xdn16, D, nullptr, 0);
       prof_end("layernorm");
     }
-    gemm("gemm_dec_q", Lr.q, xdn_h, D, Mh, nullptr, 0, qd_h, D, nullptr, 0, nullptr, 0, false, D, qscale);
+    gemm("gemm_dec_q", Lr.q, xdn16, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
     AttnArgs a{};
-    a.q = qd_h; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
-    a.k = kv16 + (size_t)H.b0 * T * ldkv + (size_t)i * 2 * D; a.v = a.k + D;
+    a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
+    a.k = kv16 + (size_t)i * 2 * D; a.v = kv16 + (size_t)i * 2 * D + D;
     a.k_bstride = a.v_bstride = (int64_t)T * ldkv; a.k_rstride = a.v_rstride = ldkv;
-    a.o = ctx_h; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
-    a.B = H.Bh; a.H = mc_.heads; a.Lq = L; a.Lk = T;
-    prof_begin("attn_cross", 4.0 * H.Bh * (double)L * T * D);
+    a.o = ctxd16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
+    a.B = B; a.H = mc_.heads; a.Lq = L; a.Lk = T;
+    prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
     launch_attention(stream_, a);
     prof_end("attn_cross");
     if (f_out) {
       const LNp& nxt = i + 1 < nd ? dec_[i + 1].norm1 : dec_final_norm1_;
       GemmRcArgs g{};
-      g.A = ctx_h; g.lda = D; g.W = Lr.out.w; g.ldw = Lr.out.Kpad; g.bias = Lr.out.bias; g.M = Mh; g.K = Lr.out.Kpad;
-      g.resid = xd_h; g.ldr = D; g.out_x = xd_h; g.ldx = D;
-      g.ln_g = nxt.g; g.ln_b = nxt.b; g.eps = 1e-12f; g.out_n16 = xdn_h; g.ldn16 = D;
-      prof_begin("gemm_dec_out", 2.0 * Mh * (double)D * D);
+      g.A = ctxd16; g.lda = D; g.W = Lr.out.w; g.ldw = Lr.out.Kpad; g.bias = Lr.out.bias; g.M = Md; g.K = Lr.out.Kpad;
+      g.resid = xd; g.ldr = D; g.out_x = xd; g.ldx = D;
+      g.ln_g = nxt.g; g.ln_b = nxt.b; g.eps = 1e-12f; g.out_n16 = xdn16; g.ldn16 = D;
+      prof_begin("gemm_dec_out", 2.0 * Md * (double)D * D);
       launch_gemm_rc(stream_, g);
       prof_end("gemm_dec_out");
-      H.have_n1 = true;
+      have_n1 = true;
     } else {
-      gemm("gemm_dec_out", Lr.out, ctx_h, D, Mh, xd_h, D, nullptr, 0, xd_h, D, nullptr, 0, false, 0, 1.f);
+      gemm("gemm_dec_out", Lr.out, ctxd16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
     }
-  };
-  logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
-  auto tail = [&](Half& H) {
-    half_t* xdn_h = xdn16 + (size_t)H.r0 * D;
-    ffn_dec(H, dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_, dec_after_,
-            hid32 ? hid32 + (size_t)H.r0 * D : nullptr, xdn_h);
-    gemm("gemm_vocab", dec_out_, xdn_h, D, H.rows, logits_ + (size_t)H.r0 * logits_ld_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0,
-         false, 0, 1.f);
-    prof_begin("argmax", 0);
-    launch_argmax(stream_, logits_ + (size_t)H.r0 * logits_ld_, H.rows, V, logits_ld_, want_logits ? 2 : 1, ids_dev_ + H.r0);
-    prof_end("argmax");
-  };
-  // layers of the two halves enqueued alternately (the host enqueues faster than the device drains either stream)
-  for (int i = 0; i < nd; ++i)
-    for (int h = 0; h < nh; ++h) { stream_ = hv[h].s; layer(hv[h], i); }
-  for (int h = 0; h < nh; ++h) { stream_ = hv[h].s; tail(hv[h]); }
-  stream_ = main_stream;
-  if (split) {
-    PF_HIP(hipEventRecord(ev_dec_b_, dec_stream2_));
-    PF_HIP(hipStreamWaitEvent(main_stream, ev_dec_b_, 0));
   }
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_, dec_after_, hid32, xdn16);
+  logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
+  gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  prof_begin("argmax", 0);
+  launch_argmax(stream_, logits_, Md, V, logits_ld_, want_logits ? 2 : 1, ids_dev_);
+  prof_end("argmax");
   if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
 }

@@ -194,8 +194,6 @@ class Engine {
   hipStream_t stream_ = nullptr;
   hipStream_t aux_stream_ = nullptr;   // carries the decoder-length read-back, so stream_ keeps running (K/V projections) meanwhile
   hipEvent_t ev_scan_ = nullptr;       // CIF scan finished
-  hipStream_t dec_stream2_ = nullptr;  // second half of the utterances through the decoder (engine.cpp predictor_and_decoder)
-  hipEvent_t ev_dec_a_ = nullptr, ev_dec_b_ = nullptr;
   bool no_rc_ = false, rc_ffn2_ = false, lstm_steps_ = false;
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)

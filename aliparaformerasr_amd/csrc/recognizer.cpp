@@ -275,6 +275,14 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   ec.frame_shift_ms = 0;
   ec.window = conf_.window.c_str();
   ec.use_itn = conf_.use_itn ? 1 : 0;
+  // `-accuracy int8` (the reference CLI's default, Examples/Program.cs:98-101) selects the arithmetic through the FILE
+  // NAME there (model.int8.onnx vs model.onnx, Examples/OfflineAliParaformerAsrRecognizer.cs:17-22); the same
+  // convention here: a container named *.int8.* runs with dynamically quantised Linear layers (math_mode 2)
+  {
+    const size_t sl = model.find_last_of("/\\");
+    const std::string fname = sl == std::string::npos ? model : model.substr(sl + 1);
+    if (fname.find(".int8.") != std::string::npos) ec.math_mode = 2;
+  }
   engine_ = std::make_shared<Engine>(ec);
   uid_ = register_recognizer();
 }

@@ -285,6 +285,10 @@ def main():
     ap.add_argument("--seconds", type=int, default=0, help="utterance length (default 30; 10 for --model sensevoice)")
     ap.add_argument("--timestamp-head", action="store_true",
                     help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
+    ap.add_argument("--accuracy", choices=("f16", "int8"), default="f16",
+                    help="int8 = the arithmetic of the reference CLI's default model.int8.onnx (Examples/Program.cs:98-101): every "
+                         "Linear as DynamicQuantizeLinear + MatMulInteger on the int8 MFMA (pf_engine_config.math_mode 2); NOT the "
+                         "headline configuration")
     ap.add_argument("--group", type=int, default=0,
                     help="N > 0: ONE process driving pf_group_recognize over N devices (the path a C# caller gets: "
                          "host audio in, utterance shards, RCCL weight broadcast + all-gather of the ids inside the C ABI) "
@@ -346,7 +350,8 @@ def main():
     del blob
     n = wdev.numel()
     torch.cuda.synchronize()
-    eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local)
+    int8 = args.accuracy == "int8"
+    eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local, math_mode=2 if int8 else 0)
 
     # ---- workload: this rank's shard of the utterance list, staged to HBM before timing
     B = args.batch
@@ -423,7 +428,7 @@ def main():
     # ... and the right one: rank 0's ids against the fp32 CPU oracle's for this workload (tests/golden/), wherever
     # the oracle is decisive.  Only the three BASELINE workloads at their own shapes have a golden file.
     ids_check = None
-    if rank == 0 and seconds == (10 if sv else SECONDS) and not (args.timestamp_head and args.model == "paraformer"):
+    if rank == 0 and not int8 and seconds == (10 if sv else SECONDS) and not (args.timestamp_head and args.model == "paraformer"):
         ids_check = golden_check(args.model, res.token_ids, res.token_num)
         assert ids_check is None or ids_check["ok"], "ids differ from the fp32 oracle on decisive positions: %r" % (ids_check,)
 
@@ -448,13 +453,14 @@ def main():
                      "gemm_out": dom_rows * (Kk * 2 + Nn * 2 + Nn * 4 + Nn * 4 + Nn * 2) + Nn * Kk * 2 + Nn * 4,
                      "gemm_ffn1": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
                      "gemm_ffn2": dom_rows * (Kk * 2 + Nn * 4 + Nn * 4) + Nn * Kk * 2}[dominant]
-        headline = not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS
+        headline = not int8 and not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS
         out = {
             "metric": "RTFx (audio-sec/wall-sec), %s offline, batch %dx%ds per GPU"
                       % ("sensevoice-small" if sv else "paraformer-large", B, seconds),
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8 (u8 x u8 -> i32 Linear layers as model.int8.onnx; f16 attention)" if int8 else "f16", "data": "synthetic",
             "config": {"workload": "%s offline%s, batch %dx%d s synthetic 16 kHz per GPU "
                                    "(BASELINE.json configs[%d]), seeded synthetic weights"
                                    % ("sensevoice-small (use_itn on)" if sv else ("SeACo-paraformer, 21 hotwords" if args.model == "seaco" else "paraformer-large-zh"),
@@ -472,7 +478,7 @@ def main():
             "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12,
             "whole_path_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
             "whole_path_frac_of_mfma_peak": flops_step * args.steps / dt / 1e12 / PEAK_F16_TFLOPS,
-            "roofline": {"bound": "mfma",
+            "roofline": {"bound": "mfma", "peak_note": "dense f16 MFMA; the int8 MFMA peak is 2x" if int8 else None,
                          "kernel": "%s (class %s, the encoder GEMM class with the largest share of the step: [%d x %d] x [%d x %d], %s)"
                                    % (dom_kernel, dominant, dom_rows, Kk, Kk, Nn, what),
                          "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,

@@ -1,4 +1,4 @@
-// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 2).
+// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 3).
 // Drop into the reference project (AliParaformerAsr/Native/) — see csharp/README.md.  Not compiled in the build
 // image of this repository (no .NET toolchain); the same entry points are exercised through the Python ctypes
 // binding aliparaformerasr_amd/_native.py by tests/.
@@ -21,7 +21,10 @@ namespace AliParaformerAsr.Native
         public float dither;
         public IntPtr window;
         public int use_itn;
-        public int frame_length_ms, frame_shift_ms, dither_seed, math_mode;
+        public int frame_length_ms, frame_shift_ms, dither_seed;
+        /// <summary>0 = f16 MFMA (model.onnx semantics, default), 1 = fp32 MFMA parity mode, 2 = dynamic int8 as the
+        /// reference's default model.int8.onnx computes (Examples/Program.cs:98-101): Linear layers on the int8 MFMA.</summary>
+        public int math_mode;
         public int reserved0, reserved1, reserved2;
     }
 
@@ -68,6 +71,17 @@ namespace AliParaformerAsr.Native
         [DllImport(Lib)] internal static extern int pf_group_recognize(IntPtr g, IntPtr[] samples, long[] nSamples, int B,
                                                                       int[]? hotwords, int nHotwords, ref PfBatchOut o);
         [DllImport(Lib)] internal static extern int pf_group_fetch(IntPtr g, ref PfBatchOut o);
+        /// <summary>Host-only rehearsal of pf_group_recognize's shard plan / rendez-vous / merge (no GPU): see paraformer_hip.h.</summary>
+        [DllImport(Lib)] internal static extern int pf_host_group_sim(int G, int B, int[] fireCount, int hasCif, int fixedL, int collective,
+                                                                     int failShard, int failStage, [Out] long[] idsOut, int lCap,
+                                                                     [Out] int[] tokenNumOut, out int L);
+
+        // ---- profiling (bench harness) ---------------------------------------------------------------------------
+        [DllImport(Lib)] internal static extern int pf_profile_enable(IntPtr e, int on);
+        [DllImport(Lib)] internal static extern int pf_profile_reset(IntPtr e);
+        [DllImport(Lib, CharSet = CharSet.Ansi)] internal static extern int pf_profile_select(IntPtr e, string? className);
+        [DllImport(Lib, CharSet = CharSet.Ansi)] internal static extern int pf_profile_get(IntPtr e, string className, out double totalMs, out long launches, out double flopsPerLaunch);
+        [DllImport(Lib, CharSet = CharSet.Ansi)] internal static extern int pf_profile_kernel(IntPtr e, string className, [Out] byte[] nameOut, int cap);
 
         // ---- whole-class mirror (OfflineRecognizer / OfflineStream) ---------------------------------------------
         [DllImport(Lib, CharSet = CharSet.Ansi)]

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2
+#define PF_ABI_VERSION 3
 
 typedef enum pf_status {
   PF_OK = 0,
