@@ -14,7 +14,7 @@ mismatch with a real file fails loudly instead of producing a silently wrong mod
     python -m aliparaformerasr_amd.convert model.pt out.pfw [--kind paraformer|seacoparaformer|sensevoicesmall]
                                                            [--timestamp]
     python -m aliparaformerasr_amd.convert model.int8.onnx out.pfw [--eb model_eb.int8.onnx] [--kind ...]
-        (ONNX graph walk, see onnx_to_state_dict; int8 files are de-quantised)
+        (ONNX graph walk, see onnx_to_state_dict; an int8 file's stored bytes are carried beside their float image)
 """
 from __future__ import annotations
 
@@ -143,6 +143,11 @@ def state_dict_to_pfw(sd: dict, cfg: dict) -> dict:
             want[0] = got[0]                                        # vocabulary-sized
         if want != got:
             raise ValueError("%s: shape %s, expected %s" % (k, got, want))
+    for k, v in nm.items():                                         # an int8 export's stored bytes travel beside the float image
+        if v + "_q" in sd and v + "_zp" in sd and v + "_scale" in sd and np.asarray(sd[v + "_q"]).shape == out[k].shape:
+            out[k + "_q"] = np.ascontiguousarray(sd[v + "_q"], np.uint8)
+            out[k + "_zp"] = np.ascontiguousarray(sd[v + "_zp"], np.uint8)
+            out[k + "_scale"] = np.ascontiguousarray(sd[v + "_scale"], np.float32)
     return out
 
 
@@ -155,12 +160,16 @@ def _reorder_gates(a, H):
     return np.concatenate([blocks[k] for k in _LSTM_IOFC_TO_IFGO], axis=0)
 
 
+_Q_SUFFIXES = ("_q", "_zp", "_scale")         # `<linear>.weight` + suffix: the stored bytes of a quantised Linear
+
+
 def onnx_to_state_dict(graph, expected_names) -> dict:
     """Initializers of a FunASR ONNX export -> {FunASR parameter name: float32 array}.
 
-    * `X_quantized` + `X_scale` + `X_zero_point` (onnxruntime quantize_dynamic naming) are de-quantised to X —
-      the int8 files are therefore run with their de-quantised weights in the f16 path, not with ORT's dynamic
-      int8 activation arithmetic.
+    * `X_quantized` + `X_scale` + `X_zero_point` (onnxruntime quantize_dynamic naming) are de-quantised to X (what
+      math modes 0 / 1 multiply) AND carried as stored: `<linear>.weight_q` (uint8 [N, K]; a signed export's bytes are
+      shifted by 128 together with the zero point, which leaves q - zp unchanged), `<linear>.weight_zp` (uint8 [N]),
+      `<linear>.weight_scale` (float32 [N]; a per-tensor scale is repeated) — what math_mode 2 multiplies.
     * torch.onnx exports nn.Linear on 3-D inputs as MatMul(x, W^T) with an anonymous initializer followed by
       Add(bias): the weight is named after the bias it feeds; the bias-free decoder `feed_forward.w_2` is named
       after the `feed_forward.norm` LayerNorm that produces its input.
@@ -171,12 +180,19 @@ def onnx_to_state_dict(graph, expected_names) -> dict:
     reported by state_dict_to_pfw as missing."""
     ini = dict(graph.initializers)
     flt = {}
+    stored = {}                      # base -> (q uint8 [K, N], zp uint8 [N], scale float32 [N]) of a 2-D quantised MatMul operand
     for name, arr in ini.items():
         if name.endswith("_quantized") and (name[:-10] + "_scale") in ini:
             base = name[:-10]
             scale = np.asarray(ini[base + "_scale"], np.float32)
-            zp = np.asarray(ini.get(base + "_zero_point", 0)).astype(np.float32)
+            zpi = np.asarray(ini.get(base + "_zero_point", 0))
+            zp = zpi.astype(np.float32)
             flt[base] = ((arr.astype(np.float32) - zp) * scale).astype(np.float32)
+            if arr.ndim == 2 and arr.dtype in (np.uint8, np.int8) and scale.size in (1, arr.shape[1]) and zpi.size in (1, arr.shape[1]):
+                shift = 128 if arr.dtype == np.int8 else 0
+                stored[base] = ((arr.astype(np.int32) + shift).astype(np.uint8),
+                                np.broadcast_to((zpi.astype(np.int32) + shift).astype(np.uint8).reshape(-1), (arr.shape[1],)).copy(),
+                                np.broadcast_to(scale.reshape(-1), (arr.shape[1],)).astype(np.float32).copy())
         elif arr.dtype in (np.float32, np.float16, np.float64) and not name.endswith(("_scale", "_zero_point")):
             flt[name] = arr.astype(np.float32)
 
@@ -213,6 +229,9 @@ def onnx_to_state_dict(graph, expected_names) -> dict:
                     val, depth = (pr.inputs[0] if pr.inputs else None), depth + 1
             if target is not None and target not in sd:
                 sd[target] = np.ascontiguousarray(wt.T)
+                if base_of(node.inputs[1]) in stored:
+                    q, zp, sc = stored[base_of(node.inputs[1])]
+                    sd[target + "_q"], sd[target + "_zp"], sd[target + "_scale"] = np.ascontiguousarray(q.T), zp, sc
     uni = 0
     for node in graph.nodes:
         if node.op_type != "LSTM" or len(node.inputs) < 3:
@@ -240,10 +259,12 @@ def onnx_to_state_dict(graph, expected_names) -> dict:
     aliases = {"embedding.weight": "bias_embed.weight", "embed.weight": "embed.weight"}
     exp = sorted(expected_names, key=len, reverse=True)
     for k, v in sd.items():
-        cands = {k, k.replace(".model.", "."), aliases.get(k, k)}
+        sfx = next((x for x in _Q_SUFFIXES if k.endswith(".weight" + x)), "")
+        k0 = k[:len(k) - len(sfx)]
+        cands = {k0, k0.replace(".model.", "."), aliases.get(k0, k0)}
         for e in exp:
             if any(c == e or c.endswith("." + e) for c in cands):
-                out.setdefault(e, v)
+                out.setdefault(e + sfx, v)
                 break
     return out
 

@@ -9,6 +9,7 @@
 #include "group.h"
 #include "online.h"
 #include "recognizer.h"
+#include "shards_sim.h"
 
 namespace pf {
 static thread_local std::string g_last_error;
@@ -366,69 +367,13 @@ int pf_group_recognize(pf_group* h, const float* const* samples, const int64_t* 
   PF_CATCH
 }
 
-// ---- pf_host_group_sim: the shard runner of pf_group with arithmetic stand-ins for the devices -------------------
-namespace {
-struct SimBackend : pf::ShardBackend {
-  int G, B, has_cif, fixed_L, collective, fail_shard, fail_stage;
-  const int32_t* fire;
-  std::vector<std::vector<char>> send;     // one block per shard
-  std::vector<size_t> sizes;               // the count each shard would hand to ncclAllGather
-  std::vector<char> recv0;                 // shard 0's receive buffer
-  pf::MaxBarrier bar;
-  std::vector<pf::HostBatchOut*> outs;
-  SimBackend(int G_) : G(G_), send((size_t)G_), sizes((size_t)G_, 0), bar(G_), outs((size_t)G_, nullptr) {}
-  void run(int g, int lo, int hi, int /*Tg*/, bool /*want_logits*/, const std::function<int(int)>& l_sync, pf::HostBatchOut& r) override {
-    if (g == fail_shard && fail_stage == 0) throw pf::Error(PF_ERR_DEVICE, "simulated failure before the decoder-length rendez-vous");
-    const int Bg = hi - lo;
-    int own = 0;
-    for (int b = lo; b < hi; ++b) own = std::max(own, fire[b]);
-    const int L = has_cif ? l_sync(own) : fixed_L;
-    if (g == fail_shard && fail_stage == 1) throw pf::Error(PF_ERR_DEVICE, "simulated failure after the decoder-length rendez-vous");
-    r = pf::HostBatchOut();
-    r.B = Bg; r.L = L; r.V = 1;
-    r.ids.resize((size_t)Bg * L);
-    r.token_num.resize((size_t)Bg); r.fire_count.resize((size_t)Bg);
-    for (int b = 0; b < Bg; ++b) {
-      for (int l = 0; l < L; ++l) r.ids[(size_t)b * L + l] = (int64_t)(lo + b) * 100000 + l;
-      r.token_num[(size_t)b] = has_cif ? fire[lo + b] : L;
-      r.fire_count[(size_t)b] = fire[lo + b];
-    }
-    outs[(size_t)g] = &r;
-  }
-  bool has_collective() const override { return collective != 0; }
-  void prepare_gather(int g, int count, int L, const pf::GatherLayout& lay, int) override {
-    if (g == fail_shard && fail_stage == 2) throw pf::Error(PF_ERR_DEVICE, "simulated failure while preparing the gather");
-    sizes[(size_t)g] = lay.block_bytes;
-    send[(size_t)g].assign(lay.block_bytes, (char)0xFF);
-    if (count > 0 && L > 0) {
-      const pf::HostBatchOut& r = *outs[(size_t)g];
-      std::memcpy(send[(size_t)g].data(), r.ids.data(), (size_t)count * L * 8);
-      if (has_cif) std::memcpy(send[(size_t)g].data() + lay.ids_bytes, r.token_num.data(), (size_t)count * 4);
-    }
-  }
-  void gather(int g, const pf::GatherLayout& lay, int) override {
-    bar.arrive_and_max(0);                                       // every block is packed
-    if (g == 0) {
-      for (int i = 0; i < G; ++i)                                // what RCCL requires of its callers
-        PF_CHECK(sizes[(size_t)i] == lay.block_bytes, PF_ERR_DEVICE, "all-gather entered with different counts on different ranks");
-      recv0.resize(lay.block_bytes * (size_t)G);
-      for (int i = 0; i < G; ++i) std::memcpy(recv0.data() + lay.block_bytes * (size_t)i, send[(size_t)i].data(), lay.block_bytes);
-    }
-    bar.arrive_and_max(0);
-  }
-  void read_gathered(std::vector<char>& host, size_t bytes) override {
-    PF_CHECK(bytes == recv0.size(), PF_ERR_DEVICE, "merge expects a different gather size than the collective produced");
-    host = recv0;
-  }
-};
-}  // namespace
-
+// ---- pf_host_group_sim: the shard runner of pf_group with arithmetic stand-ins for the devices (shards_sim.h) ----
 int pf_host_group_sim(int32_t G, int32_t B, const int32_t* fire_count, int32_t has_cif, int32_t fixed_L, int32_t collective,
                       int32_t fail_shard, int32_t fail_stage, int64_t* ids_out, int32_t l_cap, int32_t* token_num_out,
                       int32_t* L_out) {
   PF_TRY
   PF_CHECK(G > 0 && G <= 64 && B >= 0 && (B == 0 || fire_count), PF_ERR_INVALID_ARG, "pf_host_group_sim: bad arguments");
-  SimBackend be(G);
+  pf::SimBackend be(G);
   be.B = B; be.has_cif = has_cif; be.fixed_L = fixed_L; be.collective = collective; be.fail_shard = fail_shard;
   be.fail_stage = fail_stage; be.fire = fire_count;
   pf::ShardRunner runner(G);

@@ -153,7 +153,15 @@ void Engine::check_async_errors() {
 const Engine::Tensor& Engine::tensor(const std::string& name) const {
   auto it = tensors_.find(name);
   if (it == tensors_.end()) throw Error(PF_ERR_FORMAT, "weights: missing tensor '" + name + "'");
+  if (it->second.u8) throw Error(PF_ERR_FORMAT, "weights: tensor '" + name + "' must be f32");
   return it->second;
+}
+
+const Engine::Tensor* Engine::tensor_u8(const std::string& name) const {
+  auto it = tensors_.find(name);
+  if (it == tensors_.end()) return nullptr;
+  if (!it->second.u8) throw Error(PF_ERR_FORMAT, "weights: tensor '" + name + "' must be u8");
+  return &it->second;
 }
 
 void Engine::load_weights(const pf_engine_config& cfg) {
@@ -251,7 +259,9 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   for (const Json& t : jt->arr) {
     Tensor tt;
     const std::string name = t.str_or("name", "");
-    PF_CHECK(t.str_or("dtype", "f32") == "f32", PF_ERR_FORMAT, "weights: only f32 tensors are supported");
+    const std::string dt = t.str_or("dtype", "f32");
+    PF_CHECK(dt == "f32" || dt == "u8", PF_ERR_FORMAT, "weights: tensor '" + name + "' has dtype '" + dt + "' (f32 and u8 are supported)");
+    tt.u8 = dt == "u8";
     const int64_t off = (int64_t)t.num_or("offset", -1), nb = (int64_t)t.num_or("nbytes", -1);
     PF_CHECK(off >= 0 && nb >= 0 && off + nb <= data_bytes && off % 16 == 0, PF_ERR_FORMAT,
              "weights: bad tensor extent for '" + name + "'");
@@ -266,8 +276,12 @@ void Engine::load_weights(const pf_engine_config& cfg) {
         tt.shape.push_back((int64_t)dv);
         tt.numel *= (int64_t)dv;
       }
-    PF_CHECK(tt.numel * 4 == nb, PF_ERR_FORMAT, "weights: shape/nbytes mismatch for '" + name + "'");
+    PF_CHECK(tt.numel * (tt.u8 ? 1 : 4) == nb, PF_ERR_FORMAT, "weights: shape/nbytes mismatch for '" + name + "'");
     tensors_[name] = tt;
+  }
+  for (const auto& kv : tensors_) {
+    const std::string& n = kv.first;
+    if (!kv.second.u8 && n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0) lin_names_[kv.second.dev] = n.substr(0, n.size() - 7);
   }
 
   // ---- bind layers, build f16 GEMM operands

@@ -142,11 +142,12 @@ class Engine {
   int device() const { return device_; }
 
  private:
-  struct Tensor { const float* dev = nullptr; std::vector<int64_t> shape; int64_t numel = 0; };
+  struct Tensor { const float* dev = nullptr; std::vector<int64_t> shape; int64_t numel = 0; bool u8 = false; };   // u8: dev points at bytes
   struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double flops = 0; int64_t n = 0; std::string kernel; };
 
   void load_weights(const pf_engine_config& cfg);
-  const Tensor& tensor(const std::string& name) const;
+  const Tensor& tensor(const std::string& name) const;          // float32 tensors only (a u8 tensor here is a format error)
+  const Tensor* tensor_u8(const std::string& name) const;       // nullptr when absent
   bool has_tensor(const std::string& name) const { return tensors_.count(name) != 0; }
   Lin make_lin(const std::string& prefix, bool bias);
   LNp make_ln(const std::string& prefix, int width);
@@ -203,6 +204,7 @@ class Engine {
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   bool int8_mode_ = false;           // math_mode 2: Linear layers dynamically quantised to uint8, products on the int8 MFMA
   std::map<const float*, QLin> qlins_;
+  std::map<const float*, std::string> lin_names_;     // float32 `<linear>.weight` device pointer -> `<linear>` (stored int8 bytes lookup)
   DevBuf ws_q_;                      // quantised activations: a' [Mp, Kpad], row sums, {scale, zp}, min / max scratch
   int8_t* q_a_ = nullptr; int32_t* q_rowsum_ = nullptr; float* q_params_ = nullptr; unsigned* q_scratch_ = nullptr;
   int64_t q_rows_ = 0; int q_kpad_ = 0;

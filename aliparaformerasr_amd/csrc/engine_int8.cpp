@@ -8,9 +8,9 @@
 // accumulation (k_gemm.hip gemm_i8_pp3); everything else — LayerNorm, FSMN, attention (f16 MFMA), CIF, soft-max, arg-max
 // — is the f16 path's kernels.  What is NOT quantised, as in the export: the depthwise FSMN convolutions, the CIF
 // Conv1d (Conv nodes) and the N = 1 predictor output (kept fp32 here).
-// Weights: the container carries fp32 tensors; they are quantised at first use on the device with quantize_dynamic's
-// per-channel algorithm (a real model.int8.onnx is de-quantised by the converter and re-quantised here, which recovers
-// the stored bytes; carrying the bytes through the container is the remaining step).
+// Weights: a container converted from an int8 export carries the stored bytes (`<linear>.weight_q` u8, `.weight_zp` u8,
+// `.weight_scale` f32, aliparaformerasr_amd/convert.py) and those are what is multiplied; a container with fp32 tensors
+// only (the synthetic models) is quantised at first use on the device with quantize_dynamic's per-channel algorithm.
 #include <cmath>
 #include <cstring>
 
@@ -50,7 +50,18 @@ const QLin& Engine::qlin_raw(const float* w32, const float* bias, int N, int K) 
   PF_HIP(hipMemsetAsync(q.colsum, 0, (size_t)(N + 8) * 4, stream_));
   PF_HIP(hipMemsetAsync(q.wzp, 0, (size_t)(N + 8) * 4, stream_));
   PF_HIP(hipMemsetAsync(q.wscale, 0, (size_t)(N + 8) * 4, stream_));
-  launch_quantize_weight(stream_, w32, N, K, q.w, q.Kpad, q.colsum, q.wzp, q.wscale);
+  // an int8 export's container carries the stored bytes beside the float image: multiply THOSE (no re-quantisation)
+  const auto nm = lin_names_.find(w32);
+  const Tensor* sq = nm == lin_names_.end() ? nullptr : tensor_u8(nm->second + ".weight_q");
+  if (sq) {
+    const Tensor* sz = tensor_u8(nm->second + ".weight_zp");
+    const Tensor& ss = tensor(nm->second + ".weight_scale");
+    PF_CHECK(sz && sq->shape.size() == 2 && sq->shape[0] == N && sq->shape[1] == K && sz->numel == N && ss.numel == N, PF_ERR_FORMAT,
+             "weights: '" + nm->second + "' weight_q / weight_zp / weight_scale do not match the Linear's [N, K]");
+    launch_import_weight(stream_, (const uint8_t*)sq->dev, (const uint8_t*)sz->dev, ss.dev, N, K, q.w, q.Kpad, q.colsum, q.wzp, q.wscale);
+  } else {
+    launch_quantize_weight(stream_, w32, N, K, q.w, q.Kpad, q.colsum, q.wzp, q.wscale);
+  }
   q.bias = bias;
   return qlins_.emplace(w32, q).first->second;
 }

@@ -172,4 +172,32 @@ void launch_quantize_weight(hipStream_t s, const float* W, int N, int K, int8_t*
   PF_HIP(hipGetLastError());
 }
 
+// the stored bytes of an int8 export (container tensors `<linear>.weight_q` u8 [N, K], `.weight_zp` u8 [N], `.weight_scale`
+// f32 [N]; aliparaformerasr_amd/convert.py) into the matrix-core operand: w' = q - 128, its column sums, zp - 128, scale.
+__global__ __launch_bounds__(256) void import_weight_kernel(const uint8_t* __restrict__ Q, const uint8_t* __restrict__ zp,
+                                                            const float* __restrict__ scale, int N, int K, int8_t* __restrict__ out, int ld,
+                                                            int32_t* __restrict__ colsum, int32_t* __restrict__ wzp, float* __restrict__ wscale) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const uint8_t* q = Q + (int64_t)n * K;
+  int sum = 0;
+  for (int k = lane; k < ld; k += 64) {
+    int v = 0;
+    if (k < K) { v = (int)q[k] - 128; sum += v; }
+    out[(int64_t)n * ld + k] = (int8_t)v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) { colsum[n] = sum; wzp[n] = (int)zp[n] - 128; wscale[n] = scale[n]; }
+}
+
+void launch_import_weight(hipStream_t s, const uint8_t* Q, const uint8_t* zp, const float* scale, int N, int K, int8_t* out, int ld,
+                          int32_t* colsum, int32_t* wzp, float* wscale) {
+  PF_CHECK(ld >= K, PF_ERR_INVALID_ARG, "import_weight: ld < K");
+  if (N == 0) return;
+  hipLaunchKernelGGL(import_weight_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, Q, zp, scale, N, K, out, ld, colsum, wzp, wscale);
+  PF_HIP(hipGetLastError());
+}
+
 }  // namespace pf

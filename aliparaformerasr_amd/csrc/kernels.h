@@ -71,6 +71,8 @@ void launch_quantize_rows(hipStream_t s, const float* x32, const half_t* x16, in
 // does it: row n of W [N, K] (fp32): rmin = min(0, min), rmax = max(0, max), scale = (rmax - rmin) / 255,
 // zp = rne(-rmin / scale) clamped to [0, 255], q = clamp(rne(w / scale) + zp, 0, 255) -> w' = q - 128 [N, ld], colsum, wzp = zp - 128, wscale
 void launch_quantize_weight(hipStream_t s, const float* W, int N, int K, int8_t* out, int ld, int32_t* colsum, int32_t* wzp, float* wscale);
+void launch_import_weight(hipStream_t s, const uint8_t* Q, const uint8_t* zp, const float* scale, int N, int K, int8_t* out, int ld,
+                          int32_t* colsum, int32_t* wzp, float* wscale);
 
 // Row-complete GEMM for N = 512 (k_gemm_rc.hip): x = resid + A W^T + bias + FSMN(V); n = LayerNorm(x).
 // One workgroup = 64 complete rows, so the residual add, the FSMN memory and the following LayerNorm are its epilogue.

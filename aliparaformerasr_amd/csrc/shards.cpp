@@ -39,10 +39,11 @@ void MaxBarrier::reset() {
 
 // ------------------------------------------------------------------ ShardRunner ------------
 ShardRunner::ShardRunner(int G) : lbar_(G), agree_(G), ready_(G) {
-  for (int i = 0; i < G; ++i) {
-    workers_.emplace_back(new Worker());
-    workers_.back()->th = std::thread([this, i] { worker_loop(i); });
-  }
+  // every Worker exists before the first thread starts: worker_loop indexes workers_, which must not grow under it
+  // (a thread started inside the emplace_back loop read the vector while it re-allocated — a crash once in a few runs)
+  workers_.reserve((size_t)G);
+  for (int i = 0; i < G; ++i) workers_.emplace_back(new Worker());
+  for (int i = 0; i < G; ++i) workers_[(size_t)i]->th = std::thread([this, i] { worker_loop(i); });
 }
 
 ShardRunner::~ShardRunner() {

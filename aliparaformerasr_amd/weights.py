@@ -9,13 +9,19 @@ little-endian container instead:
     bytes 8..15  u64    header_len
     header_len bytes of UTF-8 JSON:
         {"config": {...ModelConfig...},
-         "tensors": [{"name", "dtype": "f32", "shape": [...], "offset", "nbytes"}, ...]}
+         "tensors": [{"name", "dtype": "f32" | "u8", "shape": [...], "offset", "nbytes"}, ...]}
     zero padding to a 256-byte boundary, then tensor data; every ``offset`` is
     relative to the start of the data section and 256-byte aligned.
 
 Linear weights use the [out, in] (= [N, K]) layout, depthwise FSMN kernels
 [D, k], the CIF conv [out, in, k].  The native library converts GEMM operands
 to its 16-bit MFMA layout at load time; the file always carries float32.
+A container made from an int8 export (``model.int8.onnx``, the reference CLI's
+default, Program.cs:98-101) additionally carries, per quantised Linear, the
+stored bytes ``<linear>.weight_q`` (u8 [N, K]), ``<linear>.weight_zp`` (u8 [N])
+and ``<linear>.weight_scale`` (f32 [N]); ``math_mode 2`` multiplies those bytes
+as they are, ``<linear>.weight`` beside them is their de-quantised float32 image
+(math modes 0 / 1).
 
 Tensor inventory follows SURVEY.md §8a ("Tensor inventory for the
 synthetic-weight generator").
@@ -217,9 +223,10 @@ def pack_pfw(cfg: dict, weights: dict) -> bytes:
     off = 0
     chunks = []
     for name, arr in weights.items():
-        a = np.ascontiguousarray(arr, dtype=np.float32)
+        u8 = isinstance(arr, np.ndarray) and arr.dtype == np.uint8      # `<linear>.weight_q` / `.weight_zp`: stored bytes of an int8 export
+        a = np.ascontiguousarray(arr, dtype=np.uint8 if u8 else np.float32)
         nbytes = a.nbytes
-        tensors.append({"name": name, "dtype": "f32", "shape": list(a.shape), "offset": off, "nbytes": nbytes})
+        tensors.append({"name": name, "dtype": "u8" if u8 else "f32", "shape": list(a.shape), "offset": off, "nbytes": nbytes})
         chunks.append((off, a))
         off += (nbytes + ALIGN - 1) // ALIGN * ALIGN
     header = json.dumps({"config": cfg, "tensors": tensors}).encode("utf-8")
@@ -252,6 +259,9 @@ def load_pfw(path_or_bytes):
     base = (16 + hlen + ALIGN - 1) // ALIGN * ALIGN
     w = {}
     for t in hdr["tensors"]:
-        a = np.frombuffer(data, dtype=np.float32, count=t["nbytes"] // 4, offset=base + t["offset"])
+        if t.get("dtype", "f32") == "u8":
+            a = np.frombuffer(data, dtype=np.uint8, count=t["nbytes"], offset=base + t["offset"])
+        else:
+            a = np.frombuffer(data, dtype=np.float32, count=t["nbytes"] // 4, offset=base + t["offset"])
         w[t["name"]] = a.reshape(t["shape"]).copy()
     return hdr["config"], w

@@ -71,7 +71,9 @@ def qlinear(x: np.ndarray, wq: np.ndarray, wscale: np.ndarray, wzp: np.ndarray, 
 
 
 class QuantizedLinears:
-    """Caches quantize_weight() per tensor name for oracle.model.Oracle(quant="int8")."""
+    """Per tensor name for oracle.model.Oracle(quant="int8"): the stored bytes of an int8 export when the container
+    carries them (`<name>.weight_q` / `.weight_zp` / `.weight_scale`, aliparaformerasr_amd/convert.py), otherwise
+    quantize_weight() of the float tensor (the synthetic models)."""
 
     def __init__(self, weights: dict):
         self.w = weights
@@ -79,6 +81,10 @@ class QuantizedLinears:
 
     def __call__(self, x, name: str, bias: bool):
         if name not in self.cache:
-            self.cache[name] = quantize_weight(self.w[name + ".weight"])
+            if name + ".weight_q" in self.w:
+                self.cache[name] = (self.w[name + ".weight_q"].astype(np.int32), self.w[name + ".weight_scale"].astype(F32),
+                                    self.w[name + ".weight_zp"].astype(np.int32))
+            else:
+                self.cache[name] = quantize_weight(self.w[name + ".weight"])
         wq, ws, wz = self.cache[name]
         return qlinear(x, wq, ws, wz, self.w[name + ".bias"] if bias else None)

@@ -159,7 +159,7 @@ class Oracle:
         if self.int8:
             from .int8 import QuantizedLinears
             self.qlin = QuantizedLinears({k: np.ascontiguousarray(v) for k, v in weights.items()
-                                          if isinstance(v, np.ndarray) and v.dtype == np.float32})
+                                          if isinstance(v, np.ndarray) and v.dtype in (np.float32, np.uint8)})
 
     # -- helpers -----------------------------------------------------------
     def lin(self, x, name, bias=True):

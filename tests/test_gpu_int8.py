@@ -135,6 +135,77 @@ def test_int8_sensevoice_vs_oracle(sv_embed):
     eng.close()
 
 
+def test_int8_stored_bytes_of_an_export_are_what_is_multiplied():
+    """A container converted from model.int8.onnx carries the export's bytes (`<linear>.weight_q` / `_zp` / `_scale`,
+    tests/test_weights.py::test_int8_export_bytes_travel_through_the_container).  math_mode 2 must multiply THOSE: here
+    they come from a different quantiser than the engine's own (signed, per tensor, shifted to uint8 as the converter
+    does), and the vocabulary projection's stored rows are rolled by 7 against its float image — an engine that
+    re-quantised the float image would put every arg-max 7 ids away."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=515)
+    w = W.synth_weights(cfg, seed=12)
+    lin = [k for k in w if k.endswith(".weight") and w[k].ndim == 2 and
+           k.rsplit(".", 2)[-2] in ("qkv", "out", "w1", "w2", "q", "kv", "output") and not k.startswith("predictor.")]
+    assert len(lin) == 2 * 4 + 2 * 5 + 2 + 1            # encoder, decoder layers, decoder.final FFN, vocabulary projection
+    for k in lin:
+        scale = np.float32(np.abs(w[k]).max() / 127.0)
+        qv = np.clip(np.rint(w[k] / scale), -127, 127).astype(np.int32)
+        w[k] = (qv.astype(np.float32) * scale).astype(np.float32)
+        w[k + "_q"] = (qv + 128).astype(np.uint8)
+        w[k + "_zp"] = np.full(w[k].shape[0], 128, np.uint8)
+        w[k + "_scale"] = np.full(w[k].shape[0], scale, np.float32)
+    w["decoder.output.weight_q"] = np.roll(w["decoder.output.weight_q"], 7, axis=0)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=2)
+    audio = [W.synth_audio(n, 25 + u) for u, n in enumerate((40000, 28000))]
+    speech = _speech(audio, cmvn)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="int8").paraformer(speech)
+    res = eng.recognize(audio, want_logits=True)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    err = np.abs(res.logits - ref["logits"])
+    print("int8 stored bytes: max|dlogp| %.3e mean %.2e" % (err.max(), err.mean()))
+    assert err.max() < 0.3 and err.mean() < 3e-2
+    srt = np.sort(ref["logits"], axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 0.3
+    np.testing.assert_array_equal(res.token_ids[safe], om.argmax_last(ref["logits"])[safe])
+    # the float image (math modes 0 / 1, or a re-quantisation of it) says something else entirely
+    flt = {k: v for k, v in w.items() if v.dtype == np.float32 and not k.endswith("_scale")}
+    other = om.Oracle(om.ModelConfig(**cfg), flt, quant="int8").paraformer(speech)
+    assert other["logits"].shape == ref["logits"].shape
+    moved = om.argmax_last(other["logits"]) != om.argmax_last(ref["logits"])
+    assert moved[safe].mean() > 0.9
+    eng.close()
+    # the f16 path of the same container multiplies the float image and never touches the u8 tensors
+    e16 = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    r16 = e16.recognize(audio)
+    valid = np.arange(r16.token_ids.shape[1])[None, :] < r16.token_num[:, None]
+    f32 = om.Oracle(om.ModelConfig(**cfg), flt, quant="fp32").paraformer(speech)
+    if np.array_equal(f32["token_num"], r16.token_num):
+        assert (r16.token_ids == om.argmax_last(f32["logits"]))[valid].mean() > 0.9
+    e16.close()
+
+
+def test_int8_stored_bytes_are_shape_checked():
+    from aliparaformerasr_amd.engine import Engine
+    from aliparaformerasr_amd._native import PfError
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=64)
+    w = W.synth_weights(cfg, 4)
+    k = "encoder.layers.0.ffn.w1.weight"
+    wq, ws, wz = q8.quantize_weight(w[k])
+    bad = dict(w)
+    bad[k + "_q"], bad[k + "_zp"], bad[k + "_scale"] = wq.astype(np.uint8)[:, :-4], wz.astype(np.uint8), ws
+    eng = Engine(weights=W.pack_pfw(cfg, bad), cmvn=W.synth_cmvn(), device=0, math_mode=2)
+    with pytest.raises(PfError) as ei:
+        eng.recognize([W.synth_audio(16000, 1)])
+    assert "weight_q" in str(ei.value)
+    eng.close()
+    bad = dict(w)
+    bad[k] = wq.astype(np.uint8)                              # a u8 tensor where the float image belongs
+    with pytest.raises(PfError) as ei:
+        Engine(weights=W.pack_pfw(cfg, bad), cmvn=W.synth_cmvn(), device=0)
+    assert "must be f32" in str(ei.value)
+
+
 def test_int8_mode_refuses_heads_it_does_not_cover():
     from aliparaformerasr_amd.engine import Engine
     from aliparaformerasr_amd._native import PfError

@@ -2,7 +2,7 @@
 model directory (model.onnx / model.int8.onnx, asr.yaml, am.mvn, tokens.txt, optional model_eb*.onnx, *.wav).
 Neither such a directory nor onnxruntime exists in the build image, so this test has never run there; it documents
 and automates the check a user with the files can make:
-  1. ONNX -> PFW through aliparaformerasr_amd.convert (graph walk, int8 de-quantised),
+  1. ONNX -> PFW through aliparaformerasr_amd.convert (graph walk; an int8 file's bytes carried beside their float image),
   2. recognise every *.wav under the directory with the HIP path,
   3. if `onnxruntime` is importable: run the same padded features through the ONNX graph on CPU and require the
      arg-max token ids to be identical wherever the ORT top-1/top-2 log-prob margin exceeds 0.1."""

@@ -81,7 +81,7 @@ def test_funasr_state_dict_mapping_round_trip():
             cv.state_dict_to_pfw(bad, cfg)
 
 
-def _synthetic_export(cfg, w, int8_names=()):
+def _synthetic_export(cfg, w, int8_names=(), stored=None):
     """Builds ONNX bytes shaped like a torch.onnx export of the FunASR modules: LayerNorm / Conv / bias tensors
     keep their parameter names (behind an 'encoder.model.'-style wrapper segment), Linear weights are anonymous
     transposed MatMul operands, LSTMs are ONNX LSTM nodes (gate order i,o,f,c), optionally int8-quantised."""
@@ -133,11 +133,19 @@ def _synthetic_export(cfg, w, int8_names=()):
                 src = "ln_out_%d" % anon[0]
                 pre = fn[: -len("w_2.weight")]
                 nodes.append(("LayerNormalization", "ln%d" % anon[0], ["h_%d" % anon[0], wrap(pre + "norm.weight"), wrap(pre + "norm.bias")], [src], {}))
-            if fn in int8_names:
+            if fn in int8_names and stored is not None:
+                # quantize_dynamic(per_channel=True, weight_type=QUInt8): uint8 [K, N], scale / zero point per output channel
+                from oracle.int8 import quantize_weight
+                wq, ws, wz = quantize_weight(a)
+                ini[wn + "_quantized"], ini[wn + "_scale"], ini[wn + "_zero_point"] = wq.T.astype(np.uint8), ws, wz.astype(np.uint8)
+                w[k] = ((wq - wz[:, None]).astype(np.float32) * ws[:, None]).astype(np.float32)
+                stored[k] = (wq.astype(np.uint8), wz.astype(np.uint8), ws)
+            if fn in int8_names and stored is None:
                 scale = np.float32(np.abs(a).max() / 127.0)
                 qv = np.clip(np.round(a.T / scale), -127, 127).astype(np.int8)
                 ini[wn + "_quantized"], ini[wn + "_scale"], ini[wn + "_zero_point"] = qv, np.asarray(scale, np.float32), np.asarray(0, np.int8)
                 w[k] = (qv.astype(np.float32) * scale).T.copy()                  # what ingestion must return
+            if fn in int8_names:
                 nodes.append(("DynamicQuantizeLinear", "dq%d" % anon[0], [src], ["aq%d" % anon[0], "as%d" % anon[0], "az%d" % anon[0]], {}))
                 nodes.append(("MatMulInteger", "mmi%d" % anon[0], ["aq%d" % anon[0], wn + "_quantized", "az%d" % anon[0], wn + "_zero_point"], ["mi%d" % anon[0]], {}))
                 nodes.append(("Cast", "c%d" % anon[0], ["mi%d" % anon[0]], ["mc%d" % anon[0]], {"to": 1}))
@@ -168,6 +176,49 @@ def test_onnx_ingestion_round_trip_including_int8():
         sd = cv.onnx_to_state_dict(g, set(cv.name_map(cfg).values()))
         cfg2 = cv.infer_config(sd, cfg["kind"])
         got = cv.state_dict_to_pfw(sd, cfg2)
-        assert set(got) == set(w)
+        qk = {k for k in got if k.endswith((".weight_q", ".weight_zp", ".weight_scale"))}
+        assert set(got) - qk == set(w) and len(qk) == 3 * len(q8)
         for k in w:
             assert np.array_equal(got[k], w[k]), k
+        for k in qk:                                  # a signed per-tensor export: bytes and zero point shifted by 128 together
+            if k.endswith("_q"):
+                stem = k[:-2]
+                assert got[k].dtype == np.uint8 and got[k].shape == w[stem].shape
+                deq = (got[k].astype(np.float32) - got[stem + "_zp"].astype(np.float32)[:, None]) * got[stem + "_scale"][:, None]
+                assert np.array_equal(deq.astype(np.float32), w[stem]), k
+
+
+def test_int8_export_bytes_travel_through_the_container():
+    """An int8 export's stored operands (uint8 weights per output channel, quantize_dynamic's layout [K, N]) arrive in
+    the container byte for byte (`<linear>.weight_q` [N, K], `.weight_zp`, `.weight_scale`) beside their de-quantised
+    float image, survive pack / load, and the int8 oracle multiplies THEM (math_mode 2 does the same on the device,
+    tests/test_gpu_int8.py)."""
+    import numpy as np
+    from aliparaformerasr_amd import convert as cv, onnx_reader as R, weights as W
+    from oracle.int8 import QuantizedLinears, qlinear
+    cfg = W.sensevoice_small_config(enc_layers=2, tp_layers=1, vocab=30)
+    w = W.synth_weights(cfg, 5)
+    names = cv.name_map(cfg)
+    q8 = {v for k, v in names.items() if k.endswith(".weight") and w[k].ndim == 2 and (".attn.qkv" in k or ".ffn." in k or k == "ctc.weight")}
+    stored = {}
+    blob = _synthetic_export(cfg, w, q8, stored)
+    assert len(stored) == len(q8) == 3 * 3 + 1
+    sd = cv.onnx_to_state_dict(R.load(blob), set(names.values()))
+    got = cv.state_dict_to_pfw(sd, cv.infer_config(sd, cfg["kind"]))
+    for k, (wq, wz, ws) in stored.items():
+        assert np.array_equal(got[k + "_q"], wq) and got[k + "_q"].dtype == np.uint8, k
+        assert np.array_equal(got[k + "_zp"], wz) and np.array_equal(got[k + "_scale"], ws), k
+        assert np.array_equal(got[k], w[k]), k
+    cfg2, back = W.load_pfw(W.pack_pfw(cfg, got))
+    assert set(back) == set(got)
+    for k in got:
+        assert back[k].dtype == got[k].dtype and np.array_equal(back[k], got[k]), k
+    # the oracle's quantised Linear uses the stored bytes, not a re-quantisation of the float image
+    k = "ctc.weight"
+    tampered = dict(back)
+    tampered[k + "_q"] = (back[k + "_q"] ^ 1).astype(np.uint8)
+    x = np.random.default_rng(0).standard_normal((5, back[k].shape[1])).astype(np.float32)
+    y0 = QuantizedLinears(back)(x, "ctc", True)
+    y1 = QuantizedLinears(tampered)(x, "ctc", True)
+    want = qlinear(x, tampered[k + "_q"].astype(np.int32), back[k + "_scale"], back[k + "_zp"].astype(np.int32), back["ctc.bias"])
+    assert np.array_equal(y1, want) and not np.array_equal(y0, y1)
