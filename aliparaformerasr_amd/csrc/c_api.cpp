@@ -888,13 +888,13 @@ int pf_online_decoder(pf_engine* h, const float* enc, int32_t B, int32_t Tc, con
 int pf_host_online_lfr(const float* fbank, int32_t t80, int32_t lfr_m, int32_t lfr_n, float* out, int64_t cap, int32_t* t_lfr) {
   PF_TRY
   NEED(t_lfr);
-  PF_CHECK(t80 >= 0 && (t80 == 0 || fbank), PF_ERR_INVALID_ARG, "online_lfr: bad arguments");
+  PF_CHECK(t80 >= 0 && (t80 == 0 || fbank) && lfr_m >= 1 && lfr_n >= 1, PF_ERR_INVALID_ARG, "online_lfr: bad arguments");
   std::vector<float> in(fbank, fbank + (size_t)t80 * 80);
   std::vector<float> o = online_apply_lfr(in, 80, lfr_m, lfr_n);
   *t_lfr = (int32_t)(o.size() / ((size_t)lfr_m * 80));
   if (out) {
     PF_CHECK(cap >= (int64_t)o.size(), PF_ERR_CAPACITY, "online_lfr: output capacity too small");
-    std::memcpy(out, o.data(), o.size() * 4);
+    if (!o.empty()) std::memcpy(out, o.data(), o.size() * 4);
   }
   return PF_OK;
   PF_CATCH
@@ -905,7 +905,7 @@ int pf_host_online_posenc(float* x, int32_t timesteps, int32_t dim, int32_t star
   PF_CHECK(timesteps >= 0 && dim >= 4 && dim % 2 == 0 && start_idx >= 0, PF_ERR_INVALID_ARG, "online_posenc: bad arguments");
   std::vector<float> v(x, x + (size_t)timesteps * dim);
   online_position_encode(v, timesteps, dim, start_idx);
-  std::memcpy(x, v.data(), v.size() * 4);
+  if (!v.empty()) std::memcpy(x, v.data(), v.size() * 4);
   return PF_OK;
   PF_CATCH
 }
@@ -915,7 +915,7 @@ int pf_host_online_dynamic_mask(float* alphas, int32_t n) {
   PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "online_dynamic_mask: negative length");
   std::vector<float> v(alphas, alphas + n);
   online_dynamic_mask(v);
-  std::memcpy(alphas, v.data(), v.size() * 4);
+  if (!v.empty()) std::memcpy(alphas, v.data(), v.size() * 4);
   return PF_OK;
   PF_CATCH
 }
@@ -1078,7 +1078,7 @@ int pf_host_wav_read(const char* path, float* out, int64_t cap, int64_t* n_out, 
   if (duration_ms) *duration_ms = dur;
   if (out) {
     PF_CHECK(cap >= (int64_t)v.size(), PF_ERR_CAPACITY, "wav_read: output capacity too small");
-    std::memcpy(out, v.data(), v.size() * 4);
+    if (!v.empty()) std::memcpy(out, v.data(), v.size() * 4);
   }
   return PF_OK;
   PF_CATCH
@@ -1094,7 +1094,7 @@ int pf_host_resample(const float* src, int64_t n, int32_t sr_in, int32_t sr_out,
   *n_out = (int64_t)v.size();
   if (out) {
     PF_CHECK(cap >= (int64_t)v.size(), PF_ERR_CAPACITY, "resample: output capacity too small");
-    std::memcpy(out, v.data(), v.size() * 4);
+    if (!v.empty()) std::memcpy(out, v.data(), v.size() * 4);
   }
   return PF_OK;
   PF_CATCH

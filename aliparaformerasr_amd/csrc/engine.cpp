@@ -203,21 +203,21 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   const Json* jt = j.get("tensors");
   PF_CHECK(jc && jt && jt->type == Json::Arr, PF_ERR_FORMAT, "weights: header lacks config/tensors");
   mc_.kind = jc->str_or("kind", mc_.kind);
-  mc_.feat_dim = (int)jc->num_or("feat_dim", mc_.feat_dim);
-  mc_.d_model = (int)jc->num_or("d_model", mc_.d_model);
-  mc_.heads = (int)jc->num_or("heads", mc_.heads);
-  mc_.ffn = (int)jc->num_or("ffn", mc_.ffn);
-  mc_.enc_layers = (int)jc->num_or("enc_layers", mc_.enc_layers);
-  mc_.tp_layers = (int)jc->num_or("tp_layers", mc_.tp_layers);
-  mc_.kernel = (int)jc->num_or("kernel", mc_.kernel);
-  mc_.dec_layers = (int)jc->num_or("dec_layers", mc_.dec_layers);
-  mc_.vocab = (int)jc->num_or("vocab", mc_.vocab);
+  mc_.feat_dim = (int)jc->int_or("feat_dim", mc_.feat_dim, INT32_MIN, INT32_MAX);
+  mc_.d_model = (int)jc->int_or("d_model", mc_.d_model, INT32_MIN, INT32_MAX);
+  mc_.heads = (int)jc->int_or("heads", mc_.heads, INT32_MIN, INT32_MAX);
+  mc_.ffn = (int)jc->int_or("ffn", mc_.ffn, INT32_MIN, INT32_MAX);
+  mc_.enc_layers = (int)jc->int_or("enc_layers", mc_.enc_layers, INT32_MIN, INT32_MAX);
+  mc_.tp_layers = (int)jc->int_or("tp_layers", mc_.tp_layers, INT32_MIN, INT32_MAX);
+  mc_.kernel = (int)jc->int_or("kernel", mc_.kernel, INT32_MIN, INT32_MAX);
+  mc_.dec_layers = (int)jc->int_or("dec_layers", mc_.dec_layers, INT32_MIN, INT32_MAX);
+  mc_.vocab = (int)jc->int_or("vocab", mc_.vocab, INT32_MIN, INT32_MAX);
   mc_.cif_threshold = (float)jc->num_or("cif_threshold", mc_.cif_threshold);
   mc_.cif_tail = (float)jc->num_or("cif_tail", mc_.cif_tail);
   mc_.cif_smooth = (float)jc->num_or("cif_smooth", mc_.cif_smooth);
   mc_.cif_noise = (float)jc->num_or("cif_noise", mc_.cif_noise);
-  mc_.cif_l_order = (int)jc->num_or("cif_l_order", mc_.cif_l_order);
-  mc_.cif_r_order = (int)jc->num_or("cif_r_order", mc_.cif_r_order);
+  mc_.cif_l_order = (int)jc->int_or("cif_l_order", mc_.cif_l_order, INT32_MIN, INT32_MAX);
+  mc_.cif_r_order = (int)jc->int_or("cif_r_order", mc_.cif_r_order, INT32_MIN, INT32_MAX);
   {
     const std::string cv = jc->str_or("cif_variant", "loop");
     PF_CHECK(cv == "loop" || cv == "cumsum", PF_ERR_UNSUPPORTED, "weights: cif_variant must be \"loop\" or \"cumsum\"");
@@ -233,12 +233,12 @@ void Engine::load_weights(const pf_engine_config& cfg) {
            "unsupported model dimensions");
   mc_.cif_smooth2 = (float)jc->num_or("cif_smooth2", mc_.cif_smooth2);
   mc_.cif_noise2 = (float)jc->num_or("cif_noise2", mc_.cif_noise2);
-  mc_.upsample = (int)jc->num_or("upsample", mc_.upsample);
-  mc_.seaco_layers = (int)jc->num_or("seaco_layers", mc_.seaco_layers);
-  mc_.seaco_ffn = (int)jc->num_or("seaco_ffn", mc_.seaco_ffn);
-  mc_.seaco_kernel = (int)jc->num_or("seaco_kernel", mc_.seaco_kernel);
-  mc_.seaco_lstm_layers = (int)jc->num_or("seaco_lstm_layers", mc_.seaco_lstm_layers);
-  mc_.seaco_nobias = (int)jc->num_or("seaco_nobias", mc_.seaco_nobias);
+  mc_.upsample = (int)jc->int_or("upsample", mc_.upsample, INT32_MIN, INT32_MAX);
+  mc_.seaco_layers = (int)jc->int_or("seaco_layers", mc_.seaco_layers, INT32_MIN, INT32_MAX);
+  mc_.seaco_ffn = (int)jc->int_or("seaco_ffn", mc_.seaco_ffn, INT32_MIN, INT32_MAX);
+  mc_.seaco_kernel = (int)jc->int_or("seaco_kernel", mc_.seaco_kernel, INT32_MIN, INT32_MAX);
+  mc_.seaco_lstm_layers = (int)jc->int_or("seaco_lstm_layers", mc_.seaco_lstm_layers, INT32_MIN, INT32_MAX);
+  mc_.seaco_nobias = (int)jc->int_or("seaco_nobias", mc_.seaco_nobias, INT32_MIN, INT32_MAX);
   if (mc_.kind == "seacoparaformer") mc_.seaco = true;
   PF_CHECK(!mc_.seaco || (mc_.seaco_ffn % 64 == 0 && mc_.seaco_lstm_layers >= 1), PF_ERR_UNSUPPORTED,
            "seaco: unsupported dimensions");
@@ -262,7 +262,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     const std::string dt = t.str_or("dtype", "f32");
     PF_CHECK(dt == "f32" || dt == "u8", PF_ERR_FORMAT, "weights: tensor '" + name + "' has dtype '" + dt + "' (f32 and u8 are supported)");
     tt.u8 = dt == "u8";
-    const int64_t off = (int64_t)t.num_or("offset", -1), nb = (int64_t)t.num_or("nbytes", -1);
+    const int64_t off = t.int_or("offset", -1), nb = t.int_or("nbytes", -1);
     PF_CHECK(off >= 0 && nb >= 0 && off + nb <= data_bytes && off % 16 == 0, PF_ERR_FORMAT,
              "weights: bad tensor extent for '" + name + "'");
     tt.dev = (const float*)(data_dev + off);

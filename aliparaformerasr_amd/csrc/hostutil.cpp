@@ -1,6 +1,9 @@
 // hostutil.cpp — see hostutil.h
 #include "hostutil.h"
 
+#include <cerrno>
+#include <climits>
+
 #include <cmath>
 #include <cstring>
 
@@ -118,6 +121,16 @@ static bool to_bool(const std::string& v, bool d) {
   return d;
 }
 
+// int.Parse-like for the yaml scalars: out-of-range text is a format error (atoi's behaviour there is undefined)
+static int yaml_int(const std::string& key, const std::string& v) {
+  errno = 0;
+  char* end = nullptr;
+  const long long x = std::strtoll(v.c_str(), &end, 10);
+  if (end == v.c_str() || errno == ERANGE || x < INT32_MIN || x > INT32_MAX)
+    throw Error(PF_ERR_FORMAT, "asr.yaml: '" + key + "' is not an integer: '" + v + "'");
+  return (int)x;
+}
+
 ConfEntity conf_from_yaml(const std::string& text) {
   ConfEntity c;
   std::string section;   // current top-level mapping key
@@ -144,14 +157,14 @@ ConfEntity conf_from_yaml(const std::string& text) {
       continue;
     }
     if (section == "frontend_conf") {
-      if (key == "fs") c.fs = std::atoi(val.c_str());
+      if (key == "fs") c.fs = yaml_int(key, val);
       else if (key == "window") c.window = val;
-      else if (key == "n_mels") c.n_mels = std::atoi(val.c_str());
-      else if (key == "frame_length") c.frame_length = std::atoi(val.c_str());
-      else if (key == "frame_shift") c.frame_shift = std::atoi(val.c_str());
+      else if (key == "n_mels") c.n_mels = yaml_int(key, val);
+      else if (key == "frame_length") c.frame_length = yaml_int(key, val);
+      else if (key == "frame_shift") c.frame_shift = yaml_int(key, val);
       else if (key == "dither") c.dither = std::strtof(val.c_str(), nullptr);
-      else if (key == "lfr_m") c.lfr_m = std::atoi(val.c_str());
-      else if (key == "lfr_n") c.lfr_n = std::atoi(val.c_str());
+      else if (key == "lfr_m") c.lfr_m = yaml_int(key, val);
+      else if (key == "lfr_n") c.lfr_n = yaml_int(key, val);
       else if (key == "snip_edges") c.snip_edges = to_bool(val, c.snip_edges);
     }
   }
@@ -164,14 +177,14 @@ ConfEntity conf_from_json(const std::string& text) {
   c.model = j.str_or("model", c.model);
   c.use_itn = j.bool_or("use_itn", c.use_itn);
   if (const Json* f = j.get("frontend_conf")) {
-    c.fs = (int)f->num_or("fs", c.fs);
+    c.fs = (int)f->int_or("fs", c.fs, INT32_MIN, INT32_MAX);
     c.window = f->str_or("window", c.window);
-    c.n_mels = (int)f->num_or("n_mels", c.n_mels);
-    c.frame_length = (int)f->num_or("frame_length", c.frame_length);
-    c.frame_shift = (int)f->num_or("frame_shift", c.frame_shift);
+    c.n_mels = (int)f->int_or("n_mels", c.n_mels, INT32_MIN, INT32_MAX);
+    c.frame_length = (int)f->int_or("frame_length", c.frame_length, INT32_MIN, INT32_MAX);
+    c.frame_shift = (int)f->int_or("frame_shift", c.frame_shift, INT32_MIN, INT32_MAX);
     c.dither = (float)f->num_or("dither", c.dither);
-    c.lfr_m = (int)f->num_or("lfr_m", c.lfr_m);
-    c.lfr_n = (int)f->num_or("lfr_n", c.lfr_n);
+    c.lfr_m = (int)f->int_or("lfr_m", c.lfr_m, INT32_MIN, INT32_MAX);
+    c.lfr_n = (int)f->int_or("lfr_n", c.lfr_n, INT32_MIN, INT32_MAX);
     c.snip_edges = f->bool_or("snip_edges", c.snip_edges);
   }
   return c;

@@ -1,5 +1,6 @@
 // json.h — minimal JSON value + recursive-descent parser (PFW1 header, asr.json).
 #pragma once
+#include <cstdint>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -29,6 +30,17 @@ struct Json {
     if (j->type == Num) return j->num;
     if (j->type == Bool) return j->b ? 1 : 0;
     return d;
+  }
+  // an integer field: the number must be finite, integral and within +-2^53 (a "1e400" or "0.5" where a size belongs is
+  // a format error, not a cast of inf to int)
+  int64_t int_or(const std::string& k, int64_t d, int64_t lo = -((int64_t)1 << 53), int64_t hi = (int64_t)1 << 53) const {
+    const Json* j = get(k);
+    if (!j) return d;
+    if (j->type == Bool) return j->b ? 1 : 0;
+    if (j->type != Num) return d;
+    if (!(j->num >= (double)lo && j->num <= (double)hi) || j->num != (double)(int64_t)j->num)
+      throw Error(PF_ERR_FORMAT, "json: '" + k + "' must be an integer in range");
+    return (int64_t)j->num;
   }
   std::string str_or(const std::string& k, const std::string& d) const {
     const Json* j = get(k);

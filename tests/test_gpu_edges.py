@@ -246,7 +246,7 @@ def test_malformed_containers_round2():
     hlen = struct.unpack("<Q", good[8:16])[0]
     hdr = json.loads(good[16:16 + hlen])
     def rebuild(h):
-        hb = json.dumps(h, separators=(",", ":")).encode()
+        hb = json.dumps(h, separators=(",", ":")).encode().replace(b"Infinity", b"1e400")
         old_off = (16 + hlen + 255) // 256 * 256
         new_off = (16 + len(hb) + 255) // 256 * 256
         return good[:8] + struct.pack("<Q", len(hb)) + hb + b"\0" * (new_off - 16 - len(hb)) + good[old_off:]
@@ -256,6 +256,14 @@ def test_malformed_containers_round2():
     fails(good[:8] + struct.pack("<Q", (1 << 64) - 8) + good[16:])           # 16 + hlen wraps to 8
     deep = b"[" * 10000
     fails(good[:8] + struct.pack("<Q", len(deep)) + deep + good[16:])
+    # integer fields must be integers in range (round 3: 1e400 used to be cast from inf)
+    for key, val in (("d_model", 1e400), ("vocab", 0.5), ("enc_layers", 3e9), ("kernel", -1e300)):
+        h3 = json.loads(json.dumps(hdr)); h3["config"][key] = val
+        fails(rebuild(h3))
+    h3 = json.loads(json.dumps(hdr)); h3["tensors"][1]["offset"] = 256.5
+    fails(rebuild(h3))
+    h3 = json.loads(json.dumps(hdr)); h3["tensors"][1]["dtype"] = "i4"
+    fails(rebuild(h3))
     fails(good, code=PF_ERR_UNSUPPORTED, frame_length_ms=20)
     fails(good, code=PF_ERR_UNSUPPORTED, frame_shift_ms=5)
     Engine(weights=good, cmvn=cmvn, device=0, frame_length_ms=25, frame_shift_ms=10).close()

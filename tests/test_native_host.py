@@ -160,3 +160,40 @@ def test_recognizer_without_device_fails_loudly(tmp_path):
     with pytest.raises(N.PfError) as ei:
         OfflineRecognizer(str(tmp_path / "model.pfw"), "", "", str(tok))
     assert ei.value.code == N.PF_ERR_DEVICE
+
+
+@pytest.mark.timeout(300)
+def test_host_parsers_under_sanitizers(tmp_path):
+    """csrc/json.h + csrc/hostutil.cpp (PFW header / asr.json / asr.yaml / am.mvn / RIFF-WAVE / resampler / UTF-8) built
+    with -fsanitize=address,undefined and fed mutated files (tests/native/host_fuzz.cpp): every input parses or is
+    rejected with a pf::Error, no report.  (Round 3: `"lfr_n": 1e400` used to be cast to int — now PF_ERR_FORMAT.)"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    cs = os.path.join(root, "aliparaformerasr_amd", "csrc")
+    exe = str(tmp_path / "host_fuzz")
+    b = subprocess.run([hipcc, "-x", "hip", "--offload-arch=gfx950", "-g", "-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                        "-std=c++17", "-I" + cs, os.path.join(root, "tests", "native", "host_fuzz.cpp"), os.path.join(cs, "hostutil.cpp"),
+                        "-o", exe], capture_output=True, text=True)
+    if b.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + b.stderr[-300:])
+    r = subprocess.run([exe, "3000", str(tmp_path)], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "Sanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.startswith("ok ")
+
+
+@pytest.mark.skipif(not os.environ.get("PF_SANITIZE_FULL"), reason="set PF_SANITIZE_FULL=1: rebuilds the whole library with ASan + UBSan (minutes)")
+@pytest.mark.timeout(3000)
+def test_every_host_entry_point_under_sanitizers(tmp_path):
+    """tools/sanitize_host.sh: the full library with -fsanitize=address,undefined, every pf_host_* entry point driven
+    with random arguments (tests/native/abi_host_fuzz.c), plus the shard-runner and parser harnesses."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "tools", "sanitize_host.sh"), str(tmp_path), "3000"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "runtime error" not in r.stdout + r.stderr and "Sanitizer" not in r.stdout + r.stderr
