@@ -68,6 +68,33 @@ def select_model_files(base: str, model: str, accuracy: str):
     )
 
 
+# ---- the GUI's display step for SenseVoice results (AliParaformerAsr.Examples.MauiApp/Utils/AEDEmojiHelper.cs:7-47; callers
+#      RecognitionForFiles.xaml.cs:478,583: `ReplaceTagsWithEmojis(result.Text.Replace("> ", ">"))`) — SURVEY §8f row 3
+_EMOJI_MAP = {
+    "Laughter": "\U0001F606", "Applause": "\U0001F44F", "HAPPY": "\U0001F600", "SAD": "\U0001F622", "ANGRY": "\U0001F621",
+    "NEUTRAL": "\U0001F610", "FEARFUL": "\U0001F628", "DISGUSTED": "\U0001F922", "SURPRISED": "\U0001F632", "Cry": "\U0001F62D",
+    "Sneeze": "\U0001F443\U0001F927", "Cough": "\U0001F912", "Sing": "\U0001F3A4",
+}
+
+
+def replace_tags_with_emojis(text: str) -> str:
+    """AEDEmojiHelper.ReplaceTagsWithEmojis (:7-36): every `<|word|>` tag becomes its emoji, or nothing when the tag is
+    not in the table (language / event / itn tags such as <|zh|>, <|Speech|>, <|woitn|> simply disappear)."""
+    import re
+    return re.sub(r"<\|(\w+)\|>", lambda m: _EMOJI_MAP.get(m.group(1), ""), text)
+
+
+def replace_tags_with_empty(text: str) -> str:
+    """AEDEmojiHelper.ReplaceTagsWithEmpty (:38-45): `<|...|>` (shortest match, anything but a newline inside) removed."""
+    import re
+    return re.sub(r"<\|.*?\|>", "", text)
+
+
+def display_text(text: str) -> str:
+    """What the GUI shows for a result (RecognitionForFiles.xaml.cs:478): DecodeMulti separates tags with "> "."""
+    return replace_tags_with_emojis(text.replace("> ", ">"))
+
+
 def _result_line(r) -> str:
     toks = ",".join('"%s"' % t for t in r.Tokens)
     ts = ",".join("[%d,%d]" % (t[0], t[-1]) for t in r.Timestamps)

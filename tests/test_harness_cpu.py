@@ -156,3 +156,16 @@ def test_wav_reader_survives_malformed_files(lib, tmp_path):
         else:
             err += 1
     assert ok > 0 and err > 0
+
+
+def test_emoji_tag_mapping_of_the_gui():
+    """AEDEmojiHelper.cs:7-47 as called at RecognitionForFiles.xaml.cs:478 on DecodeMulti's SenseVoice text
+    (`" <|zh|> <|NEUTRAL|> <|Speech|> <|woitn|> 你好"`)."""
+    from aliparaformerasr_amd import examples as ex
+    t = " <|zh|> <|NEUTRAL|> <|Speech|> <|woitn|> \u4f60\u597d"
+    assert ex.display_text(t) == " \U0001F610\u4f60\u597d"
+    assert ex.replace_tags_with_emojis("<|HAPPY|>a<|Sneeze|>b<|unknown_tag|>c<|Sing|>") == "\U0001F600a\U0001F443\U0001F927bc\U0001F3A4"
+    assert ex.replace_tags_with_emojis("<|two words|> <||> <|x") == "<|two words|> <||> <|x"      # \w+ only
+    assert ex.replace_tags_with_empty("<|two words|>a<||>b<|x") == "ab<|x"
+    assert ex.replace_tags_with_empty("<|a\n|>") == "<|a\n|>"                                       # `.` stops at a newline
+    assert ex.replace_tags_with_emojis("<|\u4e2d|>") == ""                                           # \w is Unicode in .NET too
