@@ -53,6 +53,8 @@ struct QLin {
   const float* bias = nullptr;
   int N = 0, K = 0, Kpad = 0;
 };
+// a quantised activation tensor: a' = a_q - 128 [rows, Kpad], row sums of a', {scale, zero point}
+struct QAct { int8_t* a = nullptr; int32_t* rowsum = nullptr; float* params = nullptr; };
 struct EncLayer { LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512; };
 struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
 
@@ -170,7 +172,10 @@ class Engine {
   const QLin& qlin_raw(const float* w32, const float* bias, int N, int K);
   // y = dequant(quant(x) w_q^T) + bias [* scale on the first scale_cols columns] [+ add2] [+ resid] [ReLU]; x fp32 [M, ldx] or f16
   void qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32, half_t* out16,
-             int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols, float scale);
+             int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols, float scale,
+             const LNp* ln = nullptr, const QAct* pre = nullptr);
+  // quantise an activation tensor into `dst` (min / max pass, quantise pass); ln: of LayerNorm(x32), which is never stored
+  void quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln);
   void timestamp_head_fp32(int B, int T);
   void seaco_head_fp32(int B, int L, const float* e0, const float* hid, bool want_logits);
   // fp32 LSTM over rows [Bn * Tn] of x (row b * Tn + t): hout[(b * Tn + t) * ldh + col0 .. + D); reverse = time runs backwards
@@ -208,6 +213,7 @@ class Engine {
   DevBuf ws_q_;                      // quantised activations: a' [Mp, Kpad], row sums, {scale, zp}, min / max scratch
   int8_t* q_a_ = nullptr; int32_t* q_rowsum_ = nullptr; float* q_params_ = nullptr; unsigned* q_scratch_ = nullptr;
   int64_t q_rows_ = 0; int q_kpad_ = 0;
+  float* q_part_ = nullptr;          // {min, max} per workgroup of a min / max pass (k_quant.hip)
   void ensure_q(int64_t rows, int kpad);
   ModelCfg mc_;
   FrontendCfg fc_;

@@ -71,20 +71,36 @@ const QLin& Engine::qlin(const Lin& l, bool bias) {
   return qlin_raw(l.w32, bias ? l.bias : nullptr, l.N, l.K);
 }
 
+void Engine::quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln) {
+  if (!q_part_) q_part_ = (float*)dalloc(quant_scratch_bytes());
+  prof_begin("quantize", 0);
+  if (ln) {                                            // LayerNorm(x32) is never stored: normalised in registers by both passes
+    PF_CHECK(x32 && ln->D == K && ldx == K, PF_ERR_INVALID_ARG, "quantize_act: LayerNorm rows must be dense fp32");
+    launch_ln_minmax(stream_, x32, M, K, ln->g, ln->b, q_part_);
+    launch_ln_quantize(stream_, x32, M, K, ln->g, ln->b, dst.a, kpad, dst.rowsum, dst.params, q_part_);
+  } else {
+    launch_minmax(stream_, x32, x16, M, K, ldx, q_part_);
+    launch_quantize(stream_, x32, x16, M, K, ldx, dst.a, kpad, dst.rowsum, dst.params, q_part_);
+  }
+  prof_end("quantize");
+}
+
 void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
                    half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols,
-                   float scale) {
+                   float scale, const LNp* ln, const QAct* pre) {
   if (M == 0) return;
-  if (x32 || x16) {                                    // null / null: the tensor quantised by the previous call is reused
+  QAct act;
+  if (pre) {
+    act = *pre;                                        // quantised earlier (the encoder memory: one tensor, sixteen K / V projections)
+  } else {
     ensure_q(M, w.Kpad);
-    prof_begin("quantize", 0);
-    launch_quantize_rows(stream_, x32, x16, M, w.K, ldx, q_a_, w.Kpad, q_rowsum_, q_params_, q_scratch_);   // rows packed at this GEMM's Kpad
-    prof_end("quantize");
+    act.a = q_a_; act.rowsum = q_rowsum_; act.params = q_params_;
+    if (x32 || x16) quantize_act(act, w.Kpad, x32, x16, ldx, M, w.K, ln);    // null / null: the tensor quantised by the previous call is reused
   }
   prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   GemmI8Args g{};
-  g.A = q_a_; g.lda = w.Kpad; g.W = w.w; g.ldw = w.Kpad;
-  g.rowsum = q_rowsum_; g.colsum = w.colsum; g.wzp = w.wzp; g.wscale = w.wscale; g.aparams = q_params_;
+  g.A = act.a; g.lda = w.Kpad; g.W = w.w; g.ldw = w.Kpad;
+  g.rowsum = act.rowsum; g.colsum = w.colsum; g.wzp = w.wzp; g.wscale = w.wscale; g.aparams = act.params;
   g.bias = w.bias; g.M = M; g.N = w.N; g.K = w.K; g.Kpad = w.Kpad;
   g.out_f32 = out32; g.ldc32 = ld32; g.out_f16 = out16; g.ldc16 = ld16;
   g.resid = resid; g.ldr = ldr; g.add2 = add2; g.ld2 = ld2;
@@ -103,7 +119,7 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   build_pe(T);
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
-  const size_t o_x = carve(Mp * D * 4), o_xn = carve(Mp * std::max(Fd, D) * 4), o_t = carve(Mp * std::max(Fd, D) * 4);
+  const size_t o_x = carve(Mp * D * 4), o_t = carve(Mp * std::max(Fd, D) * 4);
   const size_t o_qkv = carve(Mp * 3 * D * 2), o_ctx = carve(Mp * D * 2), o_fsm = carve(Mp * D * 4);
   const size_t o_h = carve(Mp * std::max(F, taps * D) * 2), o_H32 = carve(Mp * D * 4), o_H16 = carve(Mp * D * 2);
   const size_t o_al = carve((size_t)B * T1 * 4), o_fc = carve((size_t)B * 4), o_tn = carve((size_t)B * 4);
@@ -111,7 +127,6 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   ensure(ws_enc_, off);
   char* base = (char*)ws_enc_.p;
   x_ = (float*)(base + o_x);
-  float* xn32 = (float*)(base + o_xn);
   float* t32e = (float*)(base + o_t);
   qkv16_ = (half_t*)(base + o_qkv); ctx16_ = (half_t*)(base + o_ctx); fsm_ = (float*)(base + o_fsm); h16_ = (half_t*)(base + o_h);
   H32_ = (float*)(base + o_H32); H16_ = (half_t*)(base + o_H16); alphas_ = (float*)(base + o_al);
@@ -123,17 +138,9 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   //      out-projection (+ FSMN memory + residual, fp32) -> LayerNorm -> quantise -> FFN-up + ReLU (f16) -> quantise -> FFN-down + residual
   auto layer = [&](const EncLayer& L, bool first) {
     const int din = first ? Fd : D;
-    if (first) {
-      launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), t32e);
-      prof_begin("layernorm", 0);
-      launch_layernorm(stream_, t32e, M, Fd, L.norm1.g, L.norm1.b, nullptr, 0, xn32, Fd);
-      prof_end("layernorm");
-    } else {
-      prof_begin("layernorm", 0);
-      launch_layernorm(stream_, x_, M, D, L.norm1.g, L.norm1.b, nullptr, 0, xn32, D);
-      prof_end("layernorm");
-    }
-    qgemm("gemm_qkv", qlin(L.qkv), xn32, nullptr, din, (int)M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
+    if (first) launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), t32e);
+    qgemm("gemm_qkv", qlin(L.qkv), first ? t32e : x_, nullptr, din, (int)M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale,
+          &L.norm1);
     AttnArgs a{};
     a.q = qkv16_; a.k = qkv16_ + D; a.v = qkv16_ + 2 * D; a.o = ctx16_;
     a.q_bstride = a.k_bstride = a.v_bstride = (int64_t)T * 3 * D;
@@ -147,10 +154,7 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
     prof_end("fsmn");
     qgemm("gemm_out", qlin(L.out), nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, nullptr, 0, xn32, D);
-    prof_end("layernorm");
-    qgemm("gemm_ffn1", qlin(L.w1), xn32, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f);
+    qgemm("gemm_ffn1", qlin(L.w1), x_, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, &L.norm2);
     qgemm("gemm_ffn2", qlin(L.w2), nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f);
   };
   for (size_t i = 0; i < enc_.size(); ++i) layer(enc_[i], i == 0);
@@ -218,12 +222,13 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   const int64_t Mdp = round_up(Md, 128) + 128;
   size_t o2 = 0;
   auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
-  const size_t o_xd = c2(Mdp * D * 4), o_xdn = c2(Mdp * D * 4), o_hd = c2(Mdp * F * 4), o_hn = c2(Mdp * F * 4);
+  const size_t o_xd = c2(Mdp * D * 4), o_hd = c2(Mdp * F * 4);
   const size_t o_td = c2(Mdp * D * 4), o_tn2 = c2(Mdp * D * 4), o_q = c2(Mdp * D * 2), o_cx = c2(Mdp * D * 2);
   const size_t o_kv = c2((size_t)Mp * 2 * D * 2), o_lg = c2((size_t)Mdp * ldV * 4), o_ids = c2((size_t)Md * 8);
+  const size_t o_qh = c2((size_t)(Mp + 256) * round_up(D, 128)), o_qhr = c2((size_t)(Mp + 256) * 4), o_qhp = c2(64);
   ensure(ws_dec_, o2);
   char* b2 = (char*)ws_dec_.p;
-  float* xd = (float*)(b2 + o_xd); float* xn = (float*)(b2 + o_xdn); float* hd = (float*)(b2 + o_hd); float* hn = (float*)(b2 + o_hn);
+  float* xd = (float*)(b2 + o_xd); float* hd = (float*)(b2 + o_hd);
   float* t32 = (float*)(b2 + o_td); float* tn32 = (float*)(b2 + o_tn2);
   half_t* qd16 = (half_t*)(b2 + o_q); half_t* cx16 = (half_t*)(b2 + o_cx); half_t* kv16 = (half_t*)(b2 + o_kv);
   logits_ = (float*)(b2 + o_lg); ids_dev_ = (int64_t*)(b2 + o_ids); logits_ld_ = ldV;
@@ -232,16 +237,16 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
   prof_end("cif_misc");
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, nullptr, 0, xn, D);
-    prof_end("layernorm");
-    qgemm("gemm_dec_ffn1", qlin(w1), xn, nullptr, D, Md, hd, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f);
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, hd, Md, F, fn.g, fn.b, nullptr, 0, hn, F);
-    prof_end("layernorm");
-    qgemm("gemm_dec_ffn2", qlin(w2, false), hn, nullptr, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+    qgemm("gemm_dec_ffn1", qlin(w1), xd, nullptr, D, Md, hd, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f, &n1);
+    qgemm("gemm_dec_ffn2", qlin(w2, false), hd, nullptr, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &fn);
   };
-  bool memory_quantised = false;
+  // K / V of the encoder memory: every layer's MatMul quantises the SAME tensor — one DynamicQuantizeLinear result here
+  QAct qH;
+  {
+    const int kp = (int)round_up(D, 128);
+    qH.a = (int8_t*)(b2 + o_qh); qH.rowsum = (int32_t*)(b2 + o_qhr); qH.params = (float*)(b2 + o_qhp);
+    quantize_act(qH, kp, H32_, nullptr, D, M, D, nullptr);
+  }
   for (size_t i = 0; i < dec_.size(); ++i) {
     const DecLayer& Lr = dec_[i];
     ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
@@ -251,14 +256,9 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     prof_begin("fsmn", 0);
     launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
     prof_end("fsmn");
-    prof_begin("layernorm", 0);
-    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
-    prof_end("layernorm");
-    qgemm("gemm_dec_q", qlin(Lr.q), xn, nullptr, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
-    // K / V of the encoder memory: every layer's MatMul quantises the SAME tensor (one DynamicQuantizeLinear result)
-    (void)memory_quantised;
-    qgemm("gemm_dec_kv", qlin_raw(Lr.kv32.w32, Lr.kv32.bias, 2 * D, D), H32_, nullptr, D, (int)M, nullptr, 0, kv16, 2 * D, nullptr, 0,
-          nullptr, 0, false, 0, 1.f);
+    qgemm("gemm_dec_q", qlin(Lr.q), xd, nullptr, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale, &Lr.norm3);
+    qgemm("gemm_dec_kv", qlin_raw(Lr.kv32.w32, Lr.kv32.bias, 2 * D, D), nullptr, nullptr, D, (int)M, nullptr, 0, kv16, 2 * D, nullptr, 0,
+          nullptr, 0, false, 0, 1.f, nullptr, &qH);
     AttnArgs a{};
     a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
     a.k = kv16; a.v = kv16 + D; a.k_bstride = a.v_bstride = (int64_t)T * 2 * D; a.k_rstride = a.v_rstride = 2 * D;
@@ -270,10 +270,7 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     qgemm("gemm_dec_out", qlin(Lr.out), nullptr, cx16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
-  prof_begin("layernorm", 0);
-  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
-  prof_end("layernorm");
-  qgemm("gemm_vocab", qlin(dec_out_), xn, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  qgemm("gemm_vocab", qlin(dec_out_), t32, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &dec_after_);
   prof_begin("argmax", 0);
   launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
   prof_end("argmax");
@@ -290,7 +287,7 @@ void Engine::op_qlinear(const float* x, const float* W, const float* bias, int M
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlignQ); return o; };
   const size_t ox = carve((size_t)M * K * 4), ox16 = carve((size_t)M * K * 2), oW = carve((size_t)N * K * 4), ob = carve((size_t)(N + 8) * 4);
-  const size_t oa = carve((size_t)Mp * Kp), ors = carve((size_t)Mp * 4), opar = carve(64), osc = carve(64);
+  const size_t oa = carve((size_t)Mp * Kp), ors = carve((size_t)Mp * 4), opar = carve(64), osc = carve(quant_scratch_bytes());
   const size_t ow = carve((size_t)Np * Kp), ocs = carve((size_t)(N + 8) * 4), ozp = carve((size_t)(N + 8) * 4), ows = carve((size_t)(N + 8) * 4);
   const size_t oy = carve((size_t)Mp * ldy * 4);
   ensure(ws_tmp_, off);

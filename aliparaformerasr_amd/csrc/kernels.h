@@ -67,6 +67,15 @@ void launch_gemm_i8(hipStream_t s, const GemmI8Args& a);
 // scratch: >= 16 bytes of device memory (min / max accumulators).
 void launch_quantize_rows(hipStream_t s, const float* x32, const half_t* x16, int64_t rows, int cols, int ldx, int8_t* out, int ld,
                           int32_t* rowsum, float* params, unsigned* scratch);
+// the two passes as separate launches; part: quant_scratch_bytes() of scratch ({min, max} per workgroup of pass 1)
+size_t quant_scratch_bytes();
+void launch_minmax(hipStream_t s, const float* x32, const half_t* x16, int64_t rows, int cols, int ldx, float* part);
+void launch_quantize(hipStream_t s, const float* x32, const half_t* x16, int64_t rows, int cols, int ldx, int8_t* out, int ld,
+                     int32_t* rowsum, float* params, const float* part);
+// LayerNorm(x) quantised without ever storing LayerNorm(x): pass 1 min / max, pass 2 quantise (both normalise in registers)
+void launch_ln_minmax(hipStream_t s, const float* x, int64_t rows, int D, const float* gamma, const float* beta, float* part);
+void launch_ln_quantize(hipStream_t s, const float* x, int64_t rows, int D, const float* gamma, const float* beta, int8_t* out, int ld,
+                        int32_t* rowsum, float* params, const float* part);
 // per-output-channel weight quantisation as onnxruntime.quantization quantize_dynamic(per_channel=True, weight_type=QUInt8)
 // does it: row n of W [N, K] (fp32): rmin = min(0, min), rmax = max(0, max), scale = (rmax - rmin) / 255,
 // zp = rne(-rmin / scale) clamped to [0, 255], q = clamp(rne(w / scale) + zp, 0, 255) -> w' = q - 128 [N, ld], colsum, wzp = zp - 128, wscale
