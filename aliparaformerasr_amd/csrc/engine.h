@@ -50,6 +50,7 @@ struct QLin {
   int32_t* colsum = nullptr;      // [N] sum_k w'
   int32_t* wzp = nullptr;         // [N] w_zp - 128
   float* wscale = nullptr;        // [N]
+  int32_t* dz = nullptr;          // [N] packed column word of the f16-result kernel (kernels.h GemmI8Args::dz)
   const float* bias = nullptr;
   int N = 0, K = 0, Kpad = 0;
 };
@@ -173,9 +174,12 @@ class Engine {
   // y = dequant(quant(x) w_q^T) + bias [* scale on the first scale_cols columns] [+ add2] [+ resid] [ReLU]; x fp32 [M, ldx] or f16
   void qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32, half_t* out16,
              int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols, float scale,
-             const LNp* ln = nullptr, const QAct* pre = nullptr);
+             const LNp* ln = nullptr, const QAct* pre = nullptr, int range = 0);   // range: 1 = leave the result's {min, max} pairs
+                                                                                    // in q_part_, 2 = the input's are there already
+  enum { kRangeOut = 1, kRangeIn = 2 };
   // quantise an activation tensor into `dst` (min / max pass, quantise pass); ln: of LayerNorm(x32), which is never stored
-  void quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln);
+  void quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln,
+                    bool have_range = false);
   void timestamp_head_fp32(int B, int T);
   void seaco_head_fp32(int B, int L, const float* e0, const float* hid, bool want_logits);
   // fp32 LSTM over rows [Bn * Tn] of x (row b * Tn + t): hout[(b * Tn + t) * ldh + col0 .. + D); reverse = time runs backwards

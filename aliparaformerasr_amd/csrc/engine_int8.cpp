@@ -62,6 +62,9 @@ const QLin& Engine::qlin_raw(const float* w32, const float* bias, int N, int K) 
   } else {
     launch_quantize_weight(stream_, w32, N, K, q.w, q.Kpad, q.colsum, q.wzp, q.wscale);
   }
+  q.dz = (int32_t*)dalloc((size_t)(N + 8) * 4);
+  PF_HIP(hipMemsetAsync(q.dz, 0, (size_t)(N + 8) * 4, stream_));
+  launch_pack_dz(stream_, q.colsum, q.wzp, N, K, q.dz);
   q.bias = bias;
   return qlins_.emplace(w32, q).first->second;
 }
@@ -71,9 +74,16 @@ const QLin& Engine::qlin(const Lin& l, bool bias) {
   return qlin_raw(l.w32, bias ? l.bias : nullptr, l.N, l.K);
 }
 
-void Engine::quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln) {
+void Engine::quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln,
+                          bool have_range) {
   if (!q_part_) q_part_ = (float*)dalloc(quant_scratch_bytes());
   prof_begin("quantize", 0);
+  if (have_range) {                                    // pass 1 was the producing GEMM's epilogue
+    PF_CHECK(!ln, PF_ERR_INVALID_ARG, "quantize_act: a LayerNorm input has no producer range");
+    launch_quantize(stream_, x32, x16, M, K, ldx, dst.a, kpad, dst.rowsum, dst.params, q_part_);
+    prof_end("quantize");
+    return;
+  }
   if (ln) {                                            // LayerNorm(x32) is never stored: normalised in registers by both passes
     PF_CHECK(x32 && ln->D == K && ldx == K, PF_ERR_INVALID_ARG, "quantize_act: LayerNorm rows must be dense fp32");
     launch_ln_minmax(stream_, x32, M, K, ln->g, ln->b, q_part_);
@@ -87,7 +97,7 @@ void Engine::quantize_act(const QAct& dst, int kpad, const float* x32, const hal
 
 void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
                    half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols,
-                   float scale, const LNp* ln, const QAct* pre) {
+                   float scale, const LNp* ln, const QAct* pre, int range) {
   if (M == 0) return;
   QAct act;
   if (pre) {
@@ -95,7 +105,7 @@ void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_
   } else {
     ensure_q(M, w.Kpad);
     act.a = q_a_; act.rowsum = q_rowsum_; act.params = q_params_;
-    if (x32 || x16) quantize_act(act, w.Kpad, x32, x16, ldx, M, w.K, ln);    // null / null: the tensor quantised by the previous call is reused
+    if (x32 || x16) quantize_act(act, w.Kpad, x32, x16, ldx, M, w.K, ln, (range & kRangeIn) != 0);   // null / null: the previous call's tensor is reused
   }
   prof_begin(cls, 2.0 * M * (double)w.N * w.K);
   GemmI8Args g{};
@@ -105,6 +115,11 @@ void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_
   g.out_f32 = out32; g.ldc32 = ld32; g.out_f16 = out16; g.ldc16 = ld16;
   g.resid = resid; g.ldr = ldr; g.add2 = add2; g.ld2 = ld2;
   g.relu = relu ? 1 : 0; g.scale_cols = scale_cols; g.scale = scale;
+  g.dz = w.dz; g.out_padded = 1;                       // every f16 result of this path lands in a buffer padded to whole tiles
+  if (range & kRangeOut) {
+    if (!q_part_) q_part_ = (float*)dalloc(quant_scratch_bytes());
+    g.range_out = q_part_;
+  }
   launch_gemm_i8(stream_, g);
   prof_end(cls);
 }
@@ -154,8 +169,8 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
     prof_end("fsmn");
     qgemm("gemm_out", qlin(L.out), nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
-    qgemm("gemm_ffn1", qlin(L.w1), x_, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, &L.norm2);
-    qgemm("gemm_ffn2", qlin(L.w2), nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f);
+    qgemm("gemm_ffn1", qlin(L.w1), x_, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, &L.norm2, nullptr, kRangeOut);
+    qgemm("gemm_ffn2", qlin(L.w2), nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr, kRangeIn);
   };
   for (size_t i = 0; i < enc_.size(); ++i) layer(enc_[i], i == 0);
   prof_begin("layernorm", 0);
@@ -290,6 +305,12 @@ void Engine::op_qlinear(const float* x, const float* W, const float* bias, int M
   const size_t oa = carve((size_t)Mp * Kp), ors = carve((size_t)Mp * 4), opar = carve(64), osc = carve(quant_scratch_bytes());
   const size_t ow = carve((size_t)Np * Kp), ocs = carve((size_t)(N + 8) * 4), ozp = carve((size_t)(N + 8) * 4), ows = carve((size_t)(N + 8) * 4);
   const size_t oy = carve((size_t)Mp * ldy * 4);
+  // bit 1 of x_is_f16: the f16-result kernel (deferred packed epilogue + the result's range for the next quantiser)
+  const bool f16_result = (x_is_f16 & 2) != 0;
+  x_is_f16 &= 1;
+  const int ld16 = (int)round_up(N, 8), Kq = (int)round_up(N, 128);
+  const size_t oy16 = carve((size_t)Mp * ld16 * 2), odz = carve((size_t)(N + 8) * 4), orng = carve(quant_scratch_bytes()), osc2 = carve(quant_scratch_bytes());
+  const size_t oq2 = carve((size_t)Mp * Kq), ors2 = carve((size_t)Mp * 4), opa = carve(64), opb = carve(64);
   ensure(ws_tmp_, off);
   char* base = (char*)ws_tmp_.p;
   PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
@@ -311,9 +332,28 @@ void Engine::op_qlinear(const float* x, const float* W, const float* bias, int M
   g.A = (int8_t*)(base + oa); g.lda = Kp; g.W = (int8_t*)(base + ow); g.ldw = Kp;
   g.rowsum = (int32_t*)(base + ors); g.colsum = (int32_t*)(base + ocs); g.wzp = (int32_t*)(base + ozp); g.wscale = (float*)(base + ows);
   g.aparams = (float*)(base + opar); g.bias = bias ? (const float*)(base + ob) : nullptr;
-  g.M = M; g.N = N; g.K = K; g.Kpad = Kp; g.out_f32 = (float*)(base + oy); g.ldc32 = ldy; g.relu = relu;
-  launch_gemm_i8(stream_, g);
-  PF_HIP(hipMemcpy2DAsync(y, (size_t)N * 4, base + oy, (size_t)ldy * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
+  g.M = M; g.N = N; g.K = K; g.Kpad = Kp; g.relu = relu;
+  float pa[2] = {0, 0}, pb[2] = {1, 1};
+  std::vector<uint16_t> y16;
+  if (f16_result) {
+    launch_pack_dz(stream_, g.colsum, g.wzp, N, K, (int32_t*)(base + odz));
+    g.out_f16 = (half_t*)(base + oy16); g.ldc16 = ld16; g.dz = (int32_t*)(base + odz); g.out_padded = 1; g.range_out = (float*)(base + orng);
+    launch_gemm_i8(stream_, g);
+    PF_CHECK(std::strncmp(last_gemm_kernel(), "gemm_i8f", 8) == 0, PF_ERR_DEVICE, "op_qlinear: the f16-result kernel was not selected");
+    // the range the kernel reports must be the range a min / max pass over its output finds: quantise the output both ways
+    launch_quantize(stream_, nullptr, (const half_t*)(base + oy16), M, N, ld16, (int8_t*)(base + oq2), Kq, (int32_t*)(base + ors2),
+                    (float*)(base + opa), (const float*)(base + orng));
+    launch_quantize_rows(stream_, nullptr, (const half_t*)(base + oy16), M, N, ld16, (int8_t*)(base + oq2), Kq, (int32_t*)(base + ors2),
+                         (float*)(base + opb), (unsigned*)(base + osc2));
+    PF_HIP(hipMemcpyAsync(pa, base + opa, 8, hipMemcpyDeviceToHost, stream_));
+    PF_HIP(hipMemcpyAsync(pb, base + opb, 8, hipMemcpyDeviceToHost, stream_));
+    y16.resize((size_t)M * ld16);
+    PF_HIP(hipMemcpyAsync(y16.data(), base + oy16, y16.size() * 2, hipMemcpyDeviceToHost, stream_));
+  } else {
+    g.out_f32 = (float*)(base + oy); g.ldc32 = ldy;
+    launch_gemm_i8(stream_, g);
+    PF_HIP(hipMemcpy2DAsync(y, (size_t)N * 4, base + oy, (size_t)ldy * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
+  }
   std::vector<int8_t> aq, wq;
   std::vector<int32_t> zp((size_t)N);
   if (xq_out) { aq.resize((size_t)M * Kp); PF_HIP(hipMemcpyAsync(aq.data(), base + oa, aq.size(), hipMemcpyDeviceToHost, stream_)); }
@@ -322,6 +362,15 @@ void Engine::op_qlinear(const float* x, const float* W, const float* bias, int M
   if (wscale_out) PF_HIP(hipMemcpyAsync(wscale_out, base + ows, (size_t)N * 4, hipMemcpyDeviceToHost, stream_));
   if (wzp_out) PF_HIP(hipMemcpyAsync(zp.data(), base + ozp, (size_t)N * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
+  PF_CHECK(!f16_result || (pa[0] == pb[0] && pa[1] == pb[1]), PF_ERR_DEVICE,
+           "op_qlinear: the range reported by the GEMM epilogue differs from a min / max pass over its output");
+  if (f16_result)
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        half_t h;
+        std::memcpy(&h, &y16[(size_t)m * ld16 + n], 2);
+        y[(size_t)m * N + n] = (float)h;
+      }
   if (xq_out)
     for (int m = 0; m < M; ++m)
       for (int k = 0; k < K; ++k) xq_out[(size_t)m * K + k] = (uint8_t)((int)aq[(size_t)m * Kp + k] + 128);

@@ -76,6 +76,10 @@ struct GemmDev {
   const float* q_wscale;     // [N]
   const float* q_aparams;    // [2]  {a_scale, a_zp} of the dynamically quantised activation tensor (device, written by the quantise kernels)
   int q_k;                   // true K (before padding)
+  // f16-result int8 kernel (gemm_i8f_pp3): per column dz[n] = (colsum[n] - K w_zp'[n]) * 256 + (w_zp'[n] & 255), so that a
+  // tile's column constants are three 256-byte lines (dz, w_scale, bias) fetched by LDS-DMA a tile ahead
+  const int32_t* q_dz;       // [N]
+  float* q_part;             // null, or QMM_G {min, max} pairs: the result's range for the quantiser that consumes it (k_quant.hip)
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -142,7 +146,7 @@ typedef i4x __attribute__((may_alias)) i4xa;
 // int32 and the (KIND 2) epilogues dequantise: y = float(acc - corr) * (a_scale * w_scale[n]) + bias[n], exact integers.
 template <int KIND, int MI, bool I8>
 __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
-  static_assert(!I8 || KIND == 2, "the int8 variant uses the fp32-result epilogues");
+  static_assert(!I8 || KIND == 2 || KIND == 1, "the int8 variant has the fp32-result epilogues and the row-major f16 one");
   using acc_t = std::conditional_t<I8, i16x, f16x>;
   constexpr int BK = GEMM_BK, S = GEMM_S, BM = 128 * MI, BN = GEMM_BN, WM = 32 * MI;
   constexpr int WN = 2, NW = 8;
@@ -263,18 +267,24 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
   h8 rowv;
   half_t* rowp = nullptr;
   {                                                  // zero the bias line (bias == null -> stays zero)
-    float* bl = reinterpret_cast<float*>(scr + 1152);
+    float* bl = reinterpret_cast<float*>(scr + (I8 ? 1664 : 1152));
     bl[lane] = 0.f;
     asm volatile("" ::: "memory");
   }
   // bias of tile `tile` -> the bias line, by a 4-byte LDS-DMA per lane (no VGPR, no compiler-inserted
   // wait; counted like any other DMA — ignoring it in the wait immediates only over-waits by one piece)
   auto fetch_bias = [&](int tile) __attribute__((always_inline)) {
-    if (!p.bias) return;
     const int tn = tile - (tile / p.tiles_n) * p.tiles_n;
     int n = tn * BN + wn * 64 + lane;
     n = n < p.N ? n : p.N - 1;
-    glds4(p.bias + n, scr + 1152);
+    if constexpr (I8) {                              // int8: the tile's column constants, consumed at ITS end (three lines)
+      glds4(p.q_dz + n, scr + 1152);
+      glds4(p.q_wscale + n, scr + 1408);
+      if (p.bias) glds4(p.bias + n, scr + 1664);
+    } else {
+      if (!p.bias) return;
+      glds4(p.bias + n, scr + 1152);
+    }
   };
   // accumulators of the next tile: bias (fast path: lane's 4 columns per quad, same for every row) or 0
   auto init_acc = [&](bool with_bias) __attribute__((always_inline)) {
@@ -284,7 +294,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (with_bias) b4 = *reinterpret_cast<const float4a*>(bl + j * 32 + 8 * g);
+        if constexpr (!I8) { if (with_bias) b4 = *reinterpret_cast<const float4a*>(bl + j * 32 + 8 * g); }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           acc[i][j][4 * g + 0] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w;
@@ -356,6 +366,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
   float q_ascale = 1.f;
   int q_azp = 0;
   if constexpr (I8) { q_ascale = p.q_aparams[0]; q_azp = (int)p.q_aparams[1] - 128; }
+  float trk_lo = 0.f, trk_hi = 0.f;                   // range of the f16 results (p.q_part): the consumer's DynamicQuantizeLinear pass 1
   auto dequant = [&](int a, int rowsum, int n) __attribute__((always_inline)) -> float {
     const int wz = p.q_wzp[n];
     const int v = a - wz * rowsum - q_azp * p.q_colsum[n] + p.q_k * q_azp * wz;
@@ -408,7 +419,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
               v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+            for (int e = 0; e < 4; ++e) { v[e] = fmaxf(v[e], lo); trk_lo = fminf(trk_lo, v[e]); trk_hi = fmaxf(trk_hi, v[e]); }
             if (o32) *reinterpret_cast<float4*>(o32 + dn) = make_float4(v[0], v[1], v[2], v[3]);
             if (o16) *reinterpret_cast<h4*>(o16 + dn) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
           } else {
@@ -418,6 +429,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
               if (a_ptr) x += a_ptr[dn + e];
               if (r_ptr) x += r_ptr[dn + e];
               x = fmaxf(x, lo);
+              trk_lo = fminf(trk_lo, x); trk_hi = fmaxf(trk_hi, x);
               if (o32) o32[dn + e] = x;
               if (o16) o16[dn + e] = (half_t)x;
             }
@@ -494,6 +506,10 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
         v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
+        if (m < p.M) {
+          trk_lo = fminf(fminf(trk_lo, v.x), fminf(fminf(v.y, v.z), v.w));
+          trk_hi = fmaxf(fmaxf(trk_hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+        }
         if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc32 + n) = v;
         if (p.out_f16)
           *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
@@ -524,6 +540,41 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
     const int m0 = tm * BM + wm * WM, n0 = tn * BN + wn * 64;
     if (wave_fast(tile)) {
       const float sc = (n0 < p.scale_cols) ? p.scale : 1.f;     // scale_cols is a multiple of 64
+      if constexpr (I8) {
+        // dequantise out of the three column lines (this tile's, fetched a tile ago): the same operations in the same
+        // order as the fp32-result epilogues — float(exact integer) * (a_scale * w_scale[n]), + bias, * scale, ReLU
+        int rs[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) rs[i] = p.q_rowsum[m0 + i * 32 + (lane & 31)];     // rows up to the padded M are readable
+        const char* ln = scr + 1152 + 16 * lh;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const i4x dz = *reinterpret_cast<const i4xa*>(ln + (j * 32 + 8 * g) * 4);
+            const float4 ws = *reinterpret_cast<const float4a*>(ln + 256 + (j * 32 + 8 * g) * 4);
+            const float4 bb = *reinterpret_cast<const float4a*>(ln + 512 + (j * 32 + 8 * g) * 4);
+            const float wsv[4] = {ws.x, ws.y, ws.z, ws.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int wz = (int)(int8_t)(dz[e] & 255), d = dz[e] >> 8;
+                const int iv = acc[i][j][4 * g + e] - wz * rs[i] - q_azp * d;
+                float x = mul_rn((float)iv, mul_rn(q_ascale, wsv[e]));
+                x = mul_rn(add_rn(x, bbv[e]), sc);
+                v[e] = fmaxf(x, lo);
+              }
+              if (m0 + i * 32 + (lane & 31) < p.M) {            // pad rows hold whatever the operand buffer held
+                trk_lo = fminf(fminf(trk_lo, v[0]), fminf(fminf(v[1], v[2]), v[3]));
+                trk_hi = fmaxf(fmaxf(trk_hi, v[0]), fmaxf(fmaxf(v[1], v[2]), v[3]));
+              }
+              hq[i][j][g] = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            }
+          }
+        asm volatile("" ::: "memory");
+      } else {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -532,6 +583,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
           for (int g = 0; g < 4; ++g)
             hq[i][j][g] = h4{(half_t)fmaxf(acc[i][j][4 * g + 0] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 1] * sc, lo),
                              (half_t)fmaxf(acc[i][j][4 * g + 2] * sc, lo), (half_t)fmaxf(acc[i][j][4 * g + 3] * sc, lo)};
+      }
       if constexpr (BLK) {
         // D^T fragment -> blocked layout: lanes 0..31 (rows) x {lh} (column half) = 512 contiguous bytes per store,
         // no transposition; the 16*MI stores are spread over the next k-steps, two per step (blk_store)
@@ -549,7 +601,8 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
     }
     init_acc(wave_fast(ep_tile));                     // bias line holds the NEXT tile's bias (fetched a tile ago)
     asm volatile("" ::: "memory");
-    if (fast0 && ep_tile + G < total_tiles) fetch_bias(ep_tile + G);
+    if constexpr (I8) { if (fast0 && ep_tile < total_tiles) fetch_bias(ep_tile); }       // int8: the lines hold the CURRENT tile's constants
+    else { if (fast0 && ep_tile + G < total_tiles) fetch_bias(ep_tile + G); }
   };
 
   // 16 MFMAs with the step's DMA pieces slotted between them; `mid` (counted wait + phase barrier)
@@ -601,7 +654,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
   if (fast0) { fetch_bias(slot); wait_vmcnt<0>(); asm volatile("" ::: "memory"); }
   init_acc(wave_fast(slot));
   asm volatile("" ::: "memory");
-  if (fast0 && slot + G < total_tiles) fetch_bias(slot + G);
+  if constexpr (!I8) { if (fast0 && slot + G < total_tiles) fetch_bias(slot + G); }
 
   if (grp == 0) {
     // ================= group A =================
@@ -663,12 +716,35 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
   }
   flush();                                            // the last tile's passes
   wait_vmcnt<0>();                                    // clamped tail DMA must land before LDS is released
+  if (p.q_part) {
+    // the range of this workgroup's results, as the f16 values the consumer will read (rounding is monotone); workgroups
+    // that own no tile returned above: the launcher zeroes the pairs beyond the grid
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      trk_lo = fminf(trk_lo, __shfl_xor(trk_lo, o, 64));
+      trk_hi = fmaxf(trk_hi, __shfl_xor(trk_hi, o, 64));
+    }
+    __builtin_amdgcn_s_barrier();                     // every wave is past its last use of the ring
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) { red[2 * wave] = trk_lo; red[2 * wave + 1] = trk_hi; }
+    __syncthreads();
+    if (tid == 0) {
+      float l = 0.f, h = 0.f;
+      for (int w = 0; w < NW; ++w) { l = fminf(l, red[2 * w]); h = fmaxf(h, red[2 * w + 1]); }
+      p.q_part[2 * bid] = (float)(half_t)l;
+      p.q_part[2 * bid + 1] = (float)(half_t)h;
+    }
+    if (bid == 0)                                     // the consumer folds 256 pairs whatever this grid was
+      for (int i = G + tid; i < 256; i += 512) { p.q_part[2 * i] = 0.f; p.q_part[2 * i + 1] = 0.f; }
+  }
 }
 
 template <int KIND, int MI>
 __global__ __launch_bounds__(512, 1) void gemm_f16_pp3(GemmDev p) { gemm_pp3_impl<KIND, MI, false>(p); }
 template <int MI>
 __global__ __launch_bounds__(512, 1) void gemm_i8_pp3(GemmDev p) { gemm_pp3_impl<2, MI, true>(p); }
+template <int MI>
+__global__ __launch_bounds__(512, 1) void gemm_i8f_pp3(GemmDev p) { gemm_pp3_impl<1, MI, true>(p); }   // f16-only results, deferred packed epilogue
 
 static thread_local const char* g_last_gemm_kernel = "";
 const char* last_gemm_kernel() { return g_last_gemm_kernel; }
@@ -680,7 +756,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   PF_CHECK((!a.out_f32 || a.ldc32 % 4 == 0) && (!a.out_f16 || a.ldc16 % 4 == 0) && (!a.resid || a.ldr % 4 == 0) &&
                (!a.add2 || a.ld2 % 4 == 0) && a.scale_cols % 64 == 0,
            PF_ERR_INVALID_ARG, "gemm: output leading dimensions must keep 16-byte row alignment");
-  GemmDev d;
+  GemmDev d{};
   d.A = a.A; d.W = a.W; d.bias = a.bias;
   d.out_f32 = a.out_f32; d.out_f16 = a.out_f16; d.resid = a.resid; d.add2 = a.add2;
   d.lda = a.lda; d.ldw = a.ldw; d.ldc32 = a.ldc32; d.ldc16 = a.ldc16; d.ldr = a.ldr; d.ld2 = a.ld2;
@@ -802,6 +878,8 @@ void launch_gemm_i8(hipStream_t s, const GemmI8Args& a) {
       PF_HIP(hipGetDeviceProperties(&prop, dev));
       PF_HIP(hipFuncSetAttribute((const void*)gemm_i8_pp3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
       PF_HIP(hipFuncSetAttribute((const void*)gemm_i8_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_i8f_pp3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_i8f_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
       cus[dev] = prop.multiProcessorCount;
     }
   }
@@ -814,9 +892,20 @@ void launch_gemm_i8(hipStream_t s, const GemmI8Args& a) {
   const int total = d.tiles_m * d.tiles_n;
   if (total == 0) return;
   const int grid = std::min(cus[dev], total);
-  note_gemm_kernel(mi == 2 ? "gemm_i8_pp3<2>" : "gemm_i8_pp3<1>");
-  if (mi == 2) hipLaunchKernelGGL((gemm_i8_pp3<2>), dim3(grid), dim3(512), gemm_lds_bytes(2), s, d);
-  else hipLaunchKernelGGL((gemm_i8_pp3<1>), dim3(grid), dim3(512), gemm_lds_bytes(1), s, d);
+  PF_CHECK(!a.range_out || grid <= 256, PF_ERR_UNSUPPORTED, "gemm_i8: range output needs a grid of at most 256 workgroups");
+  d.q_dz = a.dz; d.q_part = a.range_out;
+  // f16-only results into a padded buffer: the deferred packed epilogue (gemm_i8f_pp3), as the f16 path's KIND 1
+  const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && (a.ldc16 & 7) == 0 && a.dz;
+  d.out_padded = a.out_padded;
+  if (f16_only) {
+    note_gemm_kernel(mi == 2 ? "gemm_i8f_pp3<2>" : "gemm_i8f_pp3<1>");
+    if (mi == 2) hipLaunchKernelGGL((gemm_i8f_pp3<2>), dim3(grid), dim3(512), gemm_lds_bytes(2), s, d);
+    else hipLaunchKernelGGL((gemm_i8f_pp3<1>), dim3(grid), dim3(512), gemm_lds_bytes(1), s, d);
+  } else {
+    note_gemm_kernel(mi == 2 ? "gemm_i8_pp3<2>" : "gemm_i8_pp3<1>");
+    if (mi == 2) hipLaunchKernelGGL((gemm_i8_pp3<2>), dim3(grid), dim3(512), gemm_lds_bytes(2), s, d);
+    else hipLaunchKernelGGL((gemm_i8_pp3<1>), dim3(grid), dim3(512), gemm_lds_bytes(1), s, d);
+  }
   PF_HIP(hipGetLastError());
 }
 

@@ -377,4 +377,16 @@ void launch_import_weight(hipStream_t s, const uint8_t* Q, const uint8_t* zp, co
   PF_HIP(hipGetLastError());
 }
 
+// dz[n] = (colsum[n] - K wzp'[n]) * 256 + (wzp'[n] & 255): one word per column for the f16-result int8 GEMM's column line
+__global__ void pack_dz_kernel(const int32_t* __restrict__ colsum, const int32_t* __restrict__ wzp, int N, int K, int32_t* __restrict__ dz) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) dz[n] = (colsum[n] - K * wzp[n]) * 256 + (wzp[n] & 255);
+}
+void launch_pack_dz(hipStream_t s, const int32_t* colsum, const int32_t* wzp, int N, int K, int32_t* dz) {
+  PF_CHECK(K <= 16384, PF_ERR_UNSUPPORTED, "pack_dz: K too large for the packed column word");
+  if (N == 0) return;
+  hipLaunchKernelGGL(pack_dz_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, colsum, wzp, N, K, dz);
+  PF_HIP(hipGetLastError());
+}
+
 }  // namespace pf

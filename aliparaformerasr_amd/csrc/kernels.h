@@ -59,7 +59,12 @@ struct GemmI8Args {
   float* out_f32; int ldc32; half_t* out_f16; int ldc16;
   const float* resid; int ldr; const float* add2; int ld2;
   int relu; int scale_cols; float scale;
+  // f16-only results (out_f16, nothing else) into a buffer whose rows are padded to the tile height take the deferred
+  // packed epilogue when dz is given: dz[n] = (colsum[n] - K wzp[n]) * 256 + (wzp[n] & 255)  (launch_pack_dz)
+  const int32_t* dz; int out_padded;
+  float* range_out;                    // null, or quant_scratch_bytes(): {min, max} of the results per workgroup (pass 1 of the consumer's quantiser)
 };
+void launch_pack_dz(hipStream_t s, const int32_t* colsum, const int32_t* wzp, int N, int K, int32_t* dz);
 void launch_gemm_i8(hipStream_t s, const GemmI8Args& a);
 // DynamicQuantizeLinear over the WHOLE tensor x [rows, cols] (fp32, or f16 when x16 is given): min / max (including 0)
 // -> a_scale = (max - min) / 255, a_zp = rne(clamp(-min / a_scale, 0, 255)); q = clamp(rne(x / a_scale) + a_zp, 0, 255);

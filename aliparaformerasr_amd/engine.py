@@ -264,9 +264,11 @@ class Engine:
         N.check(self._lib.pf_op_lfr_cmvn_pad(self._h, ptrs, t80, B, 1 if sentinel else 0, _fp(out), out.size, tm))
         return out
 
-    def op_qlinear(self, x, W, bias=None, relu=False, x_is_f16=False, details=False):
+    def op_qlinear(self, x, W, bias=None, relu=False, x_is_f16=False, details=False, f16_result=False):
         """One dynamically quantised Linear on the int8 MFMA (pf_op_qlinear).  details=True also returns the uint8
-        activations, (x_scale, x_zp), the uint8 weights, w_scale and w_zp."""
+        activations, (x_scale, x_zp), the uint8 weights, w_scale and w_zp.  f16_result: through the f16-result kernel
+        (QKV / FFN-up in the pipeline): y = float32 of the f16 values it stored; the call fails if the range the kernel's
+        epilogue reports for the next quantiser differs from a min / max pass over its output."""
         x, W = _f32(x), _f32(W)
         rows, depth = x.shape
         cols = W.shape[0]
@@ -279,7 +281,8 @@ class Engine:
         wz = np.zeros(cols, np.int32)
         u8 = C.POINTER(C.c_uint8)
         N.check(self._lib.pf_op_qlinear(self._h, _fp(x), _fp(W), _fp(b) if b is not None else None, rows, cols, depth,
-                                        1 if relu else 0, 1 if x_is_f16 else 0, _fp(y), xq.ctypes.data_as(u8), _fp(ap),
+                                        1 if relu else 0, (1 if x_is_f16 else 0) | (2 if f16_result else 0), _fp(y),
+                                        xq.ctypes.data_as(u8), _fp(ap),
                                         wq.ctypes.data_as(u8), _fp(ws), wz.ctypes.data_as(C.POINTER(C.c_int32))))
         return (y, xq, (float(ap[0]), int(ap[1])), wq, ws, wz) if details else y
 

@@ -253,7 +253,10 @@ int pf_op_argmax(pf_engine* e, const float* x, int64_t rows, int32_t V, int64_t*
    constant weight).  x [M, K] fp32 (x_is_f16: first rounded to f16, as the engine's f16-stored activations are),
    W [N, K] fp32 (quantised per output channel to uint8 here), y [M, N] = float(sum (x_q - x_zp)(w_q - w_zp[n])) *
    (x_scale * w_scale[n]) + bias[n] [ReLU]; the integer sum runs on v_mfma_i32_32x32x32_i8 and is exact.  Optional outputs
-   (NULL = skip): the uint8 activations [M, K], {x_scale, x_zp}, the uint8 weights [N, K], w_scale [N], w_zp [N]. */
+   (NULL = skip): the uint8 activations [M, K], {x_scale, x_zp}, the uint8 weights [N, K], w_scale [N], w_zp [N].
+   x_is_f16 is a bit set: 1 = round x to f16 first; 2 = run the f16-result kernel of the pipeline's QKV / FFN-up
+   projections (y = the stored f16 values widened; PF_ERR_DEVICE if the range its epilogue reports for the next
+   quantiser differs from a min / max pass over its output). */
 int pf_op_qlinear(pf_engine* e, const float* x, const float* W, const float* bias, int32_t M, int32_t N, int32_t K,
                   int32_t relu, int32_t x_is_f16, float* y, uint8_t* xq_out, float* aparams_out, uint8_t* wq_out,
                   float* wscale_out, int32_t* wzp_out);

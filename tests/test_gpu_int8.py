@@ -58,6 +58,24 @@ def test_qlinear_bit_exact(eng, M, N, K):
     assert np.abs(y - full).max() < 0.05 * np.abs(full).max() + 0.2
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(16000, 1536, 512, False), (16000, 2048, 512, True), (700, 1536, 560, False), (5344, 2048, 512, True),
+                                        (300, 512, 2048, False), (257, 1000, 512, True)])
+def test_qlinear_f16_result_kernel_bit_exact(eng, M, N, K, relu):
+    """The kernel QKV and FFN-up run on (`gemm_i8f_pp3`: dequantisation out of the LDS column lines, deferred packed f16
+    stores, the result's {min, max} handed to the next quantiser): the stored f16 values must be the f16 rounding of the
+    oracle's float results, bit for bit, and the reported range must equal a min / max pass (checked inside the op)."""
+    rng = np.random.default_rng(M * 3 + N + K)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.5, 2.0)).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    y = eng.op_qlinear(x, Wm, bias, relu=relu, f16_result=True)
+    gq, gs, gz = q8.quantize_weight(Wm)
+    ref = q8.qlinear(x, gq, gs, gz, bias)
+    if relu:
+        ref = np.maximum(ref, 0)
+    np.testing.assert_array_equal(y, ref.astype(np.float16).astype(np.float32))
+
+
 def test_qlinear_relu_f16_input_and_degenerate_ranges(eng):
     rng = np.random.default_rng(7)
     x = np.abs(rng.standard_normal((130, 256))).astype(np.float32)        # non-negative input (post-ReLU hidden): zero point 0
