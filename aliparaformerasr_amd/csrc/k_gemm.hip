@@ -419,7 +419,10 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
               v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = fmaxf(v[e], lo); trk_lo = fminf(trk_lo, v[e]); trk_hi = fmaxf(trk_hi, v[e]); }
+            for (int e = 0; e < 4; ++e) {
+              v[e] = fmaxf(v[e], lo);
+              if constexpr (I8) { trk_lo = fminf(trk_lo, v[e]); trk_hi = fmaxf(trk_hi, v[e]); }
+            }
             if (o32) *reinterpret_cast<float4*>(o32 + dn) = make_float4(v[0], v[1], v[2], v[3]);
             if (o16) *reinterpret_cast<h4*>(o16 + dn) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
           } else {
@@ -429,7 +432,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
               if (a_ptr) x += a_ptr[dn + e];
               if (r_ptr) x += r_ptr[dn + e];
               x = fmaxf(x, lo);
-              trk_lo = fminf(trk_lo, x); trk_hi = fmaxf(trk_hi, x);
+              if constexpr (I8) { trk_lo = fminf(trk_lo, x); trk_hi = fmaxf(trk_hi, x); }
               if (o32) o32[dn + e] = x;
               if (o16) o16[dn + e] = (half_t)x;
             }
@@ -506,9 +509,11 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
         v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
-        if (m < p.M) {
-          trk_lo = fminf(fminf(trk_lo, v.x), fminf(fminf(v.y, v.z), v.w));
-          trk_hi = fmaxf(fmaxf(trk_hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+        if constexpr (I8) {
+          if (m < p.M) {
+            trk_lo = fminf(fminf(trk_lo, v.x), fminf(fminf(v.y, v.z), v.w));
+            trk_hi = fmaxf(fmaxf(trk_hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+          }
         }
         if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc32 + n) = v;
         if (p.out_f16)
@@ -716,7 +721,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
   }
   flush();                                            // the last tile's passes
   wait_vmcnt<0>();                                    // clamped tail DMA must land before LDS is released
-  if (p.q_part) {
+  if constexpr (I8) if (p.q_part) {
     // the range of this workgroup's results, as the f16 values the consumer will read (rounding is monotone); workgroups
     // that own no tile returned above: the launcher zeroes the pairs beyond the grid
 #pragma unroll
