@@ -1347,7 +1347,7 @@ void Engine::timestamp_head(int B, int T) {
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
   const size_t o_up = carve((size_t)std::max<int64_t>(Mp * up, M3p) * D * 2), o_xg = carve((size_t)M3p * 8 * D * 4);
-  const size_t o_ho = carve((size_t)M3 * 2 * D * 4), o_hs = carve((size_t)4 * B * D * 2), o_cs = carve((size_t)2 * B * D * 4);
+  const size_t o_ho = carve((size_t)M3 * 2 * D * 4), o_hs = carve((size_t)8 * B * D * 2), o_cs = carve((size_t)2 * B * D * 4);
   const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4), o_sw = carve(256);
   ensure(ws_ts_, off);
   char* base = (char*)ws_ts_.p;

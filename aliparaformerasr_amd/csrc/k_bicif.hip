@@ -206,6 +206,98 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(LstmArgs a, unsign
   }
 }
 
+// ---- ring form of the persistent recurrence (default): the h exchange carries its own arrival information.
+// h lives in FOUR slots per direction.  Step s reads slot s % 4 (h_{s-1}), writes h_s into slot (s + 1) % 4 and — once the
+// workgroup holds all of h_{s-1}, i.e. every workgroup of its group has finished reading slot (s + 3) % 4 (the input of
+// step s - 1) — overwrites its own 16-byte granules of slot (s + 3) % 4 with a POISON pattern (f16 NaNs; a hidden state
+// is sigmoid * tanh, never NaN).  That slot receives data two steps later (h_{s+2}), so the poison store has a whole
+// step to complete and nothing waits for it (with three slots the data store of the NEXT step had to wait for it).  A consumer simply loads the granules it needs (write-through-coherent loads) and
+// repeats while any of them is still poison: no arrival counter, no separate poll, no serialised loads — the chain of a
+// step is producer store -> consumer load instead of store -> drain -> counter add -> counter poll -> eight dependent
+// loads.  Why a consumer polling for h_{s+2} can only see poison or h_{s+2} in a producer's granule, never the stale
+// h_{s-2}: it received that producer's h_{s+1}, which wave 0 of the producer stored in step s + 1 after that step's
+// polls, and every poll ends in s_waitcnt vmcnt(0) — which also retired wave 0's poison store of step s (memory
+// operations of a wave retire in order).  A granule is written by one 16-byte store of one lane (observed untorn on
+// gfx950; the poison test reads its first word).  Bounded spins + the error word as in the counter form.
+// hstate: [ndir][4][B][D], slot 0 zero, slots 1-3 poison.
+__global__ __launch_bounds__(256) void lstm_ring_kernel(LstmArgs a, unsigned* __restrict__ err) {
+  const int D = a.D;
+  const int ub = blockIdx.x, dir = blockIdx.y, bt = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kg = lane >> 5;
+  __shared__ float red[4][16][64];
+  __shared__ _Float16 hx[32][8];
+  __shared__ int s_abort;
+  const half_t* wrow = a.whh + ((size_t)dir * 4 * D + (size_t)(r & 3) * D + ub * 8 + (r >> 2)) * D;
+  const int kspan = D / 4;
+  h8v av[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const h8v*>(wrow + wave * kspan + s * 16 + kg * 8);
+  const int bb = min(bt * 32 + r, a.B - 1);
+  const int b = bt * 32 + r;
+  const int uq = ub * 8 + 2 * wave + kg;
+  float c = 0.f;
+  if (threadIdx.x == 0) s_abort = 0;
+  __syncthreads();
+  h8v poison;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) poison[e] = __builtin_bit_cast(_Float16, (unsigned short)0xFFFFu);
+  half_t* const slots = a.hstate + (size_t)dir * 4 * a.B * D;
+  for (int step = 0; step < a.T3; ++step) {
+    const int t = dir == 0 ? step : a.T3 - 1 - step;
+    const int si = step & 3, so = (step + 1) & 3, sp = (step + 3) & 3;
+    const float* xgp = a.xg + ((size_t)bb * a.T3 + t) * (size_t)(a.ndir * 4 * D) + (size_t)dir * 4 * D + uq;
+    const float xi = xgp[0], xf = xgp[D], xc = xgp[2 * D], xo = xgp[3 * D];
+    const half_t* hrow = slots + ((size_t)si * a.B + bb) * D + wave * kspan + kg * 8;
+    h8v bv[8];
+    unsigned spins = 0;
+    // cheap poll first: lane j < 16 watches the first word of producer (wave * 16 + j)'s granule for the tile's first
+    // utterance (64 bytes per wave and poll; polling with the eight full loads — 8 KB per wave — kept 4 MB per round in
+    // flight on the fabric and made a step 7 us instead of 4.2); the full loads follow and are re-checked
+    const unsigned* watch = reinterpret_cast<const unsigned*>(slots + ((size_t)si * a.B + bt * 32) * D + wave * kspan + (lane & 15) * 8);
+    for (;;) {
+      unsigned w0;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w0) : "v"(watch) : "memory");
+      bool bad = w0 == 0xFFFFFFFFu;
+      if (!__any(bad)) {
+        ld8x16_sc1(hrow, bv);
+        bad = false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bad |= (__builtin_bit_cast(uint4, bv[s]).x == 0xFFFFFFFFu);
+        if (!__any(bad)) break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22) || (lane == 0 && (spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (lane == 0) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
+        break;
+      }
+    }
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();                                           // all four K slices are in: this workgroup holds all of h_{step-1}
+    if (s_abort) return;
+    if (wave == 0 && lane < 32 && bt * 32 + lane < a.B)        // re-arm this workgroup's granules of the slot two steps ahead
+      st16_sc1(slots + ((size_t)sp * a.B + bt * 32 + lane) * D + ub * 8, poison);
+    float g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      g[q] = (red[0][4 * wave + q][lane] + red[1][4 * wave + q][lane]) + (red[2][4 * wave + q][lane] + red[3][4 * wave + q][lane]);
+    const float gi = g[0] + xi, gf = g[1] + xf, gg = g[2] + xc, go = g[3] + xo;
+    c = sigmoidf_(gf) * c + sigmoidf_(gi) * tanhf(gg);
+    const float h = sigmoidf_(go) * tanhf(c);
+    hx[r][2 * wave + kg] = (_Float16)h;
+    __syncthreads();
+    if (wave == 0 && lane < 32 && bt * 32 + lane < a.B)        // publish h_step first, everything else after it
+      st16_sc1(slots + ((size_t)so * a.B + bt * 32 + lane) * D + ub * 8, *reinterpret_cast<const h8v*>(&hx[lane][0]));
+    if (b < a.B) a.hout[((size_t)b * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + uq] = h;
+  }
+}
+
 // returns false when the persistent form cannot be used (grid larger than the device, or D != 512): caller falls
 // back to one launch per step
 bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_words /* >= 64 words, device */) {
@@ -219,8 +311,19 @@ bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_wor
   if (wgs > cus || a.ndir * tiles > 60) return false;       // every workgroup must be resident: one per CU at most
   PF_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
   LstmArgs b = a;
-  { static int var = -1; if (var < 0) { const char* e = getenv("PF_LSTM_VAR"); var = e ? atoi(e) : 0; } b.step = var; }
-  hipLaunchKernelGGL(lstm_persistent_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(256), 0, s, b, sync_words, sync_words + 63);
+  static int var = -1;                                       // PF_LSTM_VAR: 2 = ring form (default), 0 / 1 = arrival-counter form
+  if (var < 0) { const char* e = getenv("PF_LSTM_VAR"); var = e ? atoi(e) : 2; }
+  if (var == 2) {
+    // hstate [ndir][4][B][D]: slot 0 = h_{-1} = 0, slots 1 to 3 poison
+    const size_t slot = (size_t)a.B * a.D * 2;
+    PF_HIP(hipMemsetAsync(a.hstate, 0xFF, (size_t)a.ndir * 4 * slot, s));
+    for (int d = 0; d < a.ndir; ++d) PF_HIP(hipMemsetAsync(reinterpret_cast<char*>(a.hstate) + (size_t)d * 4 * slot, 0, slot, s));
+    hipLaunchKernelGGL(lstm_ring_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(256), 0, s, b, sync_words + 63);
+  } else {
+    PF_HIP(hipMemsetAsync(a.hstate, 0, (size_t)a.ndir * 2 * a.B * a.D * 2, s));
+    b.step = var;
+    hipLaunchKernelGGL(lstm_persistent_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(256), 0, s, b, sync_words, sync_words + 63);
+  }
   PF_HIP(hipGetLastError());
   return true;
 }

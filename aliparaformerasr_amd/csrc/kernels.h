@@ -212,7 +212,7 @@ void launch_cif_gather_cumsum(hipStream_t s, const float* H, const float* alphas
 struct LstmArgs {
   const half_t* whh;   // [2 dir][4D][D] f16, PyTorch gate order i,f,g,o
   const float* xg;     // [B*T3][2 dir * 4D] input-side gate pre-activations (+ both biases)
-  half_t* hstate;      // [2 dir][2 ping-pong][B][D]
+  half_t* hstate;      // [ndir][2 ping-pong][B][D]; the persistent launcher needs room for [ndir][4][B][D] (ring form) and initialises it
   float* cstate;       // [2 dir][B][D]
   float* hout;         // [B*T3][2D]  forward | reverse hidden states
   int B, T3, D, step;  // step s handles t = s (forward) and t = T3-1-s (reverse)
