@@ -220,22 +220,27 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(LstmArgs a, unsign
 // operations of a wave retire in order).  A granule is written by one 16-byte store of one lane (observed untorn on
 // gfx950; the poison test reads its first word).  Bounded spins + the error word as in the counter form.
 // hstate: [ndir][4][B][D], slot 0 zero, slots 1-3 poison.
-__global__ __launch_bounds__(256) void lstm_ring_kernel(LstmArgs a, unsigned* __restrict__ err) {
+__global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __restrict__ err) {
   const int D = a.D;
   const int ub = blockIdx.x, dir = blockIdx.y, bt = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kg = lane >> 5;
   __shared__ float red[4][16][64];
   __shared__ _Float16 hx[32][8];
+  __shared__ float hf[32][8];                               // the same slice in fp32 for hout
   __shared__ int s_abort;
+  // wave 4 is the STORE wave: poison, h and hout stores are its only memory operations, so the compute waves' polls
+  // (s_waitcnt vmcnt(0) each) never sit behind the acknowledgement of a write-through store
+  const bool storer = wave == 4;
+  const int cw = storer ? 0 : wave;                          // K slice index of a compute wave
   const half_t* wrow = a.whh + ((size_t)dir * 4 * D + (size_t)(r & 3) * D + ub * 8 + (r >> 2)) * D;
   const int kspan = D / 4;
   h8v av[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const h8v*>(wrow + wave * kspan + s * 16 + kg * 8);
+  for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const h8v*>(wrow + cw * kspan + s * 16 + kg * 8);
   const int bb = min(bt * 32 + r, a.B - 1);
   const int b = bt * 32 + r;
-  const int uq = ub * 8 + 2 * wave + kg;
+  const int uq = ub * 8 + 2 * cw + kg;
   float c = 0.f;
   if (threadIdx.x == 0) s_abort = 0;
   __syncthreads();
@@ -246,6 +251,23 @@ __global__ __launch_bounds__(256) void lstm_ring_kernel(LstmArgs a, unsigned* __
   for (int step = 0; step < a.T3; ++step) {
     const int t = dir == 0 ? step : a.T3 - 1 - step;
     const int si = step & 3, so = (step + 1) & 3, sp = (step + 3) & 3;
+    if (storer) {
+      __syncthreads();                                         // (1) the workgroup holds all of h_{step-1}
+      if (s_abort) return;
+      if (lane < 32 && bt * 32 + lane < a.B)                   // re-arm this workgroup's granules of the slot read one step ago
+        st16_sc1(slots + ((size_t)sp * a.B + bt * 32 + lane) * D + ub * 8, poison);
+      __syncthreads();                                         // (2) hx / hf hold the new slice
+      // the poison store of the PREVIOUS step must have completed before this step's h becomes visible (see above): of
+      // this wave's stores only {poison(step), hout(step-1), h(step-1)} may still be in flight
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (lane < 32 && bt * 32 + lane < a.B)
+        st16_sc1(slots + ((size_t)so * a.B + bt * 32 + lane) * D + ub * 8, *reinterpret_cast<const h8v*>(&hx[lane][0]));
+      const int ob = bt * 32 + (lane >> 1);
+      if (ob < a.B)
+        *reinterpret_cast<float4*>(a.hout + ((size_t)ob * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + ub * 8 + (lane & 1) * 4) =
+            *reinterpret_cast<const float4*>(&hf[lane >> 1][(lane & 1) * 4]);
+      continue;                                                // (the next step's barrier (1) orders these reads of hx / hf before their rewrite)
+    }
     const float* xgp = a.xg + ((size_t)bb * a.T3 + t) * (size_t)(a.ndir * 4 * D) + (size_t)dir * 4 * D + uq;
     const float xi = xgp[0], xf = xgp[D], xc = xgp[2 * D], xo = xgp[3 * D];
     const half_t* hrow = slots + ((size_t)si * a.B + bb) * D + wave * kspan + kg * 8;
@@ -255,7 +277,19 @@ __global__ __launch_bounds__(256) void lstm_ring_kernel(LstmArgs a, unsigned* __
     // utterance (64 bytes per wave and poll; polling with the eight full loads — 8 KB per wave — kept 4 MB per round in
     // flight on the fabric and made a step 7 us instead of 4.2); the full loads follow and are re-checked
     const unsigned* watch = reinterpret_cast<const unsigned*>(slots + ((size_t)si * a.B + bt * 32) * D + wave * kspan + (lane & 15) * 8);
-    for (;;) {
+    // the workgroups run in lockstep, so the others' h_{step-1} becomes visible about one store latency after this
+    // workgroup published its own: wait that long (a.step x 64 clocks), then ask for the real thing at once — when it is
+    // there the step has ONE load round trip after arrival instead of two (successful cheap poll + the full loads)
+    bool got = false;
+    if (step > 0 && a.step > 0) {
+      for (int z = 0; z < a.step; ++z) __builtin_amdgcn_s_sleep(2);
+      ld8x16_sc1(hrow, bv);
+      bool bad = false;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bad |= (__builtin_bit_cast(uint4, bv[s]).x == 0xFFFFFFFFu);
+      got = !__any(bad);
+    }
+    while (!got) {
       unsigned w0;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w0) : "v"(watch) : "memory");
       bool bad = w0 == 0xFFFFFFFFu;
@@ -279,10 +313,8 @@ __global__ __launch_bounds__(256) void lstm_ring_kernel(LstmArgs a, unsigned* __
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bv[s], acc, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
-    __syncthreads();                                           // all four K slices are in: this workgroup holds all of h_{step-1}
+    __syncthreads();                                           // (1) all four K slices are in
     if (s_abort) return;
-    if (wave == 0 && lane < 32 && bt * 32 + lane < a.B)        // re-arm this workgroup's granules of the slot two steps ahead
-      st16_sc1(slots + ((size_t)sp * a.B + bt * 32 + lane) * D + ub * 8, poison);
     float g[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -291,10 +323,8 @@ __global__ __launch_bounds__(256) void lstm_ring_kernel(LstmArgs a, unsigned* __
     c = sigmoidf_(gf) * c + sigmoidf_(gi) * tanhf(gg);
     const float h = sigmoidf_(go) * tanhf(c);
     hx[r][2 * wave + kg] = (_Float16)h;
-    __syncthreads();
-    if (wave == 0 && lane < 32 && bt * 32 + lane < a.B)        // publish h_step first, everything else after it
-      st16_sc1(slots + ((size_t)so * a.B + bt * 32 + lane) * D + ub * 8, *reinterpret_cast<const h8v*>(&hx[lane][0]));
-    if (b < a.B) a.hout[((size_t)b * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + uq] = h;
+    hf[r][2 * wave + kg] = h;
+    __syncthreads();                                           // (2)
   }
 }
 
@@ -314,11 +344,14 @@ bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_wor
   static int var = -1;                                       // PF_LSTM_VAR: 2 = ring form (default), 0 / 1 = arrival-counter form
   if (var < 0) { const char* e = getenv("PF_LSTM_VAR"); var = e ? atoi(e) : 2; }
   if (var == 2) {
+    static int delay = -1;                                   // PF_LSTM_DELAY: x 2 x 64 clocks before the first (full) load of a step
+    if (delay < 0) { const char* e = getenv("PF_LSTM_DELAY"); delay = e ? atoi(e) : 13; }
+    b.step = delay;
     // hstate [ndir][4][B][D]: slot 0 = h_{-1} = 0, slots 1 to 3 poison
     const size_t slot = (size_t)a.B * a.D * 2;
     PF_HIP(hipMemsetAsync(a.hstate, 0xFF, (size_t)a.ndir * 4 * slot, s));
     for (int d = 0; d < a.ndir; ++d) PF_HIP(hipMemsetAsync(reinterpret_cast<char*>(a.hstate) + (size_t)d * 4 * slot, 0, slot, s));
-    hipLaunchKernelGGL(lstm_ring_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(256), 0, s, b, sync_words + 63);
+    hipLaunchKernelGGL(lstm_ring_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(320), 0, s, b, sync_words + 63);
   } else {
     PF_HIP(hipMemsetAsync(a.hstate, 0, (size_t)a.ndir * 2 * a.B * a.D * 2, s));
     b.step = var;
