@@ -74,6 +74,8 @@ Engine::Engine(const pf_engine_config& cfg) {
     PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     PF_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     PF_HIP(hipEventCreateWithFlags(&ev_scan_, hipEventDisableTiming));
+    PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
+    PF_HIP(hipEventCreateWithFlags(&ev_ts_, hipEventDisableTiming));
     load_weights(cfg);
     mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
     fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
@@ -100,6 +102,8 @@ void Engine::release() {
   if (stream_) hipStreamSynchronize(stream_);
   if (aux_stream_) { hipStreamSynchronize(aux_stream_); hipStreamDestroy(aux_stream_); aux_stream_ = nullptr; }
   if (ev_scan_) { hipEventDestroy(ev_scan_); ev_scan_ = nullptr; }
+  if (ts_stream_) { hipStreamSynchronize(ts_stream_); hipStreamDestroy(ts_stream_); ts_stream_ = nullptr; }
+  if (ev_ts_) { hipEventDestroy(ev_ts_); ev_ts_ = nullptr; }
   if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
   profile_reset();
   if (fb_) { fbank_tables_destroy(fb_); fb_ = nullptr; }
@@ -125,6 +129,7 @@ void Engine::ensure(DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return;
   if (b.p) {
     PF_HIP(hipStreamSynchronize(stream_));
+    if (ts_stream_) PF_HIP(hipStreamSynchronize(ts_stream_));   // (a call that threw may have left the timestamp head unjoined)
     PF_HIP(hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
@@ -970,7 +975,30 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   PF_HIP(hipEventRecord(ev_scan_, stream_));
   last_.peak_len = 0;
   last_.cif_peak.clear();
-  if (mc_.timestamp_head) timestamp_head(B, T);
+  if (mc_.timestamp_head) {
+    static int ts_side = -1;
+    if (ts_side < 0) { const char* e = getenv("PF_TS_STREAM"); ts_side = e ? atoi(e) : 1; }
+    if (ts_side && !lstm_steps_) {
+      // beside the decoder, on its own stream: everything timestamp_head enqueues (two GEMMs, the persistent recurrence,
+      // the peaks and their copy to the host) goes to ts_stream_, which waits for the CIF scan (= the encoder too)
+      PF_HIP(hipStreamWaitEvent(ts_stream_, ev_scan_, 0));
+      std::swap(stream_, ts_stream_);
+      ts_defer_copy_ = true;
+      try {
+        timestamp_head(B, T);
+      } catch (...) {
+        std::swap(stream_, ts_stream_);
+        ts_defer_copy_ = false;
+        throw;
+      }
+      ts_defer_copy_ = false;
+      std::swap(stream_, ts_stream_);
+      PF_HIP(hipEventRecord(ev_ts_, ts_stream_));
+      ts_pending_ = true;
+    } else {
+      timestamp_head(B, T);
+    }
+  }
   // The cross-attention K/V projections of all decoder layers depend on the encoder output only, not on the decoder
   // length: they go out BEFORE the length is read back and keep the device busy during the host round trip (and,
   // in a multi-device group, during the rendez-vous that agrees on the batch-wide length).
@@ -994,7 +1022,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   if (l_hook_) L = l_hook_(L);                       // shard of a multi-device batch: the batch-wide maximum
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);
-  if (L == 0) return;
+  if (L == 0) { join_ts(); return; }
 
   const int Md = B * L;
   const int64_t Mdp = round_up(Md, 128) + 128;
@@ -1127,7 +1155,17 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   launch_argmax(stream_, logits_, Md, V, logits_ld_, want_logits ? 2 : 1, ids_dev_);
   prof_end("argmax");
   if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
+  join_ts();
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::join_ts() {
+  if (!ts_pending_) return;
+  PF_HIP(hipStreamWaitEvent(stream_, ev_ts_, 0));      // the caller's sync of stream_ then covers the timestamp head
+  if (ts_copy_floats_)
+    PF_HIP(hipMemcpyAsync(last_.cif_peak.data(), us_peak_, ts_copy_floats_ * 4, hipMemcpyDeviceToHost, stream_));
+  ts_copy_floats_ = 0;
+  ts_pending_ = false;
 }
 
 // ------------------------------------------------------------------ streaming seams -------
@@ -1395,7 +1433,10 @@ void Engine::timestamp_head(int B, int T) {
   prof_end("ts_misc");
   last_.peak_len = T3;
   last_.cif_peak.resize((size_t)M3);
-  PF_HIP(hipMemcpyAsync(last_.cif_peak.data(), us_peak_, (size_t)M3 * 4, hipMemcpyDeviceToHost, stream_));
+  // the copy to (pageable) host memory blocks the calling thread until the recurrence has finished: when the head runs
+  // beside the decoder it is issued at the join instead (join_ts), after the decoder has been enqueued
+  if (ts_defer_copy_) ts_copy_floats_ = (size_t)M3;
+  else PF_HIP(hipMemcpyAsync(last_.cif_peak.data(), us_peak_, (size_t)M3 * 4, hipMemcpyDeviceToHost, stream_));
 }
 
 void Engine::sensevoice_head(int B, int T, bool want_logits) {

@@ -204,6 +204,14 @@ class Engine {
   hipStream_t stream_ = nullptr;
   hipStream_t aux_stream_ = nullptr;   // carries the decoder-length read-back, so stream_ keeps running (K/V projections) meanwhile
   hipEvent_t ev_scan_ = nullptr;       // CIF scan finished
+  // the BiCIF timestamp head depends on the encoder output and token_num only: it runs on its own stream beside the
+  // decoder (its recurrence is 1500 dependent steps on 128 workgroups — latency, not throughput) and is joined before
+  // the call's last copy (PF_TS_STREAM=0 keeps it on the main stream)
+  hipStream_t ts_stream_ = nullptr;
+  hipEvent_t ev_ts_ = nullptr;
+  bool ts_pending_ = false, ts_defer_copy_ = false;
+  size_t ts_copy_floats_ = 0;
+  void join_ts();
   bool no_rc_ = false, rc_ffn2_ = false, lstm_steps_ = false;
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)

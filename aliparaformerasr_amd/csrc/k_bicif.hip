@@ -239,7 +239,6 @@ __global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __
 #pragma unroll
   for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const h8v*>(wrow + cw * kspan + s * 16 + kg * 8);
   const int bb = min(bt * 32 + r, a.B - 1);
-  const int b = bt * 32 + r;
   const int uq = ub * 8 + 2 * cw + kg;
   float c = 0.f;
   if (threadIdx.x == 0) s_abort = 0;

@@ -631,6 +631,10 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
         }
         if (s * MI + i == KSUB * MI - 2) {
           issue_advance();
+          // every fragment read of this step has executed before the phase barrier in `mid`: behind that barrier the
+          // OTHER group issues DMA pieces into the slot these fragments came from (the compiler's own counted lgkmcnt waits
+          // only cover the fragments of the MFMAs issued so far)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           mid();
         }
         if constexpr (!(ABL & 4))
@@ -710,6 +714,11 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
           else wait_vmcnt<WAITN>();
           s_prev2 = s_prev; s_prev = sB;
         }
+        // This group's DMA of COMPUTE(k) refills the very slot whose fragments were requested above (stage k + 3 -> slot
+        // k % 3): every wave's fragment reads must have EXECUTED before any wave of the group may issue a piece, i.e. before
+        // the barrier.  Without this wait the order held only by timing (a ds_read retires long before a DMA round trip) —
+        // until another kernel's workgroup shared the CU and kept the LDS pipe busy: wrong products (tools/interfere.py).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         burst(pidx, [&]() __attribute__((always_inline)) {
           if (sB) { if constexpr (BLK) blk_store(pidx); else pass_store(); }
