@@ -35,6 +35,9 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
     w2 = (rng.standard_normal((D, F)) / 45).astype(np.float32)
     wq = (rng.standard_normal((D, D)) / 22).astype(np.float32)
     b2 = rng.standard_normal(D).astype(np.float32)
+    xe = rng.standard_normal((16000, D)).astype(np.float32)
+    g = rng.standard_normal(D).astype(np.float32)
+    be = rng.standard_normal(D).astype(np.float32)
     q = rng.standard_normal((Bt, L, D)).astype(np.float32)
     k = rng.standard_normal((Bt, T, D)).astype(np.float32)
     v = rng.standard_normal((Bt, T, D)).astype(np.float32)
@@ -45,6 +48,9 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
         "f16-result GEMM 5344x512x512, 128-row tiles": lambda: B.op_gemm_ex(x, wq, b2, out_kind=1, tile_rows=128),
         "f16-result GEMM 5344x2048x512": lambda: B.op_gemm_ex(x, w1, None, relu=True, out_kind=1),
         "cross-attention 32x167x500": lambda: B.op_attention(q, k, v),
+        "blocked-result GEMM 16000x2048x512 (persistent 256x256 tiles)": lambda: B.op_gemm_ex(xe, w1, None, relu=True, out_kind=2),
+        "row-complete GEMM + residual + LayerNorm 16000x512x512": lambda: B.op_gemm_rc(xe, wq, b2, resid=xe, ln=(g, be))[0],
+        "self-attention 8x500x500": lambda: B.op_attention(k[:8], k[:8], v[:8]),
     }
     quiet = {name: f() for name, f in ops.items()}
     stop = []
@@ -57,7 +63,7 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
         time.sleep(1.0)
         for name, f in ops.items():
             t0, n = time.time(), 0
-            while time.time() - t0 < 2.5 or n < 8:
+            while time.time() - t0 < 2.0 or n < 6:
                 y = f()
                 n += 1
                 assert np.array_equal(y, quiet[name]), "%s: run %d beside the busy engine differs from the quiet run by %.3g" % (
