@@ -2,6 +2,7 @@
 // exceptions into a negative pf_status + thread-local message; no exception crosses the ABI.
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 
@@ -18,9 +19,13 @@ void set_last_error(const std::string& m) { g_last_error = m; }
 
 using namespace pf;
 
-// Handle shells are never returned to the allocator: a second pf_engine_destroy / pf_recognizer_free /
-// pf_stream_free on the same handle (Dispose followed by a finaliser, OfflineRecognizer.cs:448-476) finds an
-// empty shell instead of freed memory.  A shell is a few dozen bytes; the device state it pointed to IS released.
+// Handle shells outlive the objects they point to: a second pf_engine_destroy / pf_recognizer_free / pf_stream_free on
+// the same handle (Dispose followed by a finaliser, OfflineRecognizer.cs:448-476) finds an empty shell instead of freed
+// memory.  Engine / recognizer / group shells (a handful per process) are never returned to the allocator; STREAM shells
+// — one per utterance in a server — go through a quarantine (ShellPool below): a freed shell answers PF_ERR_DISPOSED for
+// as long as it sits in the queue and is handed out again only after kQuarantine younger frees, so the memory is bounded
+// (a few MB) instead of growing by one shell per stream for the life of the process.  The device / host state a shell
+// pointed to IS released at once.
 struct pf_engine {
   std::mutex mu;
   std::shared_ptr<Engine> e;
@@ -49,6 +54,34 @@ struct pf_group {
   std::shared_ptr<Group> g;
   std::vector<std::unique_ptr<pf_engine>> views;    // borrowed engine handles (pf_group_engine)
 };
+
+// Recycles shells of type T (default-constructible, with `bool freed`) through a FIFO quarantine.
+template <class T>
+class ShellPool {
+ public:
+  static constexpr size_t kQuarantine = 1 << 16;
+  T* get() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (q_.size() > kQuarantine) {
+        T* t = q_.front();
+        q_.pop_front();
+        *t = T();                                     // a stale handle older than kQuarantine frees now aliases a live stream
+        return t;
+      }
+    }
+    return new T();
+  }
+  void retire(T* t) {                                 // the caller has emptied the shell and set freed
+    std::lock_guard<std::mutex> lk(mu_);
+    q_.push_back(t);
+  }
+ private:
+  std::mutex mu_;
+  std::deque<T*> q_;
+};
+static ShellPool<pf_stream>& stream_shells() { static ShellPool<pf_stream>* p = new ShellPool<pf_stream>(); return *p; }
+static ShellPool<pf_online_stream>& online_stream_shells() { static ShellPool<pf_online_stream>* p = new ShellPool<pf_online_stream>(); return *p; }
 
 #define PF_TRY try {
 #define PF_CATCH                                                          \
@@ -624,7 +657,7 @@ int pf_recognizer_create_stream(pf_recognizer* h, pf_stream** out) {
   NEED(out);
   *out = nullptr;
   std::shared_ptr<Stream> s = R(h)->CreateOfflineStream();
-  pf_stream* sh = new pf_stream();
+  pf_stream* sh = stream_shells().get();
   sh->s = s;
   *out = sh;
   return PF_OK;
@@ -694,7 +727,8 @@ void pf_stream_free(pf_stream* h) {
   if (!h || h->freed) return;
   if (h->s) h->s->Dispose();
   h->s.reset();                                     // drops this stream's share of the recognizer object
-  h->freed = true;                                  // the shell stays (double free / use after free -> PF_ERR_DISPOSED)
+  h->freed = true;                                  // the shell stays (double free / use after free -> PF_ERR_DISPOSED) ...
+  stream_shells().retire(h);                        // ... in the quarantine
 }
 
 int pf_recognizer_get_results(pf_recognizer* h, pf_stream* const* streams, int32_t n) {
@@ -814,7 +848,7 @@ int pf_online_create_stream(pf_online_recognizer* h, pf_online_stream** out) {
   NEED(out);
   *out = nullptr;
   std::shared_ptr<OnlineStreamM> s = OR(h)->CreateOnlineStream();
-  pf_online_stream* sh = new pf_online_stream();
+  pf_online_stream* sh = online_stream_shells().get();
   sh->s = s;
   *out = sh;
   return PF_OK;
@@ -865,6 +899,7 @@ void pf_online_stream_free(pf_online_stream* h) {
   if (h->s) h->s->disposed = true;
   h->s.reset();
   h->freed = true;
+  online_stream_shells().retire(h);
 }
 int pf_online_encoder(pf_engine* h, const float* speech, int32_t B, int32_t Tc, float* enc_out, float* alphas_out) {
   PF_TRY

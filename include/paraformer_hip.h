@@ -366,7 +366,11 @@ int pf_stream_get_hotwords(pf_stream* s, int32_t* ids, int32_t ids_cap, int32_t*
 int pf_stream_num_feature_floats(pf_stream* s, int32_t* n);  /* OfflineInputEntity.SpeechLength */
 void pf_stream_dispose(pf_stream* s);            /* DisposeOfflineStream :441: drops the buffers; the handle stays
                                                     valid and later calls answer PF_ERR_DISPOSED           */
-void pf_stream_free(pf_stream* s);               /* releases the handle (and its share of the recognizer)   */
+void pf_stream_free(pf_stream* s);               /* releases the handle (and its share of the recognizer).  Idempotent: the
+                                                    handle keeps answering PF_ERR_DISPOSED (Dispose + finaliser both
+                                                    calling it is safe) until 65 536 younger stream handles have been
+                                                    freed, after which its few dozen bytes are handed out again — a
+                                                    server creating one stream per utterance does not grow          */
 
 /* GetResults(List<OfflineStream>) (OfflineRecognizer.cs:110): Forward + DecodeMulti.
    Results stay owned by the recognizer until the next GetResults call / dispose. */

@@ -213,3 +213,36 @@ def test_conf_frame_length_and_shift_are_ignored_like_the_reference(model_dir, t
     sb.AddSamples(x)
     assert sa.SpeechLength == sb.SpeechLength == 33 * 560
     assert a.GetResult(sa).Text == b.GetResult(sb).Text
+
+
+@pytest.mark.timeout(300)
+def test_stream_handles_are_quarantined_then_recycled(model_dir):
+    """One stream per utterance for the life of a server: a freed handle answers PF_ERR_DISPOSED (double free / use after
+    free, the Dispose-then-finaliser pattern of OfflineRecognizer.cs:448-476) for as long as it sits in the quarantine, and
+    its shell is handed out again after 65 536 younger frees — the process does not grow by one shell per stream."""
+    import ctypes as C
+    from aliparaformerasr_amd import _native as N
+    r = _make(model_dir)
+    lib = N.load()
+    first = C.c_void_p()
+    N.check(lib.pf_recognizer_create_stream(r._h, C.byref(first)))
+    lib.pf_stream_free(first)
+    lib.pf_stream_free(first)                                   # second free of the same handle: no-op
+    n = C.c_int32()
+    assert lib.pf_stream_num_feature_floats(first, C.byref(n)) == N.PF_ERR_DISPOSED
+    seen = set()
+    recycled = False
+    for i in range(66000):
+        h = C.c_void_p()
+        N.check(lib.pf_recognizer_create_stream(r._h, C.byref(h)))
+        if h.value == first.value:
+            recycled = True
+            assert lib.pf_stream_num_feature_floats(h, C.byref(n)) == 0 and n.value == 0     # a fresh, live stream
+        assert h.value not in seen or i > 65536
+        seen.add(h.value)
+        lib.pf_stream_free(h)
+        if i < 65000:
+            assert lib.pf_stream_num_feature_floats(first, C.byref(n)) == N.PF_ERR_DISPOSED or recycled
+    assert recycled, "the first freed shell was never handed out again"
+    assert len(seen) <= 65536 + 2
+    r.Dispose()
