@@ -29,18 +29,18 @@ fw = (0.1 * rng.standard_normal((D, 11))).astype(np.float32)
 tn = np.full(Bt, L, np.int32)
 xe = rng.standard_normal((16000, D)).astype(np.float32)
 he = np.abs(rng.standard_normal((16000, F))).astype(np.float32)
+speech = rng.standard_normal((8, 200, 560)).astype(np.float32)
+lg = rng.standard_normal((2000, 8404)).astype(np.float32)
 ops = {
-  "f32-out 5344x512x2048 auto": lambda: B.op_gemm_ex(h, w2, None),
-  "f32-out 5344x512x2048 tile 128": lambda: B.op_gemm_ex(h, w2, None, tile_rows=128),
-  "f32-out 5344x512x2048 tile 256": lambda: B.op_gemm_ex(h, w2, None, tile_rows=256),
-  "f32-out 5344x512x512 tile 128": lambda: B.op_gemm_ex(x, wq, None, tile_rows=128),
-  "f32-out 5344x512x512 tile 256": lambda: B.op_gemm_ex(x, wq, None, tile_rows=256),
-  "f16-out 5344x512x512 tile 128": lambda: B.op_gemm_ex(x, wq, None, out_kind=1, tile_rows=128),
-  "f16-out 5344x512x512 tile 256": lambda: B.op_gemm_ex(x, wq, None, out_kind=1, tile_rows=256),
-  "f32-out 16000x512x2048 (enc ffn2)": lambda: B.op_gemm_ex(he, w2, b2, resid=xe),
-  "f16-out 16000x512x512->1536? (qkv-like 512)": lambda: B.op_gemm_ex(xe, wq, b2, out_kind=1),
-  "rc 16000x512x512": lambda: B.op_gemm_rc(xe, wq, b2, resid=xe, ln=(g, be))[0] if hasattr(B, "op_gemm_rc") else xe,
-  "gemm (plain op_gemm) 300x512x512": lambda: B.op_gemm(x[:300], wq, b2),
+  "int8 qlinear 5344x2048x512 f16-result": lambda: B.op_qlinear(x, w1, b1, relu=True, f16_result=True),
+  "int8 qlinear 5344x512x2048 fp32": lambda: B.op_qlinear(h, w2, None),
+  "int8 qlinear 16000x1536x512 f16-result": lambda: B.op_qlinear(xe, np.concatenate([wq, wq, wq]), None, f16_result=True),
+  "ffn (up + down + residual) 5344": lambda: B.op_ffn(x, w1, b1, w2, b2, x),
+  "whole encoder 8x200": lambda: B.op_encoder(speech),
+  "logsoftmax + argmax 2000x8404": lambda: B.op_logsoftmax_argmax(lg)[0],
+  "fsmn_enc 32x500": lambda: B.op_fsmn_enc(v, fw),
+  "layernorm 16000x512": lambda: B.op_layernorm(xe, g, be),
+  "gemm small 83x1536x512": lambda: B.op_gemm_ex(x[:83], np.concatenate([wq, wq, wq]), None, out_kind=1),
 }
 MODE = sys.argv[2] if len(sys.argv) > 2 else "recognize"
 big = rng.standard_normal((16000, D)).astype(np.float32)
