@@ -793,7 +793,9 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
     if (can) { launch_gemm_small(s, g); return; }
   }
   // 128-row tiles when 256-row tiles would leave CUs idle (decoder GEMMs with N = 512: 84 tiles); measured
-  // A/B in one session: x = 0.9 -> 14.85 ms/step, x = 0 -> 15.15, x >= 1.5 (also the encoder N = 512 GEMMs) -> 15.9
+  // A/B in one session: x = 0.9 -> 14.85 ms/step, x = 0 -> 15.15, x >= 1.5 (also the encoder N = 512 GEMMs) -> 15.9.
+  // Round 3: x = 0.6 — between 0.6 and 0.9 of the CUs in 256-row tiles, the 128-row form needs a second round (SenseVoice's
+  // FFN-down at M = 10 880: 172 tiles -> 340 = 2 rounds x 0.58): 3.6 -> 2.87 ms per step there, 13.55 -> 12.8 ms for configs[2]
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
   dev &= 63;
@@ -815,7 +817,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
       PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
       cus[dev] = prop.multiProcessorCount;
     }
-    if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.9f; }
+    if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.6f; }
   }
   {
     // blocked-layout results (FFN-up): the persistent 256 x 256-tile kernel (k_gemm_big.hip); PF_BIGP=0 keeps this file's kernel
@@ -898,7 +900,7 @@ void launch_gemm_i8(hipStream_t s, const GemmI8Args& a) {
     }
   }
   const int t2 = cdiv(d.M, 256) * cdiv(d.N, GEMM_BN), t1 = cdiv(d.M, 128) * cdiv(d.N, GEMM_BN);
-  const bool few = (float)t2 < 0.9f * cus[dev];
+  const bool few = (float)t2 < 0.9f * cus[dev];       // (int8: 0.9 measured better than the f16 kernels' 0.6 — SenseVoice 16.9 vs 17.5 ms)
   const bool rounds1 = 0.58 * cdiv(t1, cus[dev]) < (double)cdiv(t2, cus[dev]);
   const int mi = (few || rounds1) ? 1 : 2;
   d.tiles_m = cdiv(d.M, 128 * mi);
