@@ -605,7 +605,9 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
       direct_epilogue(tile);
     }
     init_acc(wave_fast(ep_tile));                     // bias line holds the NEXT tile's bias (fetched a tile ago)
-    asm volatile("" ::: "memory");
+    // the line's reads (here, or the int8 column lines above) have EXECUTED before the DMA that refills it is issued —
+    // waited for, not timed (the same class of hazard as the fragment reads, see the group B loop)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (I8) { if (fast0 && ep_tile < total_tiles) fetch_bias(ep_tile); }       // int8: the lines hold the CURRENT tile's constants
     else { if (fast0 && ep_tile + G < total_tiles) fetch_bias(ep_tile + G); }
   };
@@ -662,7 +664,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
   int s_prev = 0, s_prev2 = 0;                        // deferred stores issued in the last two steps
   if (fast0) { fetch_bias(slot); wait_vmcnt<0>(); asm volatile("" ::: "memory"); }
   init_acc(wave_fast(slot));
-  asm volatile("" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if constexpr (!I8) { if (fast0 && slot + G < total_tiles) fetch_bias(slot + G); }
 
   if (grp == 0) {
