@@ -162,13 +162,17 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     a.q_rstride = a.k_rstride = a.v_rstride = 3 * D;
     a.o_bstride = (int64_t)T * D; a.o_rstride = D;
     a.B = B; a.H = mc_.heads; a.Lq = T; a.Lk = T;
+    if (!q_part_) q_part_ = (float*)dalloc(quant_scratch_bytes());
+    const bool ctx_range = attention_reports_range(a);   // the context's {min, max} from the attention epilogue: no min / max pass
+    a.range = ctx_range ? q_part_ : nullptr;
     prof_begin("attn_self", 4.0 * B * (double)T * T * D);
     launch_attention(stream_, a);
     prof_end("attn_self");
     prof_begin("fsmn", 0);
     launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
     prof_end("fsmn");
-    qgemm("gemm_out", qlin(L.out), nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f);
+    qgemm("gemm_out", qlin(L.out), nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f, nullptr,
+          nullptr, ctx_range ? kRangeIn : 0);
     qgemm("gemm_ffn1", qlin(L.w1), x_, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, &L.norm2, nullptr, kRangeOut);
     qgemm("gemm_ffn2", qlin(L.w2), nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr, kRangeIn);
   };
@@ -279,10 +283,13 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     a.k = kv16; a.v = kv16 + D; a.k_bstride = a.v_bstride = (int64_t)T * 2 * D; a.k_rstride = a.v_rstride = 2 * D;
     a.o = cx16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
     a.B = B; a.H = mc_.heads; a.Lq = L; a.Lk = T;
+    const bool cx_range = attention_reports_range(a);
+    a.range = cx_range ? q_part_ : nullptr;
     prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
     launch_attention(stream_, a);
     prof_end("attn_cross");
-    qgemm("gemm_dec_out", qlin(Lr.out), nullptr, cx16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
+    qgemm("gemm_dec_out", qlin(Lr.out), nullptr, cx16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr,
+          cx_range ? kRangeIn : 0);
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
   qgemm("gemm_vocab", qlin(dec_out_), t32, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &dec_after_);

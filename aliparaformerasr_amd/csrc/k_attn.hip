@@ -47,6 +47,7 @@ struct AttnDev {
   int64_t q_bs, k_bs, v_bs, o_bs;
   int q_rs, k_rs, v_rs, o_rs;
   int H, Lq, Lk;
+  float* range;      // null, or 256 {min, max} pairs (int8 path: the range of the context for its DynamicQuantizeLinear)
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
   // ---- normalise and store: lane = query q0+lc, d = db*32 + (e&3) + 8*(e>>2) + 4*lh
   const int qrow = q0 + lc;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float r_lo = 0.f, r_hi = 0.f;
   if (qrow < p.Lq) {
     const float inv = 1.0f / l_tot;
     half_t* op = ob + (int64_t)qrow * p.o_rs + 4 * lh;
@@ -327,8 +329,60 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
         h4 hv = {(half_t)(o_acc[db][4 * g + 0] * inv), (half_t)(o_acc[db][4 * g + 1] * inv),
                  (half_t)(o_acc[db][4 * g + 2] * inv), (half_t)(o_acc[db][4 * g + 3] * inv)};
         *reinterpret_cast<h4*>(op + db * 32 + 8 * g) = hv;
+        if (p.range) {                                  // of the values as stored (f16)
+          const float a0 = (float)hv[0], a1 = (float)hv[1], a2 = (float)hv[2], a3 = (float)hv[3];
+          r_lo = fminf(fminf(r_lo, a0), fminf(fminf(a1, a2), a3));
+          r_hi = fmaxf(fmaxf(r_hi, a0), fmaxf(fmaxf(a1, a2), a3));
+        }
       }
   }
+  if (p.range) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      r_lo = fminf(r_lo, __shfl_xor(r_lo, o, 64));
+      r_hi = fmaxf(r_hi, __shfl_xor(r_hi, o, 64));
+    }
+    __syncthreads();                                    // every wave is done with the K / V buffers
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) { red[2 * wave] = r_lo; red[2 * wave + 1] = r_hi; }
+    __syncthreads();
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (tid == 0) {
+      float l = 0.f, h = 0.f;
+      for (int w = 0; w < NW; ++w) { l = fminf(l, red[2 * w]); h = fmaxf(h, red[2 * w + 1]); }
+      p.range[2 * wg] = l;
+      p.range[2 * wg + 1] = h;
+    }
+    if (wg == 0)                                        // the consumer folds 256 pairs whatever this grid was
+      for (int i = total + tid; i < 256; i += 64 * NW) { p.range[2 * i] = 0.f; p.range[2 * i + 1] = 0.f; }
+  }
+}
+
+// grid of the launch below: 256-query workgroups when they cover the chip, else 128-query ones
+static int attention_grid(const AttnArgs& a, int cus, bool& nw8) {
+  static int force_nw = -1;
+  if (force_nw < 0) { const char* e = getenv("PF_ATT_NW"); force_nw = e ? atoi(e) : 0; }
+  const int wg8 = ((a.Lq + 255) / 256) * a.B * a.H;
+  nw8 = force_nw ? force_nw == 8 : wg8 >= cus;
+  return nw8 ? wg8 : ((a.Lq + ATT_BQ - 1) / ATT_BQ) * a.B * a.H;
+}
+static int attention_cus() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cus[dev & 63]) {
+    hipDeviceProp_t prop;
+    PF_HIP(hipGetDeviceProperties(&prop, dev));
+    cus[dev & 63] = prop.multiProcessorCount;
+  }
+  return cus[dev & 63];
+}
+bool attention_reports_range(const AttnArgs& a) {
+  if (a.B == 0 || a.Lq == 0 || a.Lk == 0) return false;
+  bool nw8;
+  return attention_grid(a, attention_cus(), nw8) <= 256;
 }
 
 void launch_attention(hipStream_t s, const AttnArgs& a) {
@@ -338,6 +392,8 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   d.q_bs = a.q_bstride; d.k_bs = a.k_bstride; d.v_bs = a.v_bstride; d.o_bs = a.o_bstride;
   d.q_rs = a.q_rstride; d.k_rs = a.k_rstride; d.v_rs = a.v_rstride; d.o_rs = a.o_rstride;
   d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk;
+  d.range = a.range;
+  PF_CHECK(!a.range || attention_reports_range(a), PF_ERR_INVALID_ARG, "attention: a range output needs a grid of at most 256 workgroups");
   PF_CHECK(a.q_rstride % 8 == 0 && a.k_rstride % 8 == 0 && a.v_rstride % 8 == 0 && a.o_rstride % 4 == 0,
            PF_ERR_INVALID_ARG, "attention: row strides must keep 16-byte alignment");
   static std::mutex init_mu;                         // engines on different devices launch from different threads
@@ -357,10 +413,8 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
     }
   }
   // 256-query workgroups when they still cover the chip (self-attention at T = 500: 2 x 128 workgroups); PF_ATT_NW forces
-  static int force_nw = -1;
-  if (force_nw < 0) { const char* e = getenv("PF_ATT_NW"); force_nw = e ? atoi(e) : 0; }
-  const int wg8 = ((a.Lq + 255) / 256) * a.B * a.H;
-  const bool nw8 = force_nw ? force_nw == 8 : wg8 >= cus[dev & 63];
+  bool nw8;
+  (void)attention_grid(a, cus[dev & 63], nw8);
   if (nw8) {
     dim3 grid((a.Lq + 255) / 256, a.B * a.H);
     hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(512), ATT_LDS_BYTES, s, d);

@@ -165,8 +165,11 @@ struct AttnArgs {
   const half_t* v; int64_t v_bstride; int v_rstride;
   half_t* o; int64_t o_bstride; int o_rstride;
   int B, H, Lq, Lk;                                   // head dim fixed at 128
+  float* range;                                       // null, or quant_scratch_bytes(): {min, max} of the stored context per workgroup
+                                                      // (pass 1 of the quantiser that consumes it, k_quant.hip); see attention_reports_range
 };
 void launch_attention(hipStream_t s, const AttnArgs& a);
+bool attention_reports_range(const AttnArgs& a);      // the launch has at most 256 workgroups (one {min, max} pair each)
 
 // ------------------------------------------------------------------ misc ----
 void launch_f32_to_f16(hipStream_t s, const float* x, int64_t rows, int cols, int ldx, half_t* y, int ldy);
