@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankDev p) {
   __shared__ float melw_s[FB_MAX_WEIGHTS];
   __shared__ int4 chunk_s[FB_MAX_CHUNKS];
   __shared__ float part_s[4][FB_MAX_CHUNKS];
+  __shared__ int choff_s[FB_MAX_BINS + 1];   // chunk ranges of the filters (was two global loads per filter and frame)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   {                                                     // workgroup-shared tables
     const float2 w = p.tw512[tid];
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankDev p) {
     win_s[tid + 256] = tid + 256 < FB_FRAME_LEN ? p.window[tid + 256] : 0.f;
     for (int i = tid; i < p.n_weights; i += 256) melw_s[i] = p.mel_w[i];
     for (int i = tid; i < p.n_chunks; i += 256) chunk_s[i] = p.mel_chunk[i];
+    for (int i = tid; i <= p.n_mels; i += 256) choff_s[i] = p.mel_chunk_off[i];
   }
   __syncthreads();
   float2* bufA = lds[wv][0];
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankDev p) {
   }
   wave_lds_sync();
   for (int m = lane; m < p.n_mels; m += 64) {
-    const int c0 = p.mel_chunk_off[m], c1 = p.mel_chunk_off[m + 1];
+    const int c0 = choff_s[m], c1 = choff_s[m + 1];
     float acc = 0.f;
     for (int c = c0; c < c1; ++c) acc += parts[c];
     acc = fmaxf(acc, 1.1920929e-07f);
