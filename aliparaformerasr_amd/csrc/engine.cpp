@@ -76,6 +76,7 @@ Engine::Engine(const pf_engine_config& cfg) {
     PF_HIP(hipEventCreateWithFlags(&ev_scan_, hipEventDisableTiming));
     PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
     PF_HIP(hipEventCreateWithFlags(&ev_ts_, hipEventDisableTiming));
+    PF_HIP(hipEventCreateWithFlags(&ev_enc_, hipEventDisableTiming));
     load_weights(cfg);
     mc_.use_itn = cfg.use_itn != 0 || mc_.use_itn;
     fb_ = fbank_tables_create(fc_.n_mels, fc_.fs, fc_.window.c_str());
@@ -104,6 +105,7 @@ void Engine::release() {
   if (ev_scan_) { hipEventDestroy(ev_scan_); ev_scan_ = nullptr; }
   if (ts_stream_) { hipStreamSynchronize(ts_stream_); hipStreamDestroy(ts_stream_); ts_stream_ = nullptr; }
   if (ev_ts_) { hipEventDestroy(ev_ts_); ev_ts_ = nullptr; }
+  if (ev_enc_) { hipEventDestroy(ev_enc_); ev_enc_ = nullptr; }
   if (lstm_graph_exec_) { hipGraphExecDestroy(lstm_graph_exec_); lstm_graph_exec_ = nullptr; }
   profile_reset();
   if (fb_) { fbank_tables_destroy(fb_); fb_ = nullptr; }
@@ -958,6 +960,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab;
   const int M = B * T, T1 = T + 1;
   const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
+  if (ev_enc_) PF_HIP(hipEventRecord(ev_enc_, stream_));     // the encoder output exists: all the timestamp head's GEMMs and its recurrence need
   // conv1d(k=3) as im2col GEMM; reuse the FFN hidden buffer for the [M, 3D] operand and the
   // FSMN buffer for the fp32 conv output.
   half_t* col16 = h16_;
@@ -981,7 +984,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
     if (ts_side && !lstm_steps_) {
       // beside the decoder, on its own stream: everything timestamp_head enqueues (two GEMMs, the persistent recurrence,
       // the peaks and their copy to the host) goes to ts_stream_, which waits for the CIF scan (= the encoder too)
-      PF_HIP(hipStreamWaitEvent(ts_stream_, ev_scan_, 0));
+      PF_HIP(hipStreamWaitEvent(ts_stream_, ev_enc_, 0));    // (token_num — the CIF scan — is waited for in front of the peaks only)
       std::swap(stream_, ts_stream_);
       ts_defer_copy_ = true;
       try {
@@ -1427,6 +1430,7 @@ void Engine::timestamp_head(int B, int T) {
     PF_HIP(hipGraphLaunch(lstm_graph_exec_, stream_));
   }
   prof_end("lstm");
+  if (ts_defer_copy_) PF_HIP(hipStreamWaitEvent(stream_, ev_scan_, 0));   // on the side stream: token_num comes from the CIF scan
   prof_begin("ts_misc", 0);
   launch_us_alpha(stream_, hout, M3, 2 * D, ts_out_w_, ts_out_b_, mc_.cif_smooth2, mc_.cif_noise2, al);
   launch_us_peak(stream_, al, plan_.token_num, B, T3, mc_.cif_threshold - 1e-4f, us_peak_);

@@ -208,7 +208,7 @@ class Engine {
   // decoder (its recurrence is 1500 dependent steps on 128 workgroups — latency, not throughput) and is joined before
   // the call's last copy (PF_TS_STREAM=0 keeps it on the main stream)
   hipStream_t ts_stream_ = nullptr;
-  hipEvent_t ev_ts_ = nullptr;
+  hipEvent_t ev_ts_ = nullptr, ev_enc_ = nullptr;
   bool ts_pending_ = false, ts_defer_copy_ = false;
   size_t ts_copy_floats_ = 0;
   void join_ts();
