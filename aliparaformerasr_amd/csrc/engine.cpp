@@ -1267,8 +1267,10 @@ void Engine::online_decoder(const float* enc, int B, int Tc, const float* embeds
 
 void Engine::set_hotwords(const int32_t* hw, int n) {
   PF_CHECK(n >= 0 && (n == 0 || hw), PF_ERR_INVALID_ARG, "set_hotwords: bad arguments");
+  if (n == n_hotwords_ && hotwords_.size() == (size_t)n * 10 && (n == 0 || std::memcmp(hotwords_.data(), hw, (size_t)n * 40) == 0)) return;
   hotwords_.assign(hw, hw + (size_t)n * 10);
   n_hotwords_ = n;
+  seaco_hw_valid_ = false;                            // the embedder output / K,V rows of the old list are stale
 }
 
 // SeACo bias branch (export_forward of the FunASR SeACo export; reference call site
@@ -1284,9 +1286,16 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   const int ldV = (int)round_up(V, 4);
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o_ids = carve((size_t)NJ * 4), o_e32 = carve((size_t)NJp * D * 4), o_in16 = carve((size_t)NJp * D * 2);
-  const size_t o_xg = carve((size_t)NJp * 4 * D * 4), o_ho = carve((size_t)NJp * D * 4), o_hs = carve((size_t)2 * N * D * 2);
-  const size_t o_cs = carve((size_t)N * D * 4), o_kv = carve((size_t)NJp * std::max(ns, 1) * 2 * D * 2);
+  // the hot-word side (ids, embedder, its K / V rows) lives in its own buffer and is computed once per hot-word LIST, not
+  // once per call: it is a function of the weights and the list alone (the reference re-runs model_eb every call,
+  // OfflineProjOfSeacoParaformer.cs:83-111, with the same result)
+  size_t hoff = 0;
+  auto hcarve = [&](size_t bytes) { size_t o = hoff; hoff += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o_ids = hcarve((size_t)NJ * 4), o_e32 = hcarve((size_t)NJp * D * 4), o_in16 = hcarve((size_t)NJp * D * 2);
+  const size_t o_xg = hcarve((size_t)NJp * 4 * D * 4), o_ho = hcarve((size_t)NJp * D * 4), o_hs = hcarve((size_t)2 * N * D * 2);
+  const size_t o_cs = hcarve((size_t)N * D * 4), o_kv = hcarve((size_t)NJp * std::max(ns, 1) * 2 * D * 2);
+  if (!ws_seaco_hw_.p || ws_seaco_hw_.bytes < hoff) seaco_hw_valid_ = false;
+  ensure(ws_seaco_hw_, hoff);
   const size_t o_x = carve((size_t)Rp * D * 4), o_xn = carve((size_t)Rp * D * 2), o_h32 = carve((size_t)Rp * Fs * 4);
   const size_t o_h16 = carve((size_t)Rp * Fs * 2), o_t = carve((size_t)Rp * D * 4), o_tn = carve((size_t)Rp * D * 4);
   const size_t o_q = carve((size_t)Rp * D * 2), o_ctx = carve((size_t)Rp * D * 2), o_hid = carve((size_t)Rp * D * 4);
@@ -1294,10 +1303,11 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   const size_t o_tn2 = carve((size_t)2 * B * 4);
   ensure(ws_seaco_, off);
   char* base = (char*)ws_seaco_.p;
-  int32_t* ids = (int32_t*)(base + o_ids);
-  float* e32 = (float*)(base + o_e32); half_t* in16 = (half_t*)(base + o_in16);
-  float* xg = (float*)(base + o_xg); float* hout = (float*)(base + o_ho);
-  half_t* hs = (half_t*)(base + o_hs); float* cs = (float*)(base + o_cs);
+  char* hbase = (char*)ws_seaco_hw_.p;
+  int32_t* ids = (int32_t*)(hbase + o_ids);
+  float* e32 = (float*)(hbase + o_e32); half_t* in16 = (half_t*)(hbase + o_in16);
+  float* xg = (float*)(hbase + o_xg); float* hout = (float*)(hbase + o_ho);
+  half_t* hs = (half_t*)(hbase + o_hs); float* cs = (float*)(hbase + o_cs);
   float* xs = (float*)(base + o_x); half_t* xn16 = (half_t*)(base + o_xn);
   float* h32 = (float*)(base + o_h32); half_t* h16 = (half_t*)(base + o_h16);
   float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
@@ -1305,8 +1315,10 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   float* hid = (float*)(base + o_hid); half_t* m16 = (half_t*)(base + o_m16);
   float* dha = (float*)(base + o_dha); int64_t* dha_ids = (int64_t*)(base + o_did);
   int32_t* tn2 = (int32_t*)(base + o_tn2);
-  half_t* kv16 = (half_t*)(base + o_kv);
+  half_t* kv16 = (half_t*)(hbase + o_kv);
+  const int ldkv = ns * 2 * D;
 
+  if (!seaco_hw_valid_) {
   // ---- hotword embedder: Embedding -> LSTM stack (all J outputs kept), batch-major rows n*J + j
   prof_begin("seaco_embed", 0);
   PF_HIP(hipMemcpyAsync(ids, hotwords_.data(), (size_t)NJ * 4, hipMemcpyHostToDevice, stream_));
@@ -1323,9 +1335,10 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
     launch_f32_to_f16(stream_, hout, NJ, D, D, in16, D);
     prof_end("seaco_embed");
   }
-  const int ldkv = ns * 2 * D;
   if (ns > 0)
     gemm("gemm_seaco", seaco_kv_all_, in16, D, NJ, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  seaco_hw_valid_ = true;
+  }
 
   // ---- bias decoder on [CIF embeds ; decoder hidden]
   PF_HIP(hipMemcpyAsync(xs, e0, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));

@@ -268,7 +268,8 @@ class Engine {
   float* small_ws_ = nullptr;        // short-input GEMM: split partials
   float* cif_conv_w32_ = nullptr;    // fp32 mode: the CIF conv as a [D][taps*D] GEMM operand
   float* ts_up_w32_ = nullptr;       // fp32 mode: the transposed conv as a [(j, out)][in] GEMM operand
-  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_kv_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_;
+  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_kv_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_, ws_seaco_hw_;
+  bool seaco_hw_valid_ = false;     // ws_seaco_hw_ holds the embedder output / K,V rows of the CURRENT hot-word list (f16 path)
   int pe_T_ = 0;
   // encoder views (valid after encoder())
   float* x_ = nullptr; half_t* xn16_ = nullptr; half_t* qkv16_ = nullptr; half_t* ctx16_ = nullptr;

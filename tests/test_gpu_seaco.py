@@ -110,3 +110,25 @@ def test_seaco_recognizer_hotwords(tmp_path, seaco_setup):
     with pytest.raises(RecognizerException, match="Offline recognition failed"):
         rec.GetResults([s2])
     rec.Dispose()
+
+
+def test_hotword_side_is_cached_per_list_not_per_engine(seaco_setup):
+    """The embedder output and the bias rows' K / V are computed once per hot-word LIST (round 3) — the reference re-runs
+    model_eb every call (OfflineProjOfSeacoParaformer.cs:83-111) with the same result.  A different list, a longer list
+    (workspace growth) and the first list again must each give what a fresh engine gives."""
+    from aliparaformerasr_amd.engine import Engine
+    eng, cfg, w, cmvn, audio, speech, hw, ref = seaco_setup
+    hw2 = np.asarray(glue.pad_list([[40, 41], [5, 6, 7], [1]]), np.int32)
+    hw3 = np.asarray(glue.pad_list([[i, i + 1, i + 2] for i in range(3, 90, 3)] + [[1]]), np.int32)      # 30 hot words
+    fresh = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    want = {}
+    for name, h in (("hw3", hw3), ("hw2", hw2), ("hw", hw)):
+        want[name] = fresh.forward_feats(speech, want_logits=True, hotwords=h)
+        fresh.close()
+        fresh = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+    fresh.close()
+    for name, h in (("hw", hw), ("hw", hw), ("hw2", hw2), ("hw3", hw3), ("hw", hw), ("hw2", hw2)):
+        r = eng.forward_feats(speech, want_logits=True, hotwords=h)
+        np.testing.assert_array_equal(r.token_ids, want[name].token_ids)
+        np.testing.assert_array_equal(r.logits, want[name].logits)
+    assert not np.array_equal(want["hw"].logits, want["hw2"].logits)
