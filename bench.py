@@ -45,6 +45,7 @@ SECONDS = 30
 SAMPLES = SECONDS * 16000
 LCAP = 512
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
+SUSTAINED_F16_TFLOPS = 1700.0  # measured: 256 CUs issuing v_mfma_f32_32x32x16_f16 back to back (profiles/round3_ubench_kstep.txt)
 PMC_FILE = os.path.join(ROOT, "profiles", "round3_pmc.json")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_MARGIN = 0.05          # = MARGIN of tests/test_gpu_full_depth.py (the two oracles never disagree above 0.02)
@@ -482,6 +483,9 @@ def main():
                          "kernel": "%s (class %s, the encoder GEMM class with the largest share of the step: [%d x %d] x [%d x %d], %s)"
                                    % (dom_kernel, dominant, dom_rows, Kk, Kk, Nn, what),
                          "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
+                         # what the part sustains with every CU issuing MFMAs back to back (tools/ubench/kstep.hip):
+                         # the clock settles near 1.65 GHz; informative only, `frac` is against the spec peak
+                         "sustained_peak_measured": SUSTAINED_F16_TFLOPS, "frac_of_sustained": ach / SUSTAINED_F16_TFLOPS,
                          "traffic": pmc_traffic(dom_kernel) if headline else None,
                          "traffic_unit": "bytes/launch (PMC, %s)" % os.path.relpath(PMC_FILE, ROOT),
                          "algorithmic_bytes_per_launch": alg_bytes,
