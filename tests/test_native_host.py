@@ -197,3 +197,21 @@ def test_every_host_entry_point_under_sanitizers(tmp_path):
     r = subprocess.run([os.path.join(root, "tools", "sanitize_host.sh"), str(tmp_path), "3000"], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "runtime error" not in r.stdout + r.stderr and "Sanitizer" not in r.stdout + r.stderr
+
+
+def test_header_is_plain_c99_and_cxx11(tmp_path):
+    """include/paraformer_hip.h is the contract a C# / C / C++ caller binds: it must compile on its own as strict C99 and
+    as C++11, and the abi_host_fuzz driver (C) must compile against it."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "paraformer_hip.h"\nint main(void) { pf_engine_config c; (void)c; return sizeof(pf_batch_out) > 0 ? 0 : 1; }\n')
+    inc = "-I" + os.path.join(root, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", inc, str(src)],
+                ["g++", "-x", "c++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", inc, str(src)],
+                ["gcc", "-std=c99", "-Wall", "-fsyntax-only", inc, os.path.join(root, "tests", "native", "abi_host_fuzz.c")]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, (cmd, r.stderr[-2000:])
