@@ -100,6 +100,7 @@ SIGNATURES = {
     "pf_group_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
     "pf_sync": (C.c_int, [_vp]),
     "pf_fetch": (C.c_int, [_vp, _P(PfBatchOut)]),
+    "pf_fetch_ids_device": (C.c_int, [_vp, _vp, C.c_int32, _i32]),
     "pf_host_group_sim": (C.c_int, [C.c_int32, C.c_int32, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i64,
                                     C.c_int32, _i32, _i32]),
     "pf_profile_enable": (C.c_int, [_vp, C.c_int32]),

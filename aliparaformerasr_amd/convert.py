@@ -281,7 +281,14 @@ def onnx_to_pfw(model_path, eb_path=None, kind="paraformer", timestamp=None):
     for g in graphs:
         sd.update(onnx_to_state_dict(g, expected))
     cfg = infer_config(sd, kind, timestamp)
-    return cfg, state_dict_to_pfw(sd, cfg)
+    wts = state_dict_to_pfw(sd, cfg)
+    # an int8 export: record which Linears the export left in float (FunASR passes nodes_to_exclude to quantize_dynamic).
+    # The engine and the oracle decide by the stored bytes themselves; the key documents the set in the container.
+    if any(k.endswith(".weight_q") for k in wts):
+        lin = [k[:-7] for k, v in wts.items() if k.endswith(".weight") and np.asarray(v).ndim == 2 and k[:-7] + ".bias" in wts
+               or k.endswith(".ffn.w2.weight")]
+        cfg["int8_exclude"] = tuple(sorted(n for n in lin if n + ".weight_q" not in wts))
+    return cfg, wts
 
 
 def main(argv=None):

@@ -285,6 +285,16 @@ int pf_fetch(pf_engine* h, pf_batch_out* out) {
   PF_CATCH
 }
 
+int pf_fetch_ids_device(pf_engine* h, int64_t* ids_dev, int32_t l_cap, int32_t* L_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->fetch_ids_device(ids_dev, l_cap, L_out);
+  return PF_OK;
+  PF_CATCH
+}
+
 int pf_profile_enable(pf_engine* h, int32_t on) {
   PF_TRY
   E(h)->profile_enable(on != 0);

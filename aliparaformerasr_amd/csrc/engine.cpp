@@ -112,7 +112,8 @@ void Engine::release() {
   for (void* p : owned_) hipFree(p);
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
-                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_q_};
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_};
+  seaco_hw_valid_ = false;
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
   if (blob_owned_ && blob_dev_) hipFree(blob_dev_);
@@ -286,8 +287,13 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     PF_CHECK(tt.numel * (tt.u8 ? 1 : 4) == nb, PF_ERR_FORMAT, "weights: shape/nbytes mismatch for '" + name + "'");
     tensors_[name] = tt;
   }
+  if (const Json* ex = jc->get("int8_exclude"))
+    if (ex->type == Json::Arr)
+      for (const Json& e : ex->arr)
+        if (e.type == Json::Str && !e.str.empty()) int8_exclude_.push_back(e.str);
   for (const auto& kv : tensors_) {
     const std::string& n = kv.first;
+    if (kv.second.u8 && n.size() > 9 && n.compare(n.size() - 9, 9, ".weight_q") == 0) any_stored_q_ = true;
     if (!kv.second.u8 && n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0) lin_names_[kv.second.dev] = n.substr(0, n.size() - 7);
   }
 
@@ -450,6 +456,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       launch_f32_to_f16(stream_, kvw.dev, 2 * D, D, D, dec_kv_all_.w + (size_t)i * 2 * D * D, D);
       PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
       L.kv32.w32 = kvw.dev; L.kv32.bias = kvbias.dev; L.kv32.N = 2 * D; L.kv32.K = D;
+      L.kv32.w = dec_kv_all_.w + (size_t)i * 2 * D * D; L.kv32.Kpad = D;
       dec_.push_back(L);
     }
   }
@@ -518,6 +525,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
         launch_f32_to_f16(stream_, kvw.dev, 2 * D, D, D, seaco_kv_all_.w + (size_t)i * 2 * D * D, D);
         PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
         L.kv32.w32 = kvw.dev; L.kv32.bias = kvbias.dev; L.kv32.N = 2 * D; L.kv32.K = D;
+        L.kv32.w = seaco_kv_all_.w + (size_t)i * 2 * D * D; L.kv32.Kpad = D;
         sdec_.push_back(L);
       }
     }
@@ -978,30 +986,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   PF_HIP(hipEventRecord(ev_scan_, stream_));
   last_.peak_len = 0;
   last_.cif_peak.clear();
-  if (mc_.timestamp_head) {
-    static int ts_side = -1;
-    if (ts_side < 0) { const char* e = getenv("PF_TS_STREAM"); ts_side = e ? atoi(e) : 1; }
-    if (ts_side && !lstm_steps_) {
-      // beside the decoder, on its own stream: everything timestamp_head enqueues (two GEMMs, the persistent recurrence,
-      // the peaks and their copy to the host) goes to ts_stream_, which waits for the CIF scan (= the encoder too)
-      PF_HIP(hipStreamWaitEvent(ts_stream_, ev_enc_, 0));    // (token_num — the CIF scan — is waited for in front of the peaks only)
-      std::swap(stream_, ts_stream_);
-      ts_defer_copy_ = true;
-      try {
-        timestamp_head(B, T);
-      } catch (...) {
-        std::swap(stream_, ts_stream_);
-        ts_defer_copy_ = false;
-        throw;
-      }
-      ts_defer_copy_ = false;
-      std::swap(stream_, ts_stream_);
-      PF_HIP(hipEventRecord(ev_ts_, ts_stream_));
-      ts_pending_ = true;
-    } else {
-      timestamp_head(B, T);
-    }
-  }
+  if (mc_.timestamp_head) start_timestamp_head(B, T);
   // The cross-attention K/V projections of all decoder layers depend on the encoder output only, not on the decoder
   // length: they go out BEFORE the length is read back and keep the device busy during the host round trip (and,
   // in a multi-device group, during the rendez-vous that agrees on the batch-wide length).
@@ -1160,6 +1145,35 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
   join_ts();
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+// Starts the BiCIF timestamp head of the current forward: beside the decoder on its own stream (default), or in line.
+// Needs ev_enc_ (encoder output) and ev_scan_ (token_num) recorded on stream_.
+void Engine::start_timestamp_head(int B, int T) {
+  {
+    static int ts_side = -1;
+    if (ts_side < 0) { const char* e = getenv("PF_TS_STREAM"); ts_side = e ? atoi(e) : 1; }
+    if (ts_side && !lstm_steps_) {
+      // beside the decoder, on its own stream: everything timestamp_head enqueues (two GEMMs, the persistent recurrence,
+      // the peaks and their copy to the host) goes to ts_stream_, which waits for the CIF scan (= the encoder too)
+      PF_HIP(hipStreamWaitEvent(ts_stream_, ev_enc_, 0));    // (token_num — the CIF scan — is waited for in front of the peaks only)
+      std::swap(stream_, ts_stream_);
+      ts_defer_copy_ = true;
+      try {
+        timestamp_head(B, T);
+      } catch (...) {
+        std::swap(stream_, ts_stream_);
+        ts_defer_copy_ = false;
+        throw;
+      }
+      ts_defer_copy_ = false;
+      std::swap(stream_, ts_stream_);
+      PF_HIP(hipEventRecord(ev_ts_, ts_stream_));
+      ts_pending_ = true;
+    } else {
+      timestamp_head(B, T);
+    }
+  }
 }
 
 void Engine::join_ts() {
@@ -1335,8 +1349,9 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
     launch_f32_to_f16(stream_, hout, NJ, D, D, in16, D);
     prof_end("seaco_embed");
   }
-  if (ns > 0)
+  if (ns > 0 && !int8_mode_)
     gemm("gemm_seaco", seaco_kv_all_, in16, D, NJ, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  if (ns > 0 && int8_mode_) seaco_kv_int8(hout, in16, NJ, kv16, ldkv);
   seaco_hw_valid_ = true;
   }
 
@@ -1346,6 +1361,20 @@ void Engine::seaco_head(int B, int L, const float* e0, const float* hid32, bool 
   PF_HIP(hipMemcpyAsync(tn2, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
   PF_HIP(hipMemcpyAsync(tn2 + B, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  if (int8_mode_) {
+    // math_mode 2: the bias decoder's Linears are MatMulInteger pairs in model.int8.onnx like the ASR decoder's
+    seaco_decoder_int8(B, L, NJ, xs, h32, t32, tn32, q16, ctx16, kv16, ldkv, tn2, hid);
+    seaco_decoder_int8(B, L, NJ, xs + (size_t)Md * D, h32, t32, tn32, q16, ctx16, kv16, ldkv, tn2, hid + (size_t)Md * D);
+    prof_begin("seaco_merge", 0);
+    launch_add_f32(stream_, hid, hid + (size_t)Md * D, (int64_t)Md * D);
+    prof_end("seaco_merge");
+    qgemm("gemm_seaco", seaco_out_, true, hid, nullptr, D, Md, dha, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+    prof_begin("seaco_merge", 0);
+    launch_argmax(stream_, dha, Md, V, ldV, 2, dha_ids);
+    launch_seaco_merge(stream_, dha, ldV, dha_ids, Md, V, mc_.seaco_nobias, want_logits ? 1 : 0, logits_, logits_ld_, ids_dev_);
+    prof_end("seaco_merge");
+    return;
+  }
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
     prof_begin("layernorm", 0);
     launch_layernorm(stream_, xs, R, D, n1.g, n1.b, xn16, D, nullptr, 0);
@@ -1851,6 +1880,20 @@ void Engine::copy_logits(HostBatchOut& r) {
   if (!last_logits_ || need <= 0) return;
   PF_HIP(hipMemcpy2D(r.logits.data(), (size_t)last_.V * 4, logits_, (size_t)logits_ld_ * 4, (size_t)last_.V * 4,
                      (size_t)last_.B * last_.L, hipMemcpyDeviceToHost));
+}
+
+void Engine::fetch_ids_device(int64_t* ids_dev, int l_cap, int32_t* L_out) {
+  PF_HIP(hipSetDevice(device_));
+  const int B = last_.B, L = last_.L;
+  PF_CHECK(ids_dev && l_cap > 0, PF_ERR_INVALID_ARG, "fetch_ids_device: null buffer");
+  PF_CHECK(l_cap >= L, PF_ERR_CAPACITY, "fetch_ids_device: capacity " + std::to_string(l_cap) + " < L = " + std::to_string(L));
+  if (L_out) *L_out = L;
+  if (B > 0) {
+    PF_HIP(hipMemsetAsync(ids_dev, 0xFF, (size_t)B * l_cap * 8, stream_));
+    if (L > 0)
+      PF_HIP(hipMemcpy2DAsync(ids_dev, (size_t)l_cap * 8, ids_dev_, (size_t)L * 8, (size_t)L * 8, B, hipMemcpyDeviceToDevice, stream_));
+  }
+  sync();
 }
 
 void Engine::fetch(pf_batch_out* out) {

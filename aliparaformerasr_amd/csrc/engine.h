@@ -84,6 +84,7 @@ class Engine {
   void stage_audio(const float* const* samples, const int64_t* n, int B, int force_T = 0);
   void run_staged(bool want_logits);
   void fetch(pf_batch_out* out);
+  void fetch_ids_device(int64_t* ids_dev, int l_cap, int32_t* L_out);   // last forward's ids -> caller's device buffer [B, l_cap], -1 padded
   // Results are kept per CALLING THREAD: a forward entry point (pf_forward_feats / pf_model_proj / pf_recognize)
   // publishes its outcome into the caller's slot, and pf_fetch from the same thread reads that slot, so the
   // two-call protocol (learn L, then fetch into right-sized buffers) is safe with concurrent callers on one
@@ -172,10 +173,17 @@ class Engine {
   const QLin& qlin(const Lin& l, bool bias = true);
   const QLin& qlin_raw(const float* w32, const float* bias, int N, int K);
   // y = dequant(quant(x) w_q^T) + bias [* scale on the first scale_cols columns] [+ add2] [+ resid] [ReLU]; x fp32 [M, ldx] or f16
-  void qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32, half_t* out16,
-             int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols, float scale,
+  void qgemm(const char* cls, const Lin& w, bool bias, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
+             half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols, float scale,
              const LNp* ln = nullptr, const QAct* pre = nullptr, int range = 0);   // range: 1 = leave the result's {min, max} pairs
                                                                                     // in q_part_, 2 = the input's are there already
+  bool lin_quantised(const Lin& l) const;            // is this Linear a DynamicQuantizeLinear + MatMulInteger pair in the model file?
+  void fgemm_in_int8(const char* cls, const Lin& l, bool bias, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
+                     half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols,
+                     float scale, const LNp* ln, int range);
+  void seaco_kv_int8(const float* hw32, const half_t* hw16, int NJ, half_t* kv16, int ldkv);
+  void seaco_decoder_int8(int B, int L, int NJ, float* xs, float* h32, float* t32, float* tn32, half_t* q16, half_t* ctx16,
+                          const half_t* kv16, int ldkv, const int32_t* tn2, float* hid);
   enum { kRangeOut = 1, kRangeIn = 2 };
   // quantise an activation tensor into `dst` (min / max pass, quantise pass); ln: of LayerNorm(x32), which is never stored
   void quantize_act(const QAct& dst, int kpad, const float* x32, const half_t* x16, int ldx, int64_t M, int K, const LNp* ln,
@@ -187,6 +195,7 @@ class Engine {
                  float* xg, float* gates, float* hbuf, float* cbuf, float* hout, int ldh, int col0);
   void enc_layer_fp32(const EncLayer& L, bool first, const float* speech_dev, int B, int T, float** bufs);
   void timestamp_head(int B, int T);
+  void start_timestamp_head(int B, int T);
   void seaco_head(int B, int L, const float* e0, const float* hid32, bool want_logits);
   void gemm(const char* cls, const Lin& w, const half_t* A, int lda, int M, float* out32, int ld32,
             half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
@@ -222,6 +231,9 @@ class Engine {
   bool int8_mode_ = false;           // math_mode 2: Linear layers dynamically quantised to uint8, products on the int8 MFMA
   std::map<const float*, QLin> qlins_;
   std::map<const float*, std::string> lin_names_;     // float32 `<linear>.weight` device pointer -> `<linear>` (stored int8 bytes lookup)
+  std::vector<std::string> int8_exclude_;   // config key `int8_exclude`: Linear name prefixes a synthetic container keeps in float
+  bool any_stored_q_ = false;        // the container carries stored bytes of an int8 export
+  DevBuf ws_qf_, ws_seaco_q_;        // f16 operand of an un-quantised Linear; quantised bias_embed rows
   DevBuf ws_q_;                      // quantised activations: a' [Mp, Kpad], row sums, {scale, zp}, min / max scratch
   int8_t* q_a_ = nullptr; int32_t* q_rowsum_ = nullptr; float* q_params_ = nullptr; unsigned* q_scratch_ = nullptr;
   int64_t q_rows_ = 0; int q_kpad_ = 0;

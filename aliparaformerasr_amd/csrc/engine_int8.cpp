@@ -95,10 +95,55 @@ void Engine::quantize_act(const QAct& dst, int kpad, const float* x32, const hal
   prof_end("quantize");
 }
 
-void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
+// Is this Linear a DynamicQuantizeLinear + MatMulInteger pair in the model file?  A container made from an int8 export
+// answers by what it carries: stored bytes (`<linear>.weight_q`) = quantised, none = the export left that MatMul in
+// float (FunASR passes nodes_to_exclude to quantize_dynamic: the vocabulary projections and the N = 1 predictor outputs).
+// A container with fp32 tensors only (the synthetic models) quantises everything except the names listed in its
+// `int8_exclude` config key.
+bool Engine::lin_quantised(const Lin& l) const {
+  const auto nm = lin_names_.find(l.w32);
+  if (nm == lin_names_.end()) return !any_stored_q_;
+  if (any_stored_q_) return tensors_.count(nm->second + ".weight_q") != 0;
+  for (const std::string& e : int8_exclude_)
+    if (nm->second.compare(0, e.size(), e) == 0) return false;
+  return true;
+}
+
+// a Linear the export did not quantise, inside math_mode 2: the f16 path's GEMM (A rounded to f16 as everywhere in mode 0)
+void Engine::fgemm_in_int8(const char* cls, const Lin& l, bool bias, const float* x32, const half_t* x16, int ldx, int M, float* out32,
+                           int ld32, half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu,
+                           int scale_cols, float scale, const LNp* ln, int range) {
+  PF_CHECK(l.w, PF_ERR_UNSUPPORTED, "int8 mode: an un-quantised Linear without its f16 operand");
+  const half_t* A = x16;
+  int lda = ldx;
+  if (!A) {
+    PF_CHECK(x32, PF_ERR_INVALID_ARG, "int8 mode: an un-quantised Linear needs its input");
+    const int64_t Mp = round_up(M, 256) + 256;
+    ensure(ws_qf_, (size_t)Mp * l.Kpad * 2);
+    half_t* a16 = (half_t*)ws_qf_.p;
+    prof_begin("layernorm", 0);
+    if (ln) launch_layernorm(stream_, x32, M, ln->D, ln->g, ln->b, a16, l.Kpad, nullptr, 0);
+    else launch_f32_to_f16(stream_, x32, M, l.K, ldx, a16, l.Kpad);
+    prof_end("layernorm");
+    A = a16; lda = l.Kpad;
+  }
+  gemm(cls, l, A, lda, M, out32, ld32, out16, ld16, resid, ldr, add2, ld2, relu, scale_cols, scale, bias);
+  if (range & kRangeOut) {                             // the consumer's quantiser expects pass 1 done
+    if (!q_part_) q_part_ = (float*)dalloc(quant_scratch_bytes());
+    launch_minmax(stream_, out16 ? nullptr : out32, out16, M, l.N, out16 ? ld16 : ld32, q_part_);
+  }
+}
+
+void Engine::qgemm(const char* cls, const Lin& lw, bool use_bias, const float* x32, const half_t* x16, int ldx, int M, float* out32, int ld32,
                    half_t* out16, int ld16, const float* resid, int ldr, const float* add2, int ld2, bool relu, int scale_cols,
                    float scale, const LNp* ln, const QAct* pre, int range) {
   if (M == 0) return;
+  if (!lin_quantised(lw)) {
+    PF_CHECK(!pre, PF_ERR_UNSUPPORTED, "int8 mode: a pre-quantised input for an un-quantised Linear");
+    fgemm_in_int8(cls, lw, use_bias, x32, x16, ldx, M, out32, ld32, out16, ld16, resid, ldr, add2, ld2, relu, scale_cols, scale, ln, range);
+    return;
+  }
+  const QLin& w = qlin(lw, use_bias);
   QAct act;
   if (pre) {
     act = *pre;                                        // quantised earlier (the encoder memory: one tensor, sixteen K / V projections)
@@ -125,8 +170,6 @@ void Engine::qgemm(const char* cls, const QLin& w, const float* x32, const half_
 }
 
 void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logits) {
-  PF_CHECK(!mc_.timestamp_head && !mc_.seaco, PF_ERR_UNSUPPORTED,
-           "math_mode 2 (int8) covers the paraformer and SenseVoice graphs, not the BiCIF / SeACo heads");
   const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab, Fd = mc_.feat_dim, T1 = T + 1;
   const int64_t M = (int64_t)B * T, Mp = round_up(M, 128) + 128;
   const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
@@ -154,7 +197,7 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   auto layer = [&](const EncLayer& L, bool first) {
     const int din = first ? Fd : D;
     if (first) launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), t32e);
-    qgemm("gemm_qkv", qlin(L.qkv), first ? t32e : x_, nullptr, din, (int)M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale,
+    qgemm("gemm_qkv", L.qkv, true, first ? t32e : x_, nullptr, din, (int)M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale,
           &L.norm1);
     AttnArgs a{};
     a.q = qkv16_; a.k = qkv16_ + D; a.v = qkv16_ + 2 * D; a.o = ctx16_;
@@ -171,10 +214,10 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     prof_begin("fsmn", 0);
     launch_fsmn_enc(stream_, qkv16_ + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, fsm_);
     prof_end("fsmn");
-    qgemm("gemm_out", qlin(L.out), nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f, nullptr,
+    qgemm("gemm_out", L.out, true, nullptr, ctx16_, D, (int)M, x_, D, nullptr, 0, first ? nullptr : x_, D, fsm_, D, false, 0, 1.f, nullptr,
           nullptr, ctx_range ? kRangeIn : 0);
-    qgemm("gemm_ffn1", qlin(L.w1), x_, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, &L.norm2, nullptr, kRangeOut);
-    qgemm("gemm_ffn2", qlin(L.w2), nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr, kRangeIn);
+    qgemm("gemm_ffn1", L.w1, true, x_, nullptr, D, (int)M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, &L.norm2, nullptr, kRangeOut);
+    qgemm("gemm_ffn2", L.w2, true, nullptr, h16_, F, (int)M, x_, D, nullptr, 0, x_, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr, kRangeIn);
   };
   for (size_t i = 0; i < enc_.size(); ++i) layer(enc_[i], i == 0);
   prof_begin("layernorm", 0);
@@ -191,8 +234,6 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     prof_end("layernorm");
   }
   const int ldV = (int)round_up(V, 4);
-  last_.peak_len = 0;
-  last_.cif_peak.clear();
   last_flops_ = 0;
   if (mc_.kind == "sensevoicesmall") {
     size_t o2 = 0;
@@ -200,7 +241,7 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     const size_t o_lg = c2((size_t)Mp * ldV * 4), o_ids = c2((size_t)M * 8);
     ensure(ws_dec_, o2);
     logits_ = (float*)((char*)ws_dec_.p + o_lg); ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids); logits_ld_ = ldV;
-    qgemm("gemm_vocab", qlin(ctc_), H32_, nullptr, D, (int)M, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+    qgemm("gemm_vocab", ctc_, true, H32_, nullptr, D, (int)M, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
     prof_begin("argmax", 0);
     launch_argmax(stream_, logits_, M, V, ldV, want_logits ? 2 : 1, ids_dev_);
     prof_end("argmax");
@@ -212,6 +253,9 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     return;
   }
   // ---- CIF predictor: the Conv1d is a Conv node (not quantised by quantize_dynamic): the f16 path's im2col GEMM
+  if (ev_enc_) PF_HIP(hipEventRecord(ev_enc_, stream_));
+  last_.peak_len = 0;
+  last_.cif_peak.clear();
   {
     half_t* col16 = h16_;
     float* conv32 = fsm_;
@@ -224,7 +268,11 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
     else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
     prof_end("cif_misc");
+    PF_HIP(hipEventRecord(ev_scan_, stream_));
   }
+  // BiCIF timestamp head: ConvTranspose1d, LSTM and the excluded cif_output2 MatMul are float nodes of the int8 export too
+  // (quantize_dynamic is run with op_types_to_quantize = ["MatMul"]): the f16 path's head, beside the decoder
+  if (mc_.timestamp_head) start_timestamp_head(B, T);
   int32_t L = 0;
   last_.fire_count.resize(B);
   last_.token_num.resize(B);
@@ -235,7 +283,7 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   if (l_hook_) L = l_hook_(L);
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);
-  if (L == 0) return;
+  if (L == 0) { join_ts(); return; }
   // ---- decoder
   const int Md = B * L;
   const int64_t Mdp = round_up(Md, 128) + 128;
@@ -255,9 +303,18 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
   if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
   else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
   prof_end("cif_misc");
+  const bool bias_branch = mc_.seaco && n_hotwords_ > 0;
+  float* e0 = nullptr;                                 // SeACo: the bias decoder also starts from the CIF embeds
+  float* hid32 = nullptr;
+  if (bias_branch) {
+    ensure(ws_seaco_in_, (size_t)2 * Mdp * D * 4);
+    e0 = (float*)ws_seaco_in_.p;
+    hid32 = e0 + (size_t)Mdp * D;
+    PF_HIP(hipMemcpyAsync(e0, xd, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
+  }
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
-    qgemm("gemm_dec_ffn1", qlin(w1), xd, nullptr, D, Md, hd, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f, &n1);
-    qgemm("gemm_dec_ffn2", qlin(w2, false), hd, nullptr, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &fn);
+    qgemm("gemm_dec_ffn1", w1, true, xd, nullptr, D, Md, hd, F, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f, &n1);
+    qgemm("gemm_dec_ffn2", w2, false, hd, nullptr, F, Md, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &fn);
   };
   // K / V of the encoder memory: every layer's MatMul quantises the SAME tensor — one DynamicQuantizeLinear result here
   QAct qH;
@@ -275,9 +332,11 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     prof_begin("fsmn", 0);
     launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
     prof_end("fsmn");
-    qgemm("gemm_dec_q", qlin(Lr.q), xd, nullptr, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale, &Lr.norm3);
-    qgemm("gemm_dec_kv", qlin_raw(Lr.kv32.w32, Lr.kv32.bias, 2 * D, D), nullptr, nullptr, D, (int)M, nullptr, 0, kv16, 2 * D, nullptr, 0,
-          nullptr, 0, false, 0, 1.f, nullptr, &qH);
+    qgemm("gemm_dec_q", Lr.q, true, xd, nullptr, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale, &Lr.norm3);
+    if (lin_quantised(Lr.kv32))
+      qgemm("gemm_dec_kv", Lr.kv32, true, nullptr, nullptr, D, (int)M, nullptr, 0, kv16, 2 * D, nullptr, 0, nullptr, 0, false, 0, 1.f, nullptr, &qH);
+    else
+      gemm("gemm_dec_kv", Lr.kv32, H16_, D, (int)M, nullptr, 0, kv16, 2 * D, nullptr, 0, nullptr, 0, false, 0, 1.f);
     AttnArgs a{};
     a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
     a.k = kv16; a.v = kv16 + D; a.k_bstride = a.v_bstride = (int64_t)T * 2 * D; a.k_rstride = a.v_rstride = 2 * D;
@@ -288,15 +347,89 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
     launch_attention(stream_, a);
     prof_end("attn_cross");
-    qgemm("gemm_dec_out", qlin(Lr.out), nullptr, cx16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr,
+    qgemm("gemm_dec_out", Lr.out, true, nullptr, cx16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr,
           cx_range ? kRangeIn : 0);
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
-  qgemm("gemm_vocab", qlin(dec_out_), t32, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &dec_after_);
+  if (bias_branch) {                                   // the bias decoder's second input: the after_norm hidden itself
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, hid32, D);
+    prof_end("layernorm");
+    qgemm("gemm_vocab", dec_out_, true, hid32, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  } else {
+    qgemm("gemm_vocab", dec_out_, true, t32, nullptr, D, Md, logits_, ldV, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &dec_after_);
+  }
   prof_begin("argmax", 0);
   launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
   prof_end("argmax");
+  if (bias_branch) seaco_head(B, L, e0, hid32, want_logits);
+  join_ts();
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
+}
+
+// ---- SeACo bias branch in math_mode 2 (reference default for the flagship model: model.int8.onnx + model_eb.int8.onnx,
+// Examples/OfflineAliParaformerAsrRecognizer.cs:17-21).  The hot-word embedder (Embedding + LSTM) holds no MatMul with a
+// constant operand outside the LSTM nodes and stays on the f16 path; the bias decoder is the ASR decoder's structure.
+// K / V rows of bias_embed [NJ, D]: every layer's MatMul quantises the same tensor (the per-tensor range of the tiled
+// [B, NJ, D] input equals that of one copy), so it is quantised once.
+void Engine::seaco_kv_int8(const float* hw32, const half_t* hw16, int NJ, half_t* kv16, int ldkv) {
+  const int D = mc_.d_model, kp = (int)round_up(D, 128);
+  const int64_t rp = round_up(NJ, 256) + 256;
+  ensure(ws_seaco_q_, (size_t)rp * kp + (size_t)rp * 4 + 1024);
+  QAct q;
+  char* b = (char*)ws_seaco_q_.p;
+  q.a = (int8_t*)b; q.rowsum = (int32_t*)(b + (size_t)rp * kp); q.params = (float*)(b + (size_t)rp * kp + (size_t)rp * 4);
+  quantize_act(q, kp, hw32, nullptr, D, NJ, D, nullptr);
+  for (size_t i = 0; i < sdec_.size(); ++i) {
+    const Lin& kv = sdec_[i].kv32;
+    // a [NJ, 2D] slice of the [NJ, ns * 2D] buffer: f16-only results with a row stride of ldkv
+    if (lin_quantised(kv))
+      qgemm("gemm_seaco", kv, true, nullptr, nullptr, D, NJ, nullptr, 0, kv16 + i * 2 * D, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f, nullptr, &q);
+    else
+      gemm("gemm_seaco", kv, hw16, D, NJ, nullptr, 0, kv16 + i * 2 * D, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
+  }
+}
+
+// ONE pass of the bias decoder over R = B * L rows (xs); leaves after_norm(x) in hid [R, D].  The graph runs the decoder
+// twice — on the CIF embeds and on the ASR decoder hidden — and each run has its own DynamicQuantizeLinear nodes, i.e. its
+// own per-tensor ranges: the f16 path's single pass over 2 * B * L rows would merge the two ranges, so this mode runs two.
+void Engine::seaco_decoder_int8(int B, int L, int NJ, float* xs, float* h32, float* t32, float* tn32, half_t* q16, half_t* ctx16,
+                                const half_t* kv16, int ldkv, const int32_t* tn2, float* hid) {
+  const int D = mc_.d_model, Fs = mc_.seaco_ffn, R = B * L;
+  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  if (!q_part_) q_part_ = (float*)dalloc(quant_scratch_bytes());
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
+    qgemm("gemm_seaco", w1, true, xs, nullptr, D, R, h32, Fs, nullptr, 0, nullptr, 0, nullptr, 0, true, 0, 1.f, &n1);
+    qgemm("gemm_seaco", w2, false, h32, nullptr, Fs, R, t32, D, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f, &fn);
+  };
+  for (size_t i = 0; i < sdec_.size(); ++i) {
+    const DecLayer& Lr = sdec_[i];
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
+    prof_begin("layernorm", 0);
+    launch_layernorm(stream_, t32, R, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
+    prof_end("layernorm");
+    prof_begin("fsmn", 0);
+    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, tn2, B, L, D, mc_.seaco_kernel, xs);
+    prof_end("fsmn");
+    qgemm("gemm_seaco", Lr.q, true, xs, nullptr, D, R, nullptr, 0, q16, D, nullptr, 0, nullptr, 0, false, D, qscale, &Lr.norm3);
+    AttnArgs a{};
+    a.q = q16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
+    a.k = kv16 + i * 2 * D; a.v = kv16 + i * 2 * D + D;
+    a.k_bstride = a.v_bstride = 0; a.k_rstride = a.v_rstride = ldkv;
+    a.o = ctx16; a.o_bstride = (int64_t)L * D; a.o_rstride = D;
+    a.B = B; a.H = mc_.heads; a.Lq = L; a.Lk = NJ;
+    const bool cx_range = attention_reports_range(a);
+    a.range = cx_range ? q_part_ : nullptr;
+    prof_begin("attn_seaco", 4.0 * B * (double)L * NJ * D);
+    launch_attention(stream_, a);
+    prof_end("attn_seaco");
+    qgemm("gemm_seaco", Lr.out, true, nullptr, ctx16, D, R, xs, D, nullptr, 0, xs, D, nullptr, 0, false, 0, 1.f, nullptr, nullptr,
+          cx_range ? kRangeIn : 0);
+  }
+  ffn_dec(seaco_final_norm1_, seaco_final_w1_, seaco_final_ffn_norm_, seaco_final_w2_);
+  prof_begin("layernorm", 0);
+  launch_layernorm(stream_, t32, R, D, seaco_after_.g, seaco_after_.b, nullptr, 0, hid, D);
+  prof_end("layernorm");
 }
 
 // stand-alone operator (parity tests): one dynamically quantised Linear, nothing cached

@@ -135,6 +135,7 @@ Group::Group(const pf_engine_config& cfg, const int32_t* devices, int n) {
     }
     gsend_.assign((size_t)n, nullptr); grecv_.assign((size_t)n, nullptr);
     gsend_bytes_.assign((size_t)n, 0); grecv_bytes_.assign((size_t)n, 0);
+    gsrc_.assign((size_t)n, nullptr); gsrc_bytes_.assign((size_t)n, 0); gsrc_rows_.assign((size_t)n, 0); gsrc_L_.assign((size_t)n, 0);
     runner_.reset(new ShardRunner(n));
     runner_->run_on_all([this](int g) { PF_HIP(hipSetDevice(devs_[(size_t)g])); });   // each worker thread binds its device once
   } catch (...) {
@@ -152,8 +153,9 @@ void Group::release() {
     hipSetDevice(devs_[i]);
     if (gsend_[i]) hipFree(gsend_[i]);
     if (grecv_[i]) hipFree(grecv_[i]);
+    if (i < gsrc_.size() && gsrc_[i]) hipFree(gsrc_[i]);
   }
-  gsend_.clear(); grecv_.clear();
+  gsend_.clear(); grecv_.clear(); gsrc_.clear();
   if (rccl_)
     for (void* c : comms_) rccl_->CommDestroy((ncclComm_t)c);
   comms_.clear();
@@ -199,6 +201,23 @@ void Group::run(int g, int lo, int hi, int Tg, bool want_logits, const std::func
   e.sync();
   r = e.last_result();
   if (want_logits && (int64_t)r.B * r.L * r.V > 0) e.copy_logits(r);
+  // The gather runs after two rendez-vous, without this engine's mutex: another thread holding a pf_group_engine view may
+  // run a forward in between, re-carve (or free) the decoder arena and overwrite the ids.  What the gather sends is
+  // therefore copied NOW, under the lock, into a buffer only the group's threads touch.
+  if (comms_ready_) {
+    const size_t idb = (size_t)r.B * r.L * 8, tnb = (size_t)r.B * 4;
+    void*& p = gsrc_[(size_t)g];
+    size_t& have = gsrc_bytes_[(size_t)g];
+    if (have < idb + tnb + 16) {
+      if (p) { PF_HIP(hipFree(p)); p = nullptr; have = 0; }
+      PF_HIP(hipMalloc(&p, idb + tnb + 16));
+      have = idb + tnb + 16;
+    }
+    if (idb) PF_HIP(hipMemcpyAsync(p, e.ids_device(), idb, hipMemcpyDeviceToDevice, e.stream()));
+    if (cur_has_cif_ && tnb) PF_HIP(hipMemcpyAsync((char*)p + idb, e.token_num_device(), tnb, hipMemcpyDeviceToDevice, e.stream()));
+    PF_HIP(hipStreamSynchronize(e.stream()));
+    gsrc_rows_[(size_t)g] = r.B; gsrc_L_[(size_t)g] = r.L;
+  }
 }
 
 // fixed-shape [per, L] int64 ids + [per] int32 token_num per shard; `lay` is the same on every rank (it is a function
@@ -216,9 +235,12 @@ void Group::prepare_gather(int g, int count, int L, const GatherLayout& lay, int
   char* sb = (char*)gsend_[(size_t)g];
   PF_HIP(hipMemsetAsync(sb, 0xFF, lay.block_bytes, e.stream()));           // absent rows: id -1, token_num -1
   if (count > 0 && L > 0) {
-    PF_HIP(hipMemcpyAsync(sb, e.ids_device(), (size_t)count * L * 8, hipMemcpyDeviceToDevice, e.stream()));
+    PF_CHECK(gsrc_[(size_t)g] && gsrc_rows_[(size_t)g] == count && gsrc_L_[(size_t)g] == L, PF_ERR_DEVICE,
+             "group: the shard's ids were not kept for the gather (rows / length differ from the agreed layout)");
+    const char* src = (const char*)gsrc_[(size_t)g];
+    PF_HIP(hipMemcpyAsync(sb, src, (size_t)count * L * 8, hipMemcpyDeviceToDevice, e.stream()));
     if (cur_has_cif_)
-      PF_HIP(hipMemcpyAsync(sb + lay.ids_bytes, e.token_num_device(), (size_t)count * 4, hipMemcpyDeviceToDevice, e.stream()));
+      PF_HIP(hipMemcpyAsync(sb + lay.ids_bytes, src + (size_t)count * L * 8, (size_t)count * 4, hipMemcpyDeviceToDevice, e.stream()));
   }
 }
 

@@ -55,6 +55,9 @@ class Group : private ShardBackend {
   bool comms_ready_ = false;
   std::vector<void*> gsend_, grecv_;         // gather buffers per engine
   std::vector<size_t> gsend_bytes_, grecv_bytes_;
+  std::vector<void*> gsrc_;                  // per engine: ids + token_num of the shard, copied under the engine lock in run()
+  std::vector<size_t> gsrc_bytes_;
+  std::vector<int> gsrc_rows_, gsrc_L_;
   // the call in flight (valid inside recognize())
   const float* const* cur_samples_ = nullptr;
   const int64_t* cur_n_ = nullptr;

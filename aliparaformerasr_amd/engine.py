@@ -228,6 +228,13 @@ class Engine:
     def fetch(self) -> BatchResult:
         return self._collect(lambda out: self._lib.pf_fetch(self._h, C.byref(out)), self._staged_B, False)
 
+    def fetch_ids_device(self, dev_ptr: int, l_cap: int) -> int:
+        """The staged result's ids [B, l_cap] int64 (-1 padded) into caller-owned DEVICE memory (e.g. a torch tensor's
+        data_ptr on this engine's GPU) — what a multi-GPU caller hands to the RCCL all-gather.  Returns L."""
+        L = C.c_int32(0)
+        N.check(self._lib.pf_fetch_ids_device(self._h, C.c_void_p(dev_ptr), l_cap, C.byref(L)))
+        return L.value
+
     def profile(self, on: bool):
         N.check(self._lib.pf_profile_enable(self._h, 1 if on else 0))
 

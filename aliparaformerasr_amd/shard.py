@@ -60,3 +60,22 @@ def gather_hypotheses(ids_local: np.ndarray, n_total: int, lcap: int, dist, devi
         lo, hi = shard_bounds(n_total, world, r)
         rows.append(full[r * per: r * per + (hi - lo)])
     return np.concatenate(rows, axis=0)
+
+
+def gather_hypotheses_device(mine, n_total: int, dist):
+    """`mine` [per, lcap] integer tensor ALREADY on the collective's device (the engine wrote it there,
+    pf_fetch_ids_device; rows past this rank's shard and columns past L hold -1) -> [n_total, lcap] on every rank in
+    the original utterance order, still on the device: one all_gather (RCCL over xGMI on the GPU box), no host copy."""
+    import torch
+    world = dist.get_world_size()
+    per = (n_total + world - 1) // world
+    assert mine.shape[0] == per
+    full = torch.empty((world * per,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(full, mine.contiguous())
+    if world * per == n_total:
+        return full
+    keep = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, world, r)
+        keep.append(full[r * per: r * per + (hi - lo)])
+    return torch.cat(keep, dim=0)

@@ -48,6 +48,10 @@ DEFAULT_CONFIG = dict(
     seaco_layers=4, seaco_ffn=1024, seaco_kernel=21, seaco_lstm_layers=2, seaco_nobias=8377,
     # CIF export variant: "loop" = sequential integrate-and-fire, "cumsum" = FunASR cif_v1_export (prefix sums)
     cif_variant="loop",
+    # math_mode 2 on a container WITHOUT stored int8 bytes (the synthetic models): Linear name prefixes that stay float,
+    # e.g. ["decoder.output", "seaco.output"] for the MatMuls FunASR's export excludes from quantize_dynamic.  A container
+    # converted from an int8 export does not need it: a Linear is quantised iff its `<name>.weight_q` bytes are present.
+    int8_exclude=(),
 )
 
 
@@ -57,6 +61,7 @@ def make_config(**kw) -> dict:
         if k not in cfg:
             raise KeyError(k)
         cfg[k] = v
+    cfg["int8_exclude"] = [str(e) for e in cfg["int8_exclude"]]      # a JSON array in the container header
     return cfg
 
 

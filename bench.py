@@ -85,9 +85,15 @@ def golden_check(tag, ids, token_num=None):
     g = np.load(path)
     gi, gm = g["ids"], g["margin"]
     ids = np.asarray(ids)
-    if ids.ndim != 2 or ids.shape[0] != gi.shape[0] or abs(ids.shape[1] - gi.shape[1]) > 1:
+    # A larger batch whose FIRST rows are the golden batch (--batch 128, rank 0 of --gpus 8: utterances are independent and
+    # padded to the same batch maximum) is checked on those rows; a different decoder length L = max fire count only
+    # changes how many padding columns follow an utterance's token_num, so the comparison runs on the common columns.
+    if ids.ndim != 2 or ids.shape[0] < gi.shape[0]:
         return None
     B, L = gi.shape[0], min(ids.shape[1], gi.shape[1])
+    ids = ids[:B]
+    if token_num is not None:
+        token_num = np.asarray(token_num)[:B]
     rows = np.ones(B, bool)
     tn_ok, tn_diff = True, 0
     if token_num is not None and "alpha_sum" in g.files:
@@ -98,10 +104,13 @@ def golden_check(tag, ids, token_num=None):
         tn_ok = bool((np.abs(d) <= 1).all() and (near | (d == 0)).all())
         rows = d == 0
     firm = (gm[:, :L] > GOLDEN_MARGIN) & rows[:, None]
+    if "token_num" in g.files:                       # columns past an utterance's token_num are padding rows of the decoder
+        firm &= np.arange(L)[None, :] < g["token_num"].astype(np.int64)[:, None]
     same = ids[:, :L] == gi[:, :L]
     return {"ok": bool(tn_ok and same[firm].all()), "decisive_positions": float(firm.mean()),
             "decisive_mismatches": int((~same[firm]).sum()), "agree_all_positions": float(same.mean()),
             "token_num_near_ties_resolved_differently": tn_diff, "L": [int(ids.shape[1]), int(gi.shape[1])],
+            "rows_checked": int(B),
             "margin": GOLDEN_MARGIN, "oracle": "fp32 CPU oracle, tests/golden/bench_%s.npz" % tag}
 
 
@@ -286,10 +295,11 @@ def main():
     ap.add_argument("--seconds", type=int, default=0, help="utterance length (default 30; 10 for --model sensevoice)")
     ap.add_argument("--timestamp-head", action="store_true",
                     help="BASELINE.json configs[4]-style variant: adds the BiCIF timestamp head (not the headline config)")
-    ap.add_argument("--accuracy", choices=("f16", "int8"), default="f16",
+    ap.add_argument("--accuracy", choices=("f16", "int8", "fp32"), default="f16",
                     help="int8 = the arithmetic of the reference CLI's default model.int8.onnx (Examples/Program.cs:98-101): every "
                          "Linear as DynamicQuantizeLinear + MatMulInteger on the int8 MFMA (pf_engine_config.math_mode 2); NOT the "
-                         "headline configuration")
+                         "headline configuration; fp32 = the exact path (math_mode 1: fp32 weights and activations on "
+                         "v_mfma_f32_32x32x2_f32, unfused) — what exactness costs, not the headline either")
     ap.add_argument("--group", type=int, default=0,
                     help="N > 0: ONE process driving pf_group_recognize over N devices (the path a C# caller gets: "
                          "host audio in, utterance shards, RCCL weight broadcast + all-gather of the ids inside the C ABI) "
@@ -352,7 +362,8 @@ def main():
     n = wdev.numel()
     torch.cuda.synchronize()
     int8 = args.accuracy == "int8"
-    eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local, math_mode=2 if int8 else 0)
+    fp32 = args.accuracy == "fp32"
+    eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local, math_mode=2 if int8 else (1 if fp32 else 0))
 
     # ---- workload: this rank's shard of the utterance list, staged to HBM before timing
     B = args.batch
@@ -363,12 +374,16 @@ def main():
         hws = [list(hrng.integers(3, 8000, size=int(hrng.integers(2, 5)))) for _ in range(20)] + [[1]]
         eng.set_hotwords(np.asarray([h[:10] + [0] * (10 - len(h)) for h in hws], np.int32))
     gathered = {}
+    ids_mine = torch.full((B, LCAP), -1, dtype=torch.int64, device=dev) if world > 1 else None
 
     def step():
         eng.run_staged()
-        if world > 1:                                         # gather of hypotheses over RCCL
-            r = eng.fetch()
-            gathered["ids"] = sh.gather_hypotheses(r.token_ids, world * B, LCAP, dist, dev)
+        if world > 1:
+            # gather of hypotheses over RCCL / xGMI, device to device: the engine writes its [B, LCAP] ids into a device
+            # tensor on its own stream (and waits for it), the all-gather leaves [world * B, LCAP] on every GPU; no host
+            # round trip inside the timed region (the host copy for the check below happens after the timing)
+            eng.fetch_ids_device(ids_mine.data_ptr(), LCAP)
+            gathered["ids"] = sh.gather_hypotheses_device(ids_mine, world * B, dist)
 
     for _ in range(args.warmup):
         step()
@@ -424,7 +439,7 @@ def main():
     assert (res.token_ids >= 0).all() and (res.token_ids < eng.vocab).all()
     assert (res.token_num > 0).all()
     if world > 1:
-        g = gathered["ids"]
+        g = gathered["ids"].cpu().numpy()
         assert g.shape == (world * B, LCAP) and (g[rank * B:(rank + 1) * B, :res.L] == res.token_ids).all()
     # ... and the right one: rank 0's ids against the fp32 CPU oracle's for this workload (tests/golden/), wherever
     # the oracle is decisive.  Only the three BASELINE workloads at their own shapes have a golden file.
@@ -454,14 +469,14 @@ def main():
                      "gemm_out": dom_rows * (Kk * 2 + Nn * 2 + Nn * 4 + Nn * 4 + Nn * 2) + Nn * Kk * 2 + Nn * 4,
                      "gemm_ffn1": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
                      "gemm_ffn2": dom_rows * (Kk * 2 + Nn * 4 + Nn * 4) + Nn * Kk * 2}[dominant]
-        headline = not int8 and not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS
+        headline = not int8 and not fp32 and not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS
         out = {
             "metric": "RTFx (audio-sec/wall-sec), %s offline, batch %dx%ds per GPU"
                       % ("sensevoice-small" if sv else "paraformer-large", B, seconds),
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 (u8 x u8 -> i32 Linear layers as model.int8.onnx; f16 attention)" if int8 else "f16", "data": "synthetic",
+            "dtype": "int8 (u8 x u8 -> i32 Linear layers as model.int8.onnx; f16 attention)" if int8 else ("f32" if fp32 else "f16"), "data": "synthetic",
             "config": {"workload": "%s offline%s, batch %dx%d s synthetic 16 kHz per GPU "
                                    "(BASELINE.json configs[%d]), seeded synthetic weights"
                                    % ("sensevoice-small (use_itn on)" if sv else ("SeACo-paraformer, 21 hotwords" if args.model == "seaco" else "paraformer-large-zh"),
@@ -486,6 +501,9 @@ def main():
                          # what the part sustains with every CU issuing MFMAs back to back (tools/ubench/kstep.hip):
                          # the clock settles near 1.65 GHz; informative only, `frac` is against the spec peak
                          "sustained_peak_measured": SUSTAINED_F16_TFLOPS, "frac_of_sustained": ach / SUSTAINED_F16_TFLOPS,
+                         # the same MFMA-only loop on 32 CUs runs 0.446 us per k-step against 0.64 us on 256 CUs, i.e. the all-CU
+                         # figure is a clock (DVFS) reading, not a property of the matrix pipe
+                         "sustained_peak_32cu_equivalent": 2440.0,
                          "traffic": pmc_traffic(dom_kernel) if headline else None,
                          "traffic_unit": "bytes/launch (PMC, %s)" % os.path.relpath(PMC_FILE, ROOT),
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -495,7 +513,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not sv and seconds == SECONDS:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, cmvn)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            out["gpu_over_cpu_port_standin"] = value / out["cpu_baseline"]["value"]   # NOT onnxruntime: the torch-CPU port of the oracle
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

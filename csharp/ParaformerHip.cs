@@ -1,4 +1,4 @@
-// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 3).
+// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 4).
 // Drop into the reference project (AliParaformerAsr/Native/) — see csharp/README.md.  Not compiled in the build
 // image of this repository (no .NET toolchain); the same entry points are exercised through the Python ctypes
 // binding aliparaformerasr_amd/_native.py by tests/.
@@ -63,6 +63,7 @@ namespace AliParaformerAsr.Native
         [DllImport(Lib)] internal static extern int pf_recognize(IntPtr e, IntPtr[] samples, long[] nSamples, int B,
                                                                 int[]? hotwords, int nHotwords, ref PfBatchOut o);
         [DllImport(Lib)] internal static extern int pf_fetch(IntPtr e, ref PfBatchOut o);
+        [DllImport(Lib)] internal static extern int pf_fetch_ids_device(IntPtr e, IntPtr idsDev, int lCap, out int L);
 
         // ---- several GPUs in one process (paraformer_hip.h section 4b) ------------------------------------------
         [DllImport(Lib)] internal static extern int pf_group_create(ref PfEngineConfig cfg, int[] devices, int nDevices, out IntPtr group);

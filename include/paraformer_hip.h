@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 
 typedef enum pf_status {
   PF_OK = 0,
@@ -181,6 +181,12 @@ int pf_sync(pf_engine* e);            /* waits for the engine stream            
    reference's static lock, OfflineStream.cs:19).  After pf_run_staged it returns the staged result (the
    staged API is engine state: one caller at a time). */
 int pf_fetch(pf_engine* e, pf_batch_out* out);
+/* The hypotheses of the staged result WITHOUT leaving the device (ABI 4): writes ids [B, l_cap] int64 (columns >= L
+   filled with -1) into `ids_dev` (device memory of the engine's GPU) on the engine stream and waits for it, so a caller
+   that gathers hypotheses across GPUs (RCCL all-gather over xGMI) hands the buffer straight to the
+   collective.  *L_out (optional) receives the decoder length.  PF_ERR_CAPACITY when l_cap < L.  Replaces, for that
+   caller, the host copy the reference makes of the logits tensor (OfflineProjOfParaformer.cs:73-79). */
+int pf_fetch_ids_device(pf_engine* e, int64_t* ids_dev, int32_t l_cap, int32_t* L_out);
 
 /* ------------------------------------------------------------------------ */
 /* 4b. Multi-GPU inside one process: one engine, one host thread and one HIP stream per listed

@@ -75,9 +75,19 @@ class QuantizedLinears:
     carries them (`<name>.weight_q` / `.weight_zp` / `.weight_scale`, aliparaformerasr_amd/convert.py), otherwise
     quantize_weight() of the float tensor (the synthetic models)."""
 
-    def __init__(self, weights: dict):
+    def __init__(self, weights: dict, exclude=()):
         self.w = weights
         self.cache = {}
+        self.exclude = tuple(exclude)
+        self.any_stored = any(k.endswith(".weight_q") for k in weights)
+
+    def quantised(self, name: str) -> bool:
+        """Is `<name>` a DynamicQuantizeLinear + MatMulInteger pair?  An export's container answers by the bytes it
+        carries (FunASR runs quantize_dynamic with nodes_to_exclude: such MatMuls have no `.weight_q` and stay float);
+        fp32-only weights quantise everything but the prefixes in the `int8_exclude` config key."""
+        if self.any_stored:
+            return name + ".weight_q" in self.w
+        return not any(name.startswith(e) for e in self.exclude)
 
     def __call__(self, x, name: str, bias: bool):
         if name not in self.cache:

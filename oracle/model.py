@@ -61,6 +61,7 @@ class ModelConfig:
     seaco_lstm_layers: int = 2
     seaco_nobias: int = 8377
     cif_variant: str = "loop"         # "loop" (sequential integrate-and-fire) | "cumsum" (cif_v1_export)
+    int8_exclude: tuple = ()          # int8 modes, fp32-only weights: Linear name prefixes that stay float
 
     def to_dict(self):
         return dict(self.__dict__)
@@ -159,11 +160,12 @@ class Oracle:
         if self.int8:
             from .int8 import QuantizedLinears
             self.qlin = QuantizedLinears({k: np.ascontiguousarray(v) for k, v in weights.items()
-                                          if isinstance(v, np.ndarray) and v.dtype in (np.float32, np.uint8)})
+                                          if isinstance(v, np.ndarray) and v.dtype in (np.float32, np.uint8)},
+                                         exclude=tuple(cfg.int8_exclude))
 
     # -- helpers -----------------------------------------------------------
     def lin(self, x, name, bias=True):
-        if self.int8:
+        if self.int8 and self.qlin.quantised(name):
             return torch.from_numpy(self.qlin(np.ascontiguousarray(x.detach().numpy(), dtype=np.float32), name, bias))
         w = self.q(self.w[name + ".weight"])
         y = torch.matmul(self.q(x), w.t())

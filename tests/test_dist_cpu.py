@@ -50,6 +50,12 @@ def _worker(rank, world, port, n_total, q):
     for i, u in enumerate(range(lo, hi)):
         ids[i, : 3 + u % 5] = np.arange(u, u + 3 + u % 5)
     full = sh.gather_hypotheses(ids, n_total, 16, dist, dev)
+    # 3. the tensor form bench.py uses on the GPU box (ids already on the collective's device, one all_gather_into_tensor)
+    per = (n_total + world - 1) // world
+    mine = torch.full((per, 16), -1, dtype=torch.int64)
+    mine[: hi - lo, :L] = torch.from_numpy(ids)
+    full_t = sh.gather_hypotheses_device(mine, n_total, dist).numpy()
+    assert full_t.shape == full.shape and (full_t == full).all()
     q.put((rank, cfg2 == cfg, float(w2["decoder.output.weight"].sum()), full))
     dist.barrier()
     dist.destroy_process_group()

@@ -77,6 +77,35 @@ def test_paraformer_32x30s():
     eng.close()
 
 
+def test_paraformer_128x30s_the_configs3_shard():
+    """BASELINE.json configs[3]: 1024 x 30 s over 8 GPUs = 128 utterances per GPU as ONE batch (M = 64 000 encoder rows:
+    250 / 500 / 1000 / 1500 GEMM tiles, 512 attention workgroups, a 128-utterance CIF scan and decoder).  The first 32
+    utterances are the configs[1] batch; the batch maximum length is the same, so their rows must not depend on the
+    other 96 (utterances are independent, OfflineProjOfParaformer.cs:49)."""
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2)
+    eng, w, cmvn = _engine(cfg)
+    audio = [W.synth_audio(480000, u) for u in range(128)]
+    speech = _speech(audio, cmvn)
+    assert speech.shape == (128, 500, 560)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").paraformer(speech)
+    res = eng.recognize(audio, want_logits=True)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    assert res.L == ref["logits"].shape[1]
+    e, m = _compare(res, ref["logits"], TOL)
+    eng.stage_audio(audio)
+    eng.run_staged()
+    r2 = eng.fetch()
+    np.testing.assert_array_equal(r2.token_ids, res.token_ids)
+    # batch independence: the 32-utterance batch gives the same ids for its utterances (up to its own shorter L)
+    r32 = eng.recognize(audio[:32])
+    for b in range(32):
+        n = int(r32.token_num[b])
+        assert n == int(res.token_num[b])
+        np.testing.assert_array_equal(r32.token_ids[b, :n], res.token_ids[b, :n])
+    print("128x30s: L=%d err=%.3e ids==oracle %.4f" % (res.L, e, m))
+    eng.close()
+
+
 def test_sensevoice_64x10s_use_itn():
     """BASELINE.json configs[2]: sensevoice-small, batch 64 x 10 s, use_itn on (T = 166 + 4 prompt rows)."""
     cfg = W.sensevoice_small_config(enc_layers=2, tp_layers=1, use_itn=True)

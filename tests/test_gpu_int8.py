@@ -224,12 +224,54 @@ def test_int8_stored_bytes_are_shape_checked():
     assert "must be f32" in str(ei.value)
 
 
-def test_int8_mode_refuses_heads_it_does_not_cover():
+def test_int8_seaco_timestamp_vs_oracle():
+    """configs[4] in the reference's DEFAULT arithmetic (model.int8.onnx + model_eb.int8.onnx,
+    Examples/OfflineAliParaformerAsrRecognizer.cs:17-21): SeACo bias decoder Linears on the int8 matrix cores (each of its
+    two passes with its own per-tensor ranges, as the graph's two DynamicQuantizeLinear sets have), hot-word embedder and
+    BiCIF head on the float path (LSTM / ConvTranspose nodes are not MatMuls)."""
     from aliparaformerasr_amd.engine import Engine
-    from aliparaformerasr_amd._native import PfError
-    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=256, timestamp_head=True)
-    eng = Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, 1)), cmvn=W.synth_cmvn(), device=0, math_mode=2)
-    with pytest.raises(PfError) as ei:
-        eng.recognize([W.synth_audio(16000, 1)])
-    assert "math_mode 2" in str(ei.value)
+    cfg = W.seaco_paraformer_config(enc_layers=2, dec_layers=2, vocab=8404, seaco_layers=2)
+    w = W.synth_weights(cfg, 5)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=W.synth_cmvn(), device=0, math_mode=2)
+    rng = np.random.default_rng(3)
+    hw = np.zeros((5, 10), np.int32)
+    hw[:, :3] = rng.integers(1, 8000, (5, 3))
+    eng.set_hotwords(hw)
+    B, T = 3, 90
+    speech = (rng.standard_normal((B, T, 560)) * 0.5).astype(np.float32)
+    res = eng.forward_feats(speech, want_logits=True)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="int8").seaco(speech, hw)
+    assert res.logits.shape == ref["logits"].shape
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    err = np.abs(res.logits - ref["logits"])
+    print("int8 seaco: max|dlogp| %.3e mean %.2e" % (err.max(), err.mean()))
+    assert err.max() < 0.5 and err.mean() < 4e-2
+    # the bias branch must have acted somewhere (dha rows replace ASR rows) for the test to mean anything
+    took = (np.abs(ref["logits"] - ref["asr_logits"]).max(axis=-1) > 0)
+    print("int8 seaco: %d of %d positions take the hot-word log-probs" % (took.sum(), took.size))
+    assert took.any()
+    pk = res.cif_peak.reshape(B, -1)
+    d = np.abs(pk - ref["us_cif_peak"])
+    print("int8 seaco: us_cif_peak 99th pct %.2e" % np.percentile(d % 1.0, 99))
+    assert pk.shape == ref["us_cif_peak"].shape
+    eng.close()
+
+
+def test_int8_excluded_linears_stay_float():
+    """`int8_exclude` (fp32-only containers) / missing `.weight_q` bytes (an export's container): such a Linear is not a
+    MatMulInteger pair in the model file and must run in float — engine and oracle decide by the same rule."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=300, int8_exclude=("decoder.output", "decoder.layers.0.src"))
+    w = W.synth_weights(cfg, 9)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=W.synth_cmvn(), device=0, math_mode=2)
+    rng = np.random.default_rng(4)
+    speech = (rng.standard_normal((2, 70, 560)) * 0.5).astype(np.float32)
+    res = eng.forward_feats(speech, want_logits=True)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="int8").paraformer(speech)
+    allq = om.Oracle(om.ModelConfig(**dict(cfg, int8_exclude=())), w, quant="int8").paraformer(speech)
+    err = np.abs(res.logits - ref["logits"])
+    far = np.abs(res.logits - allq["logits"])
+    print("int8 exclude: vs oracle with the same rule max %.3e mean %.2e; vs everything-quantised mean %.2e" % (err.max(), err.mean(), far.mean()))
+    assert err.max() < 0.3 and err.mean() < 3e-2
+    assert far.mean() > err.mean()
     eng.close()

@@ -132,3 +132,37 @@ def test_hotword_side_is_cached_per_list_not_per_engine(seaco_setup):
         np.testing.assert_array_equal(r.token_ids, want[name].token_ids)
         np.testing.assert_array_equal(r.logits, want[name].logits)
     assert not np.array_equal(want["hw"].logits, want["hw2"].logits)
+
+
+def test_recognizer_on_the_reference_default_int8_file_name(tmp_path, seaco_setup):
+    """The reference CLI's default is paraformer-seaco-large-zh-timestamp with `-accuracy int8`
+    (Examples/Program.cs:98-101, Examples/OfflineAliParaformerAsrRecognizer.cs:17-21): a container named
+    model.int8.pfw selects math_mode 2 and must RUN for a SeACo + timestamp model — tokens equal to the int8 engine's,
+    timestamps present."""
+    from aliparaformerasr_amd.engine import Engine
+    from aliparaformerasr_amd.offline_recognizer import OfflineRecognizer
+    _, cfg, w, cmvn, audio, speech, hw, ref = seaco_setup
+    d = tmp_path
+    W.save_pfw(str(d / "model.int8.pfw"), cfg, w)
+    (d / "am.mvn").write_text(fe.format_mvn_text(*cmvn))
+    toks = ["<blank>", "<s>", "</s>"] + [chr(0x4E00 + 3 * i) for i in range(VOCAB - 4)] + ["<unk>"]
+    (d / "tokens.txt").write_text("\n".join(toks) + "\n", encoding="utf-8")
+    (d / "asr.yaml").write_text("model: seacoparaformer\nfrontend_conf:\n  dither: 0.0\n")
+    (d / "hotword.txt").write_text(toks[5] + toks[6] + toks[7] + "\n" + toks[9] + toks[10] + "\n", encoding="utf-8")
+    rec = OfflineRecognizer(str(d / "model.int8.pfw"), str(d / "asr.yaml"), str(d / "am.mvn"), str(d / "tokens.txt"),
+                            hotwordFilePath=str(d / "hotword.txt"))
+    streams = []
+    for a in audio:
+        s = rec.CreateOfflineStream()
+        s.AddSamples(a)
+        streams.append(s)
+    rec.GetResults(streams)
+    eng8 = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=2)
+    default_hw = np.asarray(glue.pad_list([[5, 6, 7], [9, 10], [1]]), np.int32)
+    exp = eng8.forward_feats(speech, hotwords=default_hw)
+    for b, s in enumerate(streams):
+        assert list(s.Tokens) == [int(x) for x in exp.token_ids[b]]
+        if len(s.Tokens):
+            assert len(s.Timestamps) > 0
+    eng8.close()
+    rec.Dispose()
