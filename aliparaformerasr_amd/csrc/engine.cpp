@@ -2023,9 +2023,10 @@ void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, 
   const int M = ds.M, N = ds.N, K = ds.K;
   PF_CHECK(M > 0 && N > 0 && K > 0, PF_ERR_INVALID_ARG, "gemm_ex: empty problem");
   PF_CHECK(ds.out_kind >= 0 && ds.out_kind <= 2, PF_ERR_INVALID_ARG, "gemm_ex: out_kind must be 0, 1 or 2");
-  PF_CHECK(ds.tile_rows == 0 || ds.tile_rows == 32 || ds.tile_rows == 128 || ds.tile_rows == 256 || ds.tile_rows == 512 || ds.tile_rows == 1024,
-           PF_ERR_INVALID_ARG, "gemm_ex: tile_rows must be 0, 32 (= the short-input kernel), 128, 256, 512 (= the 256 x {192,256} tile kernel) "
-           "or 1024 (= its persistent form for the blocked result)");
+  PF_CHECK(ds.tile_rows == 0 || ds.tile_rows == 32 || ds.tile_rows == 128 || ds.tile_rows == 256 || ds.tile_rows == 512 || ds.tile_rows == 1024 ||
+               ds.tile_rows == 2048,
+           PF_ERR_INVALID_ARG, "gemm_ex: tile_rows must be 0, 32 (= the short-input kernel), 128, 256, 512 (= the 256 x {192,256} tile kernel), "
+           "1024 (= its persistent form for the blocked result) or 2048 (= the k-step-32 fp32-result kernel)");
   PF_CHECK(ds.out_kind == 0 || (!ds.resid && !ds.add2), PF_ERR_INVALID_ARG, "gemm_ex: residual / addend need the fp32 result kind");
   PF_CHECK(ds.out_kind != 2 || N % 64 == 0, PF_ERR_INVALID_ARG, "gemm_ex: blocked result needs N % 64 == 0");
   const int Kp = (int)round_up(K, 64);
@@ -2067,7 +2068,7 @@ void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, 
   g.scale_cols = ds.scale_cols; g.scale = ds.scale;
   g.out_padded = 1;
   g.a_blocked = ds.a_blocked ? 1 : 0;
-  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 32 ? 4 : (ds.tile_rows == 1024 ? 5 : 0)));
+  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 32 ? 4 : (ds.tile_rows == 1024 ? 5 : (ds.tile_rows == 2048 ? 6 : 0))));
   g.small_ws = small_ws_;
   if (ds.out_kind == 0) {
     g.out_f32 = (float*)(base + oC); g.ldc32 = ld32;

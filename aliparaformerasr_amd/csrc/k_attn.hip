@@ -40,7 +40,7 @@ typedef float f16x __attribute__((ext_vector_type(16)));
 #define ATT_BQ 128
 #define ATT_BK 64
 #define ATT_TILE_BYTES (ATT_BK * ATT_DK * 2)      // 16 KiB
-#define ATT_LDS_BYTES (4 * ATT_TILE_BYTES)        // K0 K1 V0 V1
+#define ATT_STAGE_BYTES (2 * ATT_TILE_BYTES)      // one ring stage: K tile | V tile
 
 struct AttnDev {
   const half_t* q; const half_t* k; const half_t* v; half_t* o;
@@ -59,14 +59,16 @@ __device__ __forceinline__ void att_glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// Per wave and tile kt: S(kt) = K(kt) Q^T, softmax arithmetic, O^T += V(kt)^T P(kt)^T.  K and V are
-// double buffered (tile kt+1 is in flight during tile kt), one workgroup barrier per tile.  (Issuing
+// Per wave and tile kt: S(kt) = K(kt) Q^T, softmax arithmetic, O^T += V(kt)^T P(kt)^T.  K and V tiles live in a ring of
+// NS stages with NS - 1 tiles in flight (round 4: with two stages the only tile in flight had exactly one tile's compute
+// time — about a microsecond — to arrive from HBM, where the QKV GEMM's write-through stores left it, and every tile
+// began with an exposed wait), one workgroup barrier per tile.  (Issuing
 // S(kt+1) ahead of the softmax of S(kt) was tried: +32 VGPRs, no gain — the two workgroups per CU already
 // interleave their phases.)
 // NW: wavefronts per workgroup (32 queries each).  4: two workgroups per CU; 8: one workgroup of 256 queries per CU — the
 // K/V tiles of a (batch, head) are then staged by half as many workgroups (half the L2 -> LDS traffic).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
+template <int NW, int NS>
+__global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void attn_kernel(AttnDev p) {
   constexpr int PPW = 16 / NW;                       // 1 KiB staging pieces (4 key rows) per wave, tile and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
     k_src[i] = (unsigned)(row * p.k_rs + ((schunk ^ (row & 15)) << 3)) * 2u;
     v_src[i] = (unsigned)(row * p.v_rs + ((schunk ^ ((row & 3) << 2)) << 3)) * 2u;
   }
-  auto stage_k = [&](int buf, int kt) __attribute__((always_inline)) {
-    char* kl = smem + buf * ATT_TILE_BYTES;
+  auto stage_k = [&](int slot, int kt) __attribute__((always_inline)) {
+    char* kl = smem + slot * ATT_STAGE_BYTES;
     const char* kg = reinterpret_cast<const char*>(kb_ + (int64_t)kt * ATT_BK * p.k_rs);
     if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
       }
     }
   };
-  auto stage_v = [&](int buf, int kt) __attribute__((always_inline)) {
-    char* vl = smem + (2 + buf) * ATT_TILE_BYTES;
+  auto stage_v = [&](int slot, int kt) __attribute__((always_inline)) {
+    char* vl = smem + slot * ATT_STAGE_BYTES + ATT_TILE_BYTES;
     const char* vg = reinterpret_cast<const char*>(vb + (int64_t)kt * ATT_BK * p.v_rs);
     if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
@@ -172,8 +174,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
   const int nkt = (p.Lk + ATT_BK - 1) / ATT_BK;
 
   // S^T = K Q^T for the K tile in buffer KB (compile-time): 8 fragments in flight per 8-MFMA chain
-  auto qk = [&](auto KB, f16x(&s)[2]) __attribute__((always_inline)) {
-    constexpr int kbase = decltype(KB)::value * ATT_TILE_BYTES;
+  auto qk = [&](const unsigned kbase, f16x(&s)[2]) __attribute__((always_inline)) {
     typedef const __attribute__((address_space(3))) h8* lds_h8;
     h8 kf0[8], kf1[8];
 #pragma unroll
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
   };
 
 #define ATT_TR(dst, db, off) \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr[db]), "n"(off))
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vcur[db]), "n"(off))
 #define ATT_ISSUE(dst, db, VB)                                                                                   \
   ATT_TR(dst[0], db, VB + 0);    ATT_TR(dst[1], db, VB + 2048);  ATT_TR(dst[2], db, VB + 4096);  ATT_TR(dst[3], db, VB + 6144); \
   ATT_TR(dst[4], db, VB + 8192); ATT_TR(dst[5], db, VB + 10240); ATT_TR(dst[6], db, VB + 12288); ATT_TR(dst[7], db, VB + 14336);
@@ -211,18 +212,37 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
 
   f16x s_cur[2];
 
-  // one tile: BUF = kt & 1 (compile time): K(kt) and V(kt) sit in the K / V buffers BUF.
-  auto tile = [&](int kt, auto BUFC) __attribute__((always_inline)) {
-    constexpr int BUF = decltype(BUFC)::value;
-    constexpr int VB = (2 + BUF) * ATT_TILE_BYTES;
-    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));          // vmcnt(0): K(kt), V(kt) pieces of this wave landed
+  // one tile: K(kt) and V(kt) sit in ring slot kt % NS; NS - 1 tiles are in flight, so this wave's pieces of tile kt are
+  // the OLDEST of its outstanding LDS-DMA operations: the counted wait leaves the younger tiles' pieces in flight
+  // (fewer of them near the end of the key range: the wait immediate is chosen among NS - 1 constants)
+  constexpr int PIECES = 2 * PPW;                     // LDS-DMA instructions per wave and tile (K + V)
+  // (the slot is a compile-time constant: the compiler then PROVES that the K-fragment reads of slot s cannot alias the
+  // LDS-DMA writes in flight into the other slots; with a run-time slot it guards every read with s_waitcnt vmcnt(0),
+  // which drains the ring)
+  auto tile = [&](int kt, auto SLOTC) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOTC)::value;
+    constexpr unsigned sb = (unsigned)slot * ATT_STAGE_BYTES;
+    constexpr int VB = 0;
+    unsigned vcur[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) vcur[db] = vaddr[db] + sb + ATT_TILE_BYTES;
+    {
+      const int ahead = nkt - 1 - kt < NS - 2 ? nkt - 1 - kt : NS - 2;   // younger tiles already requested (wave uniform)
+      if (NS == 2 || ahead <= 0) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));                       // vmcnt(0)
+      else if (ahead == 1) __builtin_amdgcn_s_waitcnt((PIECES & 15) | (7 << 4) | (15 << 8) | ((PIECES >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(((2 * PIECES) & 15) | (7 << 4) | (15 << 8) | (((2 * PIECES) >> 4) << 14));
+    }
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // ... everybody's; the buffers BUF^1 are free
+    __builtin_amdgcn_s_barrier();                                   // ... everybody's; slot (kt - 1) % NS is free
     asm volatile("" ::: "memory");
     if (!(ATT_ABL & 8)) {
-      if (kt + 1 < nkt) { stage_k(BUF ^ 1, kt + 1); stage_v(BUF ^ 1, kt + 1); }
+      if (kt + NS - 1 < nkt) {
+        constexpr int ns = slot == 0 ? NS - 1 : slot - 1;           // (kt + NS - 1) % NS
+        stage_k(ns, kt + NS - 1);
+        stage_v(ns, kt + NS - 1);
+      }
     }
-    if (!(ATT_ABL & 4)) qk(att_ic<BUF>{}, s_cur);
+    if (!(ATT_ABL & 4)) qk(sb, s_cur);
 
     // first V^T fragments (d block 0)
     fp4 va[8], vb2[8];
@@ -303,12 +323,15 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_kernel(AttnDev p) {
 #endif
   };
 
-  stage_k(0, 0);
-  stage_v(0, 0);
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nkt) { stage_k(st, st); stage_v(st, st); }
 
-  for (int kt = 0; kt < nkt; kt += 2) {
+  for (int kt = 0; kt < nkt; kt += NS) {
     tile(kt, att_ic<0>{});
     if (kt + 1 < nkt) tile(kt + 1, att_ic<1>{});
+    if constexpr (NS > 2) { if (kt + 2 < nkt) tile(kt + 2, att_ic<2>{}); }
+    if constexpr (NS > 3) { if (kt + 3 < nkt) tile(kt + 3, att_ic<3>{}); }
   }
 #undef ATT_TR
 #undef ATT_PV
@@ -399,13 +422,18 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   static std::mutex init_mu;                         // engines on different devices launch from different threads
   static bool attr_set[64] = {false};
   static int cus[64] = {0};
+  static int ns8 = 2, ns4 = 2;                       // ring stages (PF_ATT_NS8 / PF_ATT_NS4: 2 | 3 | 4 for A/B runs); round 4 measured
+                                                     // 3 and 4 SLOWER than 2 (self-attention 1.55 vs 1.44 ms per step): DMA latency is not what the tiles wait for
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
   {
     std::lock_guard<std::mutex> lk(init_mu);
     if (!attr_set[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
-      PF_HIP(hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
+      if (const char* e = getenv("PF_ATT_NS8")) { const int v = atoi(e); if (v >= 2 && v <= 4) ns8 = v; }
+      if (const char* e = getenv("PF_ATT_NS4")) { const int v = atoi(e); if (v >= 2 && v <= 4) ns4 = v; }
+#define PF_ATT_ATTR(NW, NS) PF_HIP(hipFuncSetAttribute((const void*)attn_kernel<NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * ATT_STAGE_BYTES))
+      PF_ATT_ATTR(4, 2); PF_ATT_ATTR(4, 3); PF_ATT_ATTR(4, 4); PF_ATT_ATTR(8, 2); PF_ATT_ATTR(8, 3); PF_ATT_ATTR(8, 4);
+#undef PF_ATT_ATTR
       hipDeviceProp_t prop;
       PF_HIP(hipGetDeviceProperties(&prop, dev));
       cus[dev & 63] = prop.multiProcessorCount;
@@ -417,10 +445,14 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   (void)attention_grid(a, cus[dev & 63], nw8);
   if (nw8) {
     dim3 grid((a.Lq + 255) / 256, a.B * a.H);
-    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(512), ATT_LDS_BYTES, s, d);
+    if (ns8 == 4) hipLaunchKernelGGL((attn_kernel<8, 4>), grid, dim3(512), 4 * ATT_STAGE_BYTES, s, d);
+    else if (ns8 == 3) hipLaunchKernelGGL((attn_kernel<8, 3>), grid, dim3(512), 3 * ATT_STAGE_BYTES, s, d);
+    else hipLaunchKernelGGL((attn_kernel<8, 2>), grid, dim3(512), 2 * ATT_STAGE_BYTES, s, d);
   } else {
     dim3 grid((a.Lq + ATT_BQ - 1) / ATT_BQ, a.B * a.H);
-    hipLaunchKernelGGL(attn_kernel<4>, grid, dim3(256), ATT_LDS_BYTES, s, d);
+    if (ns4 == 4) hipLaunchKernelGGL((attn_kernel<4, 4>), grid, dim3(256), 4 * ATT_STAGE_BYTES, s, d);
+    else if (ns4 == 3) hipLaunchKernelGGL((attn_kernel<4, 3>), grid, dim3(256), 3 * ATT_STAGE_BYTES, s, d);
+    else hipLaunchKernelGGL((attn_kernel<4, 2>), grid, dim3(256), 2 * ATT_STAGE_BYTES, s, d);
   }
   PF_HIP(hipGetLastError());
 }

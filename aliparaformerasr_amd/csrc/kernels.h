@@ -30,7 +30,7 @@ struct GemmArgs {
   int a_blocked;
   float* small_ws;               // scratch of the short-input kernel (k_gemm_small.hip, gemm_small_ws_bytes() bytes, one per
                                  // stream); null = never dispatch to it
-  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result)
+  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result), 6 = the k-step-32 fp32-result kernel
                                  // (stand-alone op tests; 4 / 5 fail when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
@@ -38,6 +38,10 @@ void launch_gemm(hipStream_t s, const GemmArgs& a);
 // reports as `roofline`; the same name appears in the rocprofv3 kernel trace)
 const char* last_gemm_kernel();
 void note_gemm_kernel(const char* name);
+// persistent 256 x 128 tile kernel with fp32 results for deep-K projections (FFN-down; k_gemm_k32.hip): k-steps of 32,
+// six-stage ring, five stages in flight
+bool gemm_k32_applicable(const GemmArgs& a);
+void launch_gemm_k32(hipStream_t s, const GemmArgs& a, int cus);
 // persistent 256 x 256 tile kernel for the blocked-layout result (FFN-up; k_gemm_big.hip)
 bool gemm_bigp_applicable(const GemmArgs& a);
 void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus);

@@ -280,7 +280,8 @@ typedef struct pf_gemm_desc {
                                  kernel; blocked results with fewer idle rounds: the persistent 256 x 256 kernel);
                                  128 / 256 = gemm_f16_pp3 tile heights; 512 = the 256 x {192,256} tile kernel, one tile
                                  per workgroup; 1024 = its persistent form (blocked result only); 32 = the short-input
-                                 kernel.  PF_ERR_INVALID_ARG when the named kernel does not apply.                  */
+                                 kernel; 2048 = the k-step-32 six-stage kernel (fp32 results of deep-K projections, the
+                                 encoder's FFN-down).  PF_ERR_INVALID_ARG when the named kernel does not apply.     */
   int32_t scale_cols;         /* columns n < scale_cols are multiplied by scale after the bias (q scaling)    */
   float scale;
   const float* bias;          /* [N] or NULL                                                                  */

@@ -232,24 +232,30 @@ def test_int8_seaco_timestamp_vs_oracle():
     from aliparaformerasr_amd.engine import Engine
     cfg = W.seaco_paraformer_config(enc_layers=2, dec_layers=2, vocab=8404, seaco_layers=2)
     w = W.synth_weights(cfg, 5)
+    w["seaco.output.bias"][cfg["seaco_nobias"]] += 3.0     # random heads never pick NO-BIAS: let part of the positions keep the ASR row
     eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=W.synth_cmvn(), device=0, math_mode=2)
     rng = np.random.default_rng(3)
     hw = np.zeros((5, 10), np.int32)
     hw[:, :3] = rng.integers(1, 8000, (5, 3))
-    eng.set_hotwords(hw)
     B, T = 3, 90
     speech = (rng.standard_normal((B, T, 560)) * 0.5).astype(np.float32)
-    res = eng.forward_feats(speech, want_logits=True)
+    res = eng.forward_feats(speech, want_logits=True, hotwords=hw)
     ref = om.Oracle(om.ModelConfig(**cfg), w, quant="int8").seaco(speech, hw)
     assert res.logits.shape == ref["logits"].shape
     np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    # positions whose NO-BIAS decision is not a near-tie in the oracle (a flipped decision swaps the whole row)
+    dha = ref["dha_logits"]
+    nb = cfg["seaco_nobias"]
+    other = np.where(np.arange(dha.shape[-1])[None, None, :] == nb, -np.inf, dha).max(-1)
+    clear = np.abs(dha[..., nb] - other) > 0.3
     err = np.abs(res.logits - ref["logits"])
-    print("int8 seaco: max|dlogp| %.3e mean %.2e" % (err.max(), err.mean()))
-    assert err.max() < 0.5 and err.mean() < 4e-2
-    # the bias branch must have acted somewhere (dha rows replace ASR rows) for the test to mean anything
+    print("int8 seaco: max|dlogp| %.3e mean %.2e over %d of %d clear positions" % (err[clear].max(), err[clear].mean(), clear.sum(), clear.size))
+    assert clear.mean() > 0.5
+    assert err[clear].max() < 0.5 and err[clear].mean() < 4e-2
+    # both branches must have acted for the test to mean anything
     took = (np.abs(ref["logits"] - ref["asr_logits"]).max(axis=-1) > 0)
     print("int8 seaco: %d of %d positions take the hot-word log-probs" % (took.sum(), took.size))
-    assert took.any()
+    assert took.any() and not took.all()
     pk = res.cif_peak.reshape(B, -1)
     d = np.abs(pk - ref["us_cif_peak"])
     print("int8 seaco: us_cif_peak 99th pct %.2e" % np.percentile(d % 1.0, 99))

@@ -108,6 +108,44 @@ def test_gemm_blocked_a_operand(eng, tile_rows):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
 
 
+@pytest.mark.parametrize("a_blocked", [True, False])
+def test_gemm_k32_kernel_ffn_down_shape(eng, a_blocked):
+    """The k-step-32 / six-stage kernel (k_gemm_k32.hip) at the FFN-down shape, blocked and row-major A, with bias and
+    the fp32 residual; M = 16000 is not a multiple of the 256-row tile (the last tile's rows beyond M are not written)."""
+    rng = np.random.default_rng(500 + int(a_blocked))
+    M, N, K = M_BENCH, 512, 2048
+    A = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    A += (np.arange(K)[None, :] * 1e-4).astype(np.float32)
+    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    Wm += (np.arange(N)[:, None] * 1e-4).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    ref = _ref(A, Wm, bias) + resid
+    got = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked, tile_rows=2048)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
+    assert np.array_equal(got, eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked, tile_rows=2048))
+    # the pipeline's own choice for this problem is this kernel, and the older kernel agrees with it
+    auto = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked)
+    assert np.array_equal(auto, got)
+    old = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked, tile_rows=256)
+    np.testing.assert_allclose(got, old, rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_k32_kernel_many_tiles_per_workgroup_and_edges(eng):
+    """More tiles than CUs (M = 64000, N = 512: 1000 tiles, the configs[3] shard), ReLU, no residual, no bias; a ragged
+    M (rows of the last tile beyond M stay untouched) and K = 256 (8 k-steps: the ring is longer than a tile)."""
+    rng = np.random.default_rng(510)
+    for (M, N, K, relu, with_bias) in ((64000, 512, 1024, True, False), (5000, 256, 256, False, True), (300, 128, 2048, False, True)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32) if with_bias else None
+        ref = _ref(A, Wm, bias if with_bias else 0.0)
+        if relu:
+            ref = np.maximum(ref, 0)
+        got = eng.op_gemm_ex(A, Wm, bias, relu=relu, out_kind=0, tile_rows=2048)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
+
+
 def test_gemm_ragged_edges_all_kinds(eng):
     """M and N that are not multiples of the tile, every kind x tile height."""
     rng = np.random.default_rng(77)
