@@ -381,6 +381,324 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong form for 256-query workgroups (round 4).  Counters on attn_kernel<8> (profiles/round4_feed_gap.md): matrix
+// pipe busy 32 %, issue stalls 45 % — the two waves of a SIMD run the SAME phase at the same time (both want the matrix
+// pipe for S^T = K Q^T, then both want the VALU for the soft-max, then both want the pipe again for O^T += V^T P^T), so
+// each unit idles while the other is oversubscribed.  Here waves 0-3 (group A) and 4-7 (group B; wave w + 4 shares
+// wave w's SIMD) run the same per-wave sequence ONE PHASE apart, and the sequence is re-cut so that a phase is all-matrix
+// or all-VALU:
+//     M(k) = [ O^T += V(k)^T P(k)^T ;  S(k+1) = K(k+1) Q^T ]      32 MFMAs
+//     V(k) = soft-max arithmetic of S(k) -> P(k)                   ~130 VALU
+//   phase      -1     0      1      2      3      4    ...
+//   group A   S(0)  V(0)   M(0)   V(1)   M(1)   V(2)
+//   group B         S(0)   V(0)   M(0)   V(1)   M(1)
+// One s_barrier per phase.  Tile k (K and V, one 32 KiB ring stage) is read in phases 2k-1 .. 2k+2, so a ring of NS
+// stages leaves 2 NS - 4 phases between the barrier that frees a slot and the phase that needs its next content.  All
+// LDS reads are inline asm with counted lgkmcnt waits (a run-time ring slot in compiler-visible reads makes the compiler
+// guard each of them with s_waitcnt vmcnt(0), which drains the ring).
+template <int NS>
+__global__ __launch_bounds__(512, 1) void attn_pp_kernel(AttnDev p) {
+  constexpr int NW = 8, PPW = 2, PIECES = 2 * PPW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int lh = lane >> 5, lc = lane & 31;
+  const int nqt = gridDim.x, total = gridDim.x * gridDim.y;
+  int lid = blockIdx.x + nqt * blockIdx.y;
+  {
+    const int q8 = total >> 3, r8 = total & 7, xcd = lid & 7, idx = lid >> 3;
+    lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int bh = lid / nqt, qt = lid - bh * nqt;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qt * (32 * NW) + wave * 32;
+  const int Lk = p.Lk, Lq = p.Lq;
+  const int k_rs = p.k_rs, v_rs = p.v_rs;
+
+  const half_t* qb = p.q + b * p.q_bs + h * ATT_DK;
+  const half_t* kb_ = p.k + b * p.k_bs + h * ATT_DK;
+  const half_t* vb = p.v + b * p.v_bs + h * ATT_DK;
+  half_t* ob = p.o + b * p.o_bs + h * ATT_DK;
+
+  h8 qf[8];
+  {
+    int qr = q0 + lc;
+    qr = qr < Lq ? qr : Lq - 1;
+    const half_t* qp = qb + (int64_t)qr * p.q_rs + 8 * lh;
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const h8*>(qp + 16 * ds);
+  }
+
+  const int srow = lane >> 4, schunk = lane & 15;
+  unsigned k_src[PPW], v_src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (wave * PPW + i) * 4 + srow;
+    k_src[i] = (unsigned)(row * k_rs + ((schunk ^ (row & 15)) << 3)) * 2u;
+    v_src[i] = (unsigned)(row * v_rs + ((schunk ^ ((row & 3) << 2)) << 3)) * 2u;
+  }
+  // both operands of tile kt into ring slot `slot`; rows beyond Lk re-read row Lk - 1 (see attn_kernel)
+  auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
+    char* kl = smem + slot * ATT_STAGE_BYTES;
+    char* vl = kl + ATT_TILE_BYTES;
+    const char* kg = reinterpret_cast<const char*>(kb_ + (int64_t)kt * ATT_BK * k_rs);
+    const char* vg = reinterpret_cast<const char*>(vb + (int64_t)kt * ATT_BK * v_rs);
+    const bool full = (kt + 1) * ATT_BK <= Lk;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int over = full ? 0 : kt * ATT_BK + (wave * PPW + i) * 4 + srow - (Lk - 1);
+      over = over > 0 ? over : 0;
+      att_glds16(kg + (k_src[i] - (unsigned)(over * k_rs * 2)), kl + (wave * PPW + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int over = full ? 0 : kt * ATT_BK + (wave * PPW + i) * 4 + srow - (Lk - 1);
+      over = over > 0 ? over : 0;
+      att_glds16(vg + (v_src[i] - (unsigned)(over * v_rs * 2)), vl + (wave * PPW + i) * 1024);
+    }
+  };
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned k_rd[8];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) k_rd[ds] = lds0 + lc * 256 + (((2 * ds + lh) ^ (lc & 15)) << 4);
+  const int vi = lane & 15, vg_ = (lane >> 4) & 1;
+  const int v_row_base = 4 * lh + (vi >> 2);
+  const int v_col_base = 16 * vg_ + 4 * (vi & 3);
+  const int v_rswz = (v_row_base & 3) << 2;
+  unsigned vaddr[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    vaddr[db] = lds0 + ATT_TILE_BYTES + v_row_base * 256 + ((((v_col_base >> 3) + ((4 * db) ^ v_rswz))) << 4) + ((v_col_base & 7) << 1);
+
+  f16x o_acc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o_acc[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float LOG2E = 1.4426950408889634f;
+  const f16x zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int nkt = (Lk + ATT_BK - 1) / ATT_BK;
+  f16x s_cur[2];
+  h8 pf[2][2] = {};
+
+#define APP_KRD(dst, ds, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(kcur[ds]), "n"(off))
+#define APP_KWAIT(reg, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(reg))
+  // S^T(kt) = K(kt) Q^T -> s_cur.  Chain 0 (keys 0-31) then chain 1 (keys 32-63); the fragments of chain 1 are requested
+  // one MFMA behind chain 0, so eight reads are in flight throughout chain 0.
+  auto qk = [&](int slot) __attribute__((always_inline)) {
+    unsigned kcur[8];
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) kcur[ds] = k_rd[ds] + (unsigned)slot * ATT_STAGE_BYTES;
+    h8 kf0[8], kf1[8];
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) APP_KRD(kf0[ds], ds, 0);
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      APP_KWAIT(kf0[ds], 7);
+      s_cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[ds], qf[ds], ds == 0 ? zero16 : s_cur[0], 0, 0, 0);
+      APP_KRD(kf1[ds], ds, 32 * 256);
+    }
+    APP_KWAIT(kf1[0], 7); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[0], qf[0], zero16, 0, 0, 0);
+    APP_KWAIT(kf1[1], 6); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[1], qf[1], s_cur[1], 0, 0, 0);
+    APP_KWAIT(kf1[2], 5); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[2], qf[2], s_cur[1], 0, 0, 0);
+    APP_KWAIT(kf1[3], 4); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[3], qf[3], s_cur[1], 0, 0, 0);
+    APP_KWAIT(kf1[4], 3); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[4], qf[4], s_cur[1], 0, 0, 0);
+    APP_KWAIT(kf1[5], 2); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[5], qf[5], s_cur[1], 0, 0, 0);
+    APP_KWAIT(kf1[6], 1); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[6], qf[6], s_cur[1], 0, 0, 0);
+    APP_KWAIT(kf1[7], 0); s_cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[7], qf[7], s_cur[1], 0, 0, 0);
+  };
+#undef APP_KRD
+#undef APP_KWAIT
+
+#define ATT_TR(dst, db, off) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(vcur[db]), "n"(off))
+#define ATT_ISSUE(dst, db)                                                                                   \
+  ATT_TR(dst[0], db, 0);    ATT_TR(dst[1], db, 2048);  ATT_TR(dst[2], db, 4096);  ATT_TR(dst[3], db, 6144); \
+  ATT_TR(dst[4], db, 8192); ATT_TR(dst[5], db, 10240); ATT_TR(dst[6], db, 12288); ATT_TR(dst[7], db, 14336);
+#define ATT_WAIT(cur, n)                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                 \
+               : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]),        \
+                 "+v"(cur[6]), "+v"(cur[7]));
+#define ATT_PV(cur, db)                                                                                    \
+  {                                                                                                        \
+    _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                         \
+      const h4 lo_ = __builtin_bit_cast(h4, cur[2 * f]), hi_ = __builtin_bit_cast(h4, cur[2 * f + 1]);      \
+      const h8 vf = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                              \
+      o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[f >> 1][f & 1], o_acc[db], 0, 0, 0);        \
+    }                                                                                                      \
+  }
+  // O^T += V(kt)^T P(kt)^T with pf = P(kt): fragments of d block db + 1 are requested before the MFMAs of block db
+  auto pv = [&](int slot) __attribute__((always_inline)) {
+    unsigned vcur[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) vcur[db] = vaddr[db] + (unsigned)slot * ATT_STAGE_BYTES;
+    fp4 va[8], vb2[8];
+    ATT_ISSUE(va, 0)
+    ATT_ISSUE(vb2, 1)
+    ATT_WAIT(va, 8)
+    ATT_PV(va, 0)
+    ATT_ISSUE(va, 2)
+    ATT_WAIT(vb2, 8)
+    ATT_PV(vb2, 1)
+    ATT_ISSUE(vb2, 3)
+    ATT_WAIT(va, 8)
+    ATT_PV(va, 2)
+    ATT_WAIT(vb2, 0)
+    ATT_PV(vb2, 3)
+  };
+#undef ATT_TR
+#undef ATT_PV
+#undef ATT_ISSUE
+#undef ATT_WAIT
+
+  // soft-max arithmetic of s_cur = S(kt) -> pf = P(kt) (f16), running max / sum, O^T rescale (see attn_kernel)
+  auto softmax = [&](int kt) __attribute__((always_inline)) {
+    if ((kt + 1) * ATT_BK > Lk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * ATT_BK + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (key >= Lk) s_cur[kb][e] = -INFINITY;
+        }
+    }
+    float mx[4] = {s_cur[0][0], s_cur[0][1], s_cur[1][0], s_cur[1][1]};
+#pragma unroll
+    for (int e = 2; e < 16; e += 2) {
+      mx[0] = fmaxf(mx[0], s_cur[0][e]); mx[1] = fmaxf(mx[1], s_cur[0][e + 1]);
+      mx[2] = fmaxf(mx[2], s_cur[1][e]); mx[3] = fmaxf(mx[3], s_cur[1][e + 1]);
+    }
+    float mloc = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])) * LOG2E;
+    if (__any(mloc > m_run + 8.0f)) {
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[d][e] *= alpha;
+    }
+    f2 psum4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const f2 l2 = {LOG2E, LOG2E}, nm2 = {-m_run, -m_run};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        f2& psum2 = psum4[(kb * 8 + e / 2) & 3];
+        f2 t = {s_cur[kb][e], s_cur[kb][e + 1]};
+        t = t * l2 + nm2;
+        f2 pv2 = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        psum2 += pv2;
+        pf[kb][e >> 3][e & 7] = (half_t)pv2.x;
+        pf[kb][e >> 3][(e & 7) + 1] = (half_t)pv2.y;
+      }
+    const f2 ps = (psum4[0] + psum4[1]) + (psum4[2] + psum4[3]);
+    l_run += ps.x + ps.y;
+  };
+
+  // ---- prologue: stages 0 .. NS - 2 in flight, stage 0 landed
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nkt) stage(st, st);
+  {
+    const int younger = nkt - 1 < NS - 2 ? nkt - 1 : NS - 2;
+    if (younger <= 0) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+    else if (younger == 1) __builtin_amdgcn_s_waitcnt((PIECES & 15) | (7 << 4) | (15 << 8) | ((PIECES >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(((2 * PIECES) & 15) | (7 << 4) | (15 << 8) | (((2 * PIECES) >> 4) << 14));
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // The phase sequence is written out per group (no per-phase "is there a tile" conditions around the three blocks: a
+  // conditionally executed block makes the compiler keep the old and the new S / P registers alive side by side).
+  int q = -1, slot_next = NS - 1;                       // global phase; ring slot of the stage the next odd phase requests
+  auto begin = [&]() __attribute__((always_inline)) {
+    if ((q & 1) && q >= 1) {                            // slot of tile (q - 3) / 2 was released by the barrier behind us
+      const int j = ((q - 3) >> 1) + NS;
+      if (j < nkt) stage(slot_next, j);
+      slot_next = slot_next + 1 == NS ? 0 : slot_next + 1;
+    }
+  };
+  auto end = [&]() __attribute__((always_inline)) {
+    if (!(q & 1)) {                                     // tile j is first read in the next phase: this wave's pieces of it have landed
+      const int j = (q + 2) >> 1;
+      if (j < nkt) {
+        const int younger = nkt - 1 - j < NS - 3 ? nkt - 1 - j : NS - 3;
+        if (NS <= 3 || younger <= 0) __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+        else __builtin_amdgcn_s_waitcnt((PIECES & 15) | (7 << 4) | (15 << 8) | ((PIECES >> 4) << 14));
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ++q;
+  };
+  if (grp) { begin(); end(); }                          // group B starts one phase later
+  begin(); qk(0); end();
+  begin(); softmax(0); end();
+  int sl = 0;                                           // ring slot of tile k - 1
+  for (int k = 1; k < nkt; ++k) {
+    const int sn = sl + 1 == NS ? 0 : sl + 1;
+    begin();
+    pv(sl);                                             // O^T += V(k-1)^T P(k-1)^T   (P dies here, before S(k) is born)
+    qk(sn);                                             // S(k)
+    end();
+    begin(); softmax(k); end();
+    sl = sn;
+  }
+  begin(); pv(sl); end();
+  if (!grp) { begin(); end(); }                         // group A idles in the last phase
+
+  // ---- normalise and store: lane = query q0+lc, d = db*32 + (e&3) + 8*(e>>2) + 4*lh
+  const int qrow = q0 + lc;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float r_lo = 0.f, r_hi = 0.f;
+  if (qrow < Lq) {
+    const float inv = 1.0f / l_tot;
+    half_t* op = ob + (int64_t)qrow * p.o_rs + 4 * lh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 hv = {(half_t)(o_acc[db][4 * g + 0] * inv), (half_t)(o_acc[db][4 * g + 1] * inv),
+                 (half_t)(o_acc[db][4 * g + 2] * inv), (half_t)(o_acc[db][4 * g + 3] * inv)};
+        *reinterpret_cast<h4*>(op + db * 32 + 8 * g) = hv;
+        if (p.range) {
+          const float a0 = (float)hv[0], a1 = (float)hv[1], a2 = (float)hv[2], a3 = (float)hv[3];
+          r_lo = fminf(fminf(r_lo, a0), fminf(fminf(a1, a2), a3));
+          r_hi = fmaxf(fmaxf(r_hi, a0), fmaxf(fmaxf(a1, a2), a3));
+        }
+      }
+  }
+  if (p.range) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      r_lo = fminf(r_lo, __shfl_xor(r_lo, o, 64));
+      r_hi = fmaxf(r_hi, __shfl_xor(r_hi, o, 64));
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) { red[2 * wave] = r_lo; red[2 * wave + 1] = r_hi; }
+    __syncthreads();
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (tid == 0) {
+      float l = 0.f, hh = 0.f;
+      for (int w = 0; w < NW; ++w) { l = fminf(l, red[2 * w]); hh = fmaxf(hh, red[2 * w + 1]); }
+      p.range[2 * wg] = l;
+      p.range[2 * wg + 1] = hh;
+    }
+    if (wg == 0)
+      for (int i = total + tid; i < 256; i += 64 * NW) { p.range[2 * i] = 0.f; p.range[2 * i + 1] = 0.f; }
+  }
+}
+
 // grid of the launch below: 256-query workgroups when they cover the chip, else 128-query ones
 static int attention_grid(const AttnArgs& a, int cus, bool& nw8) {
   static int force_nw = -1;
@@ -434,6 +752,8 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
 #define PF_ATT_ATTR(NW, NS) PF_HIP(hipFuncSetAttribute((const void*)attn_kernel<NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * ATT_STAGE_BYTES))
       PF_ATT_ATTR(4, 2); PF_ATT_ATTR(4, 3); PF_ATT_ATTR(4, 4); PF_ATT_ATTR(8, 2); PF_ATT_ATTR(8, 3); PF_ATT_ATTR(8, 4);
 #undef PF_ATT_ATTR
+      PF_HIP(hipFuncSetAttribute((const void*)attn_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ATT_STAGE_BYTES));
+      PF_HIP(hipFuncSetAttribute((const void*)attn_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE_BYTES));
       hipDeviceProp_t prop;
       PF_HIP(hipGetDeviceProperties(&prop, dev));
       cus[dev & 63] = prop.multiProcessorCount;
@@ -443,7 +763,19 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   // 256-query workgroups when they still cover the chip (self-attention at T = 500: 2 x 128 workgroups); PF_ATT_NW forces
   bool nw8;
   (void)attention_grid(a, cus[dev & 63], nw8);
-  if (nw8) {
+  static int use_pp = -1, pp_ns = 3;
+  if (use_pp < 0) {
+    // round-4 measurement (profiles/round4_attn_pingpong.txt): 1.58 ms per step against 1.48 for the lockstep kernel — the
+    // phase offset does NOT pay (the MI355X guide's "moving work between the two waves of a SIMD is zero- or negative-sum"
+    // holds here too); kept opt-in for experiments
+    const char* e = getenv("PF_ATT_PP"); use_pp = (e && e[0] == '1') ? 1 : 0;
+    if (const char* n = getenv("PF_ATT_PP_NS")) pp_ns = atoi(n) == 4 ? 4 : 3;
+  }
+  if (nw8 && use_pp) {
+    dim3 grid((a.Lq + 255) / 256, a.B * a.H);
+    if (pp_ns == 4) hipLaunchKernelGGL((attn_pp_kernel<4>), grid, dim3(512), 4 * ATT_STAGE_BYTES, s, d);
+    else hipLaunchKernelGGL((attn_pp_kernel<3>), grid, dim3(512), 3 * ATT_STAGE_BYTES, s, d);
+  } else if (nw8) {
     dim3 grid((a.Lq + 255) / 256, a.B * a.H);
     if (ns8 == 4) hipLaunchKernelGGL((attn_kernel<8, 4>), grid, dim3(512), 4 * ATT_STAGE_BYTES, s, d);
     else if (ns8 == 3) hipLaunchKernelGGL((attn_kernel<8, 3>), grid, dim3(512), 3 * ATT_STAGE_BYTES, s, d);

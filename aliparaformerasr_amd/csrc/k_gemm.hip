@@ -847,10 +847,11 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   const int mi = a.force_mi ? (a.force_mi == 1 ? 1 : 2) : ((few || rounds1) ? 1 : 2);
   {
     // fp32 results of a deep-K projection in 256-row tiles (the encoder's FFN-down): the k-step-32 / six-stage pipeline
-    // (k_gemm_k32.hip).  PF_K32=0 keeps this file's kernel; PF_K32_MINK moves the depth threshold (default 1024).
+    // (k_gemm_k32.hip).  Round-4 measurement: 50.3 vs 48.4 us per FFN-down launch — the deeper ring does NOT help there (A
+    // streams from HBM / the Infinity Cache), so this file's kernel stays the default; PF_K32=1 selects the k-step-32 kernel.
     static int use_k32 = -1, k32_mink = 1024;
     if (use_k32 < 0) {
-      const char* e = getenv("PF_K32"); use_k32 = (e && e[0] == '0') ? 0 : 1;
+      const char* e = getenv("PF_K32"); use_k32 = (e && e[0] == '1') ? 1 : 0;      // measured slower at the FFN-down shape: opt-in
       if (const char* m = getenv("PF_K32_MINK")) k32_mink = atoi(m);
     }
     const bool f16o = a.out_f16 && !a.out_f32 && !a.resid && !a.add2;

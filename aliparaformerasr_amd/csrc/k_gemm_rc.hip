@@ -24,7 +24,6 @@
 // (two-pass: mean, then sum of squared deviations), no cross-workgroup traffic of any kind.
 #include "kernels.h"
 
-#include <cstdlib>
 #include <mutex>
 
 namespace pf {
@@ -33,7 +32,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 typedef float4 __attribute__((may_alias)) float4a;
-typedef float f4v __attribute__((ext_vector_type(4)));   // native vector: usable as an inline-asm register operand
 
 struct RcDev {
   const half_t* A; const half_t* W; const float* bias;
@@ -42,7 +40,6 @@ struct RcDev {
   const float* ln_g; const float* ln_b; half_t* out_n16; float* out_n32;
   int lda, ldw, ldr, ldx, ldv, ldn16, ldn32;
   int M, K, T, a_blocked;
-  int prefetch;        // residual rows requested during the K loop (PF_RC_PRE=0 switches it off for A/B runs)
   float eps;
 };
 
@@ -82,7 +79,7 @@ __device__ __forceinline__ float rc_wave_sum(float v) {
 // (or the end of the buffer) — taps reaching outside the utterance contribute nothing (zero padding of the
 // depthwise conv); the condition is wave-uniform, so the masks are scalar selects.
 template <int FK, bool MASKED>
-__device__ __forceinline__ void rc_fsmn(f4v (&x)[8], const h4 (&win)[FK > 0 ? 8 + FK - 1 : 1], const float* __restrict__ wT,
+__device__ __forceinline__ void rc_fsmn(float4 (&x)[8], const h4 (&win)[FK > 0 ? 8 + FK - 1 : 1], const float* __restrict__ wT,
                                         int mb, int t_first, int T, int M) {
   constexpr int left = (FK - 1) / 2;
   float4 w[FK];
@@ -184,28 +181,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
   // between the 16 MFMAs (issued as one burst they stall the CU's address unit in front of the matrix pipe).
   const int rot = (int)((blockIdx.x >> 3) % (unsigned)nk);
   auto kk = [&](int k) __attribute__((always_inline)) -> int { const int q = k + rot; return q >= nk ? q - nk : q; };
-  // Round 4: the fp32 residual rows of this wave (8 rows x 2 x 16 bytes per lane = 16 loads) are requested DURING the K
-  // loop, behind the DMA pieces of step `pre_k`, instead of after it: the 250 workgroups run in lockstep, so HBM sat idle
-  // through every K loop and then served 100 MB of epilogue traffic at once.  The loads are inline asm (the compiler must
-  // not sink them to their first use after the loop); the counted waits below account for them: they are younger than
-  // stage pre_k + 2 and older than stage pre_k + 3, so two steps wait with 9 + 16 operations allowed in flight.
-  const int r0 = wave * 8;
-  const int mb = m0 + r0;                                  // first output row of this wave
-  f4v xv[2][8];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) xv[h][r] = f4v{0.f, 0.f, 0.f, 0.f};
-  const bool pre_ok = p.prefetch && p.resid && nk >= 5 && mb + 7 < p.M;  // wave uniform; edge waves and short K load in the epilogue
-  const int pre_k = pre_ok ? 1 : -4;
   issue(kk(0), 0);
   if (nk > 1) issue(kk(1), 1);
   for (int k = 0; k < nk; ++k) {
-    if (k + 1 < nk) {                                                  // this wave's 9 pieces of stage k have landed
-      if (k == pre_k + 1 || k == pre_k + 2) rc_wait_vmcnt<25>(); else rc_wait_vmcnt<9>();
-    } else {
-      rc_wait_vmcnt<0>();
-    }
+    if (k + 1 < nk) rc_wait_vmcnt<9>(); else rc_wait_vmcnt<0>();      // this wave's 9 pieces of stage k have landed
     __builtin_amdgcn_s_barrier();                                      // ... and everybody else's
     const char* rd = smem + (k & 1) * RC_STAGE;
     h8 af[4][2], bf[4][2];
@@ -246,35 +225,22 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
         }
       }
     __builtin_amdgcn_s_setprio(0);
-    if (k == pre_k) {
-      const unsigned voff = (unsigned)lane * 16u;          // scalar row base + one lane offset: no per-load address registers
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const float* rowp = p.resid + (size_t)(mb + r) * p.ldr;        // wave uniform
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xv[0][r]) : "v"(voff), "s"(rowp) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(xv[1][r]) : "v"(voff), "s"(rowp) : "memory");
-      }
-    }
-  }
-  // (the last step's vmcnt(0) covered the residual loads; pin their registers behind that point)
-  if (pre_ok) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(xv[h][r]));
   }
 
   // ---- epilogue.  Wave w owns rows 8w .. 8w+7 COMPLETELY; lane: columns 4*lane and 256 + 4*lane.
-  // The FSMN window (and, for edge waves, the residual rows) is requested BEFORE the accumulators are exchanged
-  // through LDS: the round trip overlaps the dump and the barrier.
-  if (!pre_ok) {
+  // The residual rows (and the first half of the FSMN window) are requested BEFORE the accumulators are exchanged
+  // through LDS: their HBM round trip overlaps the dump and the barrier.
+  const int r0 = wave * 8;
+  const int mb = m0 + r0;                                  // first output row of this wave
+  float4 xv[2][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (p.resid && mb + r < p.M)
-          xv[h][r] = *reinterpret_cast<const f4v*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane);
-  }
+    for (int r = 0; r < 8; ++r) {
+      xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.resid && mb + r < p.M)
+        xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane);
+    }
   constexpr int FKW = FK > 0 ? 8 + FK - 1 : 1;             // input rows of the FSMN window
   constexpr int left = FK > 0 ? (FK - 1) / 2 : 0, right = FK > 0 ? FK - 1 - left : 0;
   h4 vwin[2][FKW];
@@ -284,14 +250,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
     t_first = mb % p.T;                                    // position of row mb inside its utterance
     // interior: the 8 rows and their halo lie inside ONE utterance and inside [0, M): no masks at all
     interior = t_first >= left && t_first + 7 + right < p.T && mb + 7 + right < p.M;
-    // the first column half of the window now (beside the live accumulators), the second once the dump has freed them:
-    // all 36 requests at once exceed the register file next to the prefetched residual rows
 #pragma unroll
-    for (int s = 0; s < FKW; ++s) {
-      int mm = mb - left + s;
-      mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);        // address clamp only; validity is decided by the masks
-      vwin[0][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + 4 * lane);
-    }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < FKW; ++s) {
+        int mm = mb - left + s;
+        mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);      // address clamp only; validity is decided by the masks
+        vwin[h][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + h * 256 + 4 * lane);
+      }
   }
   // the 64 x 512 fp32 tile, row-major in LDS (every stage read has retired behind the last barrier and no DMA is
   // outstanding).  D^T fragment: lane = row (lane & 31), 4 consecutive columns per quad.
@@ -304,14 +270,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4a*>(rowp + (j * 32 + 8 * g) * 4) =
             make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-  }
-  if constexpr (FK > 0) {
-#pragma unroll
-    for (int s = 0; s < FKW; ++s) {
-      int mm = mb - left + s;
-      mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);
-      vwin[1][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + 256 + 4 * lane);
-    }
   }
   __syncthreads();
 #pragma unroll
@@ -331,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
     if (p.out_x) {
 #pragma unroll
       for (int r = 0; r < 8; ++r)
-        if (mb + r < p.M) *reinterpret_cast<f4v*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[h][r];
+        if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[h][r];
     }
   }
   if (!p.ln_g) return;
@@ -363,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
     const int m = mb + r;
     if (m < p.M) {
       const float k = rstd[r];
-      const f4v d0 = xv[0][r], d1 = xv[1][r];
+      const float4 d0 = xv[0][r], d1 = xv[1][r];
       const float4 y0 = make_float4(d0.x * k * g4[0].x + be4[0].x, d0.y * k * g4[0].y + be4[0].y,
                                     d0.z * k * g4[0].z + be4[0].z, d0.w * k * g4[0].w + be4[0].w);
       const float4 y1 = make_float4(d1.x * k * g4[1].x + be4[1].x, d1.y * k * g4[1].y + be4[1].y,
@@ -400,7 +358,6 @@ void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a) {
   d.lda = a.lda; d.ldw = a.ldw; d.ldr = a.ldr; d.ldx = a.ldx; d.ldv = a.ldv; d.ldn16 = a.ldn16; d.ldn32 = a.ldn32;
   d.M = a.M; d.K = a.K; d.T = a.T > 0 ? a.T : a.M; d.a_blocked = a.a_blocked;
   d.eps = a.eps;
-  { static int pre = -1; if (pre < 0) { const char* e = getenv("PF_RC_PRE"); pre = (e && e[0] == '0') ? 0 : 1; } d.prefetch = pre; }
   static std::mutex init_mu;                         // engines on different devices launch from different threads
   static bool attr_set[64] = {false};
   int dev = 0;

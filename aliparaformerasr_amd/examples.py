@@ -4,8 +4,9 @@
         [-accuracy int8] [-threads 2] -files a.wav b.wav
 
 Mirrors (file:line in /root/reference/AliParaformerAsr.Examples):
-  * argument handling and defaults — Program.cs:93-101, ParseArgs :197-252 (environment variables
-    ALIPARAFORMERASR_* are not read here; -type is mandatory, unknown flags are an error);
+  * argument handling and defaults — Program.cs:93-104, ParseArgs :197-252: the MANYSPEECH_BASE / _TYPE / _BATCH / _MODEL /
+    _ACCURACY / _THREADS environment variables are the defaults (Program.cs:20-28), command-line parameters overwrite
+    them; a recognizer type must come from one of the two, unknown flags are an error;
   * model-directory file selection — OfflineAliParaformerAsrRecognizer.cs:24-100: `model*` (not `_eb`)
     preferring a name containing ".<accuracy>.", else the last; last `asr*.yaml|json`, `am*.mvn`, `tokens*.txt`,
     `hotword*.txt` (the model file here is a .pfw container instead of .onnx);
@@ -158,9 +159,16 @@ def offline_recognizer(method="one", model="paraformer-seaco-large-zh-timestamp-
     return results
 
 
-def parse_args(argv):
-    cfg = dict(modelBasePath="", recognizerType=None, methodType="one", modelName="default-model", modelAccuracy="int8",
-               threads=2, files=[])
+def parse_args(argv, env=None):
+    # environment variables are the defaults, command-line parameters overwrite them (Program.cs:20-28, :93-104)
+    env = os.environ if env is None else env
+    try:
+        threads = int(env.get("MANYSPEECH_THREADS", "2"))
+    except ValueError:
+        raise ValueError("The number of threads must be a valid integer")
+    cfg = dict(modelBasePath=env.get("MANYSPEECH_BASE", ""), recognizerType=env.get("MANYSPEECH_TYPE"),
+               methodType=env.get("MANYSPEECH_BATCH", "one"), modelName=env.get("MANYSPEECH_MODEL", "default-model"),
+               modelAccuracy=env.get("MANYSPEECH_ACCURACY", "int8"), threads=threads, files=[])
     i = 0
     while i < len(argv):
         a = argv[i].lower()

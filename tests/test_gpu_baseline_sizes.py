@@ -106,6 +106,29 @@ def test_paraformer_128x30s_the_configs3_shard():
     eng.close()
 
 
+def test_ids_stay_on_the_device_for_the_gather():
+    """pf_fetch_ids_device (ABI 4): the staged result's ids [B, l_cap] int64, -1 padded, written into caller-owned DEVICE
+    memory — what bench.py --gpus N hands to the RCCL all-gather — equal to the host fetch."""
+    import torch
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=300)
+    eng, w, cmvn = _engine(cfg)
+    audio = [W.synth_audio(48000 + 7000 * u, 50 + u) for u in range(5)]
+    eng.stage_audio(audio)
+    eng.run_staged()
+    host = eng.fetch()
+    lcap = host.L + 9
+    buf = torch.full((len(audio), lcap), 12345, dtype=torch.int64, device="cuda:0")
+    L = eng.fetch_ids_device(buf.data_ptr(), lcap)
+    got = buf.cpu().numpy()
+    assert L == host.L
+    np.testing.assert_array_equal(got[:, :L], host.token_ids)
+    assert (got[:, L:] == -1).all()
+    from aliparaformerasr_amd._native import PfError
+    with pytest.raises(PfError):
+        eng.fetch_ids_device(buf.data_ptr(), max(host.L - 1, 1) if host.L > 1 else 0)
+    eng.close()
+
+
 def test_sensevoice_64x10s_use_itn():
     """BASELINE.json configs[2]: sensevoice-small, batch 64 x 10 s, use_itn on (T = 166 + 4 prompt rows)."""
     cfg = W.sensevoice_small_config(enc_layers=2, tp_layers=1, use_itn=True)

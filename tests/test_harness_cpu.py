@@ -169,3 +169,20 @@ def test_emoji_tag_mapping_of_the_gui():
     assert ex.replace_tags_with_empty("<|two words|>a<||>b<|x") == "ab<|x"
     assert ex.replace_tags_with_empty("<|a\n|>") == "<|a\n|>"                                       # `.` stops at a newline
     assert ex.replace_tags_with_emojis("<|\u4e2d|>") == ""                                           # \w is Unicode in .NET too
+
+
+def test_environment_variables_are_the_defaults_and_flags_overwrite_them():
+    """Program.cs:20-28, :93-104: MANYSPEECH_* give the defaults, ParseArgs overwrites them."""
+    from aliparaformerasr_amd import examples as ex
+    env = {"MANYSPEECH_TYPE": "offline", "MANYSPEECH_BATCH": "batch", "MANYSPEECH_MODEL": "m1", "MANYSPEECH_ACCURACY": "fp32",
+           "MANYSPEECH_THREADS": "6", "MANYSPEECH_BASE": "/models"}
+    cfg = ex.parse_args([], env)
+    assert (cfg["recognizerType"], cfg["methodType"], cfg["modelName"], cfg["modelAccuracy"], cfg["threads"], cfg["modelBasePath"]) == \
+        ("offline", "batch", "m1", "fp32", 6, "/models")
+    cfg = ex.parse_args(["-method", "one", "-model", "m2", "-threads", "3"], env)
+    assert (cfg["recognizerType"], cfg["methodType"], cfg["modelName"], cfg["threads"]) == ("offline", "one", "m2", 3)
+    with pytest.raises(ValueError, match="recognizer type"):
+        ex.parse_args([], {})
+    assert ex.parse_args(["-type", "offline"], {})["modelAccuracy"] == "int8"        # Program.cs:100 default
+    with pytest.raises(ValueError, match="valid integer"):
+        ex.parse_args(["-type", "offline"], {"MANYSPEECH_THREADS": "many"})
