@@ -46,7 +46,7 @@ SAMPLES = SECONDS * 16000
 LCAP = 512
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 SUSTAINED_F16_TFLOPS = 1700.0  # measured: 256 CUs issuing v_mfma_f32_32x32x16_f16 back to back (profiles/round3_ubench_kstep.txt)
-PMC_FILE = os.path.join(ROOT, "profiles", "round3_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round4_pmc.json")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_MARGIN = 0.05          # = MARGIN of tests/test_gpu_full_depth.py (the two oracles never disagree above 0.02)
 ALPHA_NEAR = 0.1              # an oracle sum(alpha) this close to an integer is a near-tie of token_num = floor(sum alpha)
@@ -325,7 +325,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
                          "(or plain `python bench.py --gpus %d`, which spawns the ranks itself)" % (args.gpus, world, args.gpus, args.gpus))
-    if world > 1:
+    # PF_BENCH_DIST=1 (set by tests/test_gpu_group.py under torch.distributed.run --nproc-per-node 1): the RCCL path — process
+    # group, weight broadcast, device-resident all-gather of the ids — with a ONE-rank communicator, which is all a 1-GPU
+    # box can execute of it
+    use_dist = world > 1 or os.environ.get("PF_BENCH_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -354,7 +358,7 @@ def main():
     if rank == 0:
         weights = W.synth_weights(cfg, 42)
         blob = W.pack_pfw(cfg, weights)
-    if world > 1:
+    if use_dist:
         wdev = sh.broadcast_bytes(blob, dist, dev)            # RCCL broadcast rank 0 -> all
     else:
         wdev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
@@ -374,11 +378,11 @@ def main():
         hws = [list(hrng.integers(3, 8000, size=int(hrng.integers(2, 5)))) for _ in range(20)] + [[1]]
         eng.set_hotwords(np.asarray([h[:10] + [0] * (10 - len(h)) for h in hws], np.int32))
     gathered = {}
-    ids_mine = torch.full((B, LCAP), -1, dtype=torch.int64, device=dev) if world > 1 else None
+    ids_mine = torch.full((B, LCAP), -1, dtype=torch.int64, device=dev) if use_dist else None
 
     def step():
         eng.run_staged()
-        if world > 1:
+        if use_dist:
             # gather of hypotheses over RCCL / xGMI, device to device: the engine writes its [B, LCAP] ids into a device
             # tensor on its own stream (and waits for it), the all-gather leaves [world * B, LCAP] on every GPU; no host
             # round trip inside the timed region (the host copy for the check below happens after the timing)
@@ -404,13 +408,13 @@ def main():
             class_ms[cls] = {"ms": round(ms, 4), "launches": cnt, "kernel": eng.profile_kernel(cls) or None,
                              "tflops": round(fpl * cnt / (ms * 1e-3) / 1e12, 1) if ms > 0 and fpl > 0 else None}
     dominant = max(GEMM_SHAPES, key=lambda c: class_ms.get(c, {"ms": 0.0})["ms"])
-    if world > 1:                                             # one decision for the whole job: rank 0's
+    if use_dist:                                             # one decision for the whole job: rank 0's
         pick = [dominant]
         dist.broadcast_object_list(pick, src=0)
         dominant = pick[0]
     dom_kernel = eng.profile_kernel(dominant)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     eng.profile_reset()
     eng.profile_select(dominant)
@@ -424,11 +428,11 @@ def main():
                                       # an event pair costs ~4 us of device time, 50 pairs per step would tax `value` by ~1.4 %
     eng.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     eng.profile(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -438,7 +442,7 @@ def main():
     assert res.L > 0 and res.token_ids.shape == (B, res.L), (res.L, res.token_ids.shape)
     assert (res.token_ids >= 0).all() and (res.token_ids < eng.vocab).all()
     assert (res.token_num > 0).all()
-    if world > 1:
+    if use_dist:
         g = gathered["ids"].cpu().numpy()
         assert g.shape == (world * B, LCAP) and (g[rank * B:(rank + 1) * B, :res.L] == res.token_ids).all()
     # ... and the right one: rank 0's ids against the fp32 CPU oracle's for this workload (tests/golden/), wherever
@@ -485,7 +489,7 @@ def main():
                        "global_batch": world * B, "samples_per_utt": samples, "T_lfr": eng.num_frames(samples), "L": int(res.L),
                        "parallelism": "dp%d (utterance shards, no data-path collective)" % world},
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
-            "rccl_ranks": world if world > 1 else 0,
+            "rccl_ranks": world if use_dist else 0,
             "ids_sha1": ids_checksum(res.token_ids),   # rank 0's [B, L] ids of the last timed step
             "ids_vs_fp32_oracle": ids_check,
             "token_num_sum": int(res.token_num.sum()),
@@ -515,7 +519,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, weights, cmvn)
             out["gpu_over_cpu_port_standin"] = value / out["cpu_baseline"]["value"]   # NOT onnxruntime: the torch-CPU port of the oracle
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -97,3 +97,28 @@ def test_group_sensevoice_and_seaco(sv_embed):
     np.testing.assert_array_equal(got.token_ids, ref.token_ids)
     np.testing.assert_allclose(got.cif_peak, ref.cif_peak, atol=2e-3)
     g.close()
+
+
+def test_bench_rccl_path_with_a_one_rank_communicator():
+    """bench.py's multi-GPU line as far as a 1-GPU box can execute it: one rank under torch.distributed.run with
+    PF_BENCH_DIST=1 — RCCL process group, weight image broadcast into device memory and adopted in place, ids written
+    into a device tensor by pf_fetch_ids_device, all_gather_into_tensor, gathered rows == the rank's own ids (asserted
+    inside bench.py), ids checked against the fp32 oracle's golden file."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PF_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    assert d["ids_vs_fp32_oracle"] and d["ids_vs_fp32_oracle"]["ok"]

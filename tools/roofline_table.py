@@ -33,7 +33,7 @@ def main():
         ("CIF im2col", "cif_im2col_kernel", None, (M * D * 2 + M * 3 * D * 2) / 1e6),
         ("CIF weighted gather", "cif_gather_kernel", None, (M * D * 4 + Md * D * 4) / 1e6),
     ]
-    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 3)\n")
+    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 4)\n")
     print("Source: `%s` (rocprofv3 --kernel-trace, average kernel duration) and the HIP-event class times of "
           "`bench.py` (`class_ms_per_step`).  L = %d.  Peaks: HBM 8 TB/s spec (6.3 TB/s achievable), dense f16 MFMA 2.5 PFLOP/s.\n" % (trace.split("/")[-1], L))
     print("## HBM-bound kernels\n\n| kernel | avg µs | launches/step | algorithmic MB | achieved TB/s | of 8 TB/s | of 6.3 TB/s |\n|---|---|---|---|---|---|---|")
