@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -33,5 +34,13 @@ using half_t = _Float16;
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// PF_CU_CAP=n: persistent kernels size their grids (and their tile-shape rules) for n compute units instead of the whole
+// device — several engines on ONE GPU then run side by side, each on its share of the CUs, instead of taking turns
+// (tools/: the two-engine overlap experiment of round 4)
+inline int cu_limit(int cus) {
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("PF_CU_CAP"); cap = e ? atoi(e) : 0; }
+  return cap > 0 && cap < cus ? cap : cus;
+}
 
 }  // namespace pf

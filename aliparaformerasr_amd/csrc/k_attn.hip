@@ -716,7 +716,7 @@ static int attention_cus() {
   if (!cus[dev & 63]) {
     hipDeviceProp_t prop;
     PF_HIP(hipGetDeviceProperties(&prop, dev));
-    cus[dev & 63] = prop.multiProcessorCount;
+    cus[dev & 63] = cu_limit(prop.multiProcessorCount);
   }
   return cus[dev & 63];
 }
@@ -756,7 +756,7 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
       PF_HIP(hipFuncSetAttribute((const void*)attn_pp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ATT_STAGE_BYTES));
       hipDeviceProp_t prop;
       PF_HIP(hipGetDeviceProperties(&prop, dev));
-      cus[dev & 63] = prop.multiProcessorCount;
+      cus[dev & 63] = cu_limit(prop.multiProcessorCount);
       attr_set[dev & 63] = true;
     }
   }

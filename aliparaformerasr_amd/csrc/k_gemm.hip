@@ -817,7 +817,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
       PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
       PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
       PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
-      cus[dev] = prop.multiProcessorCount;
+      cus[dev] = cu_limit(prop.multiProcessorCount);
     }
     if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.6f; }
   }
@@ -915,7 +915,7 @@ void launch_gemm_i8(hipStream_t s, const GemmI8Args& a) {
       PF_HIP(hipFuncSetAttribute((const void*)gemm_i8_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
       PF_HIP(hipFuncSetAttribute((const void*)gemm_i8f_pp3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2)));
       PF_HIP(hipFuncSetAttribute((const void*)gemm_i8f_pp3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
-      cus[dev] = prop.multiProcessorCount;
+      cus[dev] = cu_limit(prop.multiProcessorCount);
     }
   }
   const int t2 = cdiv(d.M, 256) * cdiv(d.N, GEMM_BN), t1 = cdiv(d.M, 128) * cdiv(d.N, GEMM_BN);
