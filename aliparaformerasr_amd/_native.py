@@ -53,7 +53,7 @@ class PfGemmRcDesc(C.Structure):
         ("fsmn_k", C.c_int32),
         ("bias", C.POINTER(C.c_float)), ("resid", C.POINTER(C.c_float)), ("fsmn_v", C.POINTER(C.c_float)),
         ("fsmn_w", C.POINTER(C.c_float)), ("ln_gamma", C.POINTER(C.c_float)), ("ln_beta", C.POINTER(C.c_float)),
-        ("short_input", C.c_int32), ("reserved", C.c_int32),
+        ("short_input", C.c_int32), ("split_k", C.c_int32),
     ]
 
 

@@ -54,6 +54,8 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_DEC_FUSE"); if (e && e[0]) dec_fuse_ = atoi(e) & 7; }
   { const char* e = getenv("PF_DEC_H32"); dec_h32_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_SMALL_NOFUSE"); no_small_fuse_ = e && e[0] == '1'; }   // A/B: short-input GEMMs without the FSMN epilogue / LayerNorm-in-reduction forms   // A/B switch for tools/: decoder launch fusions
+  { const char* e = getenv("PF_SK_MIN"); if (e && e[0]) sk_min_wgs_ = atoi(e); }
+  { const char* e = getenv("PF_SK_FFN2"); if (e && e[0]) sk_ffn2_ = e[0] != '0'; }     // A/B: split-K row-complete FFN-down + LayerNorm (k_gemm_sk.hip)
   { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
@@ -112,7 +114,8 @@ void Engine::release() {
   for (void* p : owned_) hipFree(p);
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
-                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_};
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_};
+  sk_slab_ = nullptr; sk_flags_ = nullptr; sk_err_ = nullptr;
   seaco_hw_valid_ = false;
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
@@ -148,7 +151,27 @@ void Engine::sync() {
   check_async_errors();
 }
 
+// Scratch of the split-K row-complete GEMM for one encoder pass of M rows with up to `calls` launches: the exchange slab
+// (re-used by every launch: launches of one stream do not overlap), one zeroed flag region per launch, the time-out word.
+void Engine::sk_prepare(int M, int calls) {
+  const size_t slab = round_up((int64_t)gemm_sk_slab_bytes(M), (int64_t)kAlign);
+  sk_flag_stride_ = (size_t)round_up((int64_t)gemm_sk_flag_bytes(M), (int64_t)kAlign);
+  const size_t flags = sk_flag_stride_ * (size_t)calls + kAlign;
+  ensure(ws_sk_, slab + flags);
+  sk_slab_ = (float*)ws_sk_.p;
+  sk_flags_ = (unsigned*)((char*)ws_sk_.p + slab);
+  sk_err_ = (unsigned*)((char*)ws_sk_.p + slab + sk_flag_stride_ * (size_t)calls);
+  sk_calls_ = 0; sk_calls_cap_ = calls;
+  PF_HIP(hipMemsetAsync(sk_flags_, 0, flags, stream_));
+}
+
 void Engine::check_async_errors() {
+  if (sk_used_) {                                    // a split-K pair whose partner never arrived (k_gemm_sk.hip)
+    sk_used_ = false;
+    unsigned flag = 0;
+    PF_HIP(hipMemcpy(&flag, sk_err_, 4, hipMemcpyDeviceToHost));
+    PF_CHECK(flag == 0, PF_ERR_DEVICE, "encoder: a split-K workgroup timed out waiting for its partner");
+  }
   if (!lstm_err_) return;                            // the persistent recurrence raises this word when a spin timed out
   unsigned flag = 0;
   unsigned* w = lstm_err_;
@@ -878,6 +901,22 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
   const int blk = (F % 64 == 0 && !small) ? 1 : 0;
   gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
+  if (rc && sk_ffn2_ && blk && sk_slab_ && sk_calls_ < sk_calls_cap_ && 2 * cdiv(M, 128) >= sk_min_wgs_) {
+    // split-K row-complete FFN-down + bias + residual + the NEXT LayerNorm in one launch (k_gemm_sk.hip): a pair of
+    // workgroups per 128-row block, each walks half of K and finishes 64 complete rows
+    GemmRcArgs f{};
+    f.A = h16_; f.lda = F; f.a_blocked = 1; f.W = L.w2.w; f.ldw = L.w2.Kpad; f.bias = L.w2.bias; f.M = M; f.K = L.w2.Kpad;
+    f.resid = x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
+    f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
+    if (gemm_sk_applicable(f)) {
+      prof_begin("gemm_ffn2", 2.0 * M * (double)D * F);
+      launch_gemm_sk(stream_, f, sk_slab_, (unsigned*)((char*)sk_flags_ + sk_flag_stride_ * (size_t)sk_calls_), sk_err_);
+      prof_end("gemm_ffn2");
+      ++sk_calls_;
+      sk_used_ = true;
+      return;
+    }
+  }
   if (rc && rc_ffn2_ && blk) {
     // row-complete FFN-down (+ the next LayerNorm): measured SLOWER than the persistent 256 x 128 kernel + a
     // LayerNorm launch at K = 2048 (67.7 vs 57.5 us per layer at M = 16 000: every workgroup streams the 2 MB W
@@ -921,6 +960,8 @@ void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
   plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
   plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
 
+  sk_slab_ = nullptr;
+  if (sk_ffn2_ && D == 512 && !fp32_mode_ && !int8_mode_ && M > gemm_small_max_rows()) sk_prepare((int)M, (int)(enc_.size() + tp_.size()));
   // the LayerNorm that FOLLOWS layer i's FFN-down is the next layer's norm1, or after_norm behind the last one
   const bool has_tp = !tp_.empty();
   for (size_t i = 0; i < enc_.size(); ++i) {
@@ -2179,6 +2220,13 @@ void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* 
       q.post_ln_g = g.ln_g; q.post_ln_b = g.ln_b; q.post_n16 = g.out_n16; q.ldn16 = N; q.post_n32 = g.out_n32; q.ldn32 = N;
       launch_gemm_small(stream_, q);
     }
+  } else if (ds.split_k) {
+    PF_CHECK(gemm_sk_applicable(g), PF_ERR_INVALID_ARG, "gemm_rc: the split-K form needs K >= 192 and takes no FSMN term");
+    sk_prepare(M, 1);
+    prof_begin("gemm_op", 2.0 * M * (double)N * K);
+    launch_gemm_sk(stream_, g, sk_slab_, sk_flags_, sk_err_);
+    prof_end("gemm_op");
+    sk_used_ = true;
   } else {
     prof_begin("gemm_op", 2.0 * M * (double)N * K);
     launch_gemm_rc(stream_, g);

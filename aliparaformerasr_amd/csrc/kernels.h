@@ -126,6 +126,14 @@ int gemm_small_max_rows();                       // rows up to which the pipelin
 bool gemm_small_applicable(const GemmSmallArgs& a);
 void launch_gemm_small(hipStream_t s, const GemmSmallArgs& a);
 void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a);
+// the same node sequence (no FSMN term) with 128 x 512 tiles and K split over a PAIR of workgroups that exchange their
+// partial halves in the launch (k_gemm_sk.hip): deep projections (FFN-down) + bias + residual + LayerNorm in one launch.
+// slab: gemm_sk_slab_bytes(M) of scratch; flags: gemm_sk_flag_bytes(M), ZEROED by the caller before the launch (one
+// region per launch between two zeroings); err: a device word the kernel raises when a partner never arrived.
+bool gemm_sk_applicable(const GemmRcArgs& a);
+size_t gemm_sk_slab_bytes(int M);
+size_t gemm_sk_flag_bytes(int M);
+void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err);
 
 // ---------------------------------------------------------------- fp32 parity mode (k_fp32.hip) ----
 void launch_gemm_f32(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,

@@ -366,6 +366,57 @@ def test_gemm_rc_ffn_down_blocked_a(eng):
     np.testing.assert_array_equal(x2, x)            # the operand layout does not change the arithmetic
 
 
+def test_gemm_sk_ffn_down_split_k_pairs(eng):
+    """FFN down-projection on the split-K pair kernel (k_gemm_sk.hip), as enc_layer() launches it: blocked A
+    [16000 x 2048] x [2048 x 512] + bias + fp32 residual + the NEXT LayerNorm.  Two workgroups per 128-row block walk half
+    of K each and exchange partial tiles in the launch; P0 + P1 is commutative, so repeated launches are bit-identical."""
+    rng = np.random.default_rng(511)
+    M, K = M_BENCH, 2048
+    A = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    A += (np.arange(K)[None, :] * 1e-4).astype(np.float32)
+    Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(512).astype(np.float32)
+    resid = rng.standard_normal((M, 512)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True, split_k=True)
+    np.testing.assert_allclose(x, _ref(A, Wm, bias) + resid, rtol=1e-4, atol=6e-4)
+    n_ref = _ln_ref(x, g, b)
+    np.testing.assert_allclose(n32, n_ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(n16, h16(n32))
+    again = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True, split_k=True)
+    for u, v in zip((x, n16, n32), again):
+        np.testing.assert_array_equal(u, v)
+    x2, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, a_blocked=False, split_k=True)
+    np.testing.assert_array_equal(x2, x)            # the operand layout does not change the arithmetic
+    # against the 64-row kernel: same products, a different summation tree over K
+    x3, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, a_blocked=True)
+    np.testing.assert_allclose(x, x3, rtol=2e-5, atol=2e-5)
+
+
+def test_gemm_sk_ragged_rows_and_depths(eng):
+    """Row counts that are not multiples of 128 (the last pair has rows beyond M, one pair may own nothing but padding),
+    more pairs than CUs (several dispatch rounds), the smallest depth (K = 192: three k-steps per half), no residual, no
+    LayerNorm, LayerNorm without x."""
+    rng = np.random.default_rng(512)
+    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
+    for M, K, blocked in ((1, 192, False), (129, 512, True), (5344, 2048, True), (1000, 576, False), (40000, 256, True)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(512).astype(np.float32)
+        resid = rng.standard_normal((M, 512)).astype(np.float32)
+        ref = _ref(A, Wm, bias)
+        x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=True)
+        np.testing.assert_allclose(x, ref + resid, rtol=1e-4, atol=6e-4, err_msg=f"M={M} K={K}")
+        np.testing.assert_allclose(n32, _ln_ref(x, g, b), rtol=2e-5, atol=2e-5)
+        np.testing.assert_array_equal(n16, h16(n32))
+        x0, _, _ = eng.op_gemm_rc(A, Wm, a_blocked=blocked, split_k=True)
+        np.testing.assert_allclose(x0, ref - bias, rtol=1e-4, atol=6e-4)
+        _, m16, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=True, want_x=False, want_n32=False)
+        np.testing.assert_array_equal(m16, n16)
+
+
 def test_gemm_rc_ragged_shapes_and_utterance_edges(eng):
     """M not a multiple of 64 / of T, utterances shorter than a tile, T = 8 (every wave straddles an utterance edge),
     one k-step only, and rows whose LayerNorm is ill-conditioned in fp32 (large common offset)."""
