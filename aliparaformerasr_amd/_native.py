@@ -123,6 +123,7 @@ SIGNATURES = {
     "pf_op_layernorm": (C.c_int, [_vp, _f, _f, _f, C.c_int64, C.c_int32, _f]),
     "pf_op_attention": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_qkv_attention": (C.c_int, [_vp, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f, _f, _f, _f]),
     "pf_op_cif": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _f, _i32, _i32, _i32]),
     "pf_op_encoder": (C.c_int, [_vp, _f, C.c_int32, C.c_int32, _f]),
     "pf_recognizer_create": (C.c_int, [C.c_char_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, _P(_vp)]),

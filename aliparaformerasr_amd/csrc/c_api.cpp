@@ -574,6 +574,17 @@ int pf_op_attention(pf_engine* h, const float* q, const float* k, const float* v
   return PF_OK;
   PF_CATCH
 }
+int pf_op_qkv_attention(pf_engine* h, const float* x, const float* w, const float* bias, int32_t B, int32_t T, int32_t K,
+                        float* q_out, float* k_out, float* v_out, float* ctx_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(x); NEED(w);
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_qkv_attention(x, w, bias, B, T, K, q_out, k_out, v_out, ctx_out);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_fsmn(pf_engine* h, const float* v, const float* w, const float* mask, int32_t B, int32_t T, int32_t D,
                int32_t k, float* y) {
   PF_TRY

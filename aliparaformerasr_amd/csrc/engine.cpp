@@ -30,6 +30,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   PF_HIP(hipGetDeviceProperties(&prop, device_));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw Error(PF_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  cus_ = cu_limit(prop.multiProcessorCount);
 
   fc_.fs = cfg.fs > 0 ? cfg.fs : 16000;
   fc_.n_mels = cfg.n_mels > 0 ? cfg.n_mels : 80;
@@ -54,6 +55,9 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_DEC_FUSE"); if (e && e[0]) dec_fuse_ = atoi(e) & 7; }
   { const char* e = getenv("PF_DEC_H32"); dec_h32_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_SMALL_NOFUSE"); no_small_fuse_ = e && e[0] == '1'; }   // A/B: short-input GEMMs without the FSMN epilogue / LayerNorm-in-reduction forms   // A/B switch for tools/: decoder launch fusions
+  { const char* e = getenv("PF_QKV_SPLIT"); if (e && e[0]) qkv_split_ = e[0] != '0'; }   // A/B: Q | K blocked + V row-major from the 256 x 192 kernel (k_gemm_qkv.hip)
+  { const char* e = getenv("PF_QKV_MIN"); if (e && e[0]) qkv_split_min_tiles_ = atoi(e); }
+  { const char* e = getenv("PF_QKV_FILL"); if (e && e[0]) qkv_split_min_fill_ = atoi(e); }
   { const char* e = getenv("PF_SK_MIN"); if (e && e[0]) sk_min_wgs_ = atoi(e); }
   { const char* e = getenv("PF_SK_FFN2"); if (e && e[0]) sk_ffn2_ = e[0] != '0'; }     // A/B: split-K row-complete FFN-down + LayerNorm (k_gemm_sk.hip)
   { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
@@ -333,6 +337,12 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     L.w1 = make_lin(p + ".ffn.w1", true);
     L.w2 = make_lin(p + ".ffn.w2", true);
     PF_CHECK(L.qkv.K == d_in && L.qkv.N == 3 * D, PF_ERR_FORMAT, "weights: qkv shape mismatch in " + p);
+    if (qkv_split_ && D == 512 && mc_.heads == 4 && !fp32_mode_ && !int8_mode_) {
+      // the same weight with its rows in the tile order of gemm_qkvp_kernel (k_gemm_qkv.hip)
+      L.qkv_p = (half_t*)dalloc((size_t)1536 * L.qkv.Kpad * 2);
+      L.qkv_bias_p = (float*)dalloc(1536 * 4);
+      launch_qkv_permute(stream_, L.qkv.w, L.qkv.Kpad, L.qkv.bias, L.qkv_p, L.qkv_bias_p);
+    }
     PF_CHECK(L.out.N == D && L.out.K == D && L.w1.K == D && L.w1.N == mc_.ffn && L.w2.N == D && L.w2.K == L.w1.N,
              PF_ERR_FORMAT, "weights: attn.out / ffn shape mismatch in " + p);
     return L;
@@ -873,16 +883,36 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
     gemm_small_call("gemm_ffn2", L.w2, dn);
     return;
   }
-  gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
+  const bool rc = mc_.kernel == 11 && T >= 8 && !no_rc_ && !small;
+  // Q | K blocked + V row-major from the persistent 256 x 192 kernel when the row-complete out-projection (the reader of
+  // the row-major V) runs and the launch has at least a round of tiles
+  const half_t* v16 = qkv16_ + 2 * D;
+  int ldv = 3 * D;
+  // (chosen by idle rounds: 32 x 500 rows are 504 tiles = 1.97 rounds on 256 CUs — 1.88 vs 2.06 ms per step for the 50 layers;
+  // SenseVoice's 10 944 rows are 344 tiles = 1.34 rounds and lose, 2.45 vs 2.30 ms)
+  const int qt = 8 * cdiv(M, 256);
+  const bool split = rc && L.qkv_p && qt >= qkv_split_min_tiles_ && qt * 100 >= qkv_split_min_fill_ * (int)round_up(qt, cus_) &&
+                     gemm_qkvp_applicable(M, L.qkv.Kpad, lda, L.qkv.Kpad, D);
+  if (split) {
+    const int64_t Mp = round_up((int64_t)M, 128) + 128;        // rows of every encoder buffer (>= round_up(M, 256))
+    half_t* vbuf = qkv16_ + (size_t)Mp * 2 * D;
+    prof_begin("gemm_qkv", 2.0 * M * (double)L.qkv.N * L.qkv.K);
+    launch_gemm_qkvp(stream_, xn16_, lda, L.qkv_p, L.qkv.Kpad, L.qkv_bias_p, M, L.qkv.Kpad, qscale, qkv16_, vbuf, D);
+    prof_end("gemm_qkv");
+    a.q = qkv16_; a.k = qkv16_; a.qk_blocked = 1; a.blk_groups = 2 * D / 8; a.blk_brows = T; a.blk_kgrp = D / 8;
+    a.v = vbuf; a.v_bstride = (int64_t)T * D; a.v_rstride = D;
+    v16 = vbuf; ldv = D;
+  } else {
+    gemm("gemm_qkv", L.qkv, xn16_, lda, M, nullptr, 0, qkv16_, 3 * D, nullptr, 0, nullptr, 0, false, D, qscale);
+  }
   prof_begin("attn_self", 4.0 * B * (double)T * T * D);
   launch_attention(stream_, a);
   prof_end("attn_self");
-  const bool rc = mc_.kernel == 11 && T >= 8 && !no_rc_ && !small;
   if (rc) {
     GemmRcArgs g{};
     g.A = ctx16_; g.lda = D; g.W = L.out.w; g.ldw = L.out.Kpad; g.bias = L.out.bias; g.M = M; g.K = L.out.Kpad;
     g.resid = first ? nullptr : x_; g.ldr = D; g.out_x = x_; g.ldx = D;
-    g.fsmn_v = qkv16_ + 2 * D; g.ldv = 3 * D; g.fsmn_wT = L.fsmn_wT; g.fsmn_k = mc_.kernel; g.T = T;
+    g.fsmn_v = v16; g.ldv = ldv; g.fsmn_wT = L.fsmn_wT; g.fsmn_k = mc_.kernel; g.T = T;
     g.ln_g = L.norm2.g; g.ln_b = L.norm2.b; g.eps = 1e-12f; g.out_n16 = xn16_; g.ldn16 = D;
     prof_begin("gemm_out", 2.0 * M * (double)D * D);
     launch_gemm_rc(stream_, g);
@@ -2393,6 +2423,68 @@ void Engine::op_attention(const float* q, const float* k, const float* v, int B,
     o[i] = (float)hv;
   }
   (void)oo32;
+}
+
+// The encoder's fused Q | K | V projection and its self-attention as enc_layer() launches them for long inputs: the persistent
+// 256 x 192 kernel (Q scaled and K blocked, V row-major: k_gemm_qkv.hip) followed by the attention kernel reading that layout.
+// x [B*T, K], w [1536, K] ([Q | K | V] rows), bias [1536] or null; outputs (each may be null) q / k / v / ctx [B*T, 512] as
+// fp32 copies of the stored f16 values (q / k de-blocked on the host).
+void Engine::op_qkv_attention(const float* x, const float* w, const float* bias, int B, int T, int K, float* q_out, float* k_out,
+                              float* v_out, float* ctx_out) {
+  PF_HIP(hipSetDevice(device_));
+  const int D = 512, H = 4, N = 3 * D;
+  const int M = B * T;
+  PF_CHECK(M > 0 && K > 0, PF_ERR_INVALID_ARG, "qkv_attention: empty input");
+  const int Kpad = (int)round_up(K, 64);
+  PF_CHECK(gemm_qkvp_applicable(M, Kpad, Kpad, Kpad, D), PF_ERR_INVALID_ARG, "qkv_attention: shape not covered by the 256 x 192 kernel");
+  const int64_t Mp = round_up(M, 256) + 128;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
+  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * K, (int64_t)N * K) * 4), oA = carve((size_t)Mp * Kpad * 2);
+  const size_t oW = carve((size_t)N * Kpad * 2), oWp = carve((size_t)N * Kpad * 2), ob = carve((size_t)N * 4), obp = carve((size_t)N * 4);
+  const size_t oqk = carve((size_t)Mp * 2 * D * 2), ov = carve((size_t)Mp * D * 2), oc = carve((size_t)Mp * D * 2);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + oA, 0, (size_t)Mp * Kpad * 2, stream_));
+  PF_HIP(hipMemsetAsync(base + oW, 0, (size_t)N * Kpad * 2, stream_));
+  PF_HIP(hipMemcpyAsync(base + o32, x, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
+  launch_f32_to_f16(stream_, (const float*)(base + o32), M, K, K, (half_t*)(base + oA), Kpad);
+  PF_HIP(hipStreamSynchronize(stream_));
+  PF_HIP(hipMemcpyAsync(base + o32, w, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
+  launch_f32_to_f16(stream_, (const float*)(base + o32), N, K, K, (half_t*)(base + oW), Kpad);
+  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+  launch_qkv_permute(stream_, (half_t*)(base + oW), Kpad, bias ? (const float*)(base + ob) : nullptr, (half_t*)(base + oWp), (float*)(base + obp));
+  const float qscale = 1.0f / std::sqrt((float)(D / H));
+  half_t* qk = (half_t*)(base + oqk);
+  half_t* vb = (half_t*)(base + ov);
+  prof_begin("gemm_op", 2.0 * M * (double)N * K);
+  launch_gemm_qkvp(stream_, (half_t*)(base + oA), Kpad, (half_t*)(base + oWp), Kpad, (const float*)(base + obp), M, Kpad, qscale, qk, vb, D);
+  prof_end("gemm_op");
+  AttnArgs a{};
+  a.q = qk; a.k = qk; a.qk_blocked = 1; a.blk_groups = 2 * D / 8; a.blk_brows = T; a.blk_kgrp = D / 8;
+  a.v = vb; a.v_bstride = (int64_t)T * D; a.v_rstride = D;
+  a.o = (half_t*)(base + oc); a.o_bstride = (int64_t)T * D; a.o_rstride = D;
+  a.q_rstride = a.k_rstride = 8;                          // ignored (alignment checks only)
+  a.B = B; a.H = H; a.Lq = T; a.Lk = T;
+  prof_begin("attn_op", 4.0 * B * (double)T * T * D);
+  launch_attention(stream_, a);
+  prof_end("attn_op");
+  std::vector<half_t> hqk((size_t)Mp * 2 * D), hv((size_t)M * D), hc((size_t)M * D);
+  PF_HIP(hipMemcpyAsync(hqk.data(), qk, hqk.size() * 2, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(hv.data(), vb, hv.size() * 2, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipMemcpyAsync(hc.data(), base + oc, hc.size() * 2, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  const int G = 2 * D / 8;
+  for (int m = 0; m < M; ++m)
+    for (int c = 0; c < 2 * D; ++c) {
+      const float val = (float)hqk[(((size_t)(m >> 5) * G + (c >> 3)) * 32 + (m & 31)) * 8 + (c & 7)];
+      if (c < D) { if (q_out) q_out[(size_t)m * D + c] = val; }
+      else if (k_out) k_out[(size_t)m * D + c - D] = val;
+    }
+  for (size_t i = 0; i < hv.size(); ++i) {
+    if (v_out) v_out[i] = (float)hv[i];
+    if (ctx_out) ctx_out[i] = (float)hc[i];
+  }
 }
 
 void Engine::op_fsmn(const float* v, const float* w, const float* mask, int B, int T, int D, int k, float* y) {

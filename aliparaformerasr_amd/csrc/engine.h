@@ -56,7 +56,10 @@ struct QLin {
 };
 // a quantised activation tensor: a' = a_q - 128 [rows, Kpad], row sums of a', {scale, zero point}
 struct QAct { int8_t* a = nullptr; int32_t* rowsum = nullptr; float* params = nullptr; };
-struct EncLayer { LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512; };
+struct EncLayer {
+  LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512;
+  half_t* qkv_p = nullptr; float* qkv_bias_p = nullptr;   // qkv weight rows / bias in the tile order of gemm_qkvp_kernel (null: not built)
+};
 struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
 
 struct DevBuf {       // grow-only device allocation
@@ -126,6 +129,8 @@ class Engine {
   void op_logsoftmax_argmax(const float* x, int64_t rows, int V, float* y, int64_t* ids);
   void op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y);
   void op_attention(const float* q, const float* k, const float* v, int B, int Lq, int Lk, int H, float* o);
+  void op_qkv_attention(const float* x, const float* w, const float* bias, int B, int T, int K, float* q_out, float* k_out,
+                        float* v_out, float* ctx_out);
   void op_fsmn(const float* v, const float* w, const float* mask, int B, int T, int D, int k, float* y);
   void op_cif(const float* H, const float* alphas, int B, int T, int D, float thr, int Lcap, float* E,
               int32_t* fire_count, int32_t* token_num, int32_t* L_out);
@@ -233,6 +238,10 @@ class Engine {
   float* sk_slab_ = nullptr; unsigned* sk_flags_ = nullptr; unsigned* sk_err_ = nullptr;
   size_t sk_flag_stride_ = 0; int sk_calls_ = 0, sk_calls_cap_ = 0;
   bool sk_used_ = false;
+  bool qkv_split_ = true;            // PF_QKV_SPLIT=0: the row-major 256 x 128 kernel for Q | K | V
+  int qkv_split_min_tiles_ = 256;    // PF_QKV_MIN: least number of 256 x 192 tiles for which the split form is chosen
+  int qkv_split_min_fill_ = 85;      // PF_QKV_FILL: ... and least fill (percent) of its last round of tiles
+  int cus_ = 256;                    // compute units the persistent kernels size their grids for (cu_limit)
   int sk_min_wgs_ = 128;             // PF_SK_MIN: least number of workgroups (2 per 128 rows) for which the split form is chosen
   void sk_prepare(int M, int calls);
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)

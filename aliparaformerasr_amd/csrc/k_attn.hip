@@ -48,6 +48,9 @@ struct AttnDev {
   int q_rs, k_rs, v_rs, o_rs;
   int H, Lq, Lk;
   float* range;      // null, or 256 {min, max} pairs (int8 path: the range of the context for its DynamicQuantizeLinear)
+  // Q and K in ONE blocked [rows, 8 * blk_groups] matrix (kernels.h; written by gemm_qkvp_kernel): q = k = its base, batch b
+  // starts at row b * blk_brows, head h's Q columns are groups h * 16 .., its K columns groups blk_kgrp + h * 16 ..
+  int blk, blk_groups, blk_brows, blk_kgrp;
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -97,12 +100,23 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
   {
     int qr = q0 + lc;
     qr = qr < p.Lq ? qr : p.Lq - 1;
-    const half_t* qp = qb + (int64_t)qr * p.q_rs + 8 * lh;
+    if (p.blk) {
+      // blocked: the 32 lanes of a half-wave read one 512-byte block per fragment
+      const int64_t R = (int64_t)b * p.blk_brows + qr;
+      const half_t* qp = p.q + (((R >> 5) * p.blk_groups + h * 16 + lh) * 32 + (R & 31)) * 8;
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const h8*>(qp + 16 * ds);
+      for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const h8*>(qp + ds * 512);
+    } else {
+      const half_t* qp = qb + (int64_t)qr * p.q_rs + 8 * lh;
+#pragma unroll
+      for (int ds = 0; ds < 8; ++ds) qf[ds] = *reinterpret_cast<const h8*>(qp + 16 * ds);
+    }
   }
 
   // ---- staging: wave-instruction i of this wave covers tile rows (wave*4+i)*4 .. +3
+  // (blocked K: piece pc = wave*PPW + i is key half pc >> 3, column groups 2 * (pc & 7) + (lane >> 5), key lane & 31 —
+  // 1 KiB that is contiguous in memory when the half does not straddle a 32-row block, and whose LDS image
+  // [half][group][key][16 B] is read conflict-free without a swizzle)
   const int srow = lane >> 4, schunk = lane & 15;
   unsigned k_src[PPW], v_src[PPW];                 // byte offsets inside a 64-key tile
 #pragma unroll
@@ -111,8 +125,21 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
     k_src[i] = (unsigned)(row * p.k_rs + ((schunk ^ (row & 15)) << 3)) * 2u;
     v_src[i] = (unsigned)(row * p.v_rs + ((schunk ^ ((row & 3) << 2)) << 3)) * 2u;
   }
+  auto blk_k_addr = [&](int i, int kt) __attribute__((always_inline)) -> const char* {
+    const int pc = wave * PPW + i;
+    int key = kt * ATT_BK + (pc >> 3) * 32 + (lane & 31);
+    key = key < p.Lk ? key : p.Lk - 1;             // tail: re-read the last valid key (masked in the softmax)
+    const int64_t R = (int64_t)b * p.blk_brows + key;
+    const int grp = p.blk_kgrp + h * 16 + 2 * (pc & 7) + (lane >> 5);
+    return reinterpret_cast<const char*>(p.k) + (((R >> 5) * p.blk_groups + grp) * 32 + (R & 31)) * 16;
+  };
   auto stage_k = [&](int slot, int kt) __attribute__((always_inline)) {
     char* kl = smem + slot * ATT_STAGE_BYTES;
+    if (p.blk) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) att_glds16(blk_k_addr(i, kt), kl + (wave * PPW + i) * 1024);
+      return;
+    }
     const char* kg = reinterpret_cast<const char*>(kb_ + (int64_t)kt * ATT_BK * p.k_rs);
     if ((kt + 1) * ATT_BK <= p.Lk) {
 #pragma unroll
@@ -149,7 +176,7 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
   const lds_cptr smem3 = (lds_cptr)smem;
   unsigned k_rd[8];
 #pragma unroll
-  for (int ds = 0; ds < 8; ++ds) k_rd[ds] = lc * 256 + (((2 * ds + lh) ^ (lc & 15)) << 4);
+  for (int ds = 0; ds < 8; ++ds) k_rd[ds] = p.blk ? ((2 * ds + lh) * 32 + lc) * 16 : lc * 256 + (((2 * ds + lh) ^ (lc & 15)) << 4);
   // V tr-read: key row = kb*32 + 16*s2 + 8*jj + 4*lh + (i>>2), element col = db*32 + 16*g + 4*(i&3)
   const int vi = lane & 15, vg_ = (lane >> 4) & 1;
   const int v_row_base = 4 * lh + (vi >> 2);
@@ -734,6 +761,9 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
   d.q_rs = a.q_rstride; d.k_rs = a.k_rstride; d.v_rs = a.v_rstride; d.o_rs = a.o_rstride;
   d.H = a.H; d.Lq = a.Lq; d.Lk = a.Lk;
   d.range = a.range;
+  d.blk = a.qk_blocked ? 1 : 0; d.blk_groups = a.blk_groups; d.blk_brows = a.blk_brows; d.blk_kgrp = a.blk_kgrp;
+  PF_CHECK(!a.qk_blocked || (a.q == a.k && a.blk_groups > 0 && a.blk_brows >= a.Lq && a.blk_brows >= a.Lk), PF_ERR_INVALID_ARG,
+           "attention: blocked Q | K needs one matrix and its geometry");
   PF_CHECK(!a.range || attention_reports_range(a), PF_ERR_INVALID_ARG, "attention: a range output needs a grid of at most 256 workgroups");
   PF_CHECK(a.q_rstride % 8 == 0 && a.k_rstride % 8 == 0 && a.v_rstride % 8 == 0 && a.o_rstride % 4 == 0,
            PF_ERR_INVALID_ARG, "attention: row strides must keep 16-byte alignment");
@@ -771,7 +801,7 @@ void launch_attention(hipStream_t s, const AttnArgs& a) {
     const char* e = getenv("PF_ATT_PP"); use_pp = (e && e[0] == '1') ? 1 : 0;
     if (const char* n = getenv("PF_ATT_PP_NS")) pp_ns = atoi(n) == 4 ? 4 : 3;
   }
-  if (nw8 && use_pp) {
+  if (nw8 && use_pp && !a.qk_blocked) {
     dim3 grid((a.Lq + 255) / 256, a.B * a.H);
     if (pp_ns == 4) hipLaunchKernelGGL((attn_pp_kernel<4>), grid, dim3(512), 4 * ATT_STAGE_BYTES, s, d);
     else hipLaunchKernelGGL((attn_pp_kernel<3>), grid, dim3(512), 3 * ATT_STAGE_BYTES, s, d);

@@ -42,6 +42,13 @@ void note_gemm_kernel(const char* name);
 // six-stage ring, five stages in flight
 bool gemm_k32_applicable(const GemmArgs& a);
 void launch_gemm_k32(hipStream_t s, const GemmArgs& a, int cus);
+// persistent 256 x 192 tile kernel for the encoder's fused Q | K | V projection (k_gemm_qkv.hip): Q (scaled) and K leave in
+// the blocked layout as one [Mpad, 1024] matrix, V row-major [Mpad, ldv].  Wp / bias_p: the weight rows and bias in tile order
+// (launch_qkv_permute: [1536, ldw] f16 from the [Q | K | V] weight, bias may be null -> zeros); out rows up to round_up(M, 256).
+bool gemm_qkvp_applicable(int M, int K, int lda, int ldw, int ldv);
+void launch_qkv_permute(hipStream_t s, const half_t* w, int ldw, const float* bias, half_t* wp, float* bp);
+void launch_gemm_qkvp(hipStream_t s, const half_t* A, int lda, const half_t* Wp, int ldw, const float* bias_p, int M, int K,
+                      float qscale, half_t* out_qk, half_t* out_v, int ldv);
 // persistent 256 x 256 tile kernel for the blocked-layout result (FFN-up; k_gemm_big.hip)
 bool gemm_bigp_applicable(const GemmArgs& a);
 void launch_gemm_bigp(hipStream_t s, const GemmArgs& a, int cus);
@@ -179,6 +186,10 @@ struct AttnArgs {
   int B, H, Lq, Lk;                                   // head dim fixed at 128
   float* range;                                       // null, or quant_scratch_bytes(): {min, max} of the stored context per workgroup
                                                       // (pass 1 of the quantiser that consumes it, k_quant.hip); see attention_reports_range
+  // Q and K handed over in ONE blocked matrix (the result of launch_gemm_qkvp): q == k == its base, `blk_groups` 8-column
+  // groups per row (128), utterance b starts at row b * blk_brows, head h's Q columns are groups 16 h .., its K columns
+  // groups blk_kgrp + 16 h ..; the q / k strides are ignored, V and the output stay row-major
+  int qk_blocked, blk_groups, blk_brows, blk_kgrp;
 };
 void launch_attention(hipStream_t s, const AttnArgs& a);
 bool attention_reports_range(const AttnArgs& a);      // the launch has at most 256 workgroups (one {min, max} pair each)

@@ -354,6 +354,18 @@ class Engine:
                                         _fp(n16) if n16 is not None else None, _fp(n32) if n32 is not None else None))
         return x, n16, n32
 
+    def op_qkv_attention(self, x, w, bias, B, T):
+        """Fused Q | K | V projection (persistent 256 x 192 kernel: Q, K blocked, V row-major) + self-attention on that
+        layout, as the encoder launches them for long inputs; x [B*T, K], w [1536, K]; returns (q, k, v, ctx) [B*T, 512]."""
+        x, w = _f32(x), _f32(w)
+        M, K = x.shape
+        assert M == B * T and w.shape == (1536, K)
+        bias = _f32(bias) if bias is not None else None
+        outs = [np.zeros((M, 512), np.float32) for _ in range(4)]
+        N.check(self._lib.pf_op_qkv_attention(self._h, _fp(x), _fp(w), _fp(bias) if bias is not None else None, B, T, K,
+                                              *[_fp(o) for o in outs]))
+        return tuple(outs)
+
     def op_ffn(self, x, w1, b1, w2, b2, resid) -> np.ndarray:
         x, w1, b1, w2, b2, resid = map(_f32, (x, w1, b1, w2, b2, resid))
         M, D = x.shape

@@ -333,6 +333,12 @@ int pf_op_layernorm(pf_engine* e, const float* x, const float* gamma, const floa
    converted to f16 on device as the pipeline does). */
 int pf_op_attention(pf_engine* e, const float* q, const float* k, const float* v,
                     int32_t B, int32_t Lq, int32_t Lk, int32_t heads, float* out);
+/* The encoder's fused Q | K | V projection (d_model 512, 4 heads) and its self-attention as the pipeline launches them
+   for long inputs: persistent 256 x 192 GEMM (q scaled by 1/sqrt(128); Q and K in the blocked activation layout, V
+   row-major) + the attention kernel reading that layout.  x [B*T, K], w [1536, K] = [Q | K | V] rows, bias [1536] or
+   NULL; q/k/v/ctx_out [B*T, 512] (the stored f16 values widened to fp32; each may be NULL). */
+int pf_op_qkv_attention(pf_engine* e, const float* x, const float* w, const float* bias, int32_t B, int32_t T, int32_t K,
+                        float* q_out, float* k_out, float* v_out, float* ctx_out);
 /* DFSMN memory block: y = dwconv_k(v*mask) + v*mask, *mask; v [B,T,D], w [D,k], mask [B,T] or NULL. */
 int pf_op_fsmn(pf_engine* e, const float* v, const float* w, const float* mask,
                int32_t B, int32_t T, int32_t D, int32_t k, float* y);

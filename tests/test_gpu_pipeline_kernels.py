@@ -366,6 +366,29 @@ def test_gemm_rc_ffn_down_blocked_a(eng):
     np.testing.assert_array_equal(x2, x)            # the operand layout does not change the arithmetic
 
 
+# ---------------------------------------------------------------- fused Q | K | V projection (k_gemm_qkv.hip) + attention on its layout
+def test_qkv_split_kernel_and_attention_on_the_blocked_layout(eng):
+    """The persistent 256 x 192 kernel writes Q (scaled) and K in the blocked layout and V row-major; the attention kernel
+    reads that layout.  Both must reproduce the row-major kernels bit for bit (same products, same summation order), at the
+    benchmark's shape (32 x 500: utterances start at rows that are not multiples of 32 or 64), at layer 0's depth (K = 560,
+    padded to 576), and at ragged shapes (T not a multiple of the 64-key tile, M not a multiple of 256)."""
+    rng = np.random.default_rng(520)
+    for B, T, K in ((32, 500, 512), (3, 77, 560), (5, 333, 512), (1, 2000, 512), (64, 171, 512)):
+        M = B * T
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = (rng.standard_normal((1536, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(1536).astype(np.float32)
+        q, k, v, ctx = eng.op_qkv_attention(x, w, bias, B, T)
+        ref = eng.op_gemm_ex(x, w, bias, out_kind=1, tile_rows=256, scale_cols=512, scale=float(1.0 / np.sqrt(128.0)))
+        np.testing.assert_array_equal(q, ref[:, :512], err_msg=f"Q B={B} T={T} K={K}")
+        np.testing.assert_array_equal(k, ref[:, 512:1024], err_msg=f"K B={B} T={T} K={K}")
+        np.testing.assert_array_equal(v, ref[:, 1024:], err_msg=f"V B={B} T={T} K={K}")
+        np.testing.assert_allclose(ref, h16(_ref(x, w, bias) * np.r_[np.full(512, 1 / np.sqrt(128.0)), np.ones(1024)].astype(np.float32)),
+                                   rtol=2e-3, atol=2e-3)
+        ctx_ref = eng.op_attention(q.reshape(B, T, 512), k.reshape(B, T, 512), v.reshape(B, T, 512), 4).reshape(M, 512)
+        np.testing.assert_array_equal(ctx, ctx_ref, err_msg=f"attention B={B} T={T}")
+
+
 def test_gemm_sk_ffn_down_split_k_pairs(eng):
     """FFN down-projection on the split-K pair kernel (k_gemm_sk.hip), as enc_layer() launches it: blocked A
     [16000 x 2048] x [2048 x 512] + bias + fp32 residual + the NEXT LayerNorm.  Two workgroups per 128-row block walk half
