@@ -7,7 +7,11 @@ both are printed) + utterances/s, paraformer-large, batch 32 x 30 s synthetic 16
 
 One "step" = one pass of the whole hot path (fbank -> LFR/CMVN -> SAN-M encoder x50 -> CIF ->
 SAN-M decoder x16 -> vocab GEMM -> last-index arg-max, + the gather of hypotheses when N > 1)
-over one batch per GPU, audio already resident in HBM when the timed region starts.
+over one batch per GPU, audio already resident in HBM when the timed region starts.  K steps are timed; by default TWO
+steps are in flight per GPU (`--in-flight`, round 4): two engines on the device, each with its own stream and workspaces,
+take the steps alternately, so the kernels of step k + 1 fill the CUs that step k's kernels leave idle (tile-round tails,
+the decoder's small launches, memory-bound tile ends).  Every step still runs the whole path over a whole batch and its ids
+are checked; `ms_per_step` = timed wall time / K, `ms_first_step_alone` = the first timed step, which runs alone.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -300,6 +304,13 @@ def main():
                          "Linear as DynamicQuantizeLinear + MatMulInteger on the int8 MFMA (pf_engine_config.math_mode 2); NOT the "
                          "headline configuration; fp32 = the exact path (math_mode 1: fp32 weights and activations on "
                          "v_mfma_f32_32x32x2_f32, unfused) — what exactness costs, not the headline either")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight per GPU: E engines on the GPU (own stream, own workspaces, shared fp32 weight image), "
+                         "consecutive steps alternate between them, so step k + 1's encoder overlaps step k's decoder and the "
+                         "memory-bound tile ends of one engine's kernels overlap the matrix phases of the other's.  A step is still "
+                         "one pass of the whole path over one batch; 1 = strictly one step at a time (the rounds 1-3 figure); "
+                         "0 = default: 2, except 1 for configs[4] (its timestamp head already runs beside the decoder on its own "
+                         "stream: 16.9 vs 16.7 ms measured) and for the fp32 parity mode")
     ap.add_argument("--group", type=int, default=0,
                     help="N > 0: ONE process driving pf_group_recognize over N devices (the path a C# caller gets: "
                          "host audio in, utterance shards, RCCL weight broadcast + all-gather of the ids inside the C ABI) "
@@ -367,31 +378,82 @@ def main():
     torch.cuda.synchronize()
     int8 = args.accuracy == "int8"
     fp32 = args.accuracy == "fp32"
-    eng = Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local, math_mode=2 if int8 else (1 if fp32 else 0))
+    E = args.in_flight if args.in_flight > 0 else (1 if (args.timestamp_head or fp32) else 2)
+    engs = [Engine(weights_device_ptr=wdev.data_ptr(), weights_bytes=n, cmvn=cmvn, device=local, math_mode=2 if int8 else (1 if fp32 else 0))
+            for _ in range(E)]
+    eng = engs[0]
 
-    # ---- workload: this rank's shard of the utterance list, staged to HBM before timing
+    # ---- workload: this rank's shard of the utterance list, staged to HBM (once per engine) before timing
     B = args.batch
     audio = [W.synth_audio(samples, rank * B + u) for u in range(B)]
-    eng.stage_audio(audio)
+    for e_ in engs:
+        e_.stage_audio(audio)
     if args.model == "seaco":                                 # N = 20 hotwords of 2-4 ids + the [1] terminator
         hrng = np.random.default_rng(99)
         hws = [list(hrng.integers(3, 8000, size=int(hrng.integers(2, 5)))) for _ in range(20)] + [[1]]
-        eng.set_hotwords(np.asarray([h[:10] + [0] * (10 - len(h)) for h in hws], np.int32))
+        for e_ in engs:
+            e_.set_hotwords(np.asarray([h[:10] + [0] * (10 - len(h)) for h in hws], np.int32))
     gathered = {}
-    ids_mine = torch.full((B, LCAP), -1, dtype=torch.int64, device=dev) if use_dist else None
+    # per engine TWO device id buffers: the gather of its step s reads one while its step s + 1 may already fill the other
+    ids_dev = [[torch.full((B, LCAP), -1, dtype=torch.int64, device=dev) for _ in range(2)] for _ in range(E)] if use_dist else None
 
-    def step():
-        eng.run_staged()
+    def gather(e_i, par):
+        # gather of hypotheses over RCCL / xGMI, device to device: the engine wrote its [B, LCAP] ids into a device tensor on
+        # its own stream (and waited for it), the all-gather leaves [world * B, LCAP] on every GPU; no host round trip inside
+        # the timed region (the host copy for the check below happens after the timing).  ALWAYS issued by the main thread
+        # in global step order, so every rank enters the collectives in the same order whatever its engines' pace.
+        gathered["ids"] = sh.gather_hypotheses_device(ids_dev[e_i][par], world * B, dist)
+
+    def one_step(e_i, par):
+        engs[e_i].run_staged()
         if use_dist:
-            # gather of hypotheses over RCCL / xGMI, device to device: the engine writes its [B, LCAP] ids into a device
-            # tensor on its own stream (and waits for it), the all-gather leaves [world * B, LCAP] on every GPU; no host
-            # round trip inside the timed region (the host copy for the check below happens after the timing)
-            eng.fetch_ids_device(ids_mine.data_ptr(), LCAP)
-            gathered["ids"] = sh.gather_hypotheses_device(ids_mine, world * B, dist)
+            engs[e_i].fetch_ids_device(ids_dev[e_i][par].data_ptr(), LCAP)
 
-    for _ in range(args.warmup):
-        step()
-    eng.sync()
+    def run_steps(first, count):
+        """Global steps first .. first + count - 1; step i runs on engine i % E (each engine's steps in order on its own
+        stream, issued by its own host thread: a step blocks its thread at the decoder-length read-back)."""
+        import threading
+        import queue
+        if E == 1 or count <= 1:
+            for i in range(first, first + count):
+                one_step(i % E, (i // E) & 1)
+                if use_dist:
+                    gather(i % E, (i // E) & 1)
+            return
+        done = [queue.Queue() for _ in range(E)]
+        room = [threading.Semaphore(2) for _ in range(E)]      # an engine runs at most two steps ahead of its gathers
+        errs = []
+
+        def worker(e_i):
+            try:
+                for i in range(first, first + count):
+                    if i % E != e_i:
+                        continue
+                    room[e_i].acquire()
+                    one_step(e_i, (i // E) & 1)
+                    done[e_i].put(i)
+            except BaseException as ex:                          # noqa: BLE001 — relayed to the main thread
+                errs.append(ex)
+                done[e_i].put(-1)
+
+        th = [threading.Thread(target=worker, args=(e_i,)) for e_i in range(E)]
+        for t in th:
+            t.start()
+        for i in range(first, first + count):
+            got = done[i % E].get()
+            if got < 0:
+                break
+            if use_dist:
+                gather(i % E, (i // E) & 1)
+            room[i % E].release()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run_steps(0, args.warmup * E)
+    for e_ in engs:
+        e_.sync()
     # ---- which kernel class does the roofline object describe?  An UNTIMED profiling step over every class: the
     # encoder GEMM class with the largest share of the step is the "dominant kernel" (every rank takes the same
     # decision from its own measurement of the same launches; rank 0's is printed)
@@ -421,12 +483,16 @@ def main():
     eng.profile(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-        if i == 0:
-            eng.profile(False)        # the dominant class is event-timed on the FIRST timed step only (50 launches):
-                                      # an event pair costs ~4 us of device time, 50 pairs per step would tax `value` by ~1.4 %
+    # the FIRST timed step runs alone on engine 0 with the dominant class event-timed (50 launches; an event pair costs ~4 us
+    # of device time, 50 pairs per step would tax `value` by ~1.4 %): the roofline object describes the kernel with the chip
+    # to itself; from the second step on E steps are in flight
+    run_steps(0, 1)
     eng.sync()
+    eng.profile(False)
+    solo_ms = (time.perf_counter() - t0) * 1e3
+    run_steps(1, args.steps - 1)
+    for e_ in engs:
+        e_.sync()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -436,14 +502,18 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    res = eng.fetch()
+    last_e = (args.steps - 1) % E                           # the engine that ran the last timed step
+    res = engs[last_e].fetch()
     ms_dom, n_dom, fpl_dom = eng.profile_get(dominant)
+    for e_ in engs:                                          # every engine computed the same batch: concurrency must not change a single id
+        r2 = e_.fetch()
+        assert r2.L == res.L and (r2.token_ids == res.token_ids).all() and (r2.token_num == res.token_num).all()
     # the timed steps must have produced a real transcript-shaped result: every utterance decoded, ids in range
     assert res.L > 0 and res.token_ids.shape == (B, res.L), (res.L, res.token_ids.shape)
     assert (res.token_ids >= 0).all() and (res.token_ids < eng.vocab).all()
     assert (res.token_num > 0).all()
     if use_dist:
-        g = gathered["ids"].cpu().numpy()
+        g = gathered["ids"].cpu().numpy()                   # the last gather = the last timed step's
         assert g.shape == (world * B, LCAP) and (g[rank * B:(rank + 1) * B, :res.L] == res.token_ids).all()
     # ... and the right one: rank 0's ids against the fp32 CPU oracle's for this workload (tests/golden/), wherever
     # the oracle is decisive.  Only the three BASELINE workloads at their own shapes have a golden file.
@@ -487,7 +557,10 @@ def main():
                                       " + BiCIF timestamp head" if args.timestamp_head else "", B, seconds,
                                       2 if sv else (4 if args.timestamp_head else (3 if world * B == 1024 else 1))),
                        "global_batch": world * B, "samples_per_utt": samples, "T_lfr": eng.num_frames(samples), "L": int(res.L),
-                       "parallelism": "dp%d (utterance shards, no data-path collective)" % world},
+                       "parallelism": "dp%d (utterance shards, no data-path collective)%s" % (
+                           world, "; %d batches in flight per GPU (engines on one device, consecutive steps alternate)" % E if E > 1 else ""),
+                       "steps_in_flight": E},
+            "ms_first_step_alone": solo_ms,          # the first timed step, run with nothing else in flight (and 50 event pairs)
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "rccl_ranks": world if use_dist else 0,
             "ids_sha1": ids_checksum(res.token_ids),   # rank 0's [B, L] ids of the last timed step
@@ -522,7 +595,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e_ in engs:
+        e_.close()
 
 
 if __name__ == "__main__":
