@@ -59,8 +59,8 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_QKV_MIN"); if (e && e[0]) qkv_split_min_tiles_ = atoi(e); }
   { const char* e = getenv("PF_QKV_FILL"); if (e && e[0]) qkv_split_min_fill_ = atoi(e); }
   { const char* e = getenv("PF_SK_MIN"); if (e && e[0]) sk_min_wgs_ = atoi(e); }
-  { const char* e = getenv("PF_SK_FFN2"); if (e && e[0]) sk_ffn2_ = e[0] != '0'; }     // A/B: split-K row-complete FFN-down + LayerNorm (k_gemm_sk.hip)
-  { const char* e = getenv("PF_RC_FFN2"); rc_ffn2_ = e && e[0] == '1'; }   // A/B switch for tools/: the unfused encoder sequence
+  { const char* e = getenv("PF_SK_FFN2"); if (e && e[0]) sk_ffn2_ = atoi(e); }     // A/B: split-K row-complete FFN-down + LayerNorm (k_gemm_sk.hip)
+  { const char* e = getenv("PF_RC_FFN2"); if (e && e[0]) rc_ffn2_ = e[0] != '0'; }   // A/B switch for tools/: the unfused encoder sequence
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
@@ -931,7 +931,7 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
   const int blk = (F % 64 == 0 && !small) ? 1 : 0;
   gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
-  if (rc && sk_ffn2_ && blk && sk_slab_ && sk_calls_ < sk_calls_cap_ && 2 * cdiv(M, 128) >= sk_min_wgs_) {
+  if (rc && sk_ffn2_ && blk && (sk_ffn2_ == 2 || (sk_slab_ && sk_calls_ < sk_calls_cap_)) && 2 * cdiv(M, 128) >= sk_min_wgs_) {
     // split-K row-complete FFN-down + bias + residual + the NEXT LayerNorm in one launch (k_gemm_sk.hip): a pair of
     // workgroups per 128-row block, each walks half of K and finishes 64 complete rows
     GemmRcArgs f{};
@@ -940,17 +940,21 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
     f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
     if (gemm_sk_applicable(f)) {
       prof_begin("gemm_ffn2", 2.0 * M * (double)D * F);
-      launch_gemm_sk(stream_, f, sk_slab_, (unsigned*)((char*)sk_flags_ + sk_flag_stride_ * (size_t)sk_calls_), sk_err_);
+      if (sk_ffn2_ == 2) {
+        launch_gemm_sk(stream_, f, nullptr, nullptr, nullptr, false);
+      } else {
+        launch_gemm_sk(stream_, f, sk_slab_, (unsigned*)((char*)sk_flags_ + sk_flag_stride_ * (size_t)sk_calls_), sk_err_);
+        ++sk_calls_;
+        sk_used_ = true;
+      }
       prof_end("gemm_ffn2");
-      ++sk_calls_;
-      sk_used_ = true;
       return;
     }
   }
   if (rc && rc_ffn2_ && blk) {
-    // row-complete FFN-down (+ the next LayerNorm): measured SLOWER than the persistent 256 x 128 kernel + a
-    // LayerNorm launch at K = 2048 (67.7 vs 57.5 us per layer at M = 16 000: every workgroup streams the 2 MB W
-    // panel) — kept behind PF_RC_FFN2=1 for experiments
+    // row-complete FFN-down (+ the next LayerNorm), default since round 4: 53.6 us against 47.6 + 9-11 us for the persistent
+    // 256 x 128 kernel + its LayerNorm launch (same box, same session: 12.86 -> 12.67 ms per step with one step in flight,
+    // 11.32 -> 11.06 with two; round 3 had measured the opposite, 67.7 vs 57.5 us).  PF_RC_FFN2=0 restores the two launches.
     GemmRcArgs f{};
     f.A = h16_; f.lda = F; f.a_blocked = 1; f.W = L.w2.w; f.ldw = L.w2.Kpad; f.bias = L.w2.bias; f.M = M; f.K = L.w2.Kpad;
     f.resid = x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
@@ -991,7 +995,7 @@ void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
   plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
 
   sk_slab_ = nullptr;
-  if (sk_ffn2_ && D == 512 && !fp32_mode_ && !int8_mode_ && M > gemm_small_max_rows()) sk_prepare((int)M, (int)(enc_.size() + tp_.size()));
+  if (sk_ffn2_ == 1 && D == 512 && !fp32_mode_ && !int8_mode_ && M > gemm_small_max_rows()) sk_prepare((int)M, (int)(enc_.size() + tp_.size()));
   // the LayerNorm that FOLLOWS layer i's FFN-down is the next layer's norm1, or after_norm behind the last one
   const bool has_tp = !tp_.empty();
   for (size_t i = 0; i < enc_.size(); ++i) {
@@ -2252,11 +2256,17 @@ void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* 
     }
   } else if (ds.split_k) {
     PF_CHECK(gemm_sk_applicable(g), PF_ERR_INVALID_ARG, "gemm_rc: the split-K form needs K >= 192 and takes no FSMN term");
-    sk_prepare(M, 1);
-    prof_begin("gemm_op", 2.0 * M * (double)N * K);
-    launch_gemm_sk(stream_, g, sk_slab_, sk_flags_, sk_err_);
-    prof_end("gemm_op");
-    sk_used_ = true;
+    if (ds.split_k == 2) {
+      prof_begin("gemm_op", 2.0 * M * (double)N * K);
+      launch_gemm_sk(stream_, g, nullptr, nullptr, nullptr, false);
+      prof_end("gemm_op");
+    } else {
+      sk_prepare(M, 1);
+      prof_begin("gemm_op", 2.0 * M * (double)N * K);
+      launch_gemm_sk(stream_, g, sk_slab_, sk_flags_, sk_err_);
+      prof_end("gemm_op");
+      sk_used_ = true;
+    }
   } else {
     prof_begin("gemm_op", 2.0 * M * (double)N * K);
     launch_gemm_rc(stream_, g);

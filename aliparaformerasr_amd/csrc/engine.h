@@ -226,13 +226,13 @@ class Engine {
   bool ts_pending_ = false, ts_defer_copy_ = false;
   size_t ts_copy_floats_ = 0;
   void join_ts();
-  bool no_rc_ = false, rc_ffn2_ = false, lstm_steps_ = false;
+  bool no_rc_ = false, rc_ffn2_ = true, lstm_steps_ = false;
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)
   int dec_fuse_ = 1;                 // bit 1: FSMN + norm3, bit 2: out-projection + next norm1, bit 4: FFN-down + norm2 (row-complete GEMM)
   // split-K row-complete FFN-down (k_gemm_sk.hip): exchange slab + one flag region per launch of a forward (zeroed once
   // per encoder pass) + the time-out word
-  bool sk_ffn2_ = false;             // PF_SK_FFN2=1: opt in (measured slower than the persistent 256 x 128 kernel + a LayerNorm launch: the
+  int sk_ffn2_ = 0;                  // PF_SK_FFN2=2: one workgroup per 128-row block, all of K; =1: the pair form: opt in (measured slower than the persistent 256 x 128 kernel + a LayerNorm launch: the
                                      // partial exchange is 64 MB of extra memory traffic per launch, profiles/round4_splitk_pairs.txt)
   DevBuf ws_sk_;
   float* sk_slab_ = nullptr; unsigned* sk_flags_ = nullptr; unsigned* sk_err_ = nullptr;

@@ -79,6 +79,11 @@ __device__ __forceinline__ float sk_wave_sum(float v) {
   return (a + b) + (c + d);
 }
 
+// SPLIT: the pair form described above.  !SPLIT: one workgroup per 128-row block walks ALL of K and finishes its 128 rows in two
+// 64-row passes — half as many workgroups as 64-row tiles, each staging 40 KB per 4.2 MFLOP instead of 72 KB: no faster
+// alone (125 workgroups on 256 CUs), but it costs ~45 % less CU time, which is what counts when a second engine's
+// kernels run on the CUs it leaves free (bench.py --in-flight 2).
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkDev p) {
   constexpr int NJ = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,11 +94,11 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkDev p) {
 
   // ---- pair schedule: blocks b and b ^ 8 (same XCD, adjacent in its dispatch order) share row block rb
   const int bid = blockIdx.x;
-  const int u = bid >> 3, h = u & 1;
-  const int rb = (u >> 1) * 8 + (bid & 7);
+  const int u = bid >> 3, h = SPLIT ? (u & 1) : 0;
+  const int rb = SPLIT ? (u >> 1) * 8 + (bid & 7) : bid;
   if (rb >= p.n_rb) return;                                  // both partners of a pair leave together
   const int m0 = rb * SK_BM;
-  const int Kh = p.K >> 1;                                   // this workgroup's share of K: [h * Kh, (h + 1) * Kh)
+  const int Kh = SPLIT ? (p.K >> 1) : p.K;                   // this workgroup's share of K: [h * Kh, (h + 1) * Kh)
   const int T = Kh / SK_BK;
 
   // ---- DMA cursor (uniform) and per-lane source offsets
@@ -217,8 +222,122 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkDev p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the clamped DMA of the last steps has landed ...
   __builtin_amdgcn_s_barrier();                              // ... for every wave: the ring is free for the epilogue tile
 
-  // ---- exchange: acc[1] (the rows the partner owns) goes out in accumulator layout, 1 KiB per store instruction
-  {
+  // ---- epilogue of 64 complete rows held in `a` (+ the partner's partials `pv` in the pair form): residual rows are
+  // requested first (their round trip runs under the hand-off / the dump), the tile goes row-major into LDS, then wave w
+  // finishes rows 8w .. 8w + 7 completely: lane = columns 4*lane and 256 + 4*lane.  ph: which 32-row half of each 64-row
+  // wave block these rows are.
+  auto finish = [&](int ph, f16x (&a)[NJ], bool with_partner) __attribute__((always_inline)) {
+    const int mb = m0 + (wave >> 2) * 64 + ph * 32 + (wave & 3) * 8;
+    float4 xv[2][8];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        xv[hh][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.resid && mb + r < p.M)
+          xv[hh][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + hh * 256 + 4 * lane);
+      }
+    f4v pv[16];
+    if (with_partner) {
+      const unsigned* pf = p.flags + (bid ^ 8) * 8 + wave;
+      unsigned spins = 0;
+      while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) {
+          if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      const char* in = reinterpret_cast<const char*>(p.slab) + (size_t)(bid ^ 8) * SK_SLAB + (size_t)(wave * 16) * 1024 + lane * 16;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[e]) : "v"(in + e * 1024) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]),
+                     "+v"(pv[8]), "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15])
+                   :
+                   : "memory");
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pv[e] = f4v{0.f, 0.f, 0.f, 0.f};
+    }
+    // D^T fragment: lane = row, 4 consecutive columns per register quad
+    char* rowp = smem + (size_t)(wm * 32 + (lane & 31)) * SK_XROW + (wn * (32 * NJ) + 4 * lh) * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f4v q = pv[j * 4 + g];
+        *reinterpret_cast<float4a*>(rowp + (j * 32 + 8 * g) * 4) =
+            make_float4(a[j][4 * g + 0] + q[0], a[j][4 * g + 1] + q[1], a[j][4 * g + 2] + q[2], a[j][4 * g + 3] + q[3]);
+      }
+    __syncthreads();
+    const int r0 = wave * 8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int col = hh * 256 + 4 * lane;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * SK_XROW + col * 4);
+        xv[hh][r].x += v.x + b4.x; xv[hh][r].y += v.y + b4.y; xv[hh][r].z += v.z + b4.z; xv[hh][r].w += v.w + b4.w;
+      }
+      if (p.out_x) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[hh][r];
+      }
+    }
+    if (!p.ln_g) return;
+    // LayerNorm of the complete rows (two-pass statistics; one wave = one row, reductions on the VALU via DPP)
+    float4 g4[2], be4[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      g4[hh] = *reinterpret_cast<const float4*>(p.ln_g + hh * 256 + 4 * lane);
+      be4[hh] = *reinterpret_cast<const float4*>(p.ln_b + hh * 256 + 4 * lane);
+    }
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float s = ((xv[0][r].x + xv[0][r].y) + (xv[0][r].z + xv[0][r].w)) + ((xv[1][r].x + xv[1][r].y) + (xv[1][r].z + xv[1][r].w));
+      mean[r] = sk_wave_sum(s) * (1.0f / SK_BN);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float m = mean[r];
+      xv[0][r].x -= m; xv[0][r].y -= m; xv[0][r].z -= m; xv[0][r].w -= m;
+      xv[1][r].x -= m; xv[1][r].y -= m; xv[1][r].z -= m; xv[1][r].w -= m;
+      const float q = ((xv[0][r].x * xv[0][r].x + xv[0][r].y * xv[0][r].y) + (xv[0][r].z * xv[0][r].z + xv[0][r].w * xv[0][r].w)) +
+                      ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
+      rstd[r] = 1.0f / sqrtf(sk_wave_sum(q) * (1.0f / SK_BN) + p.eps);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = mb + r;
+      if (m < p.M) {
+        const float k = rstd[r];
+        const float4 d0 = xv[0][r], d1 = xv[1][r];
+        const float4 y0 = make_float4(d0.x * k * g4[0].x + be4[0].x, d0.y * k * g4[0].y + be4[0].y,
+                                      d0.z * k * g4[0].z + be4[0].z, d0.w * k * g4[0].w + be4[0].w);
+        const float4 y1 = make_float4(d1.x * k * g4[1].x + be4[1].x, d1.y * k * g4[1].y + be4[1].y,
+                                      d1.z * k * g4[1].z + be4[1].z, d1.w * k * g4[1].w + be4[1].w);
+        if (p.out_n16) {
+          half_t* o = p.out_n16 + (size_t)m * p.ldn16 + 4 * lane;
+          *reinterpret_cast<h4*>(o) = h4{(half_t)y0.x, (half_t)y0.y, (half_t)y0.z, (half_t)y0.w};
+          *reinterpret_cast<h4*>(o + 256) = h4{(half_t)y1.x, (half_t)y1.y, (half_t)y1.z, (half_t)y1.w};
+        }
+        if (p.out_n32) {
+          float* o = p.out_n32 + (size_t)m * p.ldn32 + 4 * lane;
+          *reinterpret_cast<float4*>(o) = y0;
+          *reinterpret_cast<float4*>(o + 256) = y1;
+        }
+      }
+    }
+  };
+
+  if (SPLIT) {
+    // ---- exchange: acc[1] (the rows the partner owns) goes out in accumulator layout, 1 KiB per store instruction
     char* out = reinterpret_cast<char*>(p.slab) + (size_t)bid * SK_SLAB + (size_t)(wave * 16) * 1024 + lane * 16;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -229,133 +348,30 @@ __global__ __launch_bounds__(512, 1) void gemm_sk_kernel(SkDev p) {
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // R1: EVERY storing wave drains, then one lane publishes its wave's flag
     if (lane == 0) __hip_atomic_store(p.flags + bid * 8 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // the residual rows of the epilogue are requested now: their HBM round trip runs under the hand-off.
-  // Wave w finishes 8 COMPLETE rows; lane: columns 4*lane and 256 + 4*lane.
-  const int mb = m0 + (wave >> 2) * 64 + h * 32 + (wave & 3) * 8;
-  float4 xv[2][8];
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      xv[hh][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.resid && mb + r < p.M)
-        xv[hh][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + hh * 256 + 4 * lane);
-    }
-  {
-    const unsigned* pf = p.flags + (bid ^ 8) * 8 + wave;
-    unsigned spins = 0;
-    while (__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 22)) {
-        if (lane == 0) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-    const char* in = reinterpret_cast<const char*>(p.slab) + (size_t)(bid ^ 8) * SK_SLAB + (size_t)(wave * 16) * 1024 + lane * 16;
-    f4v pv[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[e]) : "v"(in + e * 1024) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]),
-                   "+v"(pv[8]), "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15])
-                 :
-                 : "memory");
-    // the 64 x 512 fp32 tile of the rows this workgroup keeps, row-major in LDS.  D^T fragment: lane = row, 4
-    // consecutive columns per register quad.
-    char* rowp = smem + (size_t)(wm * 32 + (lane & 31)) * SK_XROW + (wn * (32 * NJ) + 4 * lh) * 4;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f4v q = pv[j * 4 + g];
-        *reinterpret_cast<float4a*>(rowp + (j * 32 + 8 * g) * 4) =
-            make_float4(acc[0][j][4 * g + 0] + q[0], acc[0][j][4 * g + 1] + q[1], acc[0][j][4 * g + 2] + q[2], acc[0][j][4 * g + 3] + q[3]);
-      }
-  }
-  __syncthreads();
-  const int r0 = wave * 8;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    const int col = hh * 256 + 4 * lane;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + col);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * SK_XROW + col * 4);
-      xv[hh][r].x += v.x + b4.x; xv[hh][r].y += v.y + b4.y; xv[hh][r].z += v.z + b4.z; xv[hh][r].w += v.w + b4.w;
-    }
-    if (p.out_x) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[hh][r];
-    }
-  }
-  if (!p.ln_g) return;
-
-  // ---- LayerNorm of the complete rows (two-pass statistics; one wave = one row, reductions on the VALU via DPP)
-  float4 g4[2], be4[2];
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    g4[hh] = *reinterpret_cast<const float4*>(p.ln_g + hh * 256 + 4 * lane);
-    be4[hh] = *reinterpret_cast<const float4*>(p.ln_b + hh * 256 + 4 * lane);
-  }
-  float mean[8], rstd[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float s = ((xv[0][r].x + xv[0][r].y) + (xv[0][r].z + xv[0][r].w)) + ((xv[1][r].x + xv[1][r].y) + (xv[1][r].z + xv[1][r].w));
-    mean[r] = sk_wave_sum(s) * (1.0f / SK_BN);
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const float m = mean[r];
-    xv[0][r].x -= m; xv[0][r].y -= m; xv[0][r].z -= m; xv[0][r].w -= m;
-    xv[1][r].x -= m; xv[1][r].y -= m; xv[1][r].z -= m; xv[1][r].w -= m;
-    const float q = ((xv[0][r].x * xv[0][r].x + xv[0][r].y * xv[0][r].y) + (xv[0][r].z * xv[0][r].z + xv[0][r].w * xv[0][r].w)) +
-                    ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
-    rstd[r] = 1.0f / sqrtf(sk_wave_sum(q) * (1.0f / SK_BN) + p.eps);
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int m = mb + r;
-    if (m < p.M) {
-      const float k = rstd[r];
-      const float4 d0 = xv[0][r], d1 = xv[1][r];
-      const float4 y0 = make_float4(d0.x * k * g4[0].x + be4[0].x, d0.y * k * g4[0].y + be4[0].y,
-                                    d0.z * k * g4[0].z + be4[0].z, d0.w * k * g4[0].w + be4[0].w);
-      const float4 y1 = make_float4(d1.x * k * g4[1].x + be4[1].x, d1.y * k * g4[1].y + be4[1].y,
-                                    d1.z * k * g4[1].z + be4[1].z, d1.w * k * g4[1].w + be4[1].w);
-      if (p.out_n16) {
-        half_t* o = p.out_n16 + (size_t)m * p.ldn16 + 4 * lane;
-        *reinterpret_cast<h4*>(o) = h4{(half_t)y0.x, (half_t)y0.y, (half_t)y0.z, (half_t)y0.w};
-        *reinterpret_cast<h4*>(o + 256) = h4{(half_t)y1.x, (half_t)y1.y, (half_t)y1.z, (half_t)y1.w};
-      }
-      if (p.out_n32) {
-        float* o = p.out_n32 + (size_t)m * p.ldn32 + 4 * lane;
-        *reinterpret_cast<float4*>(o) = y0;
-        *reinterpret_cast<float4*>(o + 256) = y1;
-      }
-    }
+    finish(h, acc[0], true);
+  } else {
+    finish(0, acc[0], false);
+    __syncthreads();                                         // every wave has read its rows of the first half
+    finish(1, acc[1], false);
   }
 }
 
-static int sk_grid(int M) { return 16 * cdiv(cdiv(M, SK_BM), 8); }
+static int sk_grid(int M) { return 16 * cdiv(cdiv(M, SK_BM), 8); }   // pair form (the scratch is sized for it)
 size_t gemm_sk_slab_bytes(int M) { return (size_t)sk_grid(M) * SK_SLAB; }
 size_t gemm_sk_flag_bytes(int M) { return (size_t)sk_grid(M) * 8 * 4; }
 
 bool gemm_sk_applicable(const GemmRcArgs& a) {
   if (a.fsmn_v) return false;                                // the FSMN memory is the 64-row kernel's epilogue term
-  if (a.M <= 0 || a.K < 192 || a.K % 64 != 0 || a.lda % 8 != 0 || a.ldw % 8 != 0) return false;
+  if (a.M <= 0 || a.K < 192 || a.K % 64 != 0 || a.lda % 8 != 0 || a.ldw % 8 != 0) return false;   // (K >= 96 would do without the split)
   if ((a.resid && a.ldr % 4 != 0) || (a.out_x && a.ldx % 4 != 0) || (a.out_n16 && a.ldn16 % 4 != 0) || (a.out_n32 && a.ldn32 % 4 != 0))
     return false;
   if (!a.ln_g != !a.ln_b || (!a.ln_g && (a.out_n16 || a.out_n32))) return false;
   return a.out_x || a.out_n16 || a.out_n32;
 }
 
-void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err) {
-  PF_CHECK(gemm_sk_applicable(a), PF_ERR_INVALID_ARG, "gemm_sk: shape / epilogue not covered by the split-K row-complete kernel");
-  PF_CHECK(slab && flags && err, PF_ERR_INVALID_ARG, "gemm_sk: exchange scratch missing");
+void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err, bool split) {
+  PF_CHECK(gemm_sk_applicable(a), PF_ERR_INVALID_ARG, "gemm_sk: shape / epilogue not covered by the 128-row row-complete kernel");
+  PF_CHECK(!split || (slab && flags && err), PF_ERR_INVALID_ARG, "gemm_sk: exchange scratch missing");
   SkDev d;
   d.A = a.A; d.W = a.W; d.bias = a.bias; d.resid = a.resid; d.out_x = a.out_x;
   d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.out_n16 = a.out_n16; d.out_n32 = a.out_n32;
@@ -370,12 +386,14 @@ void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* f
   {
     std::lock_guard<std::mutex> lk(init_mu);
     if (!attr_set[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_sk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS));
       attr_set[dev & 63] = true;
     }
   }
-  note_gemm_kernel("gemm_sk_kernel");
-  hipLaunchKernelGGL(gemm_sk_kernel, dim3((unsigned)sk_grid(a.M)), dim3(512), SK_LDS, s, d);
+  note_gemm_kernel(split ? "gemm_sk_kernel<true>" : "gemm_sk_kernel<false>");
+  if (split) hipLaunchKernelGGL(gemm_sk_kernel<true>, dim3((unsigned)sk_grid(a.M)), dim3(512), SK_LDS, s, d);
+  else hipLaunchKernelGGL(gemm_sk_kernel<false>, dim3((unsigned)d.n_rb), dim3(512), SK_LDS, s, d);
   PF_HIP(hipGetLastError());
 }
 

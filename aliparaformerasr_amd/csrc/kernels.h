@@ -140,7 +140,9 @@ void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a);
 bool gemm_sk_applicable(const GemmRcArgs& a);
 size_t gemm_sk_slab_bytes(int M);
 size_t gemm_sk_flag_bytes(int M);
-void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err);
+// split = false: one workgroup per 128-row block walks all of K (no exchange, no scratch): half the workgroups of the 64-row
+// kernel at ~55 % of its CU time — for launches beside which another stream's kernels run
+void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err, bool split = true);
 
 // ---------------------------------------------------------------- fp32 parity mode (k_fp32.hip) ----
 void launch_gemm_f32(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,

@@ -64,7 +64,7 @@ CLASSES = ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self"
 GEMM_SHAPES = {"gemm_qkv": (1536, 512, "QKV projection + bias, q scaled"),
                "gemm_out": (512, 512, "attention out-projection + bias + residual + FSMN memory + LayerNorm"),
                "gemm_ffn1": (2048, 512, "FFN up-projection + bias + ReLU"),
-               "gemm_ffn2": (512, 2048, "FFN down-projection + bias + residual")}
+               "gemm_ffn2": (512, 2048, "FFN down-projection + bias + residual (+ the next LayerNorm when the row-complete kernel runs it)")}
 
 
 def ids_checksum(ids) -> str:

@@ -415,6 +415,11 @@ def test_gemm_sk_ffn_down_split_k_pairs(eng):
     # against the 64-row kernel: same products, a different summation tree over K
     x3, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, a_blocked=True)
     np.testing.assert_allclose(x, x3, rtol=2e-5, atol=2e-5)
+    # one workgroup per 128-row block over all of K (split_k = 2)
+    x4, m16, m32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True, split_k=2)
+    np.testing.assert_allclose(x4, x3, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(m32, _ln_ref(x4, g, b), rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(m16, h16(m32))
 
 
 def test_gemm_sk_ragged_rows_and_depths(eng):
@@ -438,6 +443,10 @@ def test_gemm_sk_ragged_rows_and_depths(eng):
         np.testing.assert_allclose(x0, ref - bias, rtol=1e-4, atol=6e-4)
         _, m16, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=True, want_x=False, want_n32=False)
         np.testing.assert_array_equal(m16, n16)
+        y, y16, y32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=2)
+        np.testing.assert_allclose(y, ref + resid, rtol=1e-4, atol=6e-4, err_msg=f"no split M={M} K={K}")
+        np.testing.assert_allclose(y32, _ln_ref(y, g, b), rtol=2e-5, atol=2e-5)
+        np.testing.assert_array_equal(y16, h16(y32))
 
 
 def test_gemm_rc_ragged_shapes_and_utterance_edges(eng):

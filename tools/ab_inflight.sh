@@ -1,11 +1,10 @@
+# A/B runs of bench.py under environment switches: bash tools/ab_inflight.sh  (results in gpurun_out/ab_*.json)
 export TMPDIR=/tmp
-run() { name=$1; shift; env "$@" timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err; }
-run base A=1
-run rcffn2 PF_RC_FFN2=1
-run decfuse7 PF_DEC_FUSE=7
-run decfuse3 PF_DEC_FUSE=3
-run decfuse5 PF_DEC_FUSE=5
-run k32 PF_K32=1
-run attpp PF_ATT_PP=1
-run skffn2 PF_SK_FFN2=1
-run base2 A=1
+run() { name=$1; shift; env "$@" timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err; }
+for rep in 1 2; do
+EXTRA="--in-flight 2" run e2_base_$rep A=1
+EXTRA="--in-flight 2" run e2_rcffn2_$rep PF_RC_FFN2=1
+EXTRA="--in-flight 2" run e2_sk2_$rep PF_SK_FFN2=2
+EXTRA="--in-flight 1" run e1_sk2_$rep PF_SK_FFN2=2
+EXTRA="--in-flight 3" run e3_sk2_$rep PF_SK_FFN2=2
+done
