@@ -542,7 +542,8 @@ def main():
         alg_bytes = {"gemm_qkv": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
                      "gemm_out": dom_rows * (Kk * 2 + Nn * 2 + Nn * 4 + Nn * 4 + Nn * 2) + Nn * Kk * 2 + Nn * 4,
                      "gemm_ffn1": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
-                     "gemm_ffn2": dom_rows * (Kk * 2 + Nn * 4 + Nn * 4) + Nn * Kk * 2}[dominant]
+                     # (+ the f16 LayerNorm result when the row-complete kernel carries the next LayerNorm)
+                     "gemm_ffn2": dom_rows * (Kk * 2 + Nn * 4 + Nn * 4 + (Nn * 2 if "gemm_rc" in dom_kernel else 0)) + Nn * Kk * 2}[dominant]
         headline = not int8 and not fp32 and not sv and args.model == "paraformer" and not args.timestamp_head and B == BATCH_PER_GPU and seconds == SECONDS
         out = {
             "metric": "RTFx (audio-sec/wall-sec), %s offline, batch %dx%ds per GPU"
