@@ -79,3 +79,70 @@ def gather_hypotheses_device(mine, n_total: int, dist):
         lo, hi = shard_bounds(n_total, world, r)
         keep.append(full[r * per: r * per + (hi - lo)])
     return torch.cat(keep, dim=0)
+
+
+class StepPipeline:
+    """K steps of a job over E engines on one device, several steps in flight (bench.py --in-flight E).
+
+    Global step i runs on engine i % E: `step_fn(e, parity)` is called by engine e's own host thread (a step blocks its
+    thread at the decoder-length read-back, so one thread cannot keep two engines busy); an engine's steps run in order.
+    `after_fn(e, parity)` — the collective that gathers the step's hypotheses — is called by the thread that called
+    `run`, in GLOBAL step order 0, 1, 2, ..: every rank therefore enters the collectives in the same order whatever the
+    pace of its engines, with one communicator.  `parity` = (i // E) & 1 names which of the engine's two output buffers
+    the step fills; an engine runs at most two steps ahead of its gathers, so a buffer is never refilled before it has
+    been gathered.  An exception in a step is re-raised by `run` after the threads have been joined."""
+
+    def __init__(self, n_engines, step_fn, after_fn=None):
+        self.E = int(n_engines)
+        self.step_fn = step_fn
+        self.after_fn = after_fn
+
+    def run(self, first, count):
+        import queue
+        import threading
+        E = self.E
+        if E == 1 or count <= 1:
+            for i in range(first, first + count):
+                self.step_fn(i % E, (i // E) & 1)
+                if self.after_fn:
+                    self.after_fn(i % E, (i // E) & 1)
+            return
+        done = [queue.Queue() for _ in range(E)]
+        room = [threading.Semaphore(2) for _ in range(E)]
+        errs = []
+        stop = threading.Event()
+
+        def worker(e):
+            try:
+                for i in range(first, first + count):
+                    if i % E != e:
+                        continue
+                    room[e].acquire()
+                    if stop.is_set():
+                        return
+                    self.step_fn(e, (i // E) & 1)
+                    done[e].put(i)
+            except BaseException as ex:                      # noqa: BLE001 — relayed to the caller
+                errs.append(ex)
+                done[e].put(-1)
+
+        th = [threading.Thread(target=worker, args=(e,)) for e in range(E)]
+        for t in th:
+            t.start()
+        try:
+            for i in range(first, first + count):
+                got = done[i % E].get()
+                if got < 0:
+                    break
+                assert got == i, (got, i)
+                if self.after_fn:
+                    self.after_fn(i % E, (i // E) & 1)
+                room[i % E].release()
+        finally:
+            stop.set()                                       # a failed run must not leave a worker waiting for room
+            for r in room:
+                r.release()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]

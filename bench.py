@@ -409,47 +409,10 @@ def main():
         if use_dist:
             engs[e_i].fetch_ids_device(ids_dev[e_i][par].data_ptr(), LCAP)
 
-    def run_steps(first, count):
-        """Global steps first .. first + count - 1; step i runs on engine i % E (each engine's steps in order on its own
-        stream, issued by its own host thread: a step blocks its thread at the decoder-length read-back)."""
-        import threading
-        import queue
-        if E == 1 or count <= 1:
-            for i in range(first, first + count):
-                one_step(i % E, (i // E) & 1)
-                if use_dist:
-                    gather(i % E, (i // E) & 1)
-            return
-        done = [queue.Queue() for _ in range(E)]
-        room = [threading.Semaphore(2) for _ in range(E)]      # an engine runs at most two steps ahead of its gathers
-        errs = []
-
-        def worker(e_i):
-            try:
-                for i in range(first, first + count):
-                    if i % E != e_i:
-                        continue
-                    room[e_i].acquire()
-                    one_step(e_i, (i // E) & 1)
-                    done[e_i].put(i)
-            except BaseException as ex:                          # noqa: BLE001 — relayed to the main thread
-                errs.append(ex)
-                done[e_i].put(-1)
-
-        th = [threading.Thread(target=worker, args=(e_i,)) for e_i in range(E)]
-        for t in th:
-            t.start()
-        for i in range(first, first + count):
-            got = done[i % E].get()
-            if got < 0:
-                break
-            if use_dist:
-                gather(i % E, (i // E) & 1)
-            room[i % E].release()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
+    # global step i runs on engine i % E in that engine's own host thread; the gathers are issued by this thread in global
+    # step order (aliparaformerasr_amd/shard.py::StepPipeline, rehearsed with gloo world-2 in tests/test_dist_cpu.py)
+    pipe = sh.StepPipeline(E, one_step, gather if use_dist else None)
+    run_steps = pipe.run
 
     run_steps(0, args.warmup * E)
     for e_ in engs:

@@ -82,3 +82,69 @@ def test_broadcast_and_gather_world2(n_total):
             n = 3 + u % 5
             np.testing.assert_array_equal(full[u, :n], np.arange(u, u + n))
             assert (full[u, n:] == -1).all()
+
+
+def _pipeline_worker(rank, world, port, E, steps, q):
+    """bench.py --gpus N --in-flight E in miniature: E fake engines per rank whose steps take random, rank-dependent times;
+    the gathers must still pair step i of every rank (one communicator, collectives in global step order)."""
+    import random
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rnd = random.Random(100 + rank)
+    bufs = [[torch.full((2, 4), -1, dtype=torch.int64) for _ in range(2)] for _ in range(E)]
+    nxt = [e for e in range(E)]                        # the global step engine e runs next
+    seen = []
+
+    def step(e, par):
+        time.sleep(rnd.uniform(0.0, 0.004) * (1 + 3 * ((rank + e) % 2)))
+        bufs[e][par].fill_(rank * 1000 + nxt[e])
+        nxt[e] += E
+
+    def after(e, par):
+        full = sh.gather_hypotheses_device(bufs[e][par], 2 * world, dist)
+        seen.append(full[:, 0].tolist())
+
+    pipe = sh.StepPipeline(E, step, after)
+    pipe.run(0, 3)                                      # "warm-up", then the timed region split as bench.py splits it
+    for e in range(E):                                  # (bench.py restarts its counters the same way: steps are global)
+        nxt[e] = e
+    seen.clear()
+    pipe.run(0, 1)
+    pipe.run(1, steps - 1)
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E", [1, 2, 3])
+def test_step_pipeline_keeps_collectives_in_global_step_order_world2(E):
+    world, steps = 2, 11
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, E, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert len(out[r]) == steps
+        for i, row in enumerate(out[r]):                # step i of EVERY rank, in rank order, two rows per rank
+            assert row == [0 * 1000 + i, 0 * 1000 + i, 1 * 1000 + i, 1 * 1000 + i], (E, r, i, row)
+
+
+def test_step_pipeline_relays_a_failing_step():
+    calls = []
+
+    def step(e, par):
+        calls.append(e)
+        if len(calls) == 5:
+            raise RuntimeError("engine failed")
+
+    with pytest.raises(RuntimeError, match="engine failed"):
+        sh.StepPipeline(2, step).run(0, 40)
+    assert len(calls) < 40
