@@ -889,7 +889,8 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   const half_t* v16 = qkv16_ + 2 * D;
   int ldv = 3 * D;
   // (chosen by idle rounds: 32 x 500 rows are 504 tiles = 1.97 rounds on 256 CUs — 1.88 vs 2.06 ms per step for the 50 layers;
-  // SenseVoice's 10 944 rows are 344 tiles = 1.34 rounds and lose, 2.45 vs 2.30 ms)
+  // SenseVoice's 10 944 rows are 344 tiles = 1.34 rounds: 2.45 vs 2.30 ms alone, but 10.19 vs 10.73 ms per step with two steps in
+  // flight — the second engine's kernels take the CUs its short second round leaves — so the fill bar is 60 %)
   const int qt = 8 * cdiv(M, 256);
   const bool split = rc && L.qkv_p && qt >= qkv_split_min_tiles_ && qt * 100 >= qkv_split_min_fill_ * (int)round_up(qt, cus_) &&
                      gemm_qkvp_applicable(M, L.qkv.Kpad, lda, L.qkv.Kpad, D);

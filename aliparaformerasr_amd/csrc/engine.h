@@ -240,7 +240,8 @@ class Engine {
   bool sk_used_ = false;
   bool qkv_split_ = true;            // PF_QKV_SPLIT=0: the row-major 256 x 128 kernel for Q | K | V
   int qkv_split_min_tiles_ = 256;    // PF_QKV_MIN: least number of 256 x 192 tiles for which the split form is chosen
-  int qkv_split_min_fill_ = 85;      // PF_QKV_FILL: ... and least fill (percent) of its last round of tiles
+  int qkv_split_min_fill_ = 60;      // PF_QKV_FILL: ... and least fill (percent) of its rounds of tiles (85 was the break-even with ONE step in
+                                     // flight; with two, the other engine's kernels run on the CUs a short last round leaves)
   int cus_ = 256;                    // compute units the persistent kernels size their grids for (cu_limit)
   int sk_min_wgs_ = 128;             // PF_SK_MIN: least number of workgroups (2 per 128 rows) for which the split form is chosen
   void sk_prepare(int M, int calls);

@@ -824,14 +824,14 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   {
     // blocked-layout results (FFN-up): the persistent 256 x 256-tile kernel (k_gemm_big.hip); PF_BIGP=0 keeps this file's kernel
     static int use_bigp = -1;
-    if (use_bigp < 0) { const char* e = getenv("PF_BIGP"); use_bigp = (e && e[0] == '0') ? 0 : 1; }
+    if (use_bigp < 0) { const char* e = getenv("PF_BIGP"); use_bigp = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }   // 2: whenever it applies and fills the chip once
     const bool can = gemm_bigp_applicable(a);
     PF_CHECK(a.force_mi != 5 || can, PF_ERR_INVALID_ARG, "gemm: the persistent 256 x 256 kernel does not apply to this problem");
     // by rounds: a 256 x 256 tile costs ~1.9 tiles of this file's kernel; whichever schedule has less idle tail wins
     // (M = 16000: 504 tiles = 2 rounds vs 1008 = 4 -> persistent; SenseVoice M = 10944: 344 = 2 rounds vs 688 = 3 -> this kernel)
     const int t_big = cdiv(a.M, 256) * (a.N / 256), t_pp3 = cdiv(a.M, 256) * cdiv(a.N, GEMM_BN);
     const bool fewer_rounds = t_big >= cus[dev] && 1.9 * cdiv(t_big, cus[dev]) <= (double)cdiv(t_pp3, cus[dev]);
-    if (can && (a.force_mi == 5 || (a.force_mi == 0 && use_bigp && fewer_rounds))) {
+    if (can && (a.force_mi == 5 || (a.force_mi == 0 && use_bigp && (fewer_rounds || (use_bigp == 2 && t_big >= cus[dev]))))) {
       launch_gemm_bigp(s, a, cus[dev]);
       return;
     }
