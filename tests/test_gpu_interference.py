@@ -41,6 +41,9 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
     q = rng.standard_normal((Bt, L, D)).astype(np.float32)
     k = rng.standard_normal((Bt, T, D)).astype(np.float32)
     v = rng.standard_normal((Bt, T, D)).astype(np.float32)
+    wqkv = (rng.standard_normal((3 * D, D)) / 22).astype(np.float32)
+    bqkv = rng.standard_normal(3 * D).astype(np.float32)
+    he = np.abs(rng.standard_normal((16000, F))).astype(np.float32)
     ops = {
         "fp32-result GEMM 5344x512x2048, 128-row tiles": lambda: B.op_gemm_ex(h, w2, None, tile_rows=128),
         "fp32-result GEMM 5344x512x2048, 256-row tiles": lambda: B.op_gemm_ex(h, w2, None, tile_rows=256),
@@ -51,6 +54,13 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
         "blocked-result GEMM 16000x2048x512 (persistent 256x256 tiles)": lambda: B.op_gemm_ex(xe, w1, None, relu=True, out_kind=2),
         "row-complete GEMM + residual + LayerNorm 16000x512x512": lambda: B.op_gemm_rc(xe, wq, b2, resid=xe, ln=(g, be))[0],
         "self-attention 8x500x500": lambda: B.op_attention(k[:8], k[:8], v[:8]),
+        # round 4: the fused Q|K|V projection on 256 x 192 tiles + attention on its blocked layout, the row-complete FFN-down
+        # (blocked A, K = 2048) with its LayerNorm, and the split-K pair form (an in-launch exchange between workgroups)
+        "Q|K|V 256x192 kernel + attention on the blocked layout 32x500": lambda: np.concatenate(B.op_qkv_attention(xe, wqkv, bqkv, 32, 500), axis=1),
+        "row-complete FFN-down + LayerNorm 16000x512x2048 (blocked A)": lambda: np.concatenate(
+            B.op_gemm_rc(he, w2, b2, resid=xe, ln=(g, be), a_blocked=True)[::2], axis=1),
+        "split-K pair FFN-down + LayerNorm 16000x512x2048": lambda: np.concatenate(
+            B.op_gemm_rc(he, w2, b2, resid=xe, ln=(g, be), a_blocked=True, split_k=True)[::2], axis=1),
     }
     quiet = {name: f() for name, f in ops.items()}
     stop = []
