@@ -115,10 +115,12 @@ def test_bench_rccl_path_with_a_one_rank_communicator():
         port = sk.getsockname()[1]
     env = dict(os.environ, PF_BENCH_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "7", "--warmup", "1", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    # two steps in flight: both engines' steps were gathered by the main thread in global step order (shard.StepPipeline)
+    assert d["config"]["steps_in_flight"] == 2 and d["steps"] == 7
     assert d["ids_vs_fp32_oracle"] and d["ids_vs_fp32_oracle"]["ok"]
