@@ -2,8 +2,9 @@
 export TMPDIR=/tmp
 run() { name=$1; shift; env "$@" timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $EXTRA > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err; }
 for rep in 1 2; do
-EXTRA="--model seaco --in-flight 1" run c1_base_$rep A=1
-EXTRA="--model seaco --in-flight 2" run c2_base_$rep A=1
-EXTRA="--model seaco --in-flight 2" run c2_inline_$rep PF_TS_STREAM=0
-EXTRA="--model seaco --in-flight 3" run c3_inline_$rep PF_TS_STREAM=0
+EXTRA="" run e2_base_$rep A=1
+EXTRA="" run e2_norc_$rep PF_NO_RC=1
+EXTRA="" run e2_norc_ffn_$rep PF_NO_RC=1 PF_RC_FFN2=0
+EXTRA="--in-flight 1" run e1_base_$rep A=1
+EXTRA="--in-flight 1" run e1_norc_$rep PF_NO_RC=1
 done
