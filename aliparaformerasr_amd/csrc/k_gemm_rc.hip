@@ -50,6 +50,7 @@ constexpr int RC_W_BYTES = RC_BN * RC_ROWB;              // 64 KiB
 constexpr int RC_STAGE = RC_A_BYTES + RC_W_BYTES;        // 72 KiB
 constexpr int RC_XROW = RC_BN * 4 + 16;                  // epilogue tile: 16-byte skew per row (conflict-free dump)
 constexpr int RC_LDS = 2 * RC_STAGE > RC_BM * RC_XROW ? 2 * RC_STAGE : RC_BM * RC_XROW;   // 144 KiB
+constexpr int RC_TOUCH = 8 * 256;                        // + a dead 256-byte line per wave: target of the A prefetch touches (PFD > 0)
 
 __device__ __forceinline__ void rc_glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -118,8 +119,13 @@ __device__ __forceinline__ void rc_fsmn(float4 (&x)[8], const h4 (&win)[FK > 0 ?
   }
 }
 
-// FK: FSMN taps (0 = no FSMN term), compile time so the tap loop and the register window unroll
-template <int FK>
+// FK: FSMN taps (0 = no FSMN term), compile time so the tap loop and the register window unroll.
+// PFD > 0: every k-step each wave also TOUCHES an eighth of the A stage PFD k-steps ahead (one 4-byte LDS-DMA per lane into
+// a dead LDS line: 64 lanes on 8 distinct 128-byte lines, the TA coalesces them) so that the stage's own DMA, two steps
+// before it is consumed, finds the activation rows in L2: A is the only COLD operand of this kernel (each row block is read
+// by exactly one workgroup, straight from HBM / the Infinity Cache), and with one stage in flight a cold line's latency is
+// exposed every step.  The touch is a tenth vector-memory operation per wave and step: the counted waits say 10, not 9.
+template <int FK, int PFD>
 __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -146,6 +152,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
                                    : reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
   const char* w_base = reinterpret_cast<const char*>(p.W);
   const int a_step = p.a_blocked ? (RC_BK / 8) * 512 : RC_BK * 2;
+  // touch line (wave * 8 + (lane & 7)) of the 64 lines of A stage k
+  const int tl = wave * 8 + (lane & 7);
+  const unsigned t_vo = p.a_blocked ? (unsigned)((tl >> 5) * (p.K >> 3) * 512 + (tl & 31) * 128) : (unsigned)(tl * p.lda * 2);
+  auto touch = [&](int k) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (size_t)k * a_step + t_vo),
+                                     (__attribute__((address_space(3))) void*)(smem + RC_LDS + wave * 256), 4, 0, 0);
+  };
+  constexpr int NOPS = PFD > 0 ? 10 : 9;                   // vector-memory operations per wave and k-step
   auto issue = [&](int k, int buf) __attribute__((always_inline)) {
     char* st = smem + buf * RC_STAGE + wave * 1024;
     rc_glds16(a_base + (size_t)k * a_step + a_vo, st);
@@ -182,9 +196,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
   const int rot = (int)((blockIdx.x >> 3) % (unsigned)nk);
   auto kk = [&](int k) __attribute__((always_inline)) -> int { const int q = k + rot; return q >= nk ? q - nk : q; };
   issue(kk(0), 0);
+  if (PFD > 0) touch(kk(PFD < nk ? PFD : nk - 1));
   if (nk > 1) issue(kk(1), 1);
   for (int k = 0; k < nk; ++k) {
-    if (k + 1 < nk) rc_wait_vmcnt<9>(); else rc_wait_vmcnt<0>();      // this wave's 9 pieces of stage k have landed
+    if (k + 1 < nk) rc_wait_vmcnt<NOPS>(); else rc_wait_vmcnt<0>();   // this wave's 9 pieces of stage k have landed
     __builtin_amdgcn_s_barrier();                                      // ... and everybody else's
     const char* rd = smem + (k & 1) * RC_STAGE;
     h8 af[4][2], bf[4][2];
@@ -203,6 +218,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rc_kernel(RcDev p) {
     char* st = smem + (k & 1) * RC_STAGE + wave * 1024;
     const char* an = a_base + (size_t)kn * a_step + a_vo;
     const char* wn_ = w_base + (size_t)kn * (RC_BK * 2);
+    if (PFD > 0 && more) { const int kt = k + 1 + PFD; touch(kk(kt < nk ? kt : nk - 1)); }
     __builtin_amdgcn_s_setprio(1);
     int piece = 0;
 #pragma unroll
@@ -360,20 +376,27 @@ void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a) {
   d.eps = a.eps;
   static std::mutex init_mu;                         // engines on different devices launch from different threads
   static bool attr_set[64] = {false};
+  static int rc_pfd = 0;                             // PF_RC_PFD = 4 | 8: A prefetch touches that many k-steps ahead (deep projections without an FSMN term)
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
   {
     std::lock_guard<std::mutex> lk(init_mu);
     if (!attr_set[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)gemm_rc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
-      PF_HIP(hipFuncSetAttribute((const void*)gemm_rc_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_rc_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_rc_kernel<11, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_rc_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS + RC_TOUCH));
+      PF_HIP(hipFuncSetAttribute((const void*)gemm_rc_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS + RC_TOUCH));
+      if (const char* e = getenv("PF_RC_PFD")) rc_pfd = atoi(e);
       attr_set[dev & 63] = true;
     }
   }
   const dim3 grid((unsigned)cdiv(a.M, RC_BM));
   note_gemm_kernel(a.fsmn_v ? "gemm_rc_kernel<11>" : "gemm_rc_kernel<0>");
-  if (a.fsmn_v) hipLaunchKernelGGL(gemm_rc_kernel<11>, grid, dim3(512), RC_LDS, s, d);
-  else hipLaunchKernelGGL(gemm_rc_kernel<0>, grid, dim3(512), RC_LDS, s, d);
+  const int nk = a.K / RC_BK;
+  if (a.fsmn_v) hipLaunchKernelGGL((gemm_rc_kernel<11, 0>), grid, dim3(512), RC_LDS, s, d);
+  else if (rc_pfd >= 8 && nk > 8) hipLaunchKernelGGL((gemm_rc_kernel<0, 8>), grid, dim3(512), RC_LDS + RC_TOUCH, s, d);
+  else if (rc_pfd >= 4 && nk > 4) hipLaunchKernelGGL((gemm_rc_kernel<0, 4>), grid, dim3(512), RC_LDS + RC_TOUCH, s, d);
+  else hipLaunchKernelGGL((gemm_rc_kernel<0, 0>), grid, dim3(512), RC_LDS, s, d);
   PF_HIP(hipGetLastError());
 }
 
