@@ -466,6 +466,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     last_e = (args.steps - 1) % E                           # the engine that ran the last timed step
+    # for comparison, outside the timed region: a few steps strictly one at a time on the engine that ran the last step
+    serial_ms = None
+    if E > 1:
+        n1 = max(1, min(5, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            engs[last_e].run_staged()
+        engs[last_e].sync()
+        serial_ms = (time.perf_counter() - t1) / n1 * 1e3
     res = engs[last_e].fetch()
     ms_dom, n_dom, fpl_dom = eng.profile_get(dominant)
     for e_ in engs:                                          # every engine computed the same batch: concurrency must not change a single id
@@ -525,6 +534,7 @@ def main():
                            world, "; %d batches in flight per GPU (engines on one device, consecutive steps alternate)" % E if E > 1 else ""),
                        "steps_in_flight": E},
             "ms_first_step_alone": solo_ms,          # the first timed step, run with nothing else in flight (and 50 event pairs)
+            "ms_per_step_one_in_flight": serial_ms,  # untimed extra steps, strictly one at a time (None when --in-flight 1: then ms_per_step is that figure)
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "rccl_ranks": world if use_dist else 0,
             "ids_sha1": ids_checksum(res.token_ids),   # rank 0's [B, L] ids of the last timed step
