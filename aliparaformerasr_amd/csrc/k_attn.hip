@@ -238,6 +238,7 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
   }
 
   f16x s_cur[2];
+  const bool wave_idle = q0 >= p.Lq;                  // wave uniform
 
   // one tile: K(kt) and V(kt) sit in ring slot kt % NS; NS - 1 tiles are in flight, so this wave's pieces of tile kt are
   // the OLDEST of its outstanding LDS-DMA operations: the counted wait leaves the younger tiles' pieces in flight
@@ -269,6 +270,10 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
         stage_v(ns, kt + NS - 1);
       }
     }
+    // a wave whose 32 queries all lie beyond Lq (the last query tile of a short sequence: decoder L = 167 -> waves 2, 3 of
+    // the second 128-query tile; SenseVoice T = 171 -> waves 6, 7 of a 256-query tile) only stages and keeps the barriers:
+    // its matrix / VALU slots go to the other waves of its SIMD
+    if (wave_idle) return;
     if (!(ATT_ABL & 4)) qk(sb, s_cur);
 
     // first V^T fragments (d block 0)
