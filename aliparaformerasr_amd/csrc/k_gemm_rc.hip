@@ -391,12 +391,20 @@ void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a) {
     }
   }
   const dim3 grid((unsigned)cdiv(a.M, RC_BM));
-  note_gemm_kernel(a.fsmn_v ? "gemm_rc_kernel<11>" : "gemm_rc_kernel<0>");
-  const int nk = a.K / RC_BK;
-  if (a.fsmn_v) hipLaunchKernelGGL((gemm_rc_kernel<11, 0>), grid, dim3(512), RC_LDS, s, d);
-  else if (rc_pfd >= 8 && nk > 8) hipLaunchKernelGGL((gemm_rc_kernel<0, 8>), grid, dim3(512), RC_LDS + RC_TOUCH, s, d);
-  else if (rc_pfd >= 4 && nk > 4) hipLaunchKernelGGL((gemm_rc_kernel<0, 4>), grid, dim3(512), RC_LDS + RC_TOUCH, s, d);
-  else hipLaunchKernelGGL((gemm_rc_kernel<0, 0>), grid, dim3(512), RC_LDS, s, d);
+  const int nk = a.K / RC_BK;                        // (the names are the ones the rocprofv3 kernel trace shows)
+  if (a.fsmn_v) {
+    note_gemm_kernel("gemm_rc_kernel<11, 0>");
+    hipLaunchKernelGGL((gemm_rc_kernel<11, 0>), grid, dim3(512), RC_LDS, s, d);
+  } else if (rc_pfd >= 8 && nk > 8) {
+    note_gemm_kernel("gemm_rc_kernel<0, 8>");
+    hipLaunchKernelGGL((gemm_rc_kernel<0, 8>), grid, dim3(512), RC_LDS + RC_TOUCH, s, d);
+  } else if (rc_pfd >= 4 && nk > 4) {
+    note_gemm_kernel("gemm_rc_kernel<0, 4>");
+    hipLaunchKernelGGL((gemm_rc_kernel<0, 4>), grid, dim3(512), RC_LDS + RC_TOUCH, s, d);
+  } else {
+    note_gemm_kernel("gemm_rc_kernel<0, 0>");
+    hipLaunchKernelGGL((gemm_rc_kernel<0, 0>), grid, dim3(512), RC_LDS, s, d);
+  }
   PF_HIP(hipGetLastError());
 }
 
