@@ -34,12 +34,11 @@ using half_t = _Float16;
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
-// PF_CU_CAP=n: persistent kernels size their grids (and their tile-shape rules) for n compute units instead of the whole
-// device — several engines on ONE GPU then run side by side, each on its share of the CUs, instead of taking turns
-// (tools/: the two-engine overlap experiment of round 4)
+// PF_CU_CAP=n: limits PERSISTENT grid sizes (and their tile-shape rules) to n compute units.  It does not partition the
+// device: the hardware still places those workgroups where it likes, and the non-persistent kernels (attention, the
+// row-complete and short-input GEMMs) ignore it (tools/: the two-engine overlap experiment of round 4)
 inline int cu_limit(int cus) {
-  static int cap = -1;
-  if (cap < 0) { const char* e = getenv("PF_CU_CAP"); cap = e ? atoi(e) : 0; }
+  static const int cap = [] { const char* e = getenv("PF_CU_CAP"); return e ? atoi(e) : 0; }();   // thread-safe initialiser
   return cap > 0 && cap < cus ? cap : cus;
 }
 

@@ -119,7 +119,7 @@ void Engine::release() {
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
                     &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_};
-  sk_slab_ = nullptr; sk_flags_ = nullptr; sk_err_ = nullptr;
+  sk_slab_ = nullptr; sk_flags_ = nullptr; sk_err_ = nullptr; sk_used_ = false;
   seaco_hw_valid_ = false;
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
@@ -160,11 +160,16 @@ void Engine::sync() {
 void Engine::sk_prepare(int M, int calls) {
   const size_t slab = round_up((int64_t)gemm_sk_slab_bytes(M), (int64_t)kAlign);
   sk_flag_stride_ = (size_t)round_up((int64_t)gemm_sk_flag_bytes(M), (int64_t)kAlign);
-  const size_t flags = sk_flag_stride_ * (size_t)calls + kAlign;
+  const size_t flags = sk_flag_stride_ * (size_t)calls;
   ensure(ws_sk_, slab + flags);
   sk_slab_ = (float*)ws_sk_.p;
   sk_flags_ = (unsigned*)((char*)ws_sk_.p + slab);
-  sk_err_ = (unsigned*)((char*)ws_sk_.p + slab + sk_flag_stride_ * (size_t)calls);
+  // the time-out word lives in its own allocation and is zeroed when it is created and after it has been read — NOT per
+  // pass: with several run_staged() calls queued before a sync an earlier pass's time-out must survive until the check
+  if (!sk_err_) {
+    sk_err_ = (unsigned*)dalloc(256);
+    PF_HIP(hipMemsetAsync(sk_err_, 0, 256, stream_));
+  }
   sk_calls_ = 0; sk_calls_cap_ = calls;
   PF_HIP(hipMemsetAsync(sk_flags_, 0, flags, stream_));
 }
@@ -173,7 +178,10 @@ void Engine::check_async_errors() {
   if (sk_used_) {                                    // a split-K pair whose partner never arrived (k_gemm_sk.hip)
     sk_used_ = false;
     unsigned flag = 0;
-    PF_HIP(hipMemcpy(&flag, sk_err_, 4, hipMemcpyDeviceToHost));
+    if (sk_err_) {
+      PF_HIP(hipMemcpy(&flag, sk_err_, 4, hipMemcpyDeviceToHost));
+      if (flag) PF_HIP(hipMemset(sk_err_, 0, 4));
+    }
     PF_CHECK(flag == 0, PF_ERR_DEVICE, "encoder: a split-K workgroup timed out waiting for its partner");
   }
   if (!lstm_err_) return;                            // the persistent recurrence raises this word when a spin timed out

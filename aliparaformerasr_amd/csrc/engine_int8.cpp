@@ -121,6 +121,9 @@ void Engine::fgemm_in_int8(const char* cls, const Lin& l, bool bias, const float
     const int64_t Mp = round_up(M, 256) + 256;
     ensure(ws_qf_, (size_t)Mp * l.Kpad * 2);
     half_t* a16 = (half_t*)ws_qf_.p;
+    // the conversion writes K of Kpad columns per row: the pad columns meet zero weight columns in the GEMM, but the
+    // arena is re-carved per call and a stale Inf / NaN bit pattern times zero is NaN — clear them
+    if (l.K != l.Kpad) PF_HIP(hipMemsetAsync(a16, 0, (size_t)Mp * l.Kpad * 2, stream_));
     prof_begin("layernorm", 0);
     if (ln) launch_layernorm(stream_, x32, M, ln->D, ln->g, ln->b, a16, l.Kpad, nullptr, 0);
     else launch_f32_to_f16(stream_, x32, M, l.K, ldx, a16, l.Kpad);

@@ -110,8 +110,9 @@ namespace AliParaformerAsr.Hip
 
         public void Dispose()
         {
-            if (_r != IntPtr.Zero) ParaformerHip.pf_recognizer_dispose(_r);      // later calls: ObjectDisposedException
-            GC.SuppressFinalize(this);
+            // frees the engine(s) now; later calls answer ObjectDisposedException.  The finaliser is NOT suppressed: it
+            // releases the handle shell (pf_recognizer_free), exactly as OfflineStream does above.
+            if (_r != IntPtr.Zero) ParaformerHip.pf_recognizer_dispose(_r);
         }
         ~OfflineRecognizer() { if (_r != IntPtr.Zero) { ParaformerHip.pf_recognizer_free(_r); _r = IntPtr.Zero; } }
     }

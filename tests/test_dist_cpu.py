@@ -84,6 +84,30 @@ def test_broadcast_and_gather_world2(n_total):
             assert (full[u, n:] == -1).all()
 
 
+def test_broadcast_and_gather_world4_unequal_shards():
+    """1025 utterances over 4 ranks: shards of 257 / 257 / 257 / 254 (ceil(B/G) blocks, the last one short) — the padded
+    rows of the short shard must be dropped and the caller's order restored, in both gather forms."""
+    n_total, world = 1025, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [sh.shard_bounds(n_total, world, r) for r in range(world)] == [(0, 257), (257, 514), (514, 771), (771, 1025)]
+    assert all(o[1] for o in outs) and len({o[2] for o in outs}) == 1
+    for _, _, _, full in outs:
+        assert full.shape == (n_total, 16)
+        for u in range(n_total):
+            n = 3 + u % 5
+            np.testing.assert_array_equal(full[u, :n], np.arange(u, u + n))
+            assert (full[u, n:] == -1).all()
+
+
 def _pipeline_worker(rank, world, port, E, steps, q):
     """bench.py --gpus N --in-flight E in miniature: E fake engines per rank whose steps take random, rank-dependent times;
     the gathers must still pair step i of every rank (one communicator, collectives in global step order)."""

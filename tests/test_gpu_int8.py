@@ -254,7 +254,7 @@ def test_int8_seaco_timestamp_vs_oracle():
     # bars: the paraformer test's (0.3 / 3e-2) scaled for the depth of this graph — the hot-word rows pass through the ASR
     # decoder AND a bias-decoder pass, every Linear of which flips a few uint8 codes at rounding boundaries (measured
     # 0.35 / 5.4e-2)
-    assert err[clear].max() < 0.7 and err[clear].mean() < 9e-2
+    assert err[clear].max() < 0.46 and err[clear].mean() < 7e-2    # 1.3 x the measured 0.35 / 5.4e-2
     # both branches must have acted for the test to mean anything
     took = (np.abs(ref["logits"] - ref["asr_logits"]).max(axis=-1) > 0)
     print("int8 seaco: %d of %d positions take the hot-word log-probs" % (took.sum(), took.size))
