@@ -521,6 +521,19 @@ int pf_op_ffn(pf_engine* h, const float* x, const float* w1, const float* b1, co
   return PF_OK;
   PF_CATCH
 }
+int pf_op_ffn_fused(pf_engine* h, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                    const float* resid, const float* g, const float* be, int32_t M, float* x_out, float* n16_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(x); NEED(w1); NEED(b1); NEED(w2); NEED(b2);
+  PF_CHECK(x_out || n16_out, PF_ERR_INVALID_ARG, "ffn_fused: no output requested");
+  PF_CHECK((g != nullptr) == (be != nullptr) && (g || !n16_out), PF_ERR_INVALID_ARG, "ffn_fused: the LayerNorm output needs gamma and beta");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_ffn_fused(x, w1, b1, w2, b2, resid, g, be, M, x_out, n16_out);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_fsmn_enc(pf_engine* h, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y) {
   PF_TRY
   std::shared_ptr<Engine> eh_ = E(h);

@@ -61,6 +61,8 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_SK_MIN"); if (e && e[0]) sk_min_wgs_ = atoi(e); }
   { const char* e = getenv("PF_SK_FFN2"); if (e && e[0]) sk_ffn2_ = atoi(e); }     // A/B: split-K row-complete FFN-down + LayerNorm (k_gemm_sk.hip)
   { const char* e = getenv("PF_RC_FFN2"); if (e && e[0]) rc_ffn2_ = e[0] != '0'; }   // A/B switch for tools/: the unfused encoder sequence
+  { const char* e = getenv("PF_FFN_FUSED"); if (e && e[0]) ffn_fused_ = e[0] != '0'; }   // A/B: the whole FFN block in one launch (k_ffn.hip)
+  { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
@@ -353,6 +355,11 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     }
     PF_CHECK(L.out.N == D && L.out.K == D && L.w1.K == D && L.w1.N == mc_.ffn && L.w2.N == D && L.w2.K == L.w1.N,
              PF_ERR_FORMAT, "weights: attn.out / ffn shape mismatch in " + p);
+    if (ffn_fused_ && ffn_fused_applicable(D, mc_.ffn) && !fp32_mode_ && !int8_mode_ && L.w1.w && L.w2.w) {
+      // W1 and W2 once more, in the fragment order the fused FFN kernel streams (4 MiB per layer)
+      L.ffn_wt = (half_t*)dalloc(ffn_fused_weight_bytes());
+      launch_ffn_retile(stream_, L.w1.w, L.w1.Kpad, L.w2.w, L.w2.Kpad, L.ffn_wt);
+    }
     return L;
   };
   for (int i = 0; i < mc_.enc_layers; ++i)
@@ -935,6 +942,18 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
     prof_begin("layernorm", 0);
     launch_layernorm(stream_, x_, M, D, L.norm2.g, L.norm2.b, xn16_, D, nullptr, 0);
     prof_end("layernorm");
+  }
+  if (rc && L.ffn_wt && M >= ffn_fused_min_rows_) {
+    // the whole feed-forward block + the NEXT LayerNorm in one launch (k_ffn.hip, round 5): the [M, 2048] hidden stays in
+    // LDS.  Measured against gemm_bigp_kernel + the row-complete FFN-down: see DESIGN.md 4.1g; PF_FFN_FUSED=0 restores them
+    FfnFusedArgs f{};
+    f.A = xn16_; f.lda = D; f.Wt = L.ffn_wt; f.b1 = L.w1.bias; f.b2 = L.w2.bias; f.M = M;
+    f.resid = x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
+    f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
+    prof_begin("gemm_ffn", 4.0 * M * (double)D * F);
+    launch_ffn_fused(stream_, f);
+    prof_end("gemm_ffn");
+    return;
   }
   // the FFN hidden lives in the blocked activation layout (kernels.h): FFN-up stores its fragments as whole
   // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
@@ -2325,6 +2344,62 @@ void Engine::op_ffn(const float* x, const float* w1, const float* b1, const floa
   gemm("gemm_ffn2", L2, (half_t*)(base + oh), F, M, xr, D, nullptr, 0, xr, D, nullptr, 0, false, 0, 1.f, true, 2);
   PF_HIP(hipMemcpyAsync(y, xr, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
+}
+
+// The encoder FFN block as enc_layer() launches it for long inputs: retile W1 / W2, then ONE launch of ffn_fused_kernel.
+void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
+                          const float* g, const float* be, int M, float* x_out, float* n16_out) {
+  PF_HIP(hipSetDevice(device_));
+  const int D = 512, F = 2048;
+  PF_CHECK(M > 0, PF_ERR_INVALID_ARG, "ffn_fused: M must be positive");
+  const int64_t Mp = round_up(M, 256) + 128;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * D, (int64_t)F * D) * 4);
+  const size_t ox16 = carve((size_t)Mp * D * 2), ow1 = carve((size_t)F * D * 2), ow2 = carve((size_t)D * F * 2);
+  const size_t owt = carve(ffn_fused_weight_bytes());
+  const size_t ob1 = carve((size_t)F * 4), ob2 = carve((size_t)D * 4), og = carve((size_t)D * 4), obe = carve((size_t)D * 4);
+  const size_t oxr = carve((size_t)Mp * D * 4), oxo = carve((size_t)Mp * D * 4), on16 = carve((size_t)Mp * D * 2);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));
+  PF_HIP(hipMemsetAsync(base + oxr, 0, (size_t)Mp * D * 4, stream_));
+  auto up16 = [&](const float* src, int rows, int cols, size_t dst) {
+    PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), cols);
+    PF_HIP(hipStreamSynchronize(stream_));
+  };
+  up16(x, M, D, ox16); up16(w1, F, D, ow1); up16(w2, D, F, ow2);
+  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+  if (resid) PF_HIP(hipMemcpyAsync(base + oxr, resid, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
+  launch_ffn_retile(stream_, (half_t*)(base + ow1), D, (half_t*)(base + ow2), F, (half_t*)(base + owt));
+  FfnFusedArgs f{};
+  f.A = (half_t*)(base + ox16); f.lda = D; f.Wt = (half_t*)(base + owt); f.b1 = (const float*)(base + ob1); f.b2 = (const float*)(base + ob2);
+  f.M = M; f.resid = (const float*)(base + oxr); f.ldr = D; f.eps = 1e-12f;
+  if (x_out) { f.out_x = (float*)(base + oxo); f.ldx = D; }
+  if (g) {
+    PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+    PF_HIP(hipMemcpyAsync(base + obe, be, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+    f.ln_g = (const float*)(base + og); f.ln_b = (const float*)(base + obe);
+    if (n16_out) { f.out_n16 = (half_t*)(base + on16); f.ldn16 = D; }
+  }
+  const char* rep = getenv("PF_OP_REPEAT");                        // tools/: repeated launches, timed as class "gemm_op_warm"
+  const int reps = rep ? std::max(1, atoi(rep)) : 1;
+  for (int r = 0; r < reps; ++r) {                                 // (resid is a separate buffer: repeats compute the same result)
+    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F);
+    launch_ffn_fused(stream_, f);
+    prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
+  }
+  if (x_out) PF_HIP(hipMemcpyAsync(x_out, base + oxo, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  std::vector<half_t> n16;
+  if (f.out_n16) {
+    n16.resize((size_t)M * D);
+    PF_HIP(hipMemcpyAsync(n16.data(), base + on16, n16.size() * 2, hipMemcpyDeviceToHost, stream_));
+  }
+  PF_HIP(hipStreamSynchronize(stream_));
+  if (f.out_n16)
+    for (size_t i = 0; i < n16.size(); ++i) n16_out[i] = (float)n16[i];
 }
 
 // Encoder FSMN exactly as enc_layer() launches it: the f16 V slice of a [M, 3D] QKV buffer (row stride 3D).

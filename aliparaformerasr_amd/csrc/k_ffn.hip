@@ -1,0 +1,432 @@
+// k_ffn.hip — the encoder's WHOLE position-wise feed-forward block in one launch (round 5):
+//
+//   h = relu(xn W1^T + b1)                     xn [M,512] f16 (LayerNorm norm2 of the residual stream), W1 [2048,512]
+//   x = x + h W2^T + b2                        W2 [512,2048]; x fp32 residual stream
+//   n = LayerNorm_next(x) * gamma + beta       -> f16 operand of the next layer's QKV projection (and / or fp32)
+//
+// i.e. the MatMul + Add + Relu + MatMul + Add + Add + LayerNormalization nodes of one SAN-M encoder layer of the graph
+// executed behind AliParaformerAsr/OfflineProjOfParaformer.cs:68.  Before: FFN-up (gemm_bigp_kernel, 40.6 us) wrote the
+// [16000 x 2048] f16 hidden to HBM (65.5 MB) and the row-complete FFN-down (52.2 us) read it back — 131 MB of the ~600 MB an
+// encoder layer moved, and two launches.  Here the hidden never leaves the compute unit.
+//
+// Geometry: one workgroup = 64 rows (M = 16 000 -> 250 workgroups on 256 CUs, one round), 8 wavefronts, hidden in 8 chunks
+// of 256 columns.  Per chunk c
+//   U: wave w computes H^T[32 hidden (its eighth of the chunk) x 64 rows] = W1[c,w] * xn^T over K = 512: 32 k-steps of
+//      2 MFMA 32x32x16, the bias is added at the end of the phase; xn comes from the resident 64 KB LDS tile, the W1 fragment of a
+//      k-step is used by this wave ONLY;
+//      relu -> f16 -> one 16-byte LDS cell per (row, 8 hidden): the cell IS the B-operand fragment of the second product
+//      (the k index of an MFMA is a summation index: W2's columns are permuted once at load so that its fragments meet
+//      the order in which a D^T accumulator holds the hidden — no transposition anywhere);
+//   D: wave w accumulates Y^T[64 output columns (its eighth) x 64 rows] += W2[w, c] * H^T: 16 k-steps of 4 MFMA; again
+//      the W2 fragments are private to the wave.
+// Because a 64-row tile leaves every weight fragment to exactly one wave, staging W through LDS would be a private FIFO
+// that costs LDS capacity (the xn tile and the hidden need 128 KB) and LDS bandwidth for nothing: W1 and W2 are PRE-TILED
+// at load into fragment order (1 KiB per wave-instruction, 32 KiB sequential per (chunk, wave)) and read straight into
+// registers with global_load_dwordx4, PF issue positions ahead of their use.  tools/ubench/ldbw3.hip: an L2-resident
+// stream reaches 114 GB/s per CU through that path with 6 loads per wave in flight (126 through LDS-DMA); a tile needs
+// 4 MiB in ~40 us = 100 GB/s.  The chunk loop is FULLY unrolled: in straight-line code the compiler's s_waitcnt insertion
+// counts the loads in flight exactly (across a loop back edge it falls back to vmcnt(0), which would drain the stream
+// at every chunk).
+// Epilogue = k_gemm_rc.hip's: the 64 x 512 fp32 tile goes through LDS, every wave owns 8 complete rows: bias + residual
+// -> x, LayerNorm (two-pass statistics on DPP wave sums) -> f16 / fp32.
+#include "kernels.h"
+
+#include <mutex>
+
+namespace pf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+typedef float4 __attribute__((may_alias)) float4a;
+
+struct FfnDev {
+  const half_t* A; const half_t* W1t; const half_t* W2t; const float* b1; const float* b2;
+  const float* resid; float* out_x;
+  const float* ln_g; const float* ln_b; half_t* out_n16; float* out_n32;
+  int lda, ldr, ldx, ldn16, ldn32;
+  int M, rot_mask;
+  float eps;
+};
+
+constexpr int FF_BM = 64, FF_D = 512, FF_F = 2048, FF_HC = 256, FF_NC = FF_F / FF_HC;   // 8 chunks
+constexpr int FF_A_BYTES = FF_BM * FF_D * 2;              // 64 KiB: 8 k-blocks of [64 rows][128 B]
+constexpr int FF_H_BYTES = FF_BM * FF_HC * 2;             // 32 KiB per hidden buffer (two of them)
+constexpr int FF_XROW = FF_D * 4 + 16;                    // epilogue tile row: 16-byte skew (conflict-free dump)
+constexpr int FF_B_OFF = FF_A_BYTES + 2 * FF_H_BYTES;      // b1 (8 KiB) behind the hidden buffers
+constexpr int FF_LDS = FF_B_OFF + FF_F * 4;                // 139 264 B (the epilogue's 64 x 2064-byte tile re-uses the front)
+static_assert(FF_BM * FF_XROW <= FF_LDS, "epilogue tile must fit");
+
+__device__ __forceinline__ void ff_glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ float ff_wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
+}
+// LDS traffic between waves: writes retired before the barrier, nothing moved across it (local address space only: the
+// weight loads in flight must NOT be drained)
+__device__ __forceinline__ void ff_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// PF: how many weight fragments (1 KiB per wave each) a wave keeps in flight ahead of the one it multiplies
+// ABL (tools/ffn_abl.sh; results are garbage, only the times matter): bit 0 = no weight loads in the main loop, bit 1 = no
+// LDS fragment reads in the main loop, bit 2 = no MFMA, bit 3 = no chunk barriers
+// XD: how many k-steps ahead of their MFMAs the LDS fragment reads are issued (ring of XD + 1 fragment pairs)
+template <int PF, int ABL = 0, int XD = 2>
+__global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lh = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * FF_BM;
+  const int rot = (int)(blockIdx.x >> 3) & p.rot_mask;     // chunk order rotated per workgroup (spreads the L2 lines in time)
+  auto swz = [](int row) __attribute__((always_inline)) -> int { return (row >> 1) & 7; };
+
+  // ---- weight stream: position gp = c * 64 + pos; pos 0..31 = W1 fragment of k-step pos, 32..63 = W2 fragment (t, j) = ((pos - 32) / 2, pos & 1)
+  // (uniform base in SGPRs + the lane's 32-bit byte offset: the saddr form of global_load, no 64-bit VGPR pointers)
+  const half_t* w1u = p.W1t + (size_t)wave * (32 * 512);
+  const half_t* w2u = p.W2t + (size_t)wave * (32 * 512);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto wload = [&](int gp) __attribute__((always_inline)) -> h8 {
+    const int c = gp >> 6, pos = gp & 63;
+    const int cc = (c + rot) & (FF_NC - 1);
+    const half_t* b = (pos < 32 ? w1u : w2u) + (size_t)cc * (8 * 32 * 512) + (pos & 31) * 512;
+    return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(b) + lane16);
+  };
+  constexpr int NPOS = FF_NC * 64;
+  h8 ring[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) ring[i] = wload(i);
+
+  // ---- the 64 x 512 xn tile -> LDS (8 k-blocks of [64 rows][128 B], 16-byte chunks XOR-swizzled by row: the fragment
+  //      reads below are conflict-free); wave w brings rows 8w .. 8w+7 of every k-block
+  {
+    const int srow = lane >> 3, schunk = lane & 7;
+    const int row = wave * 8 + srow;
+    const char* src = reinterpret_cast<const char*>(p.A + (size_t)(m0 + row) * p.lda) + ((schunk ^ swz(row)) << 4);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) ff_glds16(src + kb * 128, smem + kb * 8192 + wave * 1024);
+    // b1 (2048 floats) as it is: read back per chunk with ds_read — a global load used right behind its issue would make
+    // the compiler wait for vmcnt(0), i.e. drain the weight stream
+    ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
+  }
+  // fragment read offsets of the xn tile: row half i, 16-byte k-group (2 ss + lh) of a k-block
+  unsigned xo[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) {
+      const int ra = i * 32 + l31;
+      xo[i][ss] = (unsigned)(ra * 128 + (((2 * ss + lh) ^ swz(ra)) << 4));
+    }
+  const unsigned ho = (unsigned)(FF_A_BYTES + lane * 16);          // hidden cells: ((i * 16 + t) * 2 + lh) * 512 + row * 16
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tile (and the first PF weight fragments) have landed
+  __builtin_amdgcn_s_barrier();
+
+  f16x yacc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) yacc[i][j][e] = 0.f;
+
+#pragma unroll
+  for (int c = 0; c < FF_NC; ++c) {
+    const int cc = (c + rot) & (FF_NC - 1);
+    // ---- U: hidden^T[32 x 64] of this wave, accumulators start as the bias
+    f16x hacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) hacc[i][e] = 0.f;
+    constexpr int XR = XD + 1;
+    h8 xf[XR][2];
+#pragma unroll
+    for (int s0 = 0; s0 < XD; ++s0)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xf[s0][i] = *reinterpret_cast<const h8*>(smem + xo[i][s0 & 3] + (s0 >> 2) * 8192);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int gp = c * 64 + s;
+      if (s + XD < 32 && !(ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xf[(s + XD) % XR][i] = *reinterpret_cast<const h8*>(smem + xo[i][(s + XD) & 3] + ((s + XD) >> 2) * 8192);
+      } else if (s + XD < 32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xf[(s + XD) % XR][i] = xf[s % XR][i];
+      }
+      const h8 w = ring[gp % PF];
+      if (!(ABL & 1) && gp + PF < NPOS) ring[gp % PF] = wload(gp + PF);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!(ABL & 4)) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xf[s % XR][i], hacc[i], 0, 0, 0);
+        else { hacc[i][0] += (float)w[0]; hacc[i][1] += (float)xf[s % XR][i][0]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // relu -> f16 -> the cells of k-steps t = 2 wave, 2 wave + 1 of the second product
+    {
+      char* hb = smem + ho + (c & 1) * FF_H_BYTES;
+      float4 bias4[4];                                     // hidden columns 8 g + 4 lh + 0..3 of this wave's 32
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias4[g] = *reinterpret_cast<const float4a*>(smem + FF_B_OFF + (cc * FF_HC + wave * 32 + 8 * g + 4 * lh) * 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          h8 v;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float4 b4 = bias4[2 * tt + (q >> 2)];
+            const float f = hacc[i][8 * tt + q] + ((q & 3) == 0 ? b4.x : (q & 3) == 1 ? b4.y : (q & 3) == 2 ? b4.z : b4.w);
+            v[q] = (half_t)(f > 0.f ? f : 0.f);
+          }
+          *reinterpret_cast<h8*>(hb + (i * 16 + 2 * wave + tt) * 1024) = v;
+        }
+    }
+    if (!(ABL & 8)) ff_lds_barrier();
+    // ---- D: Y^T[64 x 64] of this wave += W2[wave, chunk] * hidden^T
+    {
+      const char* hb = smem + ho + (c & 1) * FF_H_BYTES;
+      h8 hf[XR][2];
+#pragma unroll
+      for (int t0 = 0; t0 < XD; ++t0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hf[t0][i] = *reinterpret_cast<const h8*>(hb + (i * 16 + t0) * 1024);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int gp = c * 64 + 32 + 2 * t;
+        if (t + XD < 16 && !(ABL & 2)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) hf[(t + XD) % XR][i] = *reinterpret_cast<const h8*>(hb + (i * 16 + t + XD) * 1024);
+        } else if (t + XD < 16) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) hf[(t + XD) % XR][i] = hf[t % XR][i];
+        }
+        h8 w2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          w2[j] = ring[(gp + j) % PF];
+          if (!(ABL & 1) && gp + j + PF < NPOS) ring[(gp + j) % PF] = wload(gp + j + PF);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (!(ABL & 4)) yacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[j], hf[t % XR][i], yacc[i][j], 0, 0, 0);
+            else { yacc[i][j][0] += (float)w2[j][0]; yacc[i][j][1] += (float)hf[t % XR][i][0]; }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- epilogue (k_gemm_rc.hip's): wave w owns rows 8w .. 8w+7 completely; lane: columns 4 lane and 256 + 4 lane
+  // (the lane index is re-derived here with mbcnt: keeping the work-item id alive across the unrolled main loop costs
+  //  two spilled registers, i.e. a scratch arena, for nothing)
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int lh_e = lane_e >> 5, l31_e = lane_e & 31;
+  const int r0 = wave * 8;
+  const int mb = m0 + r0;
+  float4 xv[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.resid && mb + r < p.M)
+        xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane_e);
+    }
+  ff_lds_barrier();                                        // every wave has finished reading the hidden and the xn tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    char* rowp = smem + (size_t)(i * 32 + l31_e) * FF_XROW + (wave * 64 + 4 * lh_e) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4a*>(rowp + (j * 32 + 8 * g) * 4) =
+            make_float4(yacc[i][j][4 * g + 0], yacc[i][j][4 * g + 1], yacc[i][j][4 * g + 2], yacc[i][j][4 * g + 3]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int col = h * 256 + 4 * lane_e;
+    const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * FF_XROW + col * 4);
+      xv[h][r].x += v.x + b4.x; xv[h][r].y += v.y + b4.y; xv[h][r].z += v.z + b4.z; xv[h][r].w += v.w + b4.w;
+    }
+    if (p.out_x) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[h][r];
+    }
+  }
+  if (!p.ln_g) return;
+  float4 g4[2], be4[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    g4[h] = *reinterpret_cast<const float4*>(p.ln_g + h * 256 + 4 * lane_e);
+    be4[h] = *reinterpret_cast<const float4*>(p.ln_b + h * 256 + 4 * lane_e);
+  }
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float s = ((xv[0][r].x + xv[0][r].y) + (xv[0][r].z + xv[0][r].w)) + ((xv[1][r].x + xv[1][r].y) + (xv[1][r].z + xv[1][r].w));
+    mean[r] = ff_wave_sum(s) * (1.0f / FF_D);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float m = mean[r];
+    xv[0][r].x -= m; xv[0][r].y -= m; xv[0][r].z -= m; xv[0][r].w -= m;
+    xv[1][r].x -= m; xv[1][r].y -= m; xv[1][r].z -= m; xv[1][r].w -= m;
+    const float q = ((xv[0][r].x * xv[0][r].x + xv[0][r].y * xv[0][r].y) + (xv[0][r].z * xv[0][r].z + xv[0][r].w * xv[0][r].w)) +
+                    ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
+    rstd[r] = 1.0f / sqrtf(ff_wave_sum(q) * (1.0f / FF_D) + p.eps);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = mb + r;
+    if (m < p.M) {
+      const float k = rstd[r];
+      const float4 d0 = xv[0][r], d1 = xv[1][r];
+      const float4 y0 = make_float4(d0.x * k * g4[0].x + be4[0].x, d0.y * k * g4[0].y + be4[0].y,
+                                    d0.z * k * g4[0].z + be4[0].z, d0.w * k * g4[0].w + be4[0].w);
+      const float4 y1 = make_float4(d1.x * k * g4[1].x + be4[1].x, d1.y * k * g4[1].y + be4[1].y,
+                                    d1.z * k * g4[1].z + be4[1].z, d1.w * k * g4[1].w + be4[1].w);
+      if (p.out_n16) {
+        half_t* o = p.out_n16 + (size_t)m * p.ldn16 + 4 * lane_e;
+        *reinterpret_cast<h4*>(o) = h4{(half_t)y0.x, (half_t)y0.y, (half_t)y0.z, (half_t)y0.w};
+        *reinterpret_cast<h4*>(o + 256) = h4{(half_t)y1.x, (half_t)y1.y, (half_t)y1.z, (half_t)y1.w};
+      }
+      if (p.out_n32) {
+        float* o = p.out_n32 + (size_t)m * p.ldn32 + 4 * lane_e;
+        *reinterpret_cast<float4*>(o) = y0;
+        *reinterpret_cast<float4*>(o + 256) = y1;
+      }
+    }
+  }
+}
+
+// W1 [2048, ldw1] and W2 [512, ldw2] (f16, K-contiguous) -> the fragment-ordered images the kernel streams:
+//   W1t[((c * 8 + w) * 32 + s) * 512 + l * 8 + e] = W1[c * 256 + w * 32 + (l & 31)][16 s + 8 (l >> 5) + e]
+//   W2t[((c * 8 + w) * 32 + 2 t + j) * 512 + l * 8 + q] = W2[w * 64 + j * 32 + (l & 31)][c * 256 + 16 t + 8 (q >> 2) + 4 (l >> 5) + (q & 3)]
+// one thread per 16-byte piece (131 072 pieces each)
+__global__ void ffn_retile_kernel(const half_t* __restrict__ W1, int ldw1, const half_t* __restrict__ W2, int ldw2,
+                                  half_t* __restrict__ W1t, half_t* __restrict__ W2t) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * 131072) return;
+  const int which = idx >> 17, pc = idx & 131071;
+  const int l = pc & 63, piece = (pc >> 6) & 31, w = (pc >> 11) & 7, c = pc >> 14;
+  h8 v;
+  if (which == 0) {
+    const half_t* src = W1 + (size_t)(c * 256 + w * 32 + (l & 31)) * ldw1 + 16 * piece + 8 * (l >> 5);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[e];
+    *reinterpret_cast<h8*>(W1t + (size_t)pc * 8) = v;
+  } else {
+    const int t = piece >> 1, j = piece & 1;
+    const half_t* src = W2 + (size_t)(w * 64 + j * 32 + (l & 31)) * ldw2 + c * 256 + 16 * t + 4 * (l >> 5);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = src[8 * (q >> 2) + (q & 3)];
+    *reinterpret_cast<h8*>(W2t + (size_t)pc * 8) = v;
+  }
+}
+
+size_t ffn_fused_weight_bytes() { return (size_t)2 * 131072 * 16; }      // W1t | W2t: 2 MiB each
+
+void launch_ffn_retile(hipStream_t s, const half_t* W1, int ldw1, const half_t* W2, int ldw2, half_t* Wt) {
+  hipLaunchKernelGGL(ffn_retile_kernel, dim3(2 * 131072 / 256), dim3(256), 0, s, W1, ldw1, W2, ldw2, Wt, Wt + (size_t)131072 * 8);
+  PF_HIP(hipGetLastError());
+}
+
+bool ffn_fused_applicable(int D, int F) { return D == FF_D && F == FF_F; }
+
+void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
+  PF_CHECK(a.M > 0 && a.A && a.Wt && a.b1 && a.b2, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
+  PF_CHECK(a.lda % 8 == 0 && (!a.resid || a.ldr % 4 == 0) && (!a.out_x || a.ldx % 4 == 0) && (!a.out_n16 || a.ldn16 % 4 == 0) &&
+               (!a.out_n32 || a.ldn32 % 4 == 0),
+           PF_ERR_INVALID_ARG, "ffn_fused: leading dimensions must keep 16-byte (8-byte for f16) row alignment");
+  PF_CHECK(!a.ln_g == !a.ln_b && (a.ln_g || (!a.out_n16 && !a.out_n32)), PF_ERR_INVALID_ARG, "ffn_fused: LayerNorm outputs need gamma and beta");
+  PF_CHECK(a.out_x || a.out_n16 || a.out_n32, PF_ERR_INVALID_ARG, "ffn_fused: no output requested");
+  FfnDev d;
+  d.A = a.A; d.W1t = a.Wt; d.W2t = a.Wt + (size_t)131072 * 8; d.b1 = a.b1; d.b2 = a.b2;
+  d.resid = a.resid; d.out_x = a.out_x; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.out_n16 = a.out_n16; d.out_n32 = a.out_n32;
+  d.lda = a.lda; d.ldr = a.ldr; d.ldx = a.ldx; d.ldn16 = a.ldn16; d.ldn32 = a.ldn32;
+  d.M = a.M; d.eps = a.eps;
+  static std::mutex init_mu;
+  static bool attr_set[64] = {false};
+  static int rot_mask = 7, pf = 8, xd = 2, abl = 0;
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!attr_set[dev & 63]) {
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<12, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      if (const char* e = getenv("PF_FFN_ROT")) rot_mask = atoi(e) & 7;      // 0 | 1 | 3 | 7: chunk-order rotation period - 1
+      if (const char* e = getenv("PF_FFN_ABL")) abl = atoi(e);
+      if (const char* e = getenv("PF_FFN_XD")) xd = atoi(e);                 // LDS fragment reads 1 | 2 | 3 k-steps ahead
+      if (const char* e = getenv("PF_FFN_PF")) pf = atoi(e);                 // 8 | 12 fragments in flight per wave (16 spills)
+      attr_set[dev & 63] = true;
+    }
+  }
+  d.rot_mask = rot_mask;
+  const dim3 grid((unsigned)cdiv(a.M, FF_BM));
+#ifdef PF_FFN_ABLATIONS
+  if (abl) {
+    auto go = [&](auto kern) {
+      PF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      hipLaunchKernelGGL(kern, grid, dim3(512), FF_LDS, s, d);
+    };
+    switch (abl) {
+      case 1: go(ffn_fused_kernel<8, 1, 2>); break;
+      case 2: go(ffn_fused_kernel<8, 2, 2>); break;
+      case 3: go(ffn_fused_kernel<8, 3, 2>); break;
+      case 4: go(ffn_fused_kernel<8, 4, 2>); break;
+      case 7: go(ffn_fused_kernel<8, 7, 2>); break;
+      case 8: go(ffn_fused_kernel<8, 8, 2>); break;
+      case 15: go(ffn_fused_kernel<8, 15, 2>); break;
+      default: PF_CHECK(false, PF_ERR_INVALID_ARG, "PF_FFN_ABL: 1 | 2 | 3 | 4 | 7 | 8 | 15");
+    }
+    PF_HIP(hipGetLastError());
+    return;
+  }
+#endif
+  (void)abl;
+  if (pf >= 12) {                                       // 12 fragments in flight, LDS reads one k-step ahead
+    note_gemm_kernel("ffn_fused_kernel<12, 0, 1>");
+    hipLaunchKernelGGL((ffn_fused_kernel<12, 0, 1>), grid, dim3(512), FF_LDS, s, d);
+  } else if (xd >= 3) {
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 3>");
+    hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 3>), grid, dim3(512), FF_LDS, s, d);
+  } else if (xd == 2) {
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2>");
+    hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2>), grid, dim3(512), FF_LDS, s, d);
+  } else {
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 1>");
+    hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 1>), grid, dim3(512), FF_LDS, s, d);
+  }
+  PF_HIP(hipGetLastError());
+}
+
+}  // namespace pf

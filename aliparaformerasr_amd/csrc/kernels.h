@@ -144,6 +144,24 @@ size_t gemm_sk_flag_bytes(int M);
 // kernel at ~55 % of its CU time — for launches beside which another stream's kernels run
 void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err, bool split = true);
 
+// The encoder's whole feed-forward block in one launch (k_ffn.hip): x = resid + relu(A W1^T + b1) W2^T + b2;
+// n = LayerNorm(x).  d_model 512, hidden 2048; 64-row tiles, the hidden stays in LDS, W1 / W2 are streamed from their
+// fragment-ordered images (launch_ffn_retile, once per layer at load) straight into registers.
+struct FfnFusedArgs {
+  const half_t* A; int lda;                      // [M,512] f16 (LayerNorm norm2 of the residual stream), rows readable up to round_up(M,64)
+  const half_t* Wt;                              // ffn_fused_weight_bytes(): W1t | W2t
+  const float* b1; const float* b2;              // [2048], [512]
+  int M;
+  const float* resid; int ldr;                   // fp32 [M,512] or null; may alias out_x
+  float* out_x; int ldx;                         // fp32 [M,512] or null
+  const float* ln_g; const float* ln_b; float eps;
+  half_t* out_n16; int ldn16; float* out_n32; int ldn32;
+};
+bool ffn_fused_applicable(int D, int F);
+size_t ffn_fused_weight_bytes();
+void launch_ffn_retile(hipStream_t s, const half_t* W1, int ldw1, const half_t* W2, int ldw2, half_t* Wt);
+void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a);
+
 // ---------------------------------------------------------------- fp32 parity mode (k_fp32.hip) ----
 void launch_gemm_f32(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
                      float* out, int ldc, const float* resid, int ldr, bool relu, int scale_cols, float scale);

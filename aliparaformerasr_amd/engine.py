@@ -374,6 +374,22 @@ class Engine:
         N.check(self._lib.pf_op_ffn(self._h, _fp(x), _fp(w1), _fp(b1), _fp(w2), _fp(b2), _fp(resid), M, D, F, _fp(y)))
         return y
 
+    def op_ffn_fused(self, x, w1, b1, w2, b2, resid=None, ln=None):
+        """The encoder FFN block as ONE launch (k_ffn.hip): returns (x_out, n16_out or None);
+        ln = (gamma, beta) of the LayerNorm that follows."""
+        x, w1, b1, w2, b2 = map(_f32, (x, w1, b1, w2, b2))
+        M, D = x.shape
+        assert D == 512 and w1.shape == (2048, 512) and w2.shape == (512, 2048)
+        resid = _f32(resid) if resid is not None else None
+        g = _f32(ln[0]) if ln is not None else None
+        be = _f32(ln[1]) if ln is not None else None
+        xo = np.zeros((M, D), np.float32)
+        no = np.zeros((M, D), np.float32) if ln is not None else None
+        N.check(self._lib.pf_op_ffn_fused(self._h, _fp(x), _fp(w1), _fp(b1), _fp(w2), _fp(b2),
+                                          _fp(resid) if resid is not None else None, _fp(g) if g is not None else None,
+                                          _fp(be) if be is not None else None, M, _fp(xo), _fp(no) if no is not None else None))
+        return xo, no
+
     def op_fsmn_enc(self, v, w) -> np.ndarray:
         v, w = _f32(v), _f32(w)
         B, T, D = v.shape

@@ -56,13 +56,15 @@ GOLDEN_MARGIN = 0.05          # = MARGIN of tests/test_gpu_full_depth.py (the tw
 ALPHA_NEAR = 0.1              # an oracle sum(alpha) this close to an integer is a near-tie of token_num = floor(sum alpha)
 # kernel classes of Engine::prof_begin (csrc/engine.cpp); the roofline object describes whichever encoder GEMM class
 # takes the most time in a step (found by an untimed profiling step before the timed region)
-CLASSES = ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn1",
+CLASSES = ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_ffn", "gemm_ffn1",
            "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn1", "gemm_dec_ffn2",
            "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc",
            "seaco_embed", "gemm_seaco", "attn_seaco", "seaco_merge", "quantize")
 # (N, K, what) of the encoder GEMM classes: [rows x K] x [K x N]
 GEMM_SHAPES = {"gemm_qkv": (1536, 512, "QKV projection + bias, q scaled"),
                "gemm_out": (512, 512, "attention out-projection + bias + residual + FSMN memory + LayerNorm"),
+               # the whole FFN block in one launch (k_ffn.hip, round 5): two products, 4 M D F FLOPs; (N, K) name the first
+               "gemm_ffn": (2048, 512, "whole FFN block in one launch: up-projection + bias + ReLU -> down-projection + bias + residual + the next LayerNorm, hidden kept in LDS"),
                "gemm_ffn1": (2048, 512, "FFN up-projection + bias + ReLU"),
                "gemm_ffn2": (512, 2048, "FFN down-projection + bias + residual (+ the next LayerNorm when the row-complete kernel runs it)")}
 
@@ -82,8 +84,8 @@ def roofline_object(dom_kernel, dominant, dom_rows, Nn, Kk, what, flops, alg_byt
     hbm = intensity < balance
     return {"bound": "hbm" if hbm else "mfma",
             "peak_note": "dense f16 MFMA; the int8 MFMA peak is 2x" if int8 else None,
-            "kernel": "%s (class %s, the encoder GEMM class with the largest share of the step: [%d x %d] x [%d x %d], %s)"
-                      % (dom_kernel, dominant, dom_rows, Kk, Kk, Nn, what),
+            "kernel": "%s (class %s, the encoder GEMM class with the largest share of the step: [%d x %d] x [%d x %d]%s, %s)"
+                      % (dom_kernel, dominant, dom_rows, Kk, Kk, Nn, " -> x [%d x %d]" % (Nn, Kk) if dominant == "gemm_ffn" else "", what),
             "achieved": gbps if hbm else tf, "peak": PEAK_HBM_GBPS if hbm else PEAK_F16_TFLOPS,
             "unit": "GB/s" if hbm else "TFLOP/s",
             "frac": (gbps / PEAK_HBM_GBPS) if hbm else (tf / PEAK_F16_TFLOPS),
@@ -603,8 +605,9 @@ def main():
         flops_step = eng.last_flops()
         avg_s = (ms_dom / max(n_dom, 1)) * 1e-3
         Nn, Kk, what = GEMM_SHAPES[dominant]
-        dom_rows = int(round(fpl_dom / (2.0 * Nn * Kk)))
-        alg_bytes = {"gemm_qkv": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
+        dom_rows = int(round(fpl_dom / ((4.0 if dominant == "gemm_ffn" else 2.0) * Nn * Kk)))
+        alg_bytes = {"gemm_ffn": dom_rows * (512 * 2 + 512 * 4 + 512 * 4 + 512 * 2) + 2 * 2048 * 512 * 2 + (2048 + 512) * 4,   # xn16 in, x in / out (fp32), next xn16 out, W1 + W2
+                     "gemm_qkv": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
                      "gemm_out": dom_rows * (Kk * 2 + Nn * 2 + Nn * 4 + Nn * 4 + Nn * 2) + Nn * Kk * 2 + Nn * 4,
                      "gemm_ffn1": dom_rows * (Kk * 2 + Nn * 2) + Nn * Kk * 2,
                      # (+ the f16 LayerNorm result when the row-complete kernel carries the next LayerNorm)

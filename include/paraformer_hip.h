@@ -318,6 +318,11 @@ int pf_op_gemm_rc(pf_engine* e, const pf_gemm_rc_desc* d, const float* A, const 
    x [M,D], w1 [F,D], w2 [D,F], resid / y [M,D]. */
 int pf_op_ffn(pf_engine* e, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
               const float* resid, int32_t M, int32_t D, int32_t F, float* y);
+/* The same block as the pipeline launches it for long inputs since round 5 (k_ffn.hip, ONE launch, the hidden stays in
+   LDS; d_model 512, hidden 2048): x_out = resid + W2 relu(W1 x + b1) + b2 [M,512] (may be NULL), n16_out = the f16
+   LayerNorm(x_out; gamma, beta) widened to fp32 (NULL, or with gamma / beta).  resid may be NULL (zeros). */
+int pf_op_ffn_fused(pf_engine* e, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                    const float* resid, const float* ln_gamma, const float* ln_beta, int32_t M, float* x_out, float* n16_out);
 /* Encoder FSMN kernel (f16 V slice of a [B*T, 3D] buffer in, fp32 out): y = dwconv_k(v) + v. */
 int pf_op_fsmn_enc(pf_engine* e, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y);
 /* Decoder FSMN kernel: x += (dwconv_k(tn*m) + tn*m)*m, m = (l < token_num[b]); x in/out [B,L,D]. */

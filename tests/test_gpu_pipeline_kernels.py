@@ -178,6 +178,42 @@ def test_ffn_blocked_handoff_at_bench_rows(eng):
     assert np.abs(got - ref).mean() < 1e-4
 
 
+@pytest.mark.parametrize("M", [16000, 10880, 64000, 2048 + 37, 64, 1])
+def test_ffn_fused_kernel(eng, M):
+    """The whole encoder FFN block + the next LayerNorm in ONE launch (k_ffn.hip, round 5) at the row counts of the three
+    BASELINE workloads (32 x 500, 64 x 170, 128 x 500) and ragged / tiny ones.  Reference: fp64 products of the f16-rounded
+    operands with the hidden rounded to f16 where the kernel rounds it (after bias + ReLU), then the exact LayerNorm."""
+    rng = np.random.default_rng(90 + M % 7)
+    D, F = 512, 2048
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    resid = (2 * rng.standard_normal((M, D))).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    rows = np.unique(np.concatenate([np.arange(min(M, 96)), rng.integers(0, M, 256), np.arange(max(0, M - 70), M)]))
+    xs = h16(x[rows]).astype(np.float64)
+    h = h16(np.maximum(xs @ h16(w1).T.astype(np.float64) + b1, 0).astype(np.float32)).astype(np.float64)
+    ref = h @ h16(w2).T.astype(np.float64) + b2 + resid[rows]
+    mu = ref.mean(-1, keepdims=True)
+    ln = (ref - mu) / np.sqrt(((ref - mu) ** 2).mean(-1, keepdims=True) + 1e-12) * g + be
+    got_x, got_n = eng.op_ffn_fused(x, w1, b1, w2, b2, resid, ln=(g, be))
+    # hidden values on an f16 rounding boundary may round the other way (fp32 accumulation order): each flips one
+    # operand of the second product by 2^-11 relative
+    np.testing.assert_allclose(got_x[rows], ref, rtol=2e-4, atol=2e-3)
+    assert np.abs(got_x[rows] - ref).mean() < 1e-4
+    np.testing.assert_allclose(got_n[rows], ln, rtol=2e-3, atol=2e-3)          # f16 result
+    # no residual, no LayerNorm: the bare block
+    got2, none = eng.op_ffn_fused(x, w1, b1, w2, b2)
+    assert none is None
+    np.testing.assert_allclose(got2[rows], ref - resid[rows], rtol=2e-4, atol=2e-3)
+    # and against the two-launch form the pipeline used before (same rounding points)
+    if M <= 16000:
+        np.testing.assert_allclose(got_x, eng.op_ffn(x, w1, b1, w2, b2, resid), rtol=2e-4, atol=2e-3)
+
+
 def test_fsmn_enc_kernel_f16_strided(eng):
     rng = np.random.default_rng(10)
     for (B, T) in ((32, 500), (2, 83), (3, 7), (1, 1), (2, 166)):
