@@ -138,6 +138,7 @@ SIGNATURES = {
     "pf_stream_num_feature_floats": (C.c_int, [_vp, _i32]),
     "pf_stream_dispose": (None, [_vp]),
     "pf_stream_free": (None, [_vp]),
+    "pf_recognizer_num_engines": (C.c_int, [_vp]),
     "pf_recognizer_get_results": (C.c_int, [_vp, _P(_vp), C.c_int32]),
     "pf_result_text": (C.c_int, [_vp, C.c_int32, _cpp, _i32]),
     "pf_result_num_tokens": (C.c_int, [_vp, C.c_int32, _i32]),

@@ -673,6 +673,15 @@ pf_engine* pf_recognizer_engine(pf_recognizer* h) {
   return h->eng.e ? &h->eng : nullptr;
 }
 
+static std::shared_ptr<Recognizer> R(pf_recognizer* h);
+int pf_recognizer_num_engines(pf_recognizer* h) {
+  PF_TRY
+  std::shared_ptr<Recognizer> r = R(h);
+  PF_CHECK(!r->disposed(), PF_ERR_DISPOSED, "OfflineRecognizer");
+  return r->engines_created();
+  PF_CATCH
+}
+
 static std::shared_ptr<Recognizer> R(pf_recognizer* h) {
   PF_CHECK(h != nullptr, PF_ERR_INVALID_ARG, "null recognizer");
   std::lock_guard<std::mutex> lk(h->mu);

@@ -719,6 +719,7 @@ int Engine::num_lfr_frames(int64_t n) const {
 void Engine::stage_audio(const float* const* samples, const int64_t* n, int B, int force_T) {
   PF_CHECK(B >= 0, PF_ERR_INVALID_ARG, "negative batch");
   PF_HIP(hipSetDevice(device_));
+  st_audio_ext_ = nullptr;
   st_B_ = B;
   st_n_.assign(n, n + B);
   st_t80_.resize(B);
@@ -750,6 +751,41 @@ void Engine::stage_audio(const float* const* samples, const int64_t* n, int B, i
   PF_HIP(hipStreamSynchronize(stream_));
 }
 
+void Engine::stage_device_audio(const float* const* samples_dev, const int64_t* n, int B, int force_T) {
+  PF_CHECK(B >= 0, PF_ERR_INVALID_ARG, "negative batch");
+  PF_HIP(hipSetDevice(device_));
+  st_B_ = B;
+  st_n_.assign(n, n + B);
+  st_t80_.resize(B);
+  // offsets are relative to the LOWEST of the buffers (element offsets, non-negative): the fbank kernel adds them to one base
+  uintptr_t lo = UINTPTR_MAX;
+  for (int b = 0; b < B; ++b) {
+    if (!samples_dev[b] && n[b] > 0) throw Error(PF_ERR_NULL_SAMPLES, "source");
+    PF_CHECK(n[b] >= 0 && ((uintptr_t)samples_dev[b] & 3) == 0, PF_ERR_INVALID_ARG, "device audio must be 4-byte aligned");
+    if (n[b] > 0) lo = std::min(lo, (uintptr_t)samples_dev[b]);
+  }
+  if (lo == UINTPTR_MAX) lo = 0;
+  std::vector<int64_t> meta(3 * (size_t)(B + 1), 0);   // audio_off | n_samples | frame_off
+  int64_t frames = 0;
+  int tmax = 0;
+  for (int b = 0; b < B; ++b) {
+    meta[b] = n[b] > 0 ? (int64_t)(((uintptr_t)samples_dev[b] - lo) / 4) : 0;
+    meta[(B + 1) + b] = n[b];
+    meta[2 * (B + 1) + b] = frames;
+    st_t80_[b] = num_fbank_frames(n[b]);
+    frames += st_t80_[b];
+    tmax = std::max(tmax, num_lfr_frames(n[b]));
+  }
+  meta[2 * (B + 1) + B] = frames;
+  st_total_frames_ = frames;
+  st_T_ = std::max(tmax, force_T);
+  st_audio_ext_ = (const float*)lo;
+  ensure(ws_meta_, meta.size() * 8 + (size_t)B * 4 + 64);
+  PF_HIP(hipMemcpyAsync(ws_meta_.p, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync((char*)ws_meta_.p + meta.size() * 8, st_t80_.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));               // (meta is a stack vector; 1 KB)
+}
+
 void Engine::run_staged(bool want_logits) {
   PF_HIP(hipSetDevice(device_));
   const int B = st_B_, T = st_T_;
@@ -763,7 +799,7 @@ void Engine::run_staged(bool want_logits) {
   const int P = sv_prompt_ ? 4 : 0;                 // SenseVoice: query rows prepended on the device
   ensure(ws_speech_, (size_t)B * (T + P) * W * 4);
   prof_begin("fbank", 0);
-  launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + (B + 1), meta + 2 * (B + 1), B,
+  launch_fbank(stream_, fb_, st_audio_ext_ ? st_audio_ext_ : (const float*)ws_audio_.p, meta, meta + (B + 1), meta + 2 * (B + 1), B,
                st_total_frames_, fc_.snip_edges ? 1 : 0, (float*)ws_fbank_.p, fc_.dither, next_dither_seed());
   prof_end("fbank");
   prof_begin("lfr_cmvn_pad", 0);
@@ -794,6 +830,18 @@ void Engine::frontend_host(const float* samples, int64_t n, std::vector<float>& 
   const float* arr[1] = {samples};
   const int64_t nn[1] = {n};
   stage_audio(arr, nn, 1);
+  frontend_staged_one(feats, t_lfr);
+}
+
+void Engine::frontend_from_device(const float* samples_dev, int64_t n, std::vector<float>& feats, int& t_lfr) {
+  const float* arr[1] = {samples_dev};
+  const int64_t nn[1] = {n};
+  stage_device_audio(arr, nn, 1);
+  frontend_staged_one(feats, t_lfr);
+}
+
+// fbank + LFR + CMVN of the ONE staged utterance -> host features (no padding, no sentinel)
+void Engine::frontend_staged_one(std::vector<float>& feats, int& t_lfr) {
   const int t80 = st_t80_[0];
   const bool lfr = fc_.lfr_m != 1 || fc_.lfr_n != 1;
   const int m = lfr ? fc_.lfr_m : 1, nn_ = lfr ? fc_.lfr_n : 1;
@@ -805,7 +853,7 @@ void Engine::frontend_host(const float* samples, int64_t n, std::vector<float>& 
   const int32_t* t80d = (const int32_t*)((const char*)ws_meta_.p + 3 * 2 * 8);
   ensure(ws_fbank_, (size_t)t80 * fc_.n_mels * 4);
   ensure(ws_speech_, feats.size() * 4);
-  launch_fbank(stream_, fb_, (const float*)ws_audio_.p, meta, meta + 2, meta + 4, 1, t80, fc_.snip_edges ? 1 : 0,
+  launch_fbank(stream_, fb_, st_audio_ext_ ? st_audio_ext_ : (const float*)ws_audio_.p, meta, meta + 2, meta + 4, 1, t80, fc_.snip_edges ? 1 : 0,
                (float*)ws_fbank_.p, fc_.dither, next_dither_seed());
   const bool cm = cmvn_shift_ && cmvn_dim_ == W;
   launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, meta + 4, t80d, 1, t_lfr, m, nn_, fc_.n_mels, cmvn_shift_,

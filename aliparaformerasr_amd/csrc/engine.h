@@ -78,6 +78,12 @@ class Engine {
   int num_fbank_frames(int64_t n_samples) const;
   void fbank_host(const float* samples, int64_t n, std::vector<float>& out, int& t80);
   void frontend_host(const float* samples, int64_t n, std::vector<float>& feats, int& t_lfr);
+  // the same on samples that already live on this device (OfflineStream keeps the audio of its AddSamples call there)
+  void frontend_staged_one(std::vector<float>& feats, int& t_lfr);
+  void frontend_from_device(const float* samples_dev, int64_t n, std::vector<float>& feats, int& t_lfr);
+  // stage_audio without the copy: utterance b = n[b] floats at the DEVICE address samples_dev[b] (4-byte aligned, alive until
+  // the run has been synchronised); the batched front-end of run_staged reads them where they are
+  void stage_device_audio(const float* const* samples_dev, const int64_t* n, int B, int force_T = 0);
 
   // ---- forward -----------------------------------------------------------
   // speech_dev: [B,T,feat] fp32 already on device (padded + sentinel)
@@ -152,6 +158,9 @@ class Engine {
   const std::vector<float>& embed_table() const { return embed_host_; }   // SenseVoice [16,560]
   std::mutex& mutex() { return mu_; }
   int device() const { return device_; }
+  // the batched front-end of run_staged (LFR + CMVN + pad in one kernel) computes what frontend_host + PadSequence compute
+  bool staged_frontend_matches_host() const { return fc_.lfr_m * fc_.n_mels == mc_.feat_dim && (!cmvn_shift_ || cmvn_dim_ == mc_.feat_dim); }
+  bool has_device_prompt() const { return sv_prompt_ != nullptr; }
 
  private:
   struct Tensor { const float* dev = nullptr; std::vector<int64_t> shape; int64_t numel = 0; bool u8 = false; };   // u8: dev points at bytes
@@ -320,6 +329,7 @@ class Engine {
   // staged audio
   std::vector<int64_t> st_n_; std::vector<int32_t> st_t80_; int st_B_ = 0, st_T_ = 0;
   int64_t st_total_frames_ = 0;
+  const float* st_audio_ext_ = nullptr;   // base of the externally staged audio (stage_device_audio); null: ws_audio_
   HostBatchOut last_;
   uint64_t uid_ = 0;                 // key of this engine in the per-thread result store
   static uint64_t register_uid();

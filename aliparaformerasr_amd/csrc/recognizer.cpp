@@ -211,16 +211,56 @@ static uint64_t register_recognizer() {
 
 // ------------------------------------------------------------------ Stream ----------------
 Stream::Stream(std::shared_ptr<Recognizer> r) : owner(std::move(r)) {}
+Stream::~Stream() { drop_device_audio(); }
+
+void Stream::drop_device_audio() {
+  if (dev_audio) owner->audio_free(dev_audio, dev_bytes);
+  dev_audio = nullptr; dev_bytes = 0; dev_n = 0;
+  device_form = false;
+}
+
+// device form -> host form: the features of the stored samples, computed by an engine of the pool and read back
+void Stream::materialize() {
+  if (!device_form) return;
+  Recognizer::Lease e = owner->acquire();
+  std::vector<float> feats;
+  int t = 0;
+  if (dev_n > 0) e->frontend_from_device(dev_audio, dev_n, feats, t);
+  e.release();
+  drop_device_audio();
+  Speech.swap(feats);
+  has_speech = true;
+  SpeechLength = (int)Speech.size();
+}
 
 void Stream::AddSamples(const float* samples, int64_t n) {
   if (disposed) throw Error(PF_ERR_DISPOSED, "OfflineStream");
   if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");       // ArgumentNullException("source")
-  std::shared_ptr<Engine> e = owner->engine();                     // keeps the engine alive across this call
-  if (!e) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
-  std::lock_guard<std::mutex> lk(e->mutex());                      // process-wide lock in the reference
+  if (owner->disposed()) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+  PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "negative sample count");
+  if (!has_speech && !device_form && owner->device_streams()) {
+    // first call: the samples go to the device and stay there; SpeechLength is what GetFbank + LfrCmvn would return
+    // (OfflineStream.cs:40-41) — a function of the sample count
+    size_t got = 0;
+    float* d = n > 0 ? owner->audio_alloc((size_t)n * 4, &got) : nullptr;
+    try {
+      if (n > 0) owner->upload(d, samples, (size_t)n * 4);
+    } catch (...) {
+      if (d) owner->audio_free(d, got);
+      throw;
+    }
+    dev_audio = d; dev_bytes = got; dev_n = n;
+    device_form = true;
+    has_speech = true;
+    SpeechLength = owner->feature_floats(n);
+    return;
+  }
+  materialize();                                                   // a second call appends to the FEATURES (:43-54)
+  Recognizer::Lease e = owner->acquire();
   std::vector<float> feats;
   int t = 0;
   e->frontend_host(samples, n, feats, t);
+  e.release();
   Speech.insert(Speech.end(), feats.begin(), feats.end());
   has_speech = true;
   SpeechLength = (int)Speech.size();
@@ -228,6 +268,7 @@ void Stream::AddSamples(const float* samples, int64_t n) {
 
 void Stream::Dispose() {
   disposed = true;
+  drop_device_audio();
   std::vector<float>().swap(Speech);
   std::vector<int64_t>().swap(Tokens);
   std::vector<std::vector<int32_t>>().swap(Timestamps);
@@ -238,6 +279,7 @@ void Stream::Dispose() {
 
 void Stream::RemoveChunk() {
   if (Tokens.size() > 2) {
+    drop_device_audio();
     Speech.clear();
     has_speech = false;
     SpeechLength = 0;
@@ -259,12 +301,18 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   if (tokens_.empty()) throw Error(PF_ERR_TOKENS, "tokens invalid");
   if (!hotword.empty() && file_exists(hotword))                    // :34-38, :75
     hotwords_ = hotword_ids(tokens_, read_lines(hotword), 1);
-  pf_engine_config ec;
+  device_ = device;
+  model_path_ = model; mvn_path_ = mvn; window_ = conf_.window;
+  pf_engine_config& ec = ec_;
   std::memset(&ec, 0, sizeof(ec));
   ec.struct_size = sizeof(ec);
   ec.device = device;
-  ec.weights_path = model.c_str();
-  ec.mvn_path = mvn.c_str();
+  // am.mvn is read HERE, once (the reference reads its files in the constructor only): engines created later for the pool
+  // get the parsed vectors, not the path
+  if (!mvn_path_.empty()) {
+    parse_mvn_text(read_text_file(mvn_path_.c_str()), cmvn_shift_, cmvn_scale_);
+    ec.cmvn_shift = cmvn_shift_.data(); ec.cmvn_scale = cmvn_scale_.data(); ec.cmvn_dim = (int32_t)cmvn_shift_.size();
+  }
   ec.fs = conf_.fs; ec.n_mels = conf_.n_mels; ec.lfr_m = conf_.lfr_m; ec.lfr_n = conf_.lfr_n;
   ec.snip_edges = conf_.snip_edges ? 1 : 0;
   ec.dither = conf_.dither;
@@ -273,7 +321,7 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   // (25 ms / 10 ms) — a conf with other values must run here exactly as it does there
   ec.frame_length_ms = 0;
   ec.frame_shift_ms = 0;
-  ec.window = conf_.window.c_str();
+  ec.window = window_.c_str();
   ec.use_itn = conf_.use_itn ? 1 : 0;
   // `-accuracy int8` (the reference CLI's default, Examples/Program.cs:98-101) selects the arithmetic through the FILE
   // NAME there (model.int8.onnx vs model.onnx, Examples/OfflineAliParaformerAsrRecognizer.cs:17-22); the same
@@ -283,8 +331,151 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
     const std::string fname = sl == std::string::npos ? model : model.substr(sl + 1);
     if (fname.find(".int8.") != std::string::npos) ec.math_mode = 2;
   }
-  engine_ = std::make_shared<Engine>(ec);
+  { const char* e = getenv("PF_RECOGNIZER_ENGINES"); if (e && e[0]) max_engines_ = std::max(1, std::min(8, atoi(e))); }
+  { const char* e = getenv("PF_RECOGNIZER_DEVICE_STREAMS"); if (e && e[0]) device_streams_ = e[0] != '0'; }
+  // the weight file -> ONE device image that every engine of the pool adopts in place (pf_engine_config.weights_device)
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+      throw Error(PF_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    PF_CHECK(device >= 0 && device < ndev, PF_ERR_DEVICE, "device ordinal out of range");
+    std::vector<char> file;
+    read_binary_file(model_path_.c_str(), file);
+    PF_CHECK(file.size() >= 16, PF_ERR_FORMAT, "weights: image too small");
+    PF_HIP(hipSetDevice(device_));
+    PF_HIP(hipMalloc(&image_, file.size()));
+    image_bytes_ = (int64_t)file.size();
+    if (hipMemcpy(image_, file.data(), file.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      hipFree(image_); image_ = nullptr;
+      throw Error(PF_ERR_DEVICE, "weights: upload failed");
+    }
+  }
+  ec.weights_device = image_;
+  ec.weights_bytes = image_bytes_;
+  try {
+    engines_.push_back(std::make_shared<Engine>(ec));
+  } catch (...) {
+    hipFree(image_); image_ = nullptr;
+    throw;
+  }
+  busy_.push_back(0);
+  engine_kind_ = engines_[0]->model().kind;
+  sv_device_prompt_ = engines_[0]->has_device_prompt();
+  feat_m_ = (conf_.lfr_m != 1 || conf_.lfr_n != 1) ? conf_.lfr_m : 1;
+  // the device form of a stream needs the batched front-end to compute exactly what AddSamples + PadSequence would
+  device_streams_ = device_streams_ && engines_[0]->staged_frontend_matches_host();
   uid_ = register_recognizer();
+}
+
+std::shared_ptr<Engine> Recognizer::make_engine() { return std::make_shared<Engine>(ec_); }
+
+int Recognizer::feature_floats(int64_t n) {
+  std::shared_ptr<Engine> e = engine();
+  if (!e) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+  return e->num_lfr_frames(n) * feat_m_ * conf_.n_mels;
+}
+
+Recognizer::Lease& Recognizer::Lease::operator=(Lease&& o) noexcept {
+  if (this != &o) {
+    release();
+    r_ = o.r_; idx_ = o.idx_; e_ = std::move(o.e_); lk_ = std::move(o.lk_);
+    o.r_ = nullptr; o.idx_ = -1;
+  }
+  return *this;
+}
+void Recognizer::Lease::release() {
+  if (!r_) return;
+  if (lk_.owns_lock()) lk_.unlock();
+  {
+    std::lock_guard<std::mutex> g(r_->mu_);
+    if (idx_ >= 0 && idx_ < (int)r_->busy_.size()) r_->busy_[(size_t)idx_] = 0;
+  }
+  r_->cv_.notify_all();
+  e_.reset();
+  r_ = nullptr; idx_ = -1;
+}
+
+Recognizer::Lease Recognizer::acquire() {
+  std::unique_lock<std::mutex> lk(mu_);
+  for (;;) {
+    if (disposed_ || engines_.empty()) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+    int idx = -1;
+    for (size_t i = 0; i < engines_.size(); ++i)
+      if (!busy_[i]) { idx = (int)i; break; }
+    if (idx < 0 && (int)engines_.size() + creating_ < max_engines_) {
+      // every engine is busy and the pool may grow: build one outside the lock (weight conversion takes ~1 s)
+      ++creating_;
+      lk.unlock();
+      std::shared_ptr<Engine> ne;
+      try {
+        PF_HIP(hipSetDevice(device_));
+        ne = make_engine();
+      } catch (...) {
+        lk.lock();
+        --creating_;
+        cv_.notify_all();
+        throw;
+      }
+      lk.lock();
+      --creating_;
+      if (disposed_) { lk.unlock(); ne.reset(); lk.lock(); continue; }
+      engines_.push_back(ne);
+      busy_.push_back(0);
+      idx = (int)engines_.size() - 1;
+    }
+    if (idx >= 0) {
+      busy_[(size_t)idx] = 1;
+      Lease l;
+      l.r_ = this; l.idx_ = idx; l.e_ = engines_[(size_t)idx];
+      lk.unlock();
+      l.lk_ = std::unique_lock<std::mutex>(l.e_->mutex());          // also serialises with users of pf_recognizer_engine
+      return l;
+    }
+    cv_.wait(lk);
+  }
+}
+
+float* Recognizer::audio_alloc(size_t bytes, size_t* got) {
+  const size_t cls = (size_t)round_up((int64_t)std::max<size_t>(bytes, 4), (int64_t)(256 << 10));   // 256 KiB classes
+  *got = cls;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (disposed_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+    auto it = audio_cache_.find(cls);
+    if (it != audio_cache_.end() && !it->second.empty()) {
+      float* p = it->second.back();
+      it->second.pop_back();
+      audio_cached_bytes_ -= cls;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  PF_HIP(hipSetDevice(device_));
+  PF_HIP(hipMalloc(&p, cls));
+  return (float*)p;
+}
+
+void Recognizer::audio_free(float* p, size_t bytes) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!disposed_ && audio_cached_bytes_ + bytes <= ((size_t)1 << 30)) {        // keep up to 1 GiB for re-use
+      audio_cache_[bytes].push_back(p);
+      audio_cached_bytes_ += bytes;
+      return;
+    }
+  }
+  hipSetDevice(device_);
+  hipFree(p);
+}
+
+void Recognizer::upload(float* dst, const float* src, size_t bytes) {
+  CopyLane& ln = lanes_[next_lane_.fetch_add(1) % lanes_.size()];
+  std::lock_guard<std::mutex> lk(ln.mu);
+  PF_HIP(hipSetDevice(device_));
+  if (!ln.s) PF_HIP(hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
+  PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ln.s));
+  PF_HIP(hipStreamSynchronize(ln.s));                  // the samples are on the device when AddSamples returns
 }
 
 std::shared_ptr<Stream> Recognizer::CreateOfflineStream() {
@@ -293,30 +484,56 @@ std::shared_ptr<Stream> Recognizer::CreateOfflineStream() {
 }
 
 void Recognizer::Dispose() {
-  std::shared_ptr<Engine> e;
+  std::vector<std::shared_ptr<Engine>> es;
+  std::map<size_t, std::vector<float*>> cache;
   {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::unique_lock<std::mutex> lk(mu_);
     if (disposed_.exchange(true)) return;
-    e.swap(engine_);
+    cv_.notify_all();
+    // calls in flight hold a lease: wait for them (and for engines still being built), then take the pool
+    cv_.wait(lk, [&] {
+      if (creating_ > 0) return false;
+      for (char b : busy_) if (b) return false;
+      return true;
+    });
+    es.swap(engines_);
+    busy_.clear();
+    cache.swap(audio_cache_);
+    audio_cached_bytes_ = 0;
   }
-  // a call that fetched the engine before this point still owns a reference; wait for it on the engine mutex so
-  // that Dispose returns with the device idle, then drop ours (the last owner frees the device memory)
-  if (e) { std::lock_guard<std::mutex> lk(e->mutex()); }
-  e.reset();                                       // tokens_ stays: a concurrent GetResults may still be decoding
+  // a user of pf_recognizer_engine may still hold engine 0's mutex: wait for it so that Dispose returns with the device
+  // idle, then drop ours (the last owner frees the device memory)
+  for (auto& e : es) { std::lock_guard<std::mutex> lk(e->mutex()); }
+  es.clear();                                      // tokens_ stays: a concurrent GetResults may still be decoding
+  hipSetDevice(device_);
+  for (auto& kv : cache)
+    for (float* p : kv.second) hipFree(p);
+  for (CopyLane& ln : lanes_) {
+    std::lock_guard<std::mutex> lk(ln.mu);
+    if (ln.s) { hipStreamDestroy(ln.s); ln.s = nullptr; }
+  }
+  if (image_) { hipFree(image_); image_ = nullptr; }
 }
 
 void Recognizer::Forward(const std::vector<Stream*>& streams) {
   if (streams.empty()) return;                                      // :120-123
   try {
-    std::shared_ptr<Engine> eh = engine();
-    if (disposed_ || !eh) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
-    Engine* e = eh.get();
-    std::lock_guard<std::mutex> lk(e->mutex());
+    if (disposed_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+    // the fast form needs every stream in the device form; otherwise every stream is brought to the host form first
+    bool all_dev = device_streams_;
+    for (Stream* s : streams) all_dev = all_dev && s->device_form;
+    const bool sv = engine_kind_ == "sensevoicesmall";
+    if (all_dev && sv && !sv_device_prompt_) all_dev = false;
+    if (!all_dev)
+      for (Stream* s : streams) s->materialize();
+    Lease lease = acquire();
+    Engine* e = lease.get();
     const ModelCfg& mc = e->model();
     const int W = mc.feat_dim;
-    // SenseVoice split-embed variant: prepend [emb(lang), emb(1), emb(2), emb(textnorm)] to Speech
-    // IN PLACE (OfflineProjOfSenseVoiceSmall.cs:78-106, quirk Q8); effective ids per quirk Q7.
-    if (mc.kind == "sensevoicesmall") {
+    const int B = (int)streams.size();
+    if (!all_dev && sv) {
+      // SenseVoice split-embed variant: prepend [emb(lang), emb(1), emb(2), emb(textnorm)] to Speech
+      // IN PLACE (OfflineProjOfSenseVoiceSmall.cs:78-106, quirk Q8); effective ids per quirk Q7.
       const std::vector<float>& emb = e->embed_table();
       PF_CHECK(emb.size() >= (size_t)16 * W, PF_ERR_FORMAT, "sensevoice: embed table missing from the container");
       const int languageId = mc.use_itn ? 14 : 15, textnormId = 15;
@@ -330,15 +547,9 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
         s->SpeechLength = (int)s->Speech.size();
       }
     }
-    std::vector<const float*> ptrs;
-    std::vector<int32_t> lens;
-    for (Stream* s : streams) {
+    for (Stream* s : streams)
       // PadSequence dereferences a null Speech -> NullReferenceException inside Forward's try
-      if (!s->has_speech || s->Speech.empty()) throw Error(PF_ERR_RECOGNITION, "Object reference not set (Speech is null)");
-      ptrs.push_back(s->Speech.data());
-      lens.push_back((int32_t)s->Speech.size());
-    }
-    const int B = (int)streams.size();
+      if (!s->has_speech || s->SpeechLength == 0) throw Error(PF_ERR_RECOGNITION, "Object reference not set (Speech is null)");
     if (mc.seaco) {
       // OfflineProjOfSeacoParaformer.cs:52-60: hotwords = SelectMany over the streams' Hotwords (a null list
       // throws inside ModelProj -> "Offline recognition failed"); empty -> the constructor's default list
@@ -354,8 +565,21 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
         for (int j = 0; j < 10; ++j) pad.push_back(j < (int)w.size() ? w[j] : 0);
       e->set_hotwords(pad.data(), (int)hw.size());
     }
-    e->drop_thread_result();              // this call's result is read back under the same lock, not from a slot
-    e->model_proj_host(ptrs.data(), lens.data(), B, false);
+    e->drop_thread_result();              // this call's result is read back under the same lease, not from a slot
+    if (all_dev) {
+      // the batched front-end over the samples where they are (fbank -> LFR + CMVN + PadSequence [+ the SenseVoice query
+      // rows]) and the model, one stream of launches: WavFrontend.cs:31-111 + Utils/PadHelper.cs:25 + ModelProj
+      std::vector<const float*> ptrs;
+      std::vector<int64_t> ns;
+      for (Stream* s : streams) { ptrs.push_back(s->dev_audio); ns.push_back(s->dev_n); }
+      e->stage_device_audio(ptrs.data(), ns.data(), B);
+      e->run_staged(false);
+    } else {
+      std::vector<const float*> ptrs;
+      std::vector<int32_t> lens;
+      for (Stream* s : streams) { ptrs.push_back(s->Speech.data()); lens.push_back((int32_t)s->Speech.size()); }
+      e->model_proj_host(ptrs.data(), lens.data(), B, false);
+    }
     pf_batch_out out;
     std::memset(&out, 0, sizeof(out));
     out.struct_size = sizeof(out);
@@ -368,6 +592,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     std::vector<float> peak((size_t)B * std::max(P, 1));
     if (P > 0) { out.cif_peak = peak.data(); out.cif_peak_cap = (int64_t)peak.size(); }
     e->fetch(&out);
+    lease.release();                      // the device work of this call is over: the text stage below needs no engine
     for (int b = 0; b < B; ++b) {
       Stream* s = streams[b];
       s->Tokens.assign(ids.begin() + (size_t)b * out.l_cap, ids.begin() + (size_t)b * out.l_cap + L);   // :187
@@ -377,6 +602,19 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
         for (auto& t2 : ts) s->Timestamps.push_back(t2);
       } else {
         for (int l = 0; l < L; ++l) s->Timestamps.push_back({0, 0});                                    // :151,:188
+      }
+      if (all_dev && sv && s->Tokens.size() <= 2) {
+        // quirk Q8 on the device form: the reference has prepended the query rows to Speech IN PLACE, and a stream whose
+        // chunk RemoveChunk keeps (at most two ids) carries them into its next call: give it the host form with them
+        s->materialize();
+        Lease l2 = acquire();
+        const std::vector<float>& emb = l2->embed_table();
+        const int order[4] = {l2->model().use_itn ? 14 : 15, 1, 2, 15};
+        std::vector<float> sp((size_t)4 * W + s->Speech.size());
+        for (int r = 0; r < 4; ++r) std::memcpy(&sp[(size_t)r * W], &emb[(size_t)order[r] * W], (size_t)W * 4);
+        std::memcpy(sp.data() + (size_t)4 * W, s->Speech.data(), s->Speech.size() * 4);
+        s->Speech.swap(sp);
+        s->SpeechLength = (int)s->Speech.size();
       }
       s->RemoveChunk();                                                                                  // :189
     }

@@ -3,7 +3,9 @@
 // (AliParaformerAsr/OfflineStream.cs:7-121) above the device engine.
 #pragma once
 #include <atomic>
+#include <condition_variable>
 #include <map>
+#include <array>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -39,14 +41,29 @@ class Recognizer;
 // pf_recognizer_free still reaches valid memory and answers PF_ERR_DISPOSED), the recognizer does not track
 // its streams (the reference's CreateOfflineStream does not either, OfflineRecognizer.cs:92-100), and the
 // device engine is released by Dispose() — never by the last stream going away.
+//
+// Where the features live (round 5).  The reference computes them inside AddSamples (OfflineStream.cs:40-41) and keeps them
+// in OfflineInputEntity.Speech until Forward pads and uploads them.  Nothing of the C ABI reads Speech — only its length
+// (pf_stream_num_feature_floats), a function of the sample count — so a stream that has received ONE AddSamples call
+// keeps the SAMPLES of that call on the device (one host-to-device copy, no kernel, no read-back) and the batched
+// front-end of GetResults (fbank -> LFR + CMVN + pad in two launches over the whole batch) computes the same features from
+// them.  A second AddSamples before GetResults, a SenseVoice stream that survives GetResults with its prompt rows
+// prepended (quirk Q8), or a front-end configuration the batched kernels do not cover turn the stream into the host form
+// (Speech = the feature floats, exactly as before): materialize().
 class Stream {
  public:
   explicit Stream(std::shared_ptr<Recognizer> r);
+  ~Stream();
   void AddSamples(const float* samples, int64_t n);          // OfflineStream.cs:36-57
   void Dispose();                                             // OfflineStream.cs:81-121: drops the buffers
-  std::vector<float> Speech;                                  // OfflineInputEntity.Speech
+  std::vector<float> Speech;                                  // OfflineInputEntity.Speech (host form)
   bool has_speech = false;                                    // Speech != null
   int SpeechLength = 0;                                       // float count
+  // device form: the samples of the single AddSamples call (dev_audio may be null when dev_n == 0)
+  bool device_form = false;
+  float* dev_audio = nullptr; size_t dev_bytes = 0; int64_t dev_n = 0;
+  void materialize();                                         // device form -> host form (features computed and read back)
+  void drop_device_audio();
   bool hotwords_null = false;
   std::vector<std::vector<int32_t>> Hotwords;
   std::vector<int64_t> Tokens{0, 0};                          // OfflineStream.cs:26
@@ -67,16 +84,61 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   // recognizer (the reference returns a fresh List per call; concurrent callers must not share one).
   void GetResults(const std::vector<Stream*>& streams);
   const std::vector<ResultEntity>& results_of_this_thread();
-  void Dispose();                                             // waits for calls in flight, then frees the engine
+  void Dispose();                                             // waits for calls in flight, then frees the engines
   bool disposed() const { return disposed_.load(); }
-  // the engine for the duration of one call (nullptr once disposed); callers lock engine->mutex() themselves
-  std::shared_ptr<Engine> engine() { std::lock_guard<std::mutex> lk(mu_); return engine_; }
+  // engine 0 (nullptr once disposed): what pf_recognizer_engine hands out; callers lock engine->mutex() themselves
+  std::shared_ptr<Engine> engine() { std::lock_guard<std::mutex> lk(mu_); return engines_.empty() ? nullptr : engines_[0]; }
   const std::vector<std::string>& tokens() const { return tokens_; }
+
+  // ---- engine pool (round 5; VERDICT r4 "missing" #1).  The reference's GetResults is unlocked — concurrent calls overlap
+  // inside onnxruntime (OfflineRecognizer.cs:110-198; the only lock of the path is OfflineStream.cs:19).  Here a call
+  // takes a free engine of the pool (engines on ONE device sharing the device weight image; each has its own stream, f16
+  // operands and workspaces): two callers' batches are in flight together, one's host work (audio upload, text) under the
+  // other's kernels.  Engines beyond the first are created when a call finds every engine busy (up to max_engines_).
+  class Lease {
+   public:
+    Lease() = default;
+    Lease(Lease&& o) noexcept { *this = std::move(o); }
+    Lease& operator=(Lease&& o) noexcept;
+    ~Lease() { release(); }
+    Engine* operator->() const { return e_.get(); }
+    Engine* get() const { return e_.get(); }
+    void release();
+   private:
+    friend class Recognizer;
+    Recognizer* r_ = nullptr; int idx_ = -1; std::shared_ptr<Engine> e_; std::unique_lock<std::mutex> lk_;
+  };
+  Lease acquire();                                            // throws PF_ERR_DISPOSED once disposed
+  int engines_created() { std::lock_guard<std::mutex> lk(mu_); return (int)engines_.size(); }
+  // device buffers for the streams' audio (size-class cache: a server creating one stream per utterance re-uses them)
+  float* audio_alloc(size_t bytes, size_t* got);
+  void audio_free(float* p, size_t bytes);
+  void upload(float* dst, const float* src, size_t bytes);    // host -> device on a copy stream of its own, synchronous
+  int device() const { return device_; }
+  bool device_streams() const { return device_streams_; }     // new streams keep their first AddSamples call's audio on the device
+  int feature_floats(int64_t n_samples);                      // what GetFbank + LfrCmvn return for n samples (float count)
 
  private:
   void Forward(const std::vector<Stream*>& streams);          // :118-198
-  std::mutex mu_;                                             // guards engine_
-  std::shared_ptr<Engine> engine_;
+  std::shared_ptr<Engine> make_engine();
+  std::mutex mu_;                                             // guards engines_, busy_, the audio cache
+  std::condition_variable cv_;
+  std::vector<std::shared_ptr<Engine>> engines_;
+  std::vector<char> busy_;
+  int max_engines_ = 2;                                       // PF_RECOGNIZER_ENGINES (1..8)
+  bool device_streams_ = true;                                // PF_RECOGNIZER_DEVICE_STREAMS=0: always the host form
+  int feat_m_ = 1;
+  std::string engine_kind_; bool sv_device_prompt_ = false;
+  int creating_ = 0;                                          // engines being built outside the lock
+  int device_ = 0;
+  pf_engine_config ec_{};                                     // template for further engines (strings owned below)
+  std::string model_path_, mvn_path_, window_;
+  std::vector<float> cmvn_shift_, cmvn_scale_;
+  void* image_ = nullptr; int64_t image_bytes_ = 0;           // the PFW image on the device, shared by every engine
+  std::map<size_t, std::vector<float*>> audio_cache_; size_t audio_cached_bytes_ = 0;
+  struct CopyLane { std::mutex mu; hipStream_t s = nullptr; };
+  std::array<CopyLane, 4> lanes_;
+  std::atomic<unsigned> next_lane_{0};
   std::vector<std::string> tokens_;
   ConfEntity conf_;
   std::vector<std::vector<int32_t>> hotwords_;

@@ -209,6 +209,57 @@ def synth_cmvn(dim: int = 560, seed: int = 7):
     return shift, scale
 
 
+def format_mvn_text(shift, scale) -> str:
+    """An am.mvn in the kaldi-nnet text layout WavFrontend.LoadCmvn reads (AliParaformerAsr/WavFrontend.cs:113-157):
+    <AddShift> / <Rescale> blocks whose <LearnRateCoef> line carries the vector between '[' and ']'."""
+    dim = len(shift)
+
+    def vec(v):
+        return " ".join(repr(float(np.float32(x))) for x in v)
+    return ("<Nnet> \n"
+            f"<Splice> {dim} {dim}\n[ 0 ]\n"
+            f"<AddShift> {dim} {dim} \n"
+            f"<LearnRateCoef> 0 [ {vec(shift)} ]\n"
+            f"<Rescale> {dim} {dim}\n"
+            f"<LearnRateCoef> 0 [ {vec(scale)} ]\n"
+            "</Nnet> \n")
+
+
+def synth_tokens(vocab: int):
+    """A tokens.txt of `vocab` lines in the shape of the real ones: <blank> <s> </s>, CJK characters, BPE pieces with
+    '@@' continuations and '▁' word starts (what DecodeMulti's branches act on, OfflineRecognizer.cs:304-418), <unk> last."""
+    toks = ["<blank>", "<s>", "</s>"]
+    n_cjk = min(max(vocab - 4, 0) * 3 // 4, 0x9FA5 - 0x4E00)
+    toks += [chr(0x4E00 + i) for i in range(n_cjk)]
+    i = 0
+    while len(toks) < vocab - 1:
+        w = "w%d" % i
+        toks.append(w + "@@" if i % 3 == 0 else ("\u2581" + w if i % 3 == 1 else w))
+        i += 1
+    toks.append("<unk>")
+    return toks[:vocab]
+
+
+def synth_model_dir(path: str, cfg: dict, weights: dict, cmvn=None, dither: float = 0.0, int8_name: bool = False) -> dict:
+    """Writes what `new OfflineRecognizer(modelFilePath, configFilePath, mvnFilePath, tokensFilePath)` takes
+    (OfflineRecognizer.cs:23) for a synthetic model: model[.int8].pfw, asr.yaml, am.mvn, tokens.txt.  Returns the paths."""
+    import os
+    os.makedirs(path, exist_ok=True)
+    shift, scale = cmvn if cmvn is not None else synth_cmvn()
+    out = {"model": os.path.join(path, "model.int8.pfw" if int8_name else "model.pfw"), "config": os.path.join(path, "asr.yaml"),
+           "mvn": os.path.join(path, "am.mvn"), "tokens": os.path.join(path, "tokens.txt")}
+    save_pfw(out["model"], cfg, weights)
+    kind = cfg.get("kind", "paraformer")
+    with open(out["config"], "w") as f:
+        f.write("model: %s\nuse_itn: %s\nfrontend_conf:\n  fs: 16000\n  window: hamming\n  n_mels: 80\n  dither: %r\n"
+                "  lfr_m: 7\n  lfr_n: 6\n  snip_edges: false\n" % (kind, "true" if cfg.get("use_itn") else "false", float(dither)))
+    with open(out["mvn"], "w") as f:
+        f.write(format_mvn_text(shift, scale))
+    with open(out["tokens"], "w", encoding="utf-8") as f:
+        f.write("\n".join(synth_tokens(int(cfg["vocab"]))) + "\n")
+    return out
+
+
 def synth_audio(n_samples: int, utt: int, seed: int = 1234) -> np.ndarray:
     """SURVEY §8d synthetic utterance: 0.1*N(0,1) noise + 3 sinusoids 100-4000 Hz,
     float32 in [-1, 1), default_rng(seed + utt)."""

@@ -1,4 +1,4 @@
-// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 4).
+// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 5).
 // Drop into the reference project (AliParaformerAsr/Native/) — see csharp/README.md.  Not compiled in the build
 // image of this repository (no .NET toolchain); the same entry points are exercised through the Python ctypes
 // binding aliparaformerasr_amd/_native.py by tests/.
@@ -92,6 +92,7 @@ namespace AliParaformerAsr.Native
             [MarshalAs(UnmanagedType.LPUTF8Str)] string hotword, int batchSize, int threadsNum, int device, out IntPtr recognizer);
         [DllImport(Lib)] internal static extern void pf_recognizer_dispose(IntPtr r);
         [DllImport(Lib)] internal static extern void pf_recognizer_free(IntPtr r);
+        [DllImport(Lib)] internal static extern int pf_recognizer_num_engines(IntPtr r);   // engines of the pool ($PF_RECOGNIZER_ENGINES)
         [DllImport(Lib)] internal static extern int pf_recognizer_create_stream(IntPtr r, out IntPtr stream);
         [DllImport(Lib)] internal static extern int pf_stream_add_samples(IntPtr s, float[]? samples, long n);
         [DllImport(Lib)] internal static extern int pf_stream_set_hotwords(IntPtr s, int[]? ids, int[]? lens, int nHotwords);

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 4
+#define PF_ABI_VERSION 5
 
 typedef enum pf_status {
   PF_OK = 0,
@@ -375,6 +375,11 @@ void pf_recognizer_dispose(pf_recognizer* r);   /* Dispose(): frees the engine; 
 void pf_recognizer_free(pf_recognizer* r);      /* Dispose() + drops the handle's reference; streams created from it
                                                    stay valid handles (their calls answer PF_ERR_DISPOSED)        */
 pf_engine* pf_recognizer_engine(pf_recognizer* r);
+/* The recognizer owns a POOL of engines on its device (round 5): GetResults / AddSamples calls of different threads run on
+   different engines instead of queueing — the reference's GetResults is unlocked (OfflineRecognizer.cs:110-198).  Engines
+   beyond the first are created when a call finds all of them busy, up to $PF_RECOGNIZER_ENGINES (default 2, 1..8); they share
+   the device weight image.  Returns how many exist (>= 1), or PF_ERR_DISPOSED.  pf_recognizer_engine hands out engine 0. */
+int pf_recognizer_num_engines(pf_recognizer* r);
 
 int pf_recognizer_create_stream(pf_recognizer* r, pf_stream** out);     /* CreateOfflineStream :92 */
 int pf_stream_add_samples(pf_stream* s, const float* samples, int64_t n); /* AddSamples, OfflineStream.cs:36 */

@@ -246,3 +246,192 @@ def test_stream_handles_are_quarantined_then_recycled(model_dir):
     assert recycled, "the first freed shell was never handed out again"
     assert len(seen) <= 65536 + 2
     r.Dispose()
+
+
+# ---------------------------------------------------------------- round 5: engine pool + device-form streams
+def _batch_ids(r, audio, chunks=None):
+    """One GetResults over `audio`; chunks[b] = split points: the stream of utterance b receives its samples in several
+    AddSamples calls (the host form)."""
+    streams = []
+    for b, a in enumerate(audio):
+        s = r.CreateOfflineStream()
+        cuts = [0] + list(chunks[b] if chunks else []) + [len(a)]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            s.AddSamples(a[lo:hi])
+        streams.append(s)
+    res = r.GetResults(streams)
+    return np.asarray([s.Tokens for s in streams]), [x.Text for x in res], streams
+
+
+def test_device_form_equals_host_form(model_dir, monkeypatch):
+    """A stream that received ONE AddSamples call keeps the samples on the device and GetResults runs the batched front-end
+    over them (recognizer.h); PF_RECOGNIZER_DEVICE_STREAMS=0 is the form of rounds 1-4 (features computed inside AddSamples,
+    read back, padded and uploaded by Forward).  Same ids, same text, same SpeechLength — ragged batch, incl. a 1-frame one."""
+    audio = [W.synth_audio(n, 60 + u) for u, n in enumerate((40000, 1000, 48000, 33000, 16000))]
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    s.AddSamples(audio[0])
+    assert s.SpeechLength == (40000 + 80) // 160 // 6 * 560
+    ids_d, txt_d, st = _batch_ids(r, audio)
+    assert all(x.SpeechLength == 0 for x in st)
+    monkeypatch.setenv("PF_RECOGNIZER_DEVICE_STREAMS", "0")
+    rh = _make(model_dir)
+    ids_h, txt_h, _ = _batch_ids(rh, audio)
+    np.testing.assert_array_equal(ids_d, ids_h)
+    assert txt_d == txt_h
+
+
+def test_second_add_samples_appends_features_like_the_reference(model_dir):
+    """OfflineStream.cs:40-54: every AddSamples call runs GetFbank + LfrCmvn on ITS samples and appends the features — two
+    calls are not one call on the concatenation (each call has its own frame grid and its own LFR left context).  The
+    stream leaves the device form at the second call; the result must be what per-call features give."""
+    d, cfg, w, cmvn = model_dir
+    a = W.synth_audio(40000, 71)
+    r = _make(model_dir)
+    s = r.CreateOfflineStream()
+    s.AddSamples(a[:16000])
+    n1 = s.SpeechLength
+    s.AddSamples(a[16000:])
+    conf = fe.FrontendConf(dither=0.0)
+    f1 = fe.wav_frontend(a[:16000], conf, cmvn[0], cmvn[1])
+    f2 = fe.wav_frontend(a[16000:], conf, cmvn[0], cmvn[1])
+    assert n1 == f1.size and s.SpeechLength == f1.size + f2.size
+    res = r.GetResult(s)
+    speech = np.concatenate([f1, f2], 0)[None]
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").paraformer(speech)
+    ids_ref = om.argmax_last(ref["logits"])[0]
+    srt = np.sort(ref["logits"][0], axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 0.04
+    ids = np.asarray(s.Tokens)
+    assert ids.shape == ids_ref.shape and (ids[safe] == ids_ref[safe]).all()
+    assert res.Text is not None
+    # mixed batch: one stream in the device form, one in the host form -> the whole call takes the host path, same ids
+    s1, s2 = r.CreateOfflineStream(), r.CreateOfflineStream()
+    s1.AddSamples(a)
+    s2.AddSamples(a[:16000]); s2.AddSamples(a[16000:])
+    r.GetResults([s1, s2])
+    np.testing.assert_array_equal(np.asarray(s2.Tokens)[safe], ids_ref[safe])
+
+
+@pytest.fixture(scope="module")
+def mid_model_dir(tmp_path_factory):
+    """deep enough that a GetResults over 16 x 20 s is a few milliseconds of GPU work"""
+    d = tmp_path_factory.mktemp("mid_model")
+    cfg = W.paraformer_large_config(enc_layers=24, dec_layers=6, vocab=VOCAB)
+    w = W.synth_weights(cfg, seed=78)
+    paths = W.synth_model_dir(str(d), cfg, w)
+    (d / "tokens.txt").write_text("\n".join(_tokens()) + "\n", encoding="utf-8")
+    return paths
+
+
+def _lean_batch(lib, rh, audio):
+    """CreateOfflineStream + AddSamples per utterance, ONE GetResults, ids and texts read back — through the C ABI with as
+    few Python-side calls as a caller needs (the wrapper's per-token accessors would time the interpreter, not the call)."""
+    import ctypes as C
+    from aliparaformerasr_amd import _native as N
+    B = len(audio)
+    hs = (C.c_void_p * B)()
+    for b, a in enumerate(audio):
+        h = C.c_void_p()
+        N.check(lib.pf_recognizer_create_stream(rh, C.byref(h)))
+        hs[b] = h
+        N.check(lib.pf_stream_add_samples(h, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0]))
+    N.check(lib.pf_recognizer_get_results(rh, hs, B))
+    ids, texts = [], []
+    for b in range(B):
+        txt, tl = C.c_char_p(), C.c_int32()
+        N.check(lib.pf_result_text(rh, b, C.byref(txt), tl))
+        texts.append(txt.value)
+        p, n = C.POINTER(C.c_int64)(), C.c_int32()
+        N.check(lib.pf_stream_tokens(C.c_void_p(hs[b]), C.byref(p), n))
+        ids.append(np.ctypeslib.as_array(p, shape=(n.value,)).copy())
+        lib.pf_stream_free(C.c_void_p(hs[b]))
+    return np.stack(ids), texts
+
+
+@pytest.mark.timeout(600)
+def test_two_callers_on_one_recognizer_overlap(mid_model_dir, monkeypatch):
+    """VERDICT r4 "missing" #1: the reference's GetResults is unlocked (OfflineRecognizer.cs:110-198), so two threads on ONE
+    recognizer overlap.  Here each call takes an engine of the recognizer's pool: two concurrent host-audio-in calls must
+    finish in clearly less than two serial ones (< 1.7 x one call), with exactly the ids and texts of the serial call."""
+    import threading
+    import time
+    from aliparaformerasr_amd.offline_recognizer import OfflineRecognizer
+    monkeypatch.setenv("PF_RECOGNIZER_ENGINES", "2")
+    p = mid_model_dir
+    r = OfflineRecognizer(p["model"], p["config"], p["mvn"], p["tokens"])
+    lib, rh = r._lib, r._h
+    audio = [W.synth_audio(20 * 16000, 80 + u) for u in range(24)]
+    ids0, txt0 = _lean_batch(lib, rh, audio)
+    ids_w, txt_w, _ = _batch_ids(r, audio)           # the Python wrapper agrees with the lean form
+    np.testing.assert_array_equal(ids_w, ids0)
+    assert [t.encode("utf-8") for t in txt_w] == txt0
+    out = {}
+    N_CALLS = 6                                      # back-to-back calls per caller: a server's steady state, in which one
+                                                     # caller's uploads fall under the other's kernels
+
+    def call(t):
+        for _ in range(N_CALLS):
+            out[t] = _lean_batch(lib, rh, audio)
+
+    def both():
+        th = [threading.Thread(target=call, args=(t,)) for t in range(2)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t0
+    both()                                           # creates the second engine of the pool
+    assert lib.pf_recognizer_num_engines(rh) == 2
+    one = min(_timed(lambda: call(9)) for _ in range(4))
+    two = min(both() for _ in range(4))
+    print("%d calls by one caller %.2f ms, by each of two concurrent callers %.2f ms (%.2f x)" % (N_CALLS, one * 1e3, two * 1e3, two / one))
+    for t in range(2):
+        np.testing.assert_array_equal(out[t][0], ids0)
+        assert out[t][1] == txt0
+    assert two < 1.7 * one, (one, two)
+    r.Dispose()
+
+
+def _timed(fn):
+    import time
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+def test_dispose_waits_for_calls_in_flight_and_pool_survives_errors(model_dir, monkeypatch):
+    import threading
+    from aliparaformerasr_amd.offline_recognizer import ObjectDisposedException, RecognizerException
+    monkeypatch.setenv("PF_RECOGNIZER_ENGINES", "3")
+    r = _make(model_dir)
+    audio = [W.synth_audio(32000, 90 + u) for u in range(4)]
+    ids0, _, _ = _batch_ids(r, audio)
+    # a failing call (a stream without samples) gives its engine back to the pool
+    for _ in range(5):
+        with pytest.raises(RecognizerException):
+            r.GetResults([r.CreateOfflineStream()])
+    errs, done = [], []
+
+    def loop():
+        try:
+            for _ in range(30):
+                ids, _, _ = _batch_ids(r, audio)
+                np.testing.assert_array_equal(ids, ids0)
+                done.append(1)
+        except (ObjectDisposedException, RecognizerException):
+            pass                                      # the recognizer went away under this caller: the reference throws too
+        except BaseException as ex:                   # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=loop) for _ in range(4)]
+    for x in th:
+        x.start()
+    while len(done) < 8 and all(x.is_alive() for x in th):
+        pass
+    r.Dispose()                                       # waits for the leases, frees the pool; later calls: disposed
+    for x in th:
+        x.join()
+    assert not errs, errs
+    with pytest.raises(ObjectDisposedException):
+        r.CreateOfflineStream()

@@ -20,7 +20,7 @@ def lib():
 
 def test_library_is_in_tree_and_loads(lib):
     assert os.path.dirname(N.LIB_PATH) == os.path.join(ROOT, "aliparaformerasr_amd")
-    assert lib.pf_version() == 4
+    assert lib.pf_version() == 5
 
 
 def test_exports_every_declared_symbol(lib):

@@ -15,7 +15,7 @@ run_pass() {
   for c in "$@"; do if have $c; then list="$list $c"; else echo "counter $c not available" >> $OUT/pmc_skipped.txt; fi; done
   [ -z "$list" ] && return
   rm -rf /tmp/prof_$name
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $list --output-format csv -d /tmp/prof_$name -- python $ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 1 --in-flight 1 ) > $OUT/rocprof_$name.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $list --output-format csv -d /tmp/prof_$name -- python $ROOT/bench.py --no-cpu-baseline --no-via-recognizer --steps 1 --warmup 1 --in-flight 1 ) > $OUT/rocprof_$name.log 2>&1
   find /tmp/prof_$name -name "*counter_collection.csv" -exec cp {} /tmp/pmc_$name.csv \;
   python tools/pmc_counters.py /tmp/pmc_$name.csv > $OUT/pmc_$name.json 2>> $OUT/pmc_err.txt
 }
