@@ -46,9 +46,10 @@ Engine::Engine(const pf_engine_config& cfg) {
   // the configuration must be refused, not silently ignored
   PF_CHECK((cfg.frame_length_ms == 0 || cfg.frame_length_ms == 25) && (cfg.frame_shift_ms == 0 || cfg.frame_shift_ms == 10),
            PF_ERR_UNSUPPORTED, "only frame_length = 25 ms and frame_shift = 10 ms are supported");
-  PF_CHECK(cfg.math_mode >= 0 && cfg.math_mode <= 2, PF_ERR_INVALID_ARG,
-           "math_mode must be 0 (f16 MFMA), 1 (fp32 MFMA) or 2 (dynamic int8 as model.int8.onnx, int8 MFMA)");
-  fp32_mode_ = cfg.math_mode == 1;
+  PF_CHECK(cfg.math_mode >= 0 && cfg.math_mode <= 3, PF_ERR_INVALID_ARG,
+           "math_mode must be 0 (f16 MFMA), 1 (fp32 MFMA), 2 (dynamic int8 as model.int8.onnx, int8 MFMA) or 3 (exact: split-f16 products)");
+  fp32_mode_ = cfg.math_mode == 1 || cfg.math_mode == 3;
+  x3_mode_ = cfg.math_mode == 3;
   int8_mode_ = cfg.math_mode == 2;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
@@ -120,7 +121,8 @@ void Engine::release() {
   for (void* p : owned_) hipFree(p);
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
-                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_};
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_, &ws_x3a_, &ws_x3t_};
+  x3w_.clear();
   sk_slab_ = nullptr; sk_flags_ = nullptr; sk_err_ = nullptr; sk_used_ = false;
   seaco_hw_valid_ = false;
   for (DevBuf* b : bufs)
@@ -1687,6 +1689,47 @@ void Engine::forward_device(const float* speech_dev, int B, int T, bool want_log
 // for the paraformer and SenseVoice graphs (no BiCIF head, no SeACo branch); one launch per graph node, no fusion.
 enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
 
+// One Linear of the fp32 graph.  math_mode 1: exact fp32 products on v_mfma_f32_32x32x2_f32 (k_fp32.hip).  math_mode 3
+// ("exact", round 5): operands as hi + 2^-11 lo' pairs of f16 numbers (22 mantissa bits, launch_split_x3) and
+//   x W^T = hi_x hi_W^T + 2^-11 (hi_x lo'_W^T + lo'_x hi_W^T)            (the lo lo term is 2^-22 relative: dropped)
+// as TWO launches of the pipeline's own f16 MFMA kernels with fp32 results: [hi_x] x [hi_W] (depth K) -> t, then
+// [hi_x | lo'_x] x [lo'_W | hi_W] (depth 2 K) scaled by 2^-11 in the epilogue, + t, + residual, ReLU — three times the f16
+// MFMA work at 16x the fp32 matrix rate.  The weight pairs are built on first use and kept (same bytes as the fp32 matrix).
+void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
+                    const float* resid, int ldr, bool relu, int scale_cols, float scale) {
+  if (!x3_mode_ || M < 64 || ldw != K || (scale_cols != 0 && scale_cols < N) || (ldc % 4) || (resid && ldr % 4)) {
+    launch_gemm_f32(stream_, A, lda, W, ldw, bias, M, N, K, out, ldc, resid, ldr, relu, scale_cols, scale);
+    return;
+  }
+  const int Kp = (int)round_up(K, 64);
+  const int64_t Np = round_up(N, 256), Mp = round_up(M, 256) + 128;
+  auto it = x3w_.find(W);
+  if (it == x3w_.end()) {
+    half_t* wc = (half_t*)dalloc((size_t)Np * 2 * Kp * 2);
+    PF_HIP(hipMemsetAsync(wc, 0, (size_t)Np * 2 * Kp * 2, stream_));
+    launch_split_x3(stream_, W, N, K, ldw, wc, 2 * Kp, Kp, 1);        // rows = [lo'_W | hi_W]
+    it = x3w_.emplace(W, wc).first;
+  }
+  const half_t* wcat = it->second;
+  ensure(ws_x3a_, (size_t)Mp * 2 * Kp * 2);
+  const int ldt = (int)round_up(N, 4);
+  ensure(ws_x3t_, (size_t)Mp * ldt * 4);
+  half_t* a2 = (half_t*)ws_x3a_.p;
+  float* t = (float*)ws_x3t_.p;
+  launch_split_x3(stream_, A, M, K, lda, a2, 2 * Kp, Kp, 0);          // rows = [hi_x | lo'_x]
+  GemmArgs g{};
+  g.A = a2; g.lda = 2 * Kp; g.W = wcat + Kp; g.ldw = 2 * Kp; g.bias = bias; g.M = M; g.N = N; g.K = Kp;
+  g.out_f32 = t; g.ldc32 = ldt; g.scale_cols = scale_cols ? (int)round_up(N, 64) : 0; g.scale = scale;
+  g.out_padded = 1; g.small_ws = small_ws_;
+  launch_gemm(stream_, g);                                            // t = (hi_x hi_W^T + bias) [* scale]
+  GemmArgs c{};
+  c.A = a2; c.lda = 2 * Kp; c.W = wcat; c.ldw = 2 * Kp; c.M = M; c.N = N; c.K = 2 * Kp;
+  c.out_f32 = out; c.ldc32 = ldc; c.add2 = t; c.ld2 = ldt; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
+  c.scale_cols = (int)round_up(N, 64); c.scale = (scale_cols ? scale : 1.f) * (1.0f / 2048.0f);
+  c.out_padded = 1; c.small_ws = small_ws_;
+  launch_gemm(stream_, c);                                            // out = cross * 2^-11 [* scale] + t + resid; ReLU
+}
+
 void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_dev, int B, int T, float** f) {
   const int D = mc_.d_model, M = B * T, F = mc_.ffn, Fd = mc_.feat_dim;
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
@@ -1698,21 +1741,21 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
     launch_layernorm(stream_, f[F_X], M, D, L.norm1.g, L.norm1.b, nullptr, 0, f[F_XN], D);
   }
   const float* Wq = L.qkv.w32;
-  launch_gemm_f32(stream_, f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
-  launch_gemm_f32(stream_, f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f);
-  launch_gemm_f32(stream_, f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f);
+  gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
+  gemm32(f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f);
+  gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f);
   launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
   launch_attention_f32(stream_, f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
                        (int64_t)T * D, D, B, mc_.heads, T, T);
   if (first) {
-    launch_gemm_f32(stream_, f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
+    gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
   } else {
-    launch_gemm_f32(stream_, f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_T], D, f[F_FS], D, false, 0, 1.f);   // att = lin + fsmn
+    gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_T], D, f[F_FS], D, false, 0, 1.f);   // att = lin + fsmn
     launch_add_f32(stream_, f[F_X], f[F_T], (int64_t)M * D);                                                           // x = x + att
   }
   launch_layernorm(stream_, f[F_X], M, D, L.norm2.g, L.norm2.b, nullptr, 0, f[F_XN], D);
-  launch_gemm_f32(stream_, f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f);
-  launch_gemm_f32(stream_, f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f);
+  gemm32(f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f);
+  gemm32(f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f);
 }
 
 void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logits) {
@@ -1754,7 +1797,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
     const size_t o_lg = c2((size_t)M * ldV * 4), o_ids = c2((size_t)M * 8);
     ensure(ws_dec_, o2);
     logits_ = (float*)((char*)ws_dec_.p + o_lg); ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids); logits_ld_ = ldV;
-    launch_gemm_f32(stream_, H32_, D, ctc_.w32, D, ctc_.bias, M, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
+    gemm32(H32_, D, ctc_.w32, D, ctc_.bias, M, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
     launch_argmax(stream_, logits_, M, V, ldV, want_logits ? 2 : 1, ids_dev_);
     last_.B = B; last_.L = T; last_.V = V; last_.T = T;
     last_.ids.assign((size_t)M, 0);
@@ -1766,7 +1809,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   }
   // ---- CIF predictor
   launch_im2col_f32(stream_, H32_, B, T, D, mc_.cif_l_order, mc_.cif_r_order, f[F_T]);
-  launch_gemm_f32(stream_, f[F_T], taps * D, cif_conv_w32_, taps * D, cif_conv_.bias, M, D, taps * D, f[F_FS], D, nullptr, 0, true, 0, 1.f);
+  gemm32(f[F_T], taps * D, cif_conv_w32_, taps * D, cif_conv_.bias, M, D, taps * D, f[F_FS], D, nullptr, 0, true, 0, 1.f);
   launch_cif_alpha(stream_, f[F_FS], B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
   else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
@@ -1808,9 +1851,9 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
     launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, nullptr, 0, xn, D);
-    launch_gemm_f32(stream_, xn, D, w1.w32, D, w1.bias, Md, F, D, hd, F, nullptr, 0, true, 0, 1.f);
+    gemm32(xn, D, w1.w32, D, w1.bias, Md, F, D, hd, F, nullptr, 0, true, 0, 1.f);
     launch_layernorm(stream_, hd, Md, F, fn.g, fn.b, nullptr, 0, hn, F);
-    launch_gemm_f32(stream_, hn, F, w2.w32, F, nullptr, Md, D, F, t32, D, nullptr, 0, false, 0, 1.f);
+    gemm32(hn, F, w2.w32, F, nullptr, Md, D, F, t32, D, nullptr, 0, false, 0, 1.f);
   };
   for (size_t i = 0; i < dec_.size(); ++i) {
     const DecLayer& Lr = dec_[i];
@@ -1818,15 +1861,15 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
     launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
     launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
     launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
-    launch_gemm_f32(stream_, xn, D, Lr.q.w32, D, Lr.q.bias, Md, D, D, qd, D, nullptr, 0, false, D, qscale);
-    launch_gemm_f32(stream_, H32_, D, Lr.kv32.w32, D, Lr.kv32.bias, M, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
+    gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, Md, D, D, qd, D, nullptr, 0, false, D, qscale);
+    gemm32(H32_, D, Lr.kv32.w32, D, Lr.kv32.bias, M, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
     launch_attention_f32(stream_, qd, (int64_t)L * D, D, kv, (int64_t)T * 2 * D, 2 * D, kv + D, (int64_t)T * 2 * D, 2 * D, cx,
                          (int64_t)L * D, D, B, mc_.heads, L, T);
-    launch_gemm_f32(stream_, cx, D, Lr.out.w32, D, Lr.out.bias, Md, D, D, xd, D, xd, D, false, 0, 1.f);
+    gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, Md, D, D, xd, D, xd, D, false, 0, 1.f);
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
   launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
-  launch_gemm_f32(stream_, xn, D, dec_out_.w32, D, dec_out_.bias, Md, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
+  gemm32(xn, D, dec_out_.w32, D, dec_out_.bias, Md, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
   launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
   if (bias_branch) seaco_head_fp32(B, L, e0, xn, want_logits);      // xn = the ASR decoder's after_norm hidden
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
@@ -1838,7 +1881,7 @@ void Engine::lstm_fp32(const float* x, int Bn, int Tn, const float* w_ih, const 
                        float* xg, float* gates, float* hbuf, float* cbuf, float* hout, int ldh, int col0) {
   const int D = mc_.d_model;
   // input half of the gates for every row at once: xg[b * Tn + t, 0:4D] = x W_ih^T + (b_ih + b_hh)
-  launch_gemm_f32(stream_, x, D, w_ih, D, bias, Bn * Tn, 4 * D, D, xg, 4 * D, nullptr, 0, false, 0, 1.f);
+  gemm32(x, D, w_ih, D, bias, Bn * Tn, 4 * D, D, xg, 4 * D, nullptr, 0, false, 0, 1.f);
   PF_HIP(hipMemsetAsync(hbuf, 0, (size_t)Bn * D * 4, stream_));
   PF_HIP(hipMemsetAsync(cbuf, 0, (size_t)Bn * D * 4, stream_));
   for (int st = 0; st < Tn; ++st) {
@@ -1866,7 +1909,7 @@ void Engine::timestamp_head_fp32(int B, int T) {
   float* al = (float*)(base + o_al);
   us_peak_ = (float*)(base + o_pk);
   // [M, 3D] row-major IS [3M, D]
-  launch_gemm_f32(stream_, H32_, D, ts_up_w32_, D, ts_up_.bias, M, up * D, D, up32, up * D, nullptr, 0, false, 0, 1.f);
+  gemm32(H32_, D, ts_up_w32_, D, ts_up_.bias, M, up * D, D, up32, up * D, nullptr, 0, false, 0, 1.f);
   const char* sfx[2] = {"", "_reverse"};
   for (int d = 0; d < 2; ++d)
     lstm_fp32(up32, B, T3, tensor(std::string("predictor.blstm.weight_ih") + sfx[d]).dev,
@@ -1921,9 +1964,9 @@ void Engine::seaco_head_fp32(int B, int L, const float* e0, const float* hid_asr
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
     launch_layernorm(stream_, xs, R, D, n1.g, n1.b, nullptr, 0, xn, D);
-    launch_gemm_f32(stream_, xn, D, w1.w32, D, w1.bias, R, Fs, D, hd, Fs, nullptr, 0, true, 0, 1.f);
+    gemm32(xn, D, w1.w32, D, w1.bias, R, Fs, D, hd, Fs, nullptr, 0, true, 0, 1.f);
     launch_layernorm(stream_, hd, R, Fs, fn.g, fn.b, nullptr, 0, hn, Fs);
-    launch_gemm_f32(stream_, hn, Fs, w2.w32, Fs, nullptr, R, D, Fs, t32, D, nullptr, 0, false, 0, 1.f);
+    gemm32(hn, Fs, w2.w32, Fs, nullptr, R, D, Fs, t32, D, nullptr, 0, false, 0, 1.f);
   };
   for (int i = 0; i < ns; ++i) {
     const DecLayer& Lr = sdec_[i];
@@ -1931,16 +1974,16 @@ void Engine::seaco_head_fp32(int B, int L, const float* e0, const float* hid_asr
     launch_layernorm(stream_, t32, R, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
     launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, tn2, 2 * B, L, D, mc_.seaco_kernel, xs);
     launch_layernorm(stream_, xs, R, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
-    launch_gemm_f32(stream_, xn, D, Lr.q.w32, D, Lr.q.bias, R, D, D, qd, D, nullptr, 0, false, D, qscale);
-    launch_gemm_f32(stream_, bias_embed, D, Lr.kv32.w32, D, Lr.kv32.bias, NJ, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
+    gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, R, D, D, qd, D, nullptr, 0, false, D, qscale);
+    gemm32(bias_embed, D, Lr.kv32.w32, D, Lr.kv32.bias, NJ, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
     launch_attention_f32(stream_, qd, (int64_t)L * D, D, kv, 0, 2 * D, kv + D, 0, 2 * D, cx, (int64_t)L * D, D, 2 * B, mc_.heads, L, NJ);
-    launch_gemm_f32(stream_, cx, D, Lr.out.w32, D, Lr.out.bias, R, D, D, xs, D, xs, D, false, 0, 1.f);
+    gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, R, D, D, xs, D, xs, D, false, 0, 1.f);
   }
   ffn_dec(seaco_final_norm1_, seaco_final_w1_, seaco_final_ffn_norm_, seaco_final_w2_);
   launch_layernorm(stream_, t32, R, D, seaco_after_.g, seaco_after_.b, nullptr, 0, hid, D);
   // ---- merged = cif_attended + dec_attended -> hotword_output_layer -> NO-BIAS merge with the ASR rows
   launch_add_f32(stream_, hid, hid + (size_t)Md * D, (int64_t)Md * D);
-  launch_gemm_f32(stream_, hid, D, seaco_out_.w32, D, seaco_out_.bias, Md, V, D, dha, ldV, nullptr, 0, false, 0, 1.f);
+  gemm32(hid, D, seaco_out_.w32, D, seaco_out_.bias, Md, V, D, dha, ldV, nullptr, 0, false, 0, 1.f);
   launch_argmax(stream_, dha, Md, V, ldV, 2, dha_ids);
   launch_seaco_merge(stream_, dha, ldV, dha_ids, Md, V, mc_.seaco_nobias, want_logits ? 1 : 0, logits_, logits_ld_, ids_dev_);
 }

@@ -261,6 +261,11 @@ class Engine {
   void sk_prepare(int M, int calls);
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
+  bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs
+  std::map<const float*, half_t*> x3w_;   // fp32 weight -> its [lo' | hi] f16 pair image (built on first use)
+  DevBuf ws_x3a_, ws_x3t_;
+  void gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
+              const float* resid, int ldr, bool relu, int scale_cols, float scale);
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   bool int8_mode_ = false;           // math_mode 2: Linear layers dynamically quantised to uint8, products on the int8 MFMA
   std::map<const float*, QLin> qlins_;

@@ -100,12 +100,151 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__
   o[(size_t)b * o_bs + (size_t)iq * o_rs + h * 128 + tid] = acc;
 }
 
+// The same on the fp32 matrix path (round 5; the kernel above took 135 of the 240 ms of an fp32-mode step): flash form, one
+// workgroup = 128 queries of one (utterance, head), 4 waves x 32 queries, key tiles of 32 staged through LDS as fp32 rows
+// (row stride 132 floats: the fragment reads are conflict-free).
+//   S^T[32 keys x 32 q] = K Q^T : 64 x v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation); a lane owns one query
+//     column, Q lives in 64 registers for the whole launch, a K fragment is one ds_read_b128 = four k-steps (the k index of an
+//     MFMA is a summation index: lane (row, kh) takes d = 8 g + 4 kh + e for step 4 g + e, on both operands);
+//   online softmax in fp32 (expf, running max / sum per lane, one lane^32 exchange per tile);
+//   O^T[128 d x 32 q] += V^T P^T : 64 MFMAs, the P operand of step 4 g + j IS the lane's own S register 4 g + j (D layout:
+//     keys 8 g + 4 kh + j), V^T fragments are ds_read_b32 rows of the V tile.
+// Invalid keys of the tail tile score -inf and read the last valid V row (0 x NaN of a stale row would poison O).
+constexpr int AF_KT = 32, AF_LDK = 132;
+__global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restrict__ q, int64_t q_bs, int q_rs, const float* __restrict__ k,
+                                                            int64_t k_bs, int k_rs, const float* __restrict__ v, int64_t v_bs, int v_rs,
+                                                            float* __restrict__ o, int64_t o_bs, int o_rs, int H, int Lq, int Lk) {
+  __shared__ __attribute__((aligned(16))) float Ks[AF_KT * AF_LDK], Vs[AF_KT * AF_LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = min(q0 + l31, Lq - 1);                      // (rows past Lq compute on a copy of the last row; never stored)
+  const float* qp = q + (size_t)b * q_bs + (size_t)qrow * q_rs + h * 128;
+  float qf[64];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const float4 t = *reinterpret_cast<const float4*>(qp + 8 * g + 4 * kh);
+    qf[4 * g + 0] = t.x; qf[4 * g + 1] = t.y; qf[4 * g + 2] = t.z; qf[4 * g + 3] = t.w;
+  }
+  f16x oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* kb = k + (size_t)b * k_bs + h * 128;
+  const float* vb = v + (size_t)b * v_bs + h * 128;
+  for (int k0 = 0; k0 < Lk; k0 += AF_KT) {
+    __syncthreads();                                           // everybody has finished with the previous tile
+    // 32 keys x 128 floats of K and of V: 1024 float4 each, 4 + 4 per thread
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + it * 256, r = e >> 5, c4 = e & 31;
+      const int kr = min(k0 + r, Lk - 1);
+      *reinterpret_cast<float4*>(&Ks[r * AF_LDK + 4 * c4]) = *reinterpret_cast<const float4*>(kb + (size_t)kr * k_rs + 4 * c4);
+      *reinterpret_cast<float4*>(&Vs[r * AF_LDK + 4 * c4]) = *reinterpret_cast<const float4*>(vb + (size_t)kr * v_rs + 4 * c4);
+    }
+    __syncthreads();
+    f16x sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float4 kf = *reinterpret_cast<const float4*>(&Ks[l31 * AF_LDK + 8 * g + 4 * kh]);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[4 * g + 0], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[4 * g + 1], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * g + 2], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * g + 3], sacc, 0, 0, 0);
+    }
+    // this lane: query l31, keys k0 + 8 g + 4 kh + j in register 4 g + j
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = k0 + 8 * (e >> 2) + 4 * kh + (e & 3);
+      if (key >= Lk) sacc[e] = -INFINITY;
+      mt = fmaxf(mt, sacc[e]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);                      // finite: a tile holds at least one valid key
+    const float alpha = expf(m_run - m_new);                   // first tile: exp(-inf) = 0
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { sacc[e] = expf(sacc[e] - m_new); ls += sacc[e]; }
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float vf = Vs[(8 * (e >> 2) + 4 * kh + (e & 3)) * AF_LDK + d * 32 + l31];
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sacc[e], oacc[d], 0, 0, 0);
+      }
+  }
+  if (q0 + l31 >= Lq) return;
+  const float inv = 1.0f / l_run;
+  float* op = o + (size_t)b * o_bs + (size_t)(q0 + l31) * o_rs + h * 128;
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * kh) =
+          make_float4(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+}
+
 void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
                           const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk) {
   if (B == 0 || Lq == 0 || Lk == 0) return;
+  static const bool naive = [] { const char* e = getenv("PF_ATTN_F32_NAIVE"); return e && e[0] == '1'; }();   // A/B: the one-query-per-workgroup kernel
+  const bool aligned = ((q_rs | k_rs | v_rs | o_rs) % 4 == 0) && (q_bs % 4 == 0) && (k_bs % 4 == 0) && (v_bs % 4 == 0) && (o_bs % 4 == 0) &&
+                       ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0);
+  if (!naive && aligned) {
+    hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3((unsigned)cdiv(Lq, 128), (unsigned)(B * H)), dim3(256), 0, s, q, q_bs, q_rs, k, k_bs, k_rs,
+                       v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
+    PF_HIP(hipGetLastError());
+    return;
+  }
   PF_CHECK((size_t)(128 + Lk + 4) * 4 <= 64 * 1024, PF_ERR_UNSUPPORTED, "fp32 mode: more than ~16000 keys per utterance");
   hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)Lq, (unsigned)(B * H)), dim3(128), (size_t)(128 + Lk + 4) * 4, s, q, q_bs, q_rs,
                      k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
+  PF_HIP(hipGetLastError());
+}
+
+// ---- "x3" products (math_mode 3): an fp32 value as TWO f16 numbers, hi = f16(x) and lo' = f16((x - hi) * 2^11) — 22 bits of
+// mantissa, the low part kept in the normal range by the scaling — so that x y = hi_x hi_y + 2^-11 (hi_x lo'_y + lo'_x hi_y)
+// up to 2^-22 relative: three f16 MFMA products (16x the fp32 matrix rate each) with fp32 accumulation.
+// Row r of x [rows, K] (fp32, row stride ldx) -> out[r, 0:Kp] | out[r, Kp:2 Kp] = hi | lo' (swap = 0) or lo' | hi (swap = 1);
+// columns K..Kp-1 of both halves are zeroed.
+__global__ __launch_bounds__(256) void split_x3_kernel(const float* __restrict__ x, int64_t rows, int K, int ldx, half_t* __restrict__ out,
+                                                       int ldo, int Kp, int swap) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kq = Kp >> 2;
+  if (i >= rows * kq) return;
+  const int64_t r = i / kq;
+  const int c = (int)(i - r * kq) * 4;
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float v = c + e < K ? x[(size_t)r * ldx + c + e] : 0.f;
+    const half_t hv = (half_t)v;
+    hi[e] = hv;
+    lo[e] = (half_t)((v - (float)hv) * 2048.0f);
+  }
+  half_t* o = out + (size_t)r * ldo + c;
+  *reinterpret_cast<h4*>(o + (swap ? Kp : 0)) = hi;
+  *reinterpret_cast<h4*>(o + (swap ? 0 : Kp)) = lo;
+}
+
+void launch_split_x3(hipStream_t s, const float* x, int64_t rows, int K, int ldx, half_t* out, int ldo, int Kp, int swap) {
+  if (rows <= 0) return;
+  const int64_t n = rows * (Kp >> 2);
+  hipLaunchKernelGGL(split_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, rows, K, ldx, out, ldo, Kp, swap);
   PF_HIP(hipGetLastError());
 }
 

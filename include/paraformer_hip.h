@@ -97,7 +97,10 @@ typedef struct pf_engine_config {
                                  (v_mfma_f32_32x32x2_f32: exact fp32 products, ~1/16 of the speed); 2 = the arithmetic
                                  of the reference's default model.int8.onnx (Examples/Program.cs:98-101): every
                                  Linear as DynamicQuantizeLinear + MatMulInteger on v_mfma_i32_32x32x32_i8, weights
-                                 quantised per output channel as onnxruntime's quantize_dynamic does */
+                                 quantised per output channel as onnxruntime's quantize_dynamic does; 3 = "exact" at
+                                 matrix-core speed (ABI 5): the fp32 graph of mode 1 with every large Linear as three
+                                 f16 MFMA products of (hi, 2^11 lo) operand pairs — 22 mantissa bits per operand, fp32
+                                 accumulation — and fp32-MFMA flash attention */
   int32_t reserved[3];
 } pf_engine_config;
 

@@ -4,7 +4,12 @@ three benchmark workloads of bench.py at FULL model depth — so that `bench.py`
 ids of the timed computation itself against an oracle run without repeating it (tests/test_gpu_full_depth.py also
 repeats it live and cross-checks this file).
 
-    python tests/golden/make_bench_golden.py [paraformer] [sensevoice] [seaco]
+    python tests/golden/make_bench_golden.py [paraformer] [sensevoice] [seaco] [paraformer_int8] [seaco_int8]
+
+`<name>_int8` (round 5): the same workload through `Oracle(quant="int8_ref")` — every Linear as DynamicQuantizeLinear +
+MatMulInteger + rescale in exact integer / float32 arithmetic (oracle/int8.py), no 16-bit rounding point anywhere: what
+onnxruntime computes on the reference's DEFAULT model.int8.onnx (Examples/Program.cs:98-101).  `bench.py --accuracy int8`
+checks its ids against these files (`ids_vs_int8_oracle`).
 
 Workloads = bench.py's: seeded synthetic weights (weights.synth_weights(cfg, 42)), synthetic audio
 (weights.synth_audio(samples, utt)), CMVN weights.synth_cmvn(); the audio goes through the oracle front-end
@@ -93,9 +98,13 @@ def us_fires(peak, alphas, thr):
 
 
 def run(name):
+    full_name = name
+    quant = "fp32"
+    if name.endswith("_int8"):
+        name, quant = name[:-5], "int8_ref"
     cfg, w, cmvn, audio, hw = workload(name)
     mc = om.ModelConfig(**cfg)
-    orc = om.Oracle(mc, w, quant="fp32")
+    orc = om.Oracle(mc, w, quant=quant)
     t0 = time.time()
     out = {}
     with torch.inference_mode():
@@ -121,11 +130,11 @@ def run(name):
         out["fire_count"] = np.asarray(r["fire_count"], np.int32)
     if "alphas" in r:
         out["alpha_sum"] = r["alphas"].astype(np.float64).sum(axis=1).astype(np.float32)
-    path = os.path.join(HERE, "bench_%s.npz" % name)
+    path = os.path.join(HERE, "bench_%s.npz" % full_name)
     np.savez_compressed(path, **out)
     ids = out["ids"]
     print("%s: B=%d L=%d, %d distinct ids, margin>0.04: %.3f, >0.1: %.3f, oracle %.1f s -> %s (%d bytes)"
-          % (name, ids.shape[0], ids.shape[1], len(np.unique(ids)), (margin > 0.04).mean(), (margin > 0.1).mean(),
+          % (full_name, ids.shape[0], ids.shape[1], len(np.unique(ids)), (margin > 0.04).mean(), (margin > 0.1).mean(),
              time.time() - t0, os.path.relpath(path, ROOT), os.path.getsize(path)))
 
 

@@ -20,6 +20,13 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-4
 
 
+@pytest.fixture(params=[1, 3], ids=["fp32_mfma", "exact_x3"])
+def mode(request):
+    """1 = fp32 operands on v_mfma_f32_32x32x2_f32; 3 = the same graph with every large Linear as three f16 MFMA products of
+    (hi, 2^11 lo) operand pairs — 22 mantissa bits — and the fp32-MFMA flash attention (round 5).  Same tolerances."""
+    return request.param
+
+
 def _speech(audio, cmvn):
     conf = fe.FrontendConf(dither=0.0)
     feats = [fe.wav_frontend(a, conf, cmvn[0], cmvn[1]) for a in audio]
@@ -37,13 +44,13 @@ def _ids_match(res, ref_logits, margin=1e-3):
 
 
 @pytest.mark.parametrize("variant", ["loop", "cumsum"])
-def test_fp32_mode_small_paraformer(variant):
+def test_fp32_mode_small_paraformer(variant, mode):
     from aliparaformerasr_amd.engine import Engine
     cfg = W.paraformer_large_config(enc_layers=3, dec_layers=2, vocab=515)     # V not a multiple of 4
     cfg["cif_variant"] = variant
     w = W.synth_weights(cfg, seed=33)
     cmvn = W.synth_cmvn()
-    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=mode)
     audio = [W.synth_audio(n, 5 + u) for u, n in enumerate((48000, 30000, 41000))]
     speech = _speech(audio, cmvn)
     ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").paraformer(speech)
@@ -58,7 +65,7 @@ def test_fp32_mode_small_paraformer(variant):
     eng.close()
 
 
-def test_fp32_mode_full_depth_is_closer_than_f16_mode():
+def test_fp32_mode_full_depth_is_closer_than_f16_mode(mode):
     from aliparaformerasr_amd.engine import Engine
     cfg = W.paraformer_large_config()
     w = W.synth_weights(cfg, seed=42)
@@ -67,7 +74,7 @@ def test_fp32_mode_full_depth_is_closer_than_f16_mode():
     audio = [W.synth_audio(80000, u) for u in range(2)]
     speech = _speech(audio, cmvn)
     ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32", fast=True).paraformer(speech)
-    e32 = Engine(weights=blob, cmvn=cmvn, device=0, math_mode=1)
+    e32 = Engine(weights=blob, cmvn=cmvn, device=0, math_mode=mode)
     r32 = e32.forward_feats(speech, want_logits=True)
     e32.close()
     e16 = Engine(weights=blob, cmvn=cmvn, device=0)
@@ -83,13 +90,13 @@ def test_fp32_mode_full_depth_is_closer_than_f16_mode():
     assert agree > 0.99
 
 
-def test_fp32_mode_sensevoice(sv_embed):
+def test_fp32_mode_sensevoice(sv_embed, mode):
     from aliparaformerasr_amd.engine import Engine
     cfg = W.sensevoice_small_config(enc_layers=3, tp_layers=2, vocab=403)
     w = W.synth_weights(cfg, seed=9)
     w["embed.weight"] = sv_embed.astype(np.float32)
     cmvn = W.synth_cmvn()
-    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=mode)
     conf = fe.FrontendConf(dither=0.0)
     audio = [W.synth_audio(n, 70 + u) for u, n in enumerate((32000, 24000))]
     feats = [glue.sensevoice_prepend(fe.wav_frontend(a, conf, cmvn[0], cmvn[1]), sv_embed, use_itn=True) for a in audio]
@@ -104,7 +111,7 @@ def test_fp32_mode_sensevoice(sv_embed):
     eng.close()
 
 
-def test_fp32_mode_bicif_timestamp_head():
+def test_fp32_mode_bicif_timestamp_head(mode):
     """configs[4]'s timestamp head in fp32 (ConvTranspose1d, BiLSTM, Linear(1024, 1), renormalisation, cif_wo_hidden):
     us_cif_peak within 2e-4 of the fp32 oracle modulo the integrator reset, the SAME fire frames wherever the oracle's
     crossing clears the threshold by 1e-3, recognizer-side timestamps (integer milliseconds) identical on those."""
@@ -112,7 +119,7 @@ def test_fp32_mode_bicif_timestamp_head():
     cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=256, timestamp_head=True)
     w = W.synth_weights(cfg, seed=1)
     cmvn = W.synth_cmvn()
-    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=mode)
     audio = [W.synth_audio(n, 11 + u) for u, n in enumerate((48000, 36000))]
     speech = _speech(audio, cmvn)
     ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").paraformer(speech)
@@ -138,7 +145,7 @@ def test_fp32_mode_bicif_timestamp_head():
     eng.close()
 
 
-def test_fp32_mode_seaco_bias_decoder():
+def test_fp32_mode_seaco_bias_decoder(mode):
     """configs[4]'s SeACo branch in fp32: hotword embedder (Embedding + 2 x LSTM), the bias decoder on [CIF embeds ;
     decoder hidden], hotword_output_layer, NO-BIAS merge — merged log-probs within 2e-4 of the fp32 oracle on every
     row whose NO-BIAS decision is not a near-tie, ids identical off the near-ties; + the timestamp head of the same model."""
@@ -147,7 +154,7 @@ def test_fp32_mode_seaco_bias_decoder():
     w = W.synth_weights(cfg, seed=6)
     w["seaco.output.bias"][290] += 2.6          # random heads never pick NO-BIAS: lift it so that both sides of the merge occur
     cmvn = W.synth_cmvn()
-    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=1)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=mode)
     audio = [W.synth_audio(n, 40 + u) for u, n in enumerate((32000, 48000, 40000))]
     speech = _speech(audio, cmvn)
     hw = np.asarray(glue.pad_list([[11, 12], [100, 200, 30], [7, 8, 9, 10], [1]]), np.int32)
