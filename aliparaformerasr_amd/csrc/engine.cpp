@@ -121,7 +121,8 @@ void Engine::release() {
   for (void* p : owned_) hipFree(p);
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
-                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_, &ws_x3a_, &ws_x3t_};
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_, &ws_x3a_, &ws_x3t_, &ws_x3h_};
+  x3_pair_live_ = false; x3a_src_ = nullptr;
   x3w_.clear();
   sk_slab_ = nullptr; sk_flags_ = nullptr; sk_err_ = nullptr; sk_used_ = false;
   seaco_hw_valid_ = false;
@@ -1695,10 +1696,21 @@ enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
 // as TWO launches of the pipeline's own f16 MFMA kernels with fp32 results: [hi_x] x [hi_W] (depth K) -> t, then
 // [hi_x | lo'_x] x [lo'_W | hi_W] (depth 2 K) scaled by 2^-11 in the epilogue, + t, + residual, ReLU — three times the f16
 // MFMA work at 16x the fp32 matrix rate.  The weight pairs are built on first use and kept (same bytes as the fp32 matrix).
+// flags: kX3OutPair — the result is only the A operand of the NEXT gemm32 (FFN hidden): in mode 3 it is written as its
+// (hi | lo') pair by the product's epilogue and `out` is not touched; kX3InPair — A is that pair (the `A` pointer is ignored in
+// mode 3).  Mode 1 ignores both flags.  resid2: a second fp32 addend with the row stride of resid (the FSMN memory beside the
+// residual stream).
 void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
-                    const float* resid, int ldr, bool relu, int scale_cols, float scale) {
-  if (!x3_mode_ || M < 64 || ldw != K || (scale_cols != 0 && scale_cols < N) || (ldc % 4) || (resid && ldr % 4)) {
+                    const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
+  const bool x3 = x3_mode_ && M >= 64 && ldw == K && (scale_cols == 0 || scale_cols >= N) && (ldc % 4) == 0 && (!resid || ldr % 4 == 0);
+  const bool pair_ok = x3 && M > gemm_small_max_rows();
+  if (!x3) {
+    PF_CHECK(!(flags & kX3InPair) || !x3_pair_live_, PF_ERR_UNSUPPORTED, "gemm32: operand pair without its consumer");
     launch_gemm_f32(stream_, A, lda, W, ldw, bias, M, N, K, out, ldc, resid, ldr, relu, scale_cols, scale);
+    if (resid2) {
+      PF_CHECK(ldc == N && ldr == N, PF_ERR_UNSUPPORTED, "gemm32: a second addend needs contiguous rows");
+      launch_add_f32(stream_, out, resid2, (int64_t)M * N);
+    }
     return;
   }
   const int Kp = (int)round_up(K, 64);
@@ -1711,20 +1723,43 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
     it = x3w_.emplace(W, wc).first;
   }
   const half_t* wcat = it->second;
-  ensure(ws_x3a_, (size_t)Mp * 2 * Kp * 2);
   const int ldt = (int)round_up(N, 4);
   ensure(ws_x3t_, (size_t)Mp * ldt * 4);
-  half_t* a2 = (half_t*)ws_x3a_.p;
   float* t = (float*)ws_x3t_.p;
-  launch_split_x3(stream_, A, M, K, lda, a2, 2 * Kp, Kp, 0);          // rows = [hi_x | lo'_x]
+  half_t* a2;
+  if ((flags & kX3InPair) && x3_pair_live_) {
+    PF_CHECK(x3_pair_M_ == M && x3_pair_K_ == K, PF_ERR_INVALID_ARG, "gemm32: operand pair of another shape");
+    a2 = (half_t*)ws_x3h_.p;                                          // written by the producing product's epilogue
+    x3_pair_live_ = false; x3a_src_ = nullptr;
+  } else {
+    ensure(ws_x3a_, (size_t)Mp * 2 * Kp * 2);
+    a2 = (half_t*)ws_x3a_.p;
+    // kX3SameInput: the caller states that A is the (unchanged) operand of its previous gemm32 call — Q, K and V share one
+    const bool same = (flags & kX3SameInput) && x3a_src_ == A && x3a_M_ == M && x3a_K_ == K && x3a_ld_ == lda && x3a_buf_ == a2;
+    if (!same) launch_split_x3(stream_, A, M, K, lda, a2, 2 * Kp, Kp, 0);   // rows = [hi_x | lo'_x]
+    x3a_src_ = A; x3a_M_ = M; x3a_K_ = K; x3a_ld_ = lda; x3a_buf_ = a2;
+  }
+  const bool out_pair = (flags & kX3OutPair) && pair_ok && N % 64 == 0;
+  const int Np64 = (int)round_up(N, 64);
+  if (out_pair) {
+    ensure(ws_x3h_, (size_t)Mp * 2 * Np64 * 2);
+    PF_CHECK((void*)ws_x3h_.p != (void*)a2, PF_ERR_UNSUPPORTED, "gemm32: chained operand pairs");
+  }
   GemmArgs g{};
   g.A = a2; g.lda = 2 * Kp; g.W = wcat + Kp; g.ldw = 2 * Kp; g.bias = bias; g.M = M; g.N = N; g.K = Kp;
   g.out_f32 = t; g.ldc32 = ldt; g.scale_cols = scale_cols ? (int)round_up(N, 64) : 0; g.scale = scale;
+  g.add2 = resid2; g.ld2 = ldr;
   g.out_padded = 1; g.small_ws = small_ws_;
-  launch_gemm(stream_, g);                                            // t = (hi_x hi_W^T + bias) [* scale]
+  launch_gemm(stream_, g);                                            // t = (hi_x hi_W^T + bias) [* scale] [+ resid2]
   GemmArgs c{};
   c.A = a2; c.lda = 2 * Kp; c.W = wcat; c.ldw = 2 * Kp; c.M = M; c.N = N; c.K = 2 * Kp;
-  c.out_f32 = out; c.ldc32 = ldc; c.add2 = t; c.ld2 = ldt; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
+  if (out_pair) {
+    c.out_f16 = (half_t*)ws_x3h_.p; c.ldc16 = 2 * Np64; c.f16_lo_off = Np64;
+    x3_pair_live_ = true; x3_pair_M_ = M; x3_pair_K_ = N;
+  } else {
+    c.out_f32 = out; c.ldc32 = ldc;
+  }
+  c.add2 = t; c.ld2 = ldt; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
   c.scale_cols = (int)round_up(N, 64); c.scale = (scale_cols ? scale : 1.f) * (1.0f / 2048.0f);
   c.out_padded = 1; c.small_ws = small_ws_;
   launch_gemm(stream_, c);                                            // out = cross * 2^-11 [* scale] + t + resid; ReLU
@@ -1742,20 +1777,21 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
   }
   const float* Wq = L.qkv.w32;
   gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
-  gemm32(f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f);
-  gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f);
+  gemm32(f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
+  gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
   launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
   launch_attention_f32(stream_, f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
                        (int64_t)T * D, D, B, mc_.heads, T, T);
   if (first) {
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
   } else {
-    gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_T], D, f[F_FS], D, false, 0, 1.f);   // att = lin + fsmn
-    launch_add_f32(stream_, f[F_X], f[F_T], (int64_t)M * D);                                                           // x = x + att
+    // x = x + (lin + fsmn): the fp32 graph adds the attention block's two terms first; here the sum of three is formed in the
+    // product's epilogue as (lin + fsmn) + x up to one rounding of the association
+    gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_X], D, false, 0, 1.f, 0, f[F_FS]);
   }
   launch_layernorm(stream_, f[F_X], M, D, L.norm2.g, L.norm2.b, nullptr, 0, f[F_XN], D);
-  gemm32(f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f);
-  gemm32(f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f);
+  gemm32(f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f, kX3OutPair);
+  gemm32(f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f, kX3InPair);
 }
 
 void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logits) {

@@ -263,9 +263,12 @@ class Engine {
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
   bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs
   std::map<const float*, half_t*> x3w_;   // fp32 weight -> its [lo' | hi] f16 pair image (built on first use)
-  DevBuf ws_x3a_, ws_x3t_;
+  DevBuf ws_x3a_, ws_x3t_, ws_x3h_;
+  bool x3_pair_live_ = false; int x3_pair_M_ = 0, x3_pair_K_ = 0;   // ws_x3h_ holds the (hi | lo') pair the next gemm32 consumes
+  enum { kX3OutPair = 1, kX3InPair = 2, kX3SameInput = 4 };
+  const float* x3a_src_ = nullptr; int x3a_M_ = 0, x3a_K_ = 0, x3a_ld_ = 0; half_t* x3a_buf_ = nullptr;   // what ws_x3a_ holds the pair of
   void gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
-              const float* resid, int ldr, bool relu, int scale_cols, float scale);
+              const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags = 0, const float* resid2 = nullptr);
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
   bool int8_mode_ = false;           // math_mode 2: Linear layers dynamically quantised to uint8, products on the int8 MFMA
   std::map<const float*, QLin> qlins_;

@@ -68,6 +68,7 @@ struct GemmDev {
   int relu, scale_cols; float scale;
   int out_padded;
   int out_blocked, a_blocked;
+  int f16_lo_off;            // > 0: out_f16 receives the result as an x3 pair: hi at column n, lo' = f16((v - hi) * 2^11) at n + f16_lo_off
   // int8 variant (gemm_i8_pp3): A / W hold SIGNED bytes a' = a_q - 128, w' = w_q - 128 (K counted in bytes);
   // acc = sum a' w' is corrected to sum (a_q - a_zp)(w_q - w_zp[n]) with the row / column sums and dequantised
   const int32_t* q_rowsum;   // [M]  sum_k a'[m,k]
@@ -424,7 +425,14 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
               if constexpr (I8) { trk_lo = fminf(trk_lo, v[e]); trk_hi = fmaxf(trk_hi, v[e]); }
             }
             if (o32) *reinterpret_cast<float4*>(o32 + dn) = make_float4(v[0], v[1], v[2], v[3]);
-            if (o16) *reinterpret_cast<h4*>(o16 + dn) = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            if (o16) {
+              const h4 hv = h4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              *reinterpret_cast<h4*>(o16 + dn) = hv;
+              if (p.f16_lo_off > 0)      // math_mode 3: the next product's operand pair, written where it is produced
+                *reinterpret_cast<h4*>(o16 + dn + p.f16_lo_off) =
+                    h4{(half_t)((v[0] - (float)hv[0]) * 2048.f), (half_t)((v[1] - (float)hv[1]) * 2048.f),
+                       (half_t)((v[2] - (float)hv[2]) * 2048.f), (half_t)((v[3] - (float)hv[3]) * 2048.f)};
+            }
           } else {
             for (int e = 0; e < 4 && n + e < p.N; ++e) {
               float x = v[e] + (p.bias ? p.bias[n + e] : 0.f);
@@ -434,7 +442,10 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
               x = fmaxf(x, lo);
               if constexpr (I8) { trk_lo = fminf(trk_lo, x); trk_hi = fmaxf(trk_hi, x); }
               if (o32) o32[dn + e] = x;
-              if (o16) o16[dn + e] = (half_t)x;
+              if (o16) {
+                o16[dn + e] = (half_t)x;
+                if (p.f16_lo_off > 0) o16[dn + e + p.f16_lo_off] = (half_t)((x - (float)(half_t)x) * 2048.f);
+              }
             }
           }
         }
@@ -780,6 +791,9 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   d.relu = a.relu; d.scale_cols = a.scale_cols; d.scale = a.scale_cols > 0 ? a.scale : 1.f;
   d.out_padded = a.out_padded;
   d.out_blocked = a.out_blocked; d.a_blocked = a.a_blocked;
+  d.f16_lo_off = a.f16_lo_off;
+  PF_CHECK(a.f16_lo_off == 0 || (a.out_f16 && a.add2 && !a.out_blocked && a.f16_lo_off % 4 == 0 && a.M > gemm_small_max_rows()),
+           PF_ERR_INVALID_ARG, "gemm: the x3 pair output is an option of the fp32-kind epilogue (add2 given, M above the short-input threshold)");
   PF_CHECK(!a.out_blocked || (a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && a.N % 64 == 0),
            PF_ERR_INVALID_ARG, "gemm: blocked output needs an f16-only padded result with N % 64 == 0");
   PF_CHECK(!a.a_blocked || a.K % 64 == 0, PF_ERR_INVALID_ARG, "gemm: blocked A operand needs K % 64 == 0");

@@ -30,6 +30,8 @@ struct GemmArgs {
   int a_blocked;
   float* small_ws;               // scratch of the short-input kernel (k_gemm_small.hip, gemm_small_ws_bytes() bytes, one per
                                  // stream); null = never dispatch to it
+  int f16_lo_off;                // > 0 (fp32-kind epilogue only: add2 given): out_f16 receives the result as the operand pair of an
+                                 // "x3" product (math_mode 3): hi = f16(v) at column n, lo' = f16((v - hi) * 2^11) at n + f16_lo_off
   int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result), 6 = the k-step-32 fp32-result kernel
                                  // (stand-alone op tests; 4 / 5 fail when that kernel does not apply)
 };
