@@ -118,6 +118,7 @@ SIGNATURES = {
     "pf_op_gemm_rc": (C.c_int, [_vp, _P(PfGemmRcDesc), _f, _f, _f, _f, _f]),
     "pf_op_ffn": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_ffn_fused": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int32, _f, _f]),
+    "pf_op_attn_ffn_fused": (C.c_int, [_vp, _vp, _f, _f]),
     "pf_op_fsmn_enc": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn_dec": (C.c_int, [_vp, _f, _f, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_logsoftmax_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _f, _i64]),
@@ -205,6 +206,12 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+class PfAttnFfnDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("M", C.c_int32), ("T", C.c_int32), ("reserved", C.c_int32)] + \
+               [(n, C.POINTER(C.c_float)) for n in ("ctx", "wo", "bo", "v", "fsmn_w", "ln2_gamma", "ln2_beta", "resid",
+                                                    "w1", "b1", "w2", "b2", "ln_gamma", "ln_beta")]
 
 
 class PfError(RuntimeError):

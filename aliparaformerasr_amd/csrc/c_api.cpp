@@ -534,6 +534,22 @@ int pf_op_ffn_fused(pf_engine* h, const float* x, const float* w1, const float* 
   return PF_OK;
   PF_CATCH
 }
+int pf_op_attn_ffn_fused(pf_engine* h, const pf_attn_ffn_desc* d, float* x_out, float* n16_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(d);
+  PF_CHECK(d->struct_size == (int32_t)sizeof(pf_attn_ffn_desc), PF_ERR_INVALID_ARG, "pf_attn_ffn_desc.struct_size mismatch");
+  NEED(d->ctx); NEED(d->wo); NEED(d->bo); NEED(d->v); NEED(d->fsmn_w); NEED(d->ln2_gamma); NEED(d->ln2_beta);
+  NEED(d->w1); NEED(d->b1); NEED(d->w2); NEED(d->b2);
+  PF_CHECK(x_out || n16_out, PF_ERR_INVALID_ARG, "attn_ffn_fused: no output requested");
+  PF_CHECK((d->ln_gamma != nullptr) == (d->ln_beta != nullptr) && (d->ln_gamma || !n16_out), PF_ERR_INVALID_ARG,
+           "attn_ffn_fused: the LayerNorm output needs gamma and beta");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_ffn_fused(nullptr, d->w1, d->b1, d->w2, d->b2, d->resid, d->ln_gamma, d->ln_beta, d->M, x_out, n16_out, d);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_fsmn_enc(pf_engine* h, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y) {
   PF_TRY
   std::shared_ptr<Engine> eh_ = E(h);

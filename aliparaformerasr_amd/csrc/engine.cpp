@@ -64,6 +64,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_RC_FFN2"); if (e && e[0]) rc_ffn2_ = e[0] != '0'; }   // A/B switch for tools/: the unfused encoder sequence
   { const char* e = getenv("PF_FFN_FUSED"); if (e && e[0]) ffn_fused_ = e[0] != '0'; }   // A/B: the whole FFN block in one launch (k_ffn.hip)
   { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
+  { const char* e = getenv("PF_ATTN_FFN"); if (e && e[0]) attn_ffn_ = e[0] != '0'; }
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
@@ -362,6 +363,10 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       // W1 and W2 once more, in the fragment order the fused FFN kernel streams (4 MiB per layer)
       L.ffn_wt = (half_t*)dalloc(ffn_fused_weight_bytes());
       launch_ffn_retile(stream_, L.w1.w, L.w1.Kpad, L.w2.w, L.w2.Kpad, L.ffn_wt);
+      if (attn_ffn_ && L.out.w && L.out.bias && mc_.kernel == 11) {
+        L.out_wt = (half_t*)dalloc(ffn_outproj_weight_bytes());
+        launch_ffn_retile_out(stream_, L.out.w, L.out.Kpad, L.out_wt);
+      }
     }
     return L;
   };
@@ -975,6 +980,20 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   prof_begin("attn_self", 4.0 * B * (double)T * T * D);
   launch_attention(stream_, a);
   prof_end("attn_self");
+  if (rc && L.ffn_wt && L.out_wt && M >= ffn_fused_min_rows_) {
+    // out-projection + bias + residual + FSMN memory + norm2 + the whole FFN block + the NEXT LayerNorm: ONE launch per 64-row
+    // tile (k_ffn.hip, OP = 1): norm2's result never leaves LDS, x_mid goes through a scratch the same lanes read back
+    FfnFusedArgs f{};
+    f.ctx = ctx16_; f.lda_c = D; f.Wot = L.out_wt; f.bo = L.out.bias; f.fsmn_v = v16; f.ldv = ldv; f.fsmn_wT = L.fsmn_wT; f.T = T;
+    f.ln2_g = L.norm2.g; f.ln2_b = L.norm2.b; f.xmid = fsm_;
+    f.Wt = L.ffn_wt; f.b1 = L.w1.bias; f.b2 = L.w2.bias; f.M = M;
+    f.resid = first ? nullptr : x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
+    f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
+    prof_begin("gemm_outffn", 2.0 * M * (double)D * D + 4.0 * M * (double)D * F);
+    launch_ffn_fused(stream_, f);
+    prof_end("gemm_outffn");
+    return;
+  }
   if (rc) {
     GemmRcArgs g{};
     g.A = ctx16_; g.lda = D; g.W = L.out.w; g.ldw = L.out.Kpad; g.bias = L.out.bias; g.M = M; g.K = L.out.Kpad;
@@ -2475,10 +2494,11 @@ void Engine::op_ffn(const float* x, const float* w1, const float* b1, const floa
 
 // The encoder FFN block as enc_layer() launches it for long inputs: retile W1 / W2, then ONE launch of ffn_fused_kernel.
 void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
-                          const float* g, const float* be, int M, float* x_out, float* n16_out) {
+                          const float* g, const float* be, int M, float* x_out, float* n16_out, const pf_attn_ffn_desc* op) {
   PF_HIP(hipSetDevice(device_));
   const int D = 512, F = 2048;
   PF_CHECK(M > 0, PF_ERR_INVALID_ARG, "ffn_fused: M must be positive");
+  PF_CHECK(op || x, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
   const int64_t Mp = round_up(M, 256) + 128;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
@@ -2487,23 +2507,47 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
   const size_t owt = carve(ffn_fused_weight_bytes());
   const size_t ob1 = carve((size_t)F * 4), ob2 = carve((size_t)D * 4), og = carve((size_t)D * 4), obe = carve((size_t)D * 4);
   const size_t oxr = carve((size_t)Mp * D * 4), oxo = carve((size_t)Mp * D * 4), on16 = carve((size_t)Mp * D * 2);
+  // out-projection form: Wo (f16 + its image), bias, the V slice inside a [M, 3 D] QKV-shaped buffer, taps, norm2, x_mid scratch
+  const size_t owo = carve((size_t)D * D * 2), owot = carve(ffn_outproj_weight_bytes()), obo = carve((size_t)D * 4);
+  const size_t ov = carve((size_t)(Mp + 128) * 3 * D * 2), owT = carve((size_t)11 * D * 4), og2 = carve((size_t)D * 4), obe2 = carve((size_t)D * 4);
+  const size_t oxm = carve((size_t)Mp * D * 4);
   ensure(ws_tmp_, off);
   char* base = (char*)ws_tmp_.p;
   PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));
   PF_HIP(hipMemsetAsync(base + oxr, 0, (size_t)Mp * D * 4, stream_));
-  auto up16 = [&](const float* src, int rows, int cols, size_t dst) {
+  auto up16 = [&](const float* src, int rows, int cols, size_t dst, int ldo) {
     PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), cols);
+    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), ldo);
     PF_HIP(hipStreamSynchronize(stream_));
   };
-  up16(x, M, D, ox16); up16(w1, F, D, ow1); up16(w2, D, F, ow2);
+  up16(op ? op->ctx : x, M, D, ox16, D); up16(w1, F, D, ow1, D); up16(w2, D, F, ow2, F);
   PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
   PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
   if (resid) PF_HIP(hipMemcpyAsync(base + oxr, resid, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
   launch_ffn_retile(stream_, (half_t*)(base + ow1), D, (half_t*)(base + ow2), F, (half_t*)(base + owt));
   FfnFusedArgs f{};
   f.A = (half_t*)(base + ox16); f.lda = D; f.Wt = (half_t*)(base + owt); f.b1 = (const float*)(base + ob1); f.b2 = (const float*)(base + ob2);
-  f.M = M; f.resid = (const float*)(base + oxr); f.ldr = D; f.eps = 1e-12f;
+  f.M = M; f.resid = resid || !op ? (const float*)(base + oxr) : nullptr; f.ldr = D; f.eps = 1e-12f;
+  std::vector<float> wT;
+  if (op) {
+    up16(op->wo, D, D, owo, D);
+    launch_ffn_retile_out(stream_, (half_t*)(base + owo), D, (half_t*)(base + owot));
+    PF_HIP(hipMemsetAsync(base + ov, 0, (size_t)(Mp + 128) * 3 * D * 2, stream_));
+    PF_HIP(hipMemcpyAsync(base + o32, op->v, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + o32), M, D, D, (half_t*)(base + ov) + 2 * D, 3 * D);
+    PF_HIP(hipStreamSynchronize(stream_));
+    wT.resize((size_t)11 * D);
+    for (int c = 0; c < D; ++c)
+      for (int j = 0; j < 11; ++j) wT[(size_t)j * D + c] = op->fsmn_w[(size_t)c * 11 + j];
+    PF_HIP(hipMemcpyAsync(base + owT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
+    PF_HIP(hipMemcpyAsync(base + obo, op->bo, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+    PF_HIP(hipMemcpyAsync(base + og2, op->ln2_gamma, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+    PF_HIP(hipMemcpyAsync(base + obe2, op->ln2_beta, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+    f.ctx = (half_t*)(base + ox16); f.lda_c = D; f.Wot = (half_t*)(base + owot); f.bo = (const float*)(base + obo);
+    f.fsmn_v = (half_t*)(base + ov) + 2 * D; f.ldv = 3 * D; f.fsmn_wT = (const float*)(base + owT); f.T = op->T > 0 ? op->T : M;
+    f.ln2_g = (const float*)(base + og2); f.ln2_b = (const float*)(base + obe2); f.xmid = (float*)(base + oxm);
+    f.A = nullptr;
+  }
   if (x_out) { f.out_x = (float*)(base + oxo); f.ldx = D; }
   if (g) {
     PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
@@ -2514,7 +2558,7 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
   const char* rep = getenv("PF_OP_REPEAT");                        // tools/: repeated launches, timed as class "gemm_op_warm"
   const int reps = rep ? std::max(1, atoi(rep)) : 1;
   for (int r = 0; r < reps; ++r) {                                 // (resid is a separate buffer: repeats compute the same result)
-    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F);
+    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F + (op ? 2.0 * M * (double)D * D : 0.0));
     launch_ffn_fused(stream_, f);
     prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
   }

@@ -60,6 +60,7 @@ struct EncLayer {
   LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512;
   half_t* qkv_p = nullptr; float* qkv_bias_p = nullptr;   // qkv weight rows / bias in the tile order of gemm_qkvp_kernel (null: not built)
   half_t* ffn_wt = nullptr;                               // W1 | W2 in the fragment order of ffn_fused_kernel (k_ffn.hip; null: not built)
+  half_t* out_wt = nullptr;                               // the attention out-projection weight in the same kernel's fragment order
 };
 struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
 
@@ -130,7 +131,7 @@ class Engine {
   void op_qlinear(const float* x, const float* W, const float* bias, int M, int N, int K, int relu, int x_is_f16, float* y,
                   uint8_t* xq_out, float* aparams_out, uint8_t* wq_out, float* wscale_out, int32_t* wzp_out);
   void op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
-                    const float* g, const float* be, int M, float* x_out, float* n16_out);
+                    const float* g, const float* be, int M, float* x_out, float* n16_out, const pf_attn_ffn_desc* op = nullptr);
   void op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
               int M, int D, int F, float* y);
   void op_fsmn_enc(const float* v, const float* w, int B, int T, int D, int k, float* y);
@@ -239,6 +240,7 @@ class Engine {
   size_t ts_copy_floats_ = 0;
   void join_ts();
   bool no_rc_ = false, rc_ffn2_ = true, lstm_steps_ = false;
+  bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
   int ffn_fused_min_rows_ = 2048;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels win
   bool no_small_fuse_ = false;

@@ -48,15 +48,22 @@ struct FfnDev {
   int lda, ldr, ldx, ldn16, ldn32;
   int M, rot_mask;
   float eps;
+  // OP = 1 (attention out-projection in front of the block, one launch for two thirds of an encoder layer):
+  //   x_mid = resid + ctx Wo^T + bo + FSMN(V);  A = LayerNorm_2(x_mid) never leaves LDS;  x = x_mid + FFN(A)
+  const half_t* ctx; const half_t* Wot; const float* bo;      // ctx [M,512] f16 (row stride lda_c), Wo in fragment order, bias
+  const half_t* fsmn_v; const float* fsmn_wT;                 // V slice [M, ldv] f16, taps [11][512]
+  const float* ln2_g; const float* ln2_b;                     // norm2
+  float* xmid;                                                // fp32 [M,512] scratch for x_mid (row stride 512), re-read by the epilogue
+  int lda_c, ldv, T;
 };
 
 constexpr int FF_BM = 64, FF_D = 512, FF_F = 2048, FF_HC = 256, FF_NC = FF_F / FF_HC;   // 8 chunks
 constexpr int FF_A_BYTES = FF_BM * FF_D * 2;              // 64 KiB: 8 k-blocks of [64 rows][128 B]
 constexpr int FF_H_BYTES = FF_BM * FF_HC * 2;             // 32 KiB per hidden buffer (two of them)
 constexpr int FF_XROW = FF_D * 4 + 16;                    // epilogue tile row: 16-byte skew (conflict-free dump)
-constexpr int FF_B_OFF = FF_A_BYTES + 2 * FF_H_BYTES;      // b1 (8 KiB) behind the hidden buffers
-constexpr int FF_LDS = FF_B_OFF + FF_F * 4;                // 139 264 B (the epilogue's 64 x 2064-byte tile re-uses the front)
-static_assert(FF_BM * FF_XROW <= FF_LDS, "epilogue tile must fit");
+constexpr int FF_B_OFF = FF_BM * FF_XROW;                  // b1 (8 KiB) behind the 64 x 2064-byte fp32 tile of the epilogues (which re-use the front)
+constexpr int FF_LDS = FF_B_OFF + FF_F * 4;                // 140 288 B
+static_assert(FF_A_BYTES + 2 * FF_H_BYTES <= FF_B_OFF, "tile + hidden buffers must end before the bias copy");
 
 __device__ __forceinline__ void ff_glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -81,11 +88,52 @@ __device__ __forceinline__ void ff_lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// FSMN memory of 8 consecutive output rows x 4 columns of one lane (k_gemm_rc.hip's rc_fsmn, 11 taps): taps reaching outside
+// the utterance contribute nothing; MASKED only for rows near an utterance edge or the end of the buffer (wave-uniform)
+template <bool MASKED>
+__device__ __forceinline__ void ff_fsmn(float4 (&x)[8], const h4 (&win)[18], const float* __restrict__ wT, int mb, int t_first, int T, int M) {
+  constexpr int FK = 11, left = 5;
+  float4 w[FK];
+#pragma unroll
+  for (int j = 0; j < FK; ++j) w[j] = *reinterpret_cast<const float4*>(wT + (size_t)j * FF_D);
+#pragma unroll
+  for (int s = 0; s < 8 + FK - 1; ++s) {
+    const h4 hv = win[s];
+    float4 xf = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+    if (MASKED) {
+      const int mm = mb - left + s;
+      if (mm < 0 || mm >= M) xf = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < FK; ++j) {
+      const int r = s - j;
+      if (r >= 0 && r < 8) {
+        bool ok = true;
+        if (MASKED) {
+          int t_out = t_first + r;
+          t_out = t_out >= T ? t_out - T : t_out;
+          const int t_in = t_out + j - left;
+          ok = t_in >= 0 && t_in < T;
+        }
+        if (ok) { x[r].x += w[j].x * xf.x; x[r].y += w[j].y * xf.y; x[r].z += w[j].z * xf.z; x[r].w += w[j].w * xf.w; }
+      }
+    }
+    const int rc = s - left;
+    if (rc >= 0 && rc < 8) {
+      bool ok = true;
+      if (MASKED) { const int mm = mb + rc; ok = mm < M; }
+      if (ok) { x[rc].x += xf.x; x[rc].y += xf.y; x[rc].z += xf.z; x[rc].w += xf.w; }
+    }
+  }
+}
+
 // PF: how many weight fragments (1 KiB per wave each) a wave keeps in flight ahead of the one it multiplies
 // ABL (tools/ffn_abl.sh; results are garbage, only the times matter): bit 0 = no weight loads in the main loop, bit 1 = no
 // LDS fragment reads in the main loop, bit 2 = no MFMA, bit 3 = no chunk barriers
 // XD: how many k-steps ahead of their MFMAs the LDS fragment reads are issued (ring of XD + 1 fragment pairs)
-template <int PF, int ABL = 0, int XD = 2>
+// OP: 1 = the attention out-projection (+ bias + residual + FSMN memory + LayerNorm norm2) runs in front of the block on the
+// same 64 rows: its result is the block's LDS operand tile and never visits HBM as f16
+template <int PF, int ABL = 0, int XD = 2, int OP = 0>
 __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -108,20 +156,23 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
   };
   constexpr int NPOS = FF_NC * 64;
   h8 ring[PF];
+  if (!OP) {
 #pragma unroll
-  for (int i = 0; i < PF; ++i) ring[i] = wload(i);
+    for (int i = 0; i < PF; ++i) ring[i] = wload(i);
+  }
 
-  // ---- the 64 x 512 xn tile -> LDS (8 k-blocks of [64 rows][128 B], 16-byte chunks XOR-swizzled by row: the fragment
+  // ---- the 64 x 512 xn tile (OP: the attention context tile) -> LDS (8 k-blocks of [64 rows][128 B], 16-byte chunks XOR-swizzled by row: the fragment
   //      reads below are conflict-free); wave w brings rows 8w .. 8w+7 of every k-block
   {
     const int srow = lane >> 3, schunk = lane & 7;
     const int row = wave * 8 + srow;
-    const char* src = reinterpret_cast<const char*>(p.A + (size_t)(m0 + row) * p.lda) + ((schunk ^ swz(row)) << 4);
+    const char* src = OP ? reinterpret_cast<const char*>(p.ctx + (size_t)(m0 + row) * p.lda_c) + ((schunk ^ swz(row)) << 4)
+                         : reinterpret_cast<const char*>(p.A + (size_t)(m0 + row) * p.lda) + ((schunk ^ swz(row)) << 4);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) ff_glds16(src + kb * 128, smem + kb * 8192 + wave * 1024);
     // b1 (2048 floats) as it is: read back per chunk with ds_read — a global load used right behind its issue would make
     // the compiler wait for vmcnt(0), i.e. drain the weight stream
-    ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
+    if (!OP) ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
   }
   // fragment read offsets of the xn tile: row half i, 16-byte k-group (2 ss + lh) of a k-block
   unsigned xo[2][4];
@@ -133,9 +184,6 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
       xo[i][ss] = (unsigned)(ra * 128 + (((2 * ss + lh) ^ swz(ra)) << 4));
     }
   const unsigned ho = (unsigned)(FF_A_BYTES + lane * 16);          // hidden cells: ((i * 16 + t) * 2 + lh) * 512 + row * 16
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tile (and the first PF weight fragments) have landed
-  __builtin_amdgcn_s_barrier();
-
   f16x yacc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -143,6 +191,142 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) yacc[i][j][e] = 0.f;
+
+  if constexpr (OP != 0) {
+    // ---- P1: Y^T[64 out columns of this wave x 64 rows] = Wo[wave] ctx^T over K = 512: 32 k-steps of 4 MFMAs, Wo fragments
+    //      (2 per step, private to the wave) straight from their fragment-ordered image, ctx fragments from the LDS tile
+    const half_t* wou = p.Wot + (size_t)wave * (64 * 512);
+    auto woload = [&](int pos) __attribute__((always_inline)) -> h8 {
+      return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(wou + pos * 512) + lane16);
+    };
+    h8 oring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) oring[i] = woload(i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the context tile (and the first PF fragments) have landed
+    __builtin_amdgcn_s_barrier();
+    {
+      constexpr int XR = XD + 1;
+      h8 xf[XR][2];
+#pragma unroll
+      for (int s0 = 0; s0 < XD; ++s0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xf[s0][i] = *reinterpret_cast<const h8*>(smem + xo[i][s0 & 3] + (s0 >> 2) * 8192);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        if (s + XD < 32) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) xf[(s + XD) % XR][i] = *reinterpret_cast<const h8*>(smem + xo[i][(s + XD) & 3] + ((s + XD) >> 2) * 8192);
+        }
+        h8 wo[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          wo[j] = oring[(2 * s + j) % PF];
+          if (2 * s + j + PF < 64) oring[(2 * s + j) % PF] = woload(2 * s + j + PF);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) yacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wo[j], xf[s % XR][i], yacc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- P2 (k_gemm_rc.hip's epilogue): the fp32 tile through LDS; wave w owns rows 8w .. 8w+7 completely
+    const int r0 = wave * 8, mb = m0 + r0;
+    float4 xv[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.resid && mb + r < p.M) xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane);
+      }
+    h4 vwin[2][18];
+    const int t_first = mb % p.T;
+    const bool interior = t_first >= 5 && t_first + 7 + 5 < p.T && mb + 7 + 5 < p.M;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        int mm = mb - 5 + s;
+        mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);
+        vwin[h][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + h * 256 + 4 * lane);
+      }
+    ff_lds_barrier();                                              // every wave has finished reading the context tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* rowp = smem + (size_t)(i * 32 + l31) * FF_XROW + (wave * 64 + 4 * lh) * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          *reinterpret_cast<float4a*>(rowp + (j * 32 + 8 * g) * 4) =
+              make_float4(yacc[i][j][4 * g + 0], yacc[i][j][4 * g + 1], yacc[i][j][4 * g + 2], yacc[i][j][4 * g + 3]);
+          yacc[i][j][4 * g + 0] = 0.f; yacc[i][j][4 * g + 1] = 0.f; yacc[i][j][4 * g + 2] = 0.f; yacc[i][j][4 * g + 3] = 0.f;
+        }
+    }
+    ff_lds_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = h * 256 + 4 * lane;
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bo + col);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * FF_XROW + col * 4);
+        xv[h][r].x += v.x + b4.x; xv[h][r].y += v.y + b4.y; xv[h][r].z += v.z + b4.z; xv[h][r].w += v.w + b4.w;
+      }
+      if (interior) ff_fsmn<false>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+      else ff_fsmn<true>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (mb + r < p.M) *reinterpret_cast<float4*>(p.xmid + (size_t)(mb + r) * FF_D + col) = xv[h][r];
+    }
+    // LayerNorm norm2 of the complete rows -> f16 -> the block's operand tile (swizzled k-block layout)
+    float4 g4[2], be4[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      g4[h] = *reinterpret_cast<const float4*>(p.ln2_g + h * 256 + 4 * lane);
+      be4[h] = *reinterpret_cast<const float4*>(p.ln2_b + h * 256 + 4 * lane);
+    }
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float sm = ((xv[0][r].x + xv[0][r].y) + (xv[0][r].z + xv[0][r].w)) + ((xv[1][r].x + xv[1][r].y) + (xv[1][r].z + xv[1][r].w));
+      mean[r] = ff_wave_sum(sm) * (1.0f / FF_D);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float m = mean[r];
+      xv[0][r].x -= m; xv[0][r].y -= m; xv[0][r].z -= m; xv[0][r].w -= m;
+      xv[1][r].x -= m; xv[1][r].y -= m; xv[1][r].z -= m; xv[1][r].w -= m;
+      const float q = ((xv[0][r].x * xv[0][r].x + xv[0][r].y * xv[0][r].y) + (xv[0][r].z * xv[0][r].z + xv[0][r].w * xv[0][r].w)) +
+                      ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
+      rstd[r] = 1.0f / sqrtf(ff_wave_sum(q) * (1.0f / FF_D) + p.eps);
+    }
+    ff_lds_barrier();                                              // every wave has its rows of the fp32 tile in registers
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = r0 + r;
+      const float k = rstd[r];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 d = xv[h][r];
+        const h4 y = h4{(half_t)(d.x * k * g4[h].x + be4[h].x), (half_t)(d.y * k * g4[h].y + be4[h].y),
+                        (half_t)(d.z * k * g4[h].z + be4[h].z), (half_t)(d.w * k * g4[h].w + be4[h].w)};
+        const int c = h * 256 + 4 * lane;                          // column -> k-block c >> 6, 16-byte chunk (c & 63) >> 3, 8 bytes inside it
+        *reinterpret_cast<h4*>(smem + (c >> 6) * 8192 + row * 128 + ((((c & 63) >> 3) ^ swz(row)) << 4) + (c & 7) * 2) = y;
+      }
+    }
+    // b1 -> LDS now (its place was inside the fp32 tile's footprint? no: behind it — but the DMA is cheapest here, off the
+    // critical path), then the block's first weight fragments
+    ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = wload(i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ff_lds_barrier();                                              // the operand tile is complete
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the tile (and the first PF weight fragments) have landed
+    __builtin_amdgcn_s_barrier();
+  }
 
 #pragma unroll
   for (int c = 0; c < FF_NC; ++c) {
@@ -249,8 +433,11 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.resid && mb + r < p.M)
+      if (OP) {                                            // x_mid, written by this very lane in P2
+        if (mb + r < p.M) xv[h][r] = *reinterpret_cast<const float4*>(p.xmid + (size_t)(mb + r) * FF_D + h * 256 + 4 * lane_e);
+      } else if (p.resid && mb + r < p.M) {
         xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane_e);
+      }
     }
   ff_lds_barrier();                                        // every wave has finished reading the hidden and the xn tile
 #pragma unroll
@@ -350,7 +537,25 @@ __global__ void ffn_retile_kernel(const half_t* __restrict__ W1, int ldw1, const
   }
 }
 
+// Wo [512, ldw] -> Wot[((w * 32 + t) * 2 + j) * 512 + l * 8 + e] = Wo[w * 64 + j * 32 + (l & 31)][16 t + 8 (l >> 5) + e]  (32 768 pieces)
+__global__ void ffn_retile_out_kernel(const half_t* __restrict__ Wo, int ldw, half_t* __restrict__ Wot) {
+  const int pc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pc >= 32768) return;
+  const int l = pc & 63, j = (pc >> 6) & 1, t = (pc >> 7) & 31, w = pc >> 12;
+  const half_t* src = Wo + (size_t)(w * 64 + j * 32 + (l & 31)) * ldw + 16 * t + 8 * (l >> 5);
+  h8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = src[e];
+  *reinterpret_cast<h8*>(Wot + (size_t)pc * 8) = v;
+}
+
 size_t ffn_fused_weight_bytes() { return (size_t)2 * 131072 * 16; }      // W1t | W2t: 2 MiB each
+size_t ffn_outproj_weight_bytes() { return (size_t)32768 * 16; }          // Wot: 512 KiB
+
+void launch_ffn_retile_out(hipStream_t s, const half_t* Wo, int ldw, half_t* Wot) {
+  hipLaunchKernelGGL(ffn_retile_out_kernel, dim3(32768 / 256), dim3(256), 0, s, Wo, ldw, Wot);
+  PF_HIP(hipGetLastError());
+}
 
 void launch_ffn_retile(hipStream_t s, const half_t* W1, int ldw1, const half_t* W2, int ldw2, half_t* Wt) {
   hipLaunchKernelGGL(ffn_retile_kernel, dim3(2 * 131072 / 256), dim3(256), 0, s, W1, ldw1, W2, ldw2, Wt, Wt + (size_t)131072 * 8);
@@ -360,7 +565,7 @@ void launch_ffn_retile(hipStream_t s, const half_t* W1, int ldw1, const half_t* 
 bool ffn_fused_applicable(int D, int F) { return D == FF_D && F == FF_F; }
 
 void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
-  PF_CHECK(a.M > 0 && a.A && a.Wt && a.b1 && a.b2, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
+  PF_CHECK(a.M > 0 && a.Wt && a.b1 && a.b2, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
   PF_CHECK(a.lda % 8 == 0 && (!a.resid || a.ldr % 4 == 0) && (!a.out_x || a.ldx % 4 == 0) && (!a.out_n16 || a.ldn16 % 4 == 0) &&
                (!a.out_n32 || a.ldn32 % 4 == 0),
            PF_ERR_INVALID_ARG, "ffn_fused: leading dimensions must keep 16-byte (8-byte for f16) row alignment");
@@ -371,6 +576,12 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
   d.resid = a.resid; d.out_x = a.out_x; d.ln_g = a.ln_g; d.ln_b = a.ln_b; d.out_n16 = a.out_n16; d.out_n32 = a.out_n32;
   d.lda = a.lda; d.ldr = a.ldr; d.ldx = a.ldx; d.ldn16 = a.ldn16; d.ldn32 = a.ldn32;
   d.M = a.M; d.eps = a.eps;
+  d.ctx = a.ctx; d.Wot = a.Wot; d.bo = a.bo; d.fsmn_v = a.fsmn_v; d.fsmn_wT = a.fsmn_wT; d.ln2_g = a.ln2_g; d.ln2_b = a.ln2_b;
+  d.xmid = a.xmid; d.lda_c = a.lda_c; d.ldv = a.ldv; d.T = a.T > 0 ? a.T : a.M;
+  const bool op = a.ctx != nullptr;
+  PF_CHECK(!op || (a.Wot && a.bo && a.fsmn_v && a.fsmn_wT && a.ln2_g && a.ln2_b && a.xmid && a.lda_c % 8 == 0 && a.ldv % 4 == 0 && d.T >= 8),
+           PF_ERR_INVALID_ARG, "ffn_fused: the out-projection form needs ctx, Wo, bias, the V slice, FSMN taps, norm2 and the x_mid scratch");
+  PF_CHECK(op || a.A, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
   static std::mutex init_mu;
   static bool attr_set[64] = {false};
   static int rot_mask = 7, pf = 8, xd = 2, abl = 0;
@@ -383,6 +594,7 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
       PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
       PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
       PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<12, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
       if (const char* e = getenv("PF_FFN_ROT")) rot_mask = atoi(e) & 7;      // 0 | 1 | 3 | 7: chunk-order rotation period - 1
       if (const char* e = getenv("PF_FFN_ABL")) abl = atoi(e);
       if (const char* e = getenv("PF_FFN_XD")) xd = atoi(e);                 // LDS fragment reads 1 | 2 | 3 k-steps ahead
@@ -413,6 +625,12 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
   }
 #endif
   (void)abl;
+  if (op) {
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1>");
+    hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 1>), grid, dim3(512), FF_LDS, s, d);
+    PF_HIP(hipGetLastError());
+    return;
+  }
   if (pf >= 12) {                                       // 12 fragments in flight, LDS reads one k-step ahead
     note_gemm_kernel("ffn_fused_kernel<12, 0, 1>");
     hipLaunchKernelGGL((ffn_fused_kernel<12, 0, 1>), grid, dim3(512), FF_LDS, s, d);

@@ -390,6 +390,25 @@ class Engine:
                                           _fp(be) if be is not None else None, M, _fp(xo), _fp(no) if no is not None else None))
         return xo, no
 
+    def op_attn_ffn_fused(self, ctx, wo, bo, v, fsmn_w, T, ln2, w1, b1, w2, b2, resid=None, ln=None):
+        """Out-projection + FSMN + norm2 + the FFN block + the next LayerNorm as the ONE launch the pipeline runs
+        (k_ffn.hip, OP = 1): returns (x_out, n16_out or None)."""
+        arrs = {k: _f32(a) for k, a in dict(ctx=ctx, wo=wo, bo=bo, v=v, fsmn_w=fsmn_w, ln2_gamma=ln2[0], ln2_beta=ln2[1],
+                                             w1=w1, b1=b1, w2=w2, b2=b2).items()}
+        if resid is not None:
+            arrs["resid"] = _f32(resid)
+        if ln is not None:
+            arrs["ln_gamma"], arrs["ln_beta"] = _f32(ln[0]), _f32(ln[1])
+        M = arrs["ctx"].shape[0]
+        d = N.PfAttnFfnDesc()
+        d.struct_size, d.M, d.T = C.sizeof(N.PfAttnFfnDesc), M, T
+        for k, a in arrs.items():
+            setattr(d, k, _fp(a))
+        xo = np.zeros((M, 512), np.float32)
+        no = np.zeros((M, 512), np.float32) if ln is not None else None
+        N.check(self._lib.pf_op_attn_ffn_fused(self._h, C.byref(d), _fp(xo), _fp(no) if no is not None else None))
+        return xo, no
+
     def op_fsmn_enc(self, v, w) -> np.ndarray:
         v, w = _f32(v), _f32(w)
         B, T, D = v.shape

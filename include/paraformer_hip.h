@@ -326,6 +326,18 @@ int pf_op_ffn(pf_engine* e, const float* x, const float* w1, const float* b1, co
    LayerNorm(x_out; gamma, beta) widened to fp32 (NULL, or with gamma / beta).  resid may be NULL (zeros). */
 int pf_op_ffn_fused(pf_engine* e, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                     const float* resid, const float* ln_gamma, const float* ln_beta, int32_t M, float* x_out, float* n16_out);
+/* The same launch with the attention out-projection in front of the block, as the pipeline runs two thirds of an encoder
+   layer since round 5: x_mid = resid + ctx wo^T + bo + FSMN(v) (11 taps, utterances = runs of T rows);
+   x_out = x_mid + W2 relu(W1 LayerNorm(x_mid; ln2) + b1) + b2; n16_out = f16 LayerNorm(x_out; ln_gamma, ln_beta).
+   ctx, v [M,512]; wo [512,512]; fsmn_w [512,11]; resid may be NULL. */
+typedef struct pf_attn_ffn_desc {
+  int32_t struct_size; int32_t M; int32_t T; int32_t reserved;
+  const float* ctx; const float* wo; const float* bo; const float* v; const float* fsmn_w;
+  const float* ln2_gamma; const float* ln2_beta; const float* resid;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  const float* ln_gamma; const float* ln_beta;
+} pf_attn_ffn_desc;
+int pf_op_attn_ffn_fused(pf_engine* e, const pf_attn_ffn_desc* d, float* x_out, float* n16_out);
 /* Encoder FSMN kernel (f16 V slice of a [B*T, 3D] buffer in, fp32 out): y = dwconv_k(v) + v. */
 int pf_op_fsmn_enc(pf_engine* e, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y);
 /* Decoder FSMN kernel: x += (dwconv_k(tn*m) + tn*m)*m, m = (l < token_num[b]); x in/out [B,L,D]. */

@@ -214,6 +214,51 @@ def test_ffn_fused_kernel(eng, M):
         np.testing.assert_allclose(got_x, eng.op_ffn(x, w1, b1, w2, b2, resid), rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,T", [(32, 500), (64, 170), (5, 83 + 40), (3, 9)])
+def test_attn_out_ffn_fused_kernel(eng, B, T):
+    """Two thirds of an encoder layer in ONE launch (k_ffn.hip, OP = 1): out-projection + bias + residual + FSMN memory of
+    the V slice + LayerNorm norm2 (its result stays in LDS) + the FFN block + the next LayerNorm.  Reference: fp64 products of
+    the f16-rounded operands, the norm2 result and the hidden rounded to f16 where the kernel rounds them."""
+    rng = np.random.default_rng(190 + T)
+    M, D, F = B * T, 512, 2048
+    ctx = rng.standard_normal((M, D)).astype(np.float32)
+    v = rng.standard_normal((M, D)).astype(np.float32)
+    wo = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    bo = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    fw = (0.1 * rng.standard_normal((D, 11))).astype(np.float32)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    resid = (2 * rng.standard_normal((M, D))).astype(np.float32)
+    g2, be2, g, be = [(s + 0.1 * rng.standard_normal(D)).astype(np.float32) for s in (1, 0, 1, 0)]
+
+    def ln_(x, gg, bb):
+        mu = x.mean(-1, keepdims=True)
+        return (x - mu) / np.sqrt(((x - mu) ** 2).mean(-1, keepdims=True) + 1e-12) * gg + bb
+    # rows: whole utterances at the start / end + random ones (the FSMN window needs neighbours, so the reference runs on
+    # complete utterances)
+    utts = sorted(set([0, B - 1] + list(rng.integers(0, B, 3))))
+    fs = om.fsmn(torch.from_numpy(h16(v).reshape(B, T, D)[utts]), torch.from_numpy(fw), 11).numpy().astype(np.float64)
+    rows = np.concatenate([np.arange(u * T, (u + 1) * T) for u in utts])
+    xmid = h16(ctx[rows]).astype(np.float64) @ h16(wo).T.astype(np.float64) + bo + resid[rows] + fs.reshape(-1, D)
+    a = h16(ln_(xmid, g2, be2).astype(np.float32)).astype(np.float64)
+    hid = h16(np.maximum(a @ h16(w1).T.astype(np.float64) + b1, 0).astype(np.float32)).astype(np.float64)
+    ref = xmid + hid @ h16(w2).T.astype(np.float64) + b2
+    got_x, got_n = eng.op_attn_ffn_fused(ctx, wo, bo, v, fw, T, (g2, be2), w1, b1, w2, b2, resid=resid, ln=(g, be))
+    # the norm2 result and the hidden are f16 operands of the next product: a value on a rounding boundary may round the
+    # other way (fp32 vs fp64 accumulation), each flips one operand by 2^-11 relative
+    np.testing.assert_allclose(got_x[rows], ref, rtol=3e-4, atol=4e-3)
+    assert np.abs(got_x[rows] - ref).mean() < 2e-4
+    np.testing.assert_allclose(got_n[rows], ln_(ref, g, be), rtol=3e-3, atol=3e-3)
+    # no residual (the first encoder layer)
+    got0, _ = eng.op_attn_ffn_fused(ctx, wo, bo, v, fw, T, (g2, be2), w1, b1, w2, b2)
+    xmid0 = xmid - resid[rows]
+    a0 = h16(ln_(xmid0, g2, be2).astype(np.float32)).astype(np.float64)
+    hid0 = h16(np.maximum(a0 @ h16(w1).T.astype(np.float64) + b1, 0).astype(np.float32)).astype(np.float64)
+    np.testing.assert_allclose(got0[rows], xmid0 + hid0 @ h16(w2).T.astype(np.float64) + b2, rtol=3e-4, atol=4e-3)
+
+
 def test_fsmn_enc_kernel_f16_strided(eng):
     rng = np.random.default_rng(10)
     for (B, T) in ((32, 500), (2, 83), (3, 7), (1, 1), (2, 166)):
