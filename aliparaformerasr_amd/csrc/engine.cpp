@@ -59,8 +59,6 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_QKV_SPLIT"); if (e && e[0]) qkv_split_ = e[0] != '0'; }   // A/B: Q | K blocked + V row-major from the 256 x 192 kernel (k_gemm_qkv.hip)
   { const char* e = getenv("PF_QKV_MIN"); if (e && e[0]) qkv_split_min_tiles_ = atoi(e); }
   { const char* e = getenv("PF_QKV_FILL"); if (e && e[0]) qkv_split_min_fill_ = atoi(e); }
-  { const char* e = getenv("PF_SK_MIN"); if (e && e[0]) sk_min_wgs_ = atoi(e); }
-  { const char* e = getenv("PF_SK_FFN2"); if (e && e[0]) sk_ffn2_ = atoi(e); }     // A/B: split-K row-complete FFN-down + LayerNorm (k_gemm_sk.hip)
   { const char* e = getenv("PF_RC_FFN2"); if (e && e[0]) rc_ffn2_ = e[0] != '0'; }   // A/B switch for tools/: the unfused encoder sequence
   { const char* e = getenv("PF_FFN_FUSED"); if (e && e[0]) ffn_fused_ = e[0] != '0'; }   // A/B: the whole FFN block in one launch (k_ffn.hip)
   { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
@@ -122,10 +120,9 @@ void Engine::release() {
   for (void* p : owned_) hipFree(p);
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
-                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_sk_, &ws_x3a_, &ws_x3t_, &ws_x3h_};
+                    &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_x3a_, &ws_x3t_, &ws_x3h_};
   x3_pair_live_ = false; x3a_src_ = nullptr;
   x3w_.clear();
-  sk_slab_ = nullptr; sk_flags_ = nullptr; sk_err_ = nullptr; sk_used_ = false;
   seaco_hw_valid_ = false;
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
@@ -161,35 +158,7 @@ void Engine::sync() {
   check_async_errors();
 }
 
-// Scratch of the split-K row-complete GEMM for one encoder pass of M rows with up to `calls` launches: the exchange slab
-// (re-used by every launch: launches of one stream do not overlap), one zeroed flag region per launch, the time-out word.
-void Engine::sk_prepare(int M, int calls) {
-  const size_t slab = round_up((int64_t)gemm_sk_slab_bytes(M), (int64_t)kAlign);
-  sk_flag_stride_ = (size_t)round_up((int64_t)gemm_sk_flag_bytes(M), (int64_t)kAlign);
-  const size_t flags = sk_flag_stride_ * (size_t)calls;
-  ensure(ws_sk_, slab + flags);
-  sk_slab_ = (float*)ws_sk_.p;
-  sk_flags_ = (unsigned*)((char*)ws_sk_.p + slab);
-  // the time-out word lives in its own allocation and is zeroed when it is created and after it has been read — NOT per
-  // pass: with several run_staged() calls queued before a sync an earlier pass's time-out must survive until the check
-  if (!sk_err_) {
-    sk_err_ = (unsigned*)dalloc(256);
-    PF_HIP(hipMemsetAsync(sk_err_, 0, 256, stream_));
-  }
-  sk_calls_ = 0; sk_calls_cap_ = calls;
-  PF_HIP(hipMemsetAsync(sk_flags_, 0, flags, stream_));
-}
-
 void Engine::check_async_errors() {
-  if (sk_used_) {                                    // a split-K pair whose partner never arrived (k_gemm_sk.hip)
-    sk_used_ = false;
-    unsigned flag = 0;
-    if (sk_err_) {
-      PF_HIP(hipMemcpy(&flag, sk_err_, 4, hipMemcpyDeviceToHost));
-      if (flag) PF_HIP(hipMemset(sk_err_, 0, 4));
-    }
-    PF_CHECK(flag == 0, PF_ERR_DEVICE, "encoder: a split-K workgroup timed out waiting for its partner");
-  }
   if (!lstm_err_) return;                            // the persistent recurrence raises this word when a spin timed out
   unsigned flag = 0;
   unsigned* w = lstm_err_;
@@ -1029,26 +998,6 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   // lines without the LDS transposition, FFN-down's LDS-DMA reads 1 KiB contiguous pieces
   const int blk = (F % 64 == 0 && !small) ? 1 : 0;
   gemm("gemm_ffn1", L.w1, xn16_, D, M, nullptr, 0, h16_, F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, blk);
-  if (rc && sk_ffn2_ && blk && (sk_ffn2_ == 2 || (sk_slab_ && sk_calls_ < sk_calls_cap_)) && 2 * cdiv(M, 128) >= sk_min_wgs_) {
-    // split-K row-complete FFN-down + bias + residual + the NEXT LayerNorm in one launch (k_gemm_sk.hip): a pair of
-    // workgroups per 128-row block, each walks half of K and finishes 64 complete rows
-    GemmRcArgs f{};
-    f.A = h16_; f.lda = F; f.a_blocked = 1; f.W = L.w2.w; f.ldw = L.w2.Kpad; f.bias = L.w2.bias; f.M = M; f.K = L.w2.Kpad;
-    f.resid = x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
-    f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
-    if (gemm_sk_applicable(f)) {
-      prof_begin("gemm_ffn2", 2.0 * M * (double)D * F);
-      if (sk_ffn2_ == 2) {
-        launch_gemm_sk(stream_, f, nullptr, nullptr, nullptr, false);
-      } else {
-        launch_gemm_sk(stream_, f, sk_slab_, (unsigned*)((char*)sk_flags_ + sk_flag_stride_ * (size_t)sk_calls_), sk_err_);
-        ++sk_calls_;
-        sk_used_ = true;
-      }
-      prof_end("gemm_ffn2");
-      return;
-    }
-  }
   if (rc && rc_ffn2_ && blk) {
     // row-complete FFN-down (+ the next LayerNorm), default since round 4: 53.6 us against 47.6 + 9-11 us for the persistent
     // 256 x 128 kernel + its LayerNorm launch (same box, same session: 12.86 -> 12.67 ms per step with one step in flight,
@@ -1092,8 +1041,6 @@ void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
   plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
   plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
 
-  sk_slab_ = nullptr;
-  if (sk_ffn2_ == 1 && D == 512 && !fp32_mode_ && !int8_mode_ && M > gemm_small_max_rows()) sk_prepare((int)M, (int)(enc_.size() + tp_.size()));
   // the LayerNorm that FOLLOWS layer i's FFN-down is the next layer's norm1, or after_norm behind the last one
   const bool has_tp = !tp_.empty();
   for (size_t i = 0; i < enc_.size(); ++i) {
@@ -2411,6 +2358,7 @@ void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* 
     if (n32_out) { g.out_n32 = (float*)(base + oN32); g.ldn32 = N; }
   }
   if (x_out) { g.out_x = (float*)(base + oX); g.ldx = N; }
+  PF_CHECK(!ds.split_k, PF_ERR_UNSUPPORTED, "gemm_rc: the split-K forms (k_gemm_sk.hip) were removed in round 5 — the fused FFN block replaced them (numbers: profiles/round4_splitk_pairs.txt)");
   if (ds.short_input) {
     // the short-input forms of the same nodes, as enc_layer / the decoder run them for M <= 512 rows
     PF_CHECK(!ds.a_blocked, PF_ERR_INVALID_ARG, "gemm_rc: the short-input kernels take a row-major A");
@@ -2427,19 +2375,6 @@ void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* 
       PF_CHECK(!g.fsmn_v, PF_ERR_INVALID_ARG, "gemm_rc: the split short-input form has no FSMN term");
       q.post_ln_g = g.ln_g; q.post_ln_b = g.ln_b; q.post_n16 = g.out_n16; q.ldn16 = N; q.post_n32 = g.out_n32; q.ldn32 = N;
       launch_gemm_small(stream_, q);
-    }
-  } else if (ds.split_k) {
-    PF_CHECK(gemm_sk_applicable(g), PF_ERR_INVALID_ARG, "gemm_rc: the split-K form needs K >= 192 and takes no FSMN term");
-    if (ds.split_k == 2) {
-      prof_begin("gemm_op", 2.0 * M * (double)N * K);
-      launch_gemm_sk(stream_, g, nullptr, nullptr, nullptr, false);
-      prof_end("gemm_op");
-    } else {
-      sk_prepare(M, 1);
-      prof_begin("gemm_op", 2.0 * M * (double)N * K);
-      launch_gemm_sk(stream_, g, sk_slab_, sk_flags_, sk_err_);
-      prof_end("gemm_op");
-      sk_used_ = true;
     }
   } else {
     prof_begin("gemm_op", 2.0 * M * (double)N * K);

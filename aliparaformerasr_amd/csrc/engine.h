@@ -246,21 +246,11 @@ class Engine {
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)
   int dec_fuse_ = 1;                 // bit 1: FSMN + norm3, bit 2: out-projection + next norm1, bit 4: FFN-down + norm2 (row-complete GEMM)
-  // split-K row-complete FFN-down (k_gemm_sk.hip): exchange slab + one flag region per launch of a forward (zeroed once
-  // per encoder pass) + the time-out word
-  int sk_ffn2_ = 0;                  // PF_SK_FFN2=2: one workgroup per 128-row block, all of K; =1: the pair form: opt in (measured slower than the persistent 256 x 128 kernel + a LayerNorm launch: the
-                                     // partial exchange is 64 MB of extra memory traffic per launch, profiles/round4_splitk_pairs.txt)
-  DevBuf ws_sk_;
-  float* sk_slab_ = nullptr; unsigned* sk_flags_ = nullptr; unsigned* sk_err_ = nullptr;
-  size_t sk_flag_stride_ = 0; int sk_calls_ = 0, sk_calls_cap_ = 0;
-  bool sk_used_ = false;
   bool qkv_split_ = true;            // PF_QKV_SPLIT=0: the row-major 256 x 128 kernel for Q | K | V
   int qkv_split_min_tiles_ = 256;    // PF_QKV_MIN: least number of 256 x 192 tiles for which the split form is chosen
   int qkv_split_min_fill_ = 60;      // PF_QKV_FILL: ... and least fill (percent) of its rounds of tiles (85 was the break-even with ONE step in
                                      // flight; with two, the other engine's kernels run on the CUs a short last round leaves)
   int cus_ = 256;                    // compute units the persistent kernels size their grids for (cu_limit)
-  int sk_min_wgs_ = 128;             // PF_SK_MIN: least number of workgroups (2 per 128 rows) for which the split form is chosen
-  void sk_prepare(int M, int calls);
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
   bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs

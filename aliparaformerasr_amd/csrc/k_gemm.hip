@@ -859,23 +859,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   const bool few = (float)t2 < mi_x * cus[dev];
   const bool rounds1 = by_rounds && 0.58 * cdiv(t1, cus[dev]) < (double)cdiv(t2, cus[dev]);
   const int mi = a.force_mi ? (a.force_mi == 1 ? 1 : 2) : ((few || rounds1) ? 1 : 2);
-  {
-    // fp32 results of a deep-K projection in 256-row tiles (the encoder's FFN-down): the k-step-32 / six-stage pipeline
-    // (k_gemm_k32.hip).  Round-4 measurement: 50.3 vs 48.4 us per FFN-down launch — the deeper ring does NOT help there (A
-    // streams from HBM / the Infinity Cache), so this file's kernel stays the default; PF_K32=1 selects the k-step-32 kernel.
-    static int use_k32 = -1, k32_mink = 1024;
-    if (use_k32 < 0) {
-      const char* e = getenv("PF_K32"); use_k32 = (e && e[0] == '1') ? 1 : 0;      // measured slower at the FFN-down shape: opt-in
-      if (const char* m = getenv("PF_K32_MINK")) k32_mink = atoi(m);
-    }
-    const bool f16o = a.out_f16 && !a.out_f32 && !a.resid && !a.add2;
-    const bool can = gemm_k32_applicable(a);
-    PF_CHECK(a.force_mi != 6 || can, PF_ERR_INVALID_ARG, "gemm: the k-step-32 kernel does not apply to this problem");
-    if (can && (a.force_mi == 6 || (a.force_mi == 0 && use_k32 && mi == 2 && !f16o && a.K >= k32_mink))) {
-      launch_gemm_k32(s, a, cus[dev]);
-      return;
-    }
-  }
+  PF_CHECK(a.force_mi != 6, PF_ERR_UNSUPPORTED, "gemm: the k-step-32 kernel was removed in round 5 (numbers: profiles/round4_k32_microbench.txt)");
   d.tiles_m = cdiv(d.M, 128 * mi);
   d.tiles_n = cdiv(d.N, GEMM_BN);
   const int total = d.tiles_m * d.tiles_n;

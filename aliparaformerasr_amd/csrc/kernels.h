@@ -32,7 +32,7 @@ struct GemmArgs {
                                  // stream); null = never dispatch to it
   int f16_lo_off;                // > 0 (fp32-kind epilogue only: add2 given): out_f16 receives the result as the operand pair of an
                                  // "x3" product (math_mode 3): hi = f16(v) at column n, lo' = f16((v - hi) * 2^11) at n + f16_lo_off
-  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result), 6 = the k-step-32 fp32-result kernel
+  int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result)
                                  // (stand-alone op tests; 4 / 5 fail when that kernel does not apply)
 };
 void launch_gemm(hipStream_t s, const GemmArgs& a);
@@ -40,10 +40,6 @@ void launch_gemm(hipStream_t s, const GemmArgs& a);
 // reports as `roofline`; the same name appears in the rocprofv3 kernel trace)
 const char* last_gemm_kernel();
 void note_gemm_kernel(const char* name);
-// persistent 256 x 128 tile kernel with fp32 results for deep-K projections (FFN-down; k_gemm_k32.hip): k-steps of 32,
-// six-stage ring, five stages in flight
-bool gemm_k32_applicable(const GemmArgs& a);
-void launch_gemm_k32(hipStream_t s, const GemmArgs& a, int cus);
 // persistent 256 x 192 tile kernel for the encoder's fused Q | K | V projection (k_gemm_qkv.hip): Q (scaled) and K leave in
 // the blocked layout as one [Mpad, 1024] matrix, V row-major [Mpad, ldv].  Wp / bias_p: the weight rows and bias in tile order
 // (launch_qkv_permute: [1536, ldw] f16 from the [Q | K | V] weight, bias may be null -> zeros); out rows up to round_up(M, 256).
@@ -135,17 +131,6 @@ int gemm_small_max_rows();                       // rows up to which the pipelin
 bool gemm_small_applicable(const GemmSmallArgs& a);
 void launch_gemm_small(hipStream_t s, const GemmSmallArgs& a);
 void launch_gemm_rc(hipStream_t s, const GemmRcArgs& a);
-// the same node sequence (no FSMN term) with 128 x 512 tiles and K split over a PAIR of workgroups that exchange their
-// partial halves in the launch (k_gemm_sk.hip): deep projections (FFN-down) + bias + residual + LayerNorm in one launch.
-// slab: gemm_sk_slab_bytes(M) of scratch; flags: gemm_sk_flag_bytes(M), ZEROED by the caller before the launch (one
-// region per launch between two zeroings); err: a device word the kernel raises when a partner never arrived.
-bool gemm_sk_applicable(const GemmRcArgs& a);
-size_t gemm_sk_slab_bytes(int M);
-size_t gemm_sk_flag_bytes(int M);
-// split = false: one workgroup per 128-row block walks all of K (no exchange, no scratch): half the workgroups of the 64-row
-// kernel at ~55 % of its CU time — for launches beside which another stream's kernels run
-void launch_gemm_sk(hipStream_t s, const GemmRcArgs& a, float* slab, unsigned* flags, unsigned* err, bool split = true);
-
 // The encoder's whole feed-forward block in one launch (k_ffn.hip): x = resid + relu(A W1^T + b1) W2^T + b2;
 // n = LayerNorm(x).  d_model 512, hidden 2048; 64-row tiles, the hidden stays in LDS, W1 / W2 are streamed from their
 // fragment-ordered images (launch_ffn_retile, once per layer at load) straight into registers.

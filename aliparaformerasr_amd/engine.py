@@ -329,17 +329,16 @@ class Engine:
         return out
 
     def op_gemm_rc(self, A, W, bias=None, resid=None, fsmn_v=None, fsmn_w=None, T=0, ln=None, a_blocked=False,
-                   want_x=True, want_n16=True, want_n32=True, short_input=False, split_k=False):
+                   want_x=True, want_n16=True, want_n32=True, short_input=False):
         """Row-complete GEMM (N = 512) + fused epilogue; returns (x, n16, n32) (n* = None without `ln`).
-        short_input: the short-input kernels of the same graph nodes (k_gemm_small.hip); split_k: the pair form the
-        encoder runs FFN-down on (k_gemm_sk.hip)."""
+        short_input: the short-input kernels of the same graph nodes (k_gemm_small.hip)."""
         A, W = _f32(A), _f32(W)
         M, K = A.shape
         d = N.PfGemmRcDesc()
         d.struct_size = C.sizeof(N.PfGemmRcDesc)
         d.M, d.K, d.a_blocked, d.T = M, K, int(a_blocked), T
         d.short_input = int(short_input)
-        d.split_k = int(split_k)
+        d.split_k = 0
         keep = [_f32(t) if t is not None else None for t in (bias, resid, fsmn_v, fsmn_w)]
         d.bias, d.resid, d.fsmn_v, d.fsmn_w = [_fp(t) if t is not None else None for t in keep]
         d.fsmn_k = keep[3].shape[1] if keep[3] is not None else 0

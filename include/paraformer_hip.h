@@ -310,8 +310,8 @@ typedef struct pf_gemm_rc_desc {
   int32_t short_input;        /* 1 = the kernels the pipeline uses for M <= 512 rows (k_gemm_small.hip): K <= 576:
                                  one-shot GEMM with the FSMN memory as an epilogue term, then the LayerNorm kernel;
                                  K > 576: split partials + the reduction that carries the LayerNorm (no FSMN term) */
-  int32_t split_k;            /* k_gemm_sk.hip (128-row blocks, no FSMN term): 1 = the split-K pair form (two workgroups per
-                                 block exchange partial tiles in the launch), 2 = one workgroup per block, all of K    */
+  int32_t split_k;            /* must be 0: the split-K forms of round 4 (k_gemm_sk.hip) lost to the fused FFN block and
+                                 were removed in round 5 (PF_ERR_UNSUPPORTED); the field keeps the struct layout     */
 } pf_gemm_rc_desc;
 /* x_out [M,512] fp32 (may be NULL), n16_out [M,512] (the f16 LayerNorm result widened to fp32, may be NULL),
    n32_out [M,512] fp32 LayerNorm result (may be NULL). */

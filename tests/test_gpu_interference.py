@@ -44,6 +44,8 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
     wqkv = (rng.standard_normal((3 * D, D)) / 22).astype(np.float32)
     bqkv = rng.standard_normal(3 * D).astype(np.float32)
     he = np.abs(rng.standard_normal((16000, F))).astype(np.float32)
+    b1f = rng.standard_normal(F).astype(np.float32)
+    fw = (0.1 * rng.standard_normal((D, 11))).astype(np.float32)
     ops = {
         "fp32-result GEMM 5344x512x2048, 128-row tiles": lambda: B.op_gemm_ex(h, w2, None, tile_rows=128),
         "fp32-result GEMM 5344x512x2048, 256-row tiles": lambda: B.op_gemm_ex(h, w2, None, tile_rows=256),
@@ -59,8 +61,12 @@ def test_operators_are_bit_stable_beside_a_busy_second_engine():
         "Q|K|V 256x192 kernel + attention on the blocked layout 32x500": lambda: np.concatenate(B.op_qkv_attention(xe, wqkv, bqkv, 32, 500), axis=1),
         "row-complete FFN-down + LayerNorm 16000x512x2048 (blocked A)": lambda: np.concatenate(
             B.op_gemm_rc(he, w2, b2, resid=xe, ln=(g, be), a_blocked=True)[::2], axis=1),
-        "split-K pair FFN-down + LayerNorm 16000x512x2048": lambda: np.concatenate(
-            B.op_gemm_rc(he, w2, b2, resid=xe, ln=(g, be), a_blocked=True, split_k=True)[::2], axis=1),
+        # round 5: the fused FFN block (weights streamed straight into registers, the hidden in LDS) and the same launch with
+        # the attention out-projection + FSMN + norm2 in front of it
+        "fused FFN block + LayerNorm 16000 rows (k_ffn.hip)": lambda: np.concatenate(
+            B.op_ffn_fused(xe, w1, b1f, w2, b2, resid=xe, ln=(g, be)), axis=1),
+        "out-projection + FSMN + norm2 + FFN + LayerNorm 32x500 (k_ffn.hip, OP = 1)": lambda: np.concatenate(
+            B.op_attn_ffn_fused(xe, wq, b2, xe, fw, 500, (g, be), w1, b1f, w2, b2, resid=xe, ln=(g, be)), axis=1),
     }
     quiet = {name: f() for name, f in ops.items()}
     stop = []

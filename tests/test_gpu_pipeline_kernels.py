@@ -108,40 +108,6 @@ def test_gemm_blocked_a_operand(eng, tile_rows):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
 
 
-@pytest.mark.parametrize("a_blocked", [True, False])
-def test_gemm_k32_kernel_ffn_down_shape(eng, a_blocked):
-    """The k-step-32 / six-stage kernel (k_gemm_k32.hip) at the FFN-down shape, blocked and row-major A, with bias and
-    the fp32 residual; M = 16000 is not a multiple of the 256-row tile (the last tile's rows beyond M are not written)."""
-    rng = np.random.default_rng(500 + int(a_blocked))
-    M, N, K = M_BENCH, 512, 2048
-    A = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
-    A += (np.arange(K)[None, :] * 1e-4).astype(np.float32)
-    Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-    Wm += (np.arange(N)[:, None] * 1e-4).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    resid = rng.standard_normal((M, N)).astype(np.float32)
-    ref = _ref(A, Wm, bias) + resid
-    got = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked, tile_rows=2048)
-    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
-    assert np.array_equal(got, eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked, tile_rows=2048))
-    # the pipeline's default kernel for this problem agrees with it
-    old = eng.op_gemm_ex(A, Wm, bias, resid=resid, out_kind=0, a_blocked=a_blocked, tile_rows=256)
-    np.testing.assert_allclose(got, old, rtol=1e-5, atol=1e-4)
-
-
-def test_gemm_k32_kernel_many_tiles_per_workgroup_and_edges(eng):
-    """More tiles than CUs (M = 64000, N = 512: 1000 tiles, the configs[3] shard), ReLU, no residual, no bias; a ragged
-    M (rows of the last tile beyond M stay untouched) and K = 256 (8 k-steps: the ring is longer than a tile)."""
-    rng = np.random.default_rng(510)
-    for (M, N, K, relu, with_bias) in ((64000, 512, 1024, True, False), (5000, 256, 256, False, True), (300, 128, 2048, False, True)):
-        A = rng.standard_normal((M, K)).astype(np.float32)
-        Wm = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-        bias = rng.standard_normal(N).astype(np.float32) if with_bias else None
-        ref = _ref(A, Wm, bias if with_bias else 0.0)
-        if relu:
-            ref = np.maximum(ref, 0)
-        got = eng.op_gemm_ex(A, Wm, bias, relu=relu, out_kind=0, tile_rows=2048)
-        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=6e-4)
 
 
 def test_gemm_ragged_edges_all_kinds(eng):
@@ -470,64 +436,6 @@ def test_qkv_split_kernel_and_attention_on_the_blocked_layout(eng):
         np.testing.assert_array_equal(ctx, ctx_ref, err_msg=f"attention B={B} T={T}")
 
 
-def test_gemm_sk_ffn_down_split_k_pairs(eng):
-    """FFN down-projection on the split-K pair kernel (k_gemm_sk.hip), as enc_layer() launches it: blocked A
-    [16000 x 2048] x [2048 x 512] + bias + fp32 residual + the NEXT LayerNorm.  Two workgroups per 128-row block walk half
-    of K each and exchange partial tiles in the launch; P0 + P1 is commutative, so repeated launches are bit-identical."""
-    rng = np.random.default_rng(511)
-    M, K = M_BENCH, 2048
-    A = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
-    A += (np.arange(K)[None, :] * 1e-4).astype(np.float32)
-    Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
-    bias = rng.standard_normal(512).astype(np.float32)
-    resid = rng.standard_normal((M, 512)).astype(np.float32)
-    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
-    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
-    x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True, split_k=True)
-    np.testing.assert_allclose(x, _ref(A, Wm, bias) + resid, rtol=1e-4, atol=6e-4)
-    n_ref = _ln_ref(x, g, b)
-    np.testing.assert_allclose(n32, n_ref, rtol=2e-5, atol=2e-5)
-    np.testing.assert_array_equal(n16, h16(n32))
-    again = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True, split_k=True)
-    for u, v in zip((x, n16, n32), again):
-        np.testing.assert_array_equal(u, v)
-    x2, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, a_blocked=False, split_k=True)
-    np.testing.assert_array_equal(x2, x)            # the operand layout does not change the arithmetic
-    # against the 64-row kernel: same products, a different summation tree over K
-    x3, _, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, a_blocked=True)
-    np.testing.assert_allclose(x, x3, rtol=2e-5, atol=2e-5)
-    # one workgroup per 128-row block over all of K (split_k = 2)
-    x4, m16, m32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=True, split_k=2)
-    np.testing.assert_allclose(x4, x3, rtol=2e-5, atol=2e-5)
-    np.testing.assert_allclose(m32, _ln_ref(x4, g, b), rtol=2e-5, atol=2e-5)
-    np.testing.assert_array_equal(m16, h16(m32))
-
-
-def test_gemm_sk_ragged_rows_and_depths(eng):
-    """Row counts that are not multiples of 128 (the last pair has rows beyond M, one pair may own nothing but padding),
-    more pairs than CUs (several dispatch rounds), the smallest depth (K = 192: three k-steps per half), no residual, no
-    LayerNorm, LayerNorm without x."""
-    rng = np.random.default_rng(512)
-    g = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
-    b = (0.1 * rng.standard_normal(512)).astype(np.float32)
-    for M, K, blocked in ((1, 192, False), (129, 512, True), (5344, 2048, True), (1000, 576, False), (40000, 256, True)):
-        A = rng.standard_normal((M, K)).astype(np.float32)
-        Wm = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32)
-        bias = rng.standard_normal(512).astype(np.float32)
-        resid = rng.standard_normal((M, 512)).astype(np.float32)
-        ref = _ref(A, Wm, bias)
-        x, n16, n32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=True)
-        np.testing.assert_allclose(x, ref + resid, rtol=1e-4, atol=6e-4, err_msg=f"M={M} K={K}")
-        np.testing.assert_allclose(n32, _ln_ref(x, g, b), rtol=2e-5, atol=2e-5)
-        np.testing.assert_array_equal(n16, h16(n32))
-        x0, _, _ = eng.op_gemm_rc(A, Wm, a_blocked=blocked, split_k=True)
-        np.testing.assert_allclose(x0, ref - bias, rtol=1e-4, atol=6e-4)
-        _, m16, _ = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=True, want_x=False, want_n32=False)
-        np.testing.assert_array_equal(m16, n16)
-        y, y16, y32 = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), a_blocked=blocked, split_k=2)
-        np.testing.assert_allclose(y, ref + resid, rtol=1e-4, atol=6e-4, err_msg=f"no split M={M} K={K}")
-        np.testing.assert_allclose(y32, _ln_ref(y, g, b), rtol=2e-5, atol=2e-5)
-        np.testing.assert_array_equal(y16, h16(y32))
 
 
 def test_gemm_rc_ragged_shapes_and_utterance_edges(eng):
