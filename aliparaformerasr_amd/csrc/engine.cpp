@@ -954,7 +954,7 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
     // tile (k_ffn.hip, OP = 1): norm2's result never leaves LDS, x_mid goes through a scratch the same lanes read back
     FfnFusedArgs f{};
     f.ctx = ctx16_; f.lda_c = D; f.Wot = L.out_wt; f.bo = L.out.bias; f.fsmn_v = v16; f.ldv = ldv; f.fsmn_wT = L.fsmn_wT; f.T = T;
-    f.ln2_g = L.norm2.g; f.ln2_b = L.norm2.b; f.xmid = fsm_;
+    f.ln2_g = L.norm2.g; f.ln2_b = L.norm2.b;
     f.Wt = L.ffn_wt; f.b1 = L.w1.bias; f.b2 = L.w2.bias; f.M = M;
     f.resid = first ? nullptr : x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
     f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
@@ -2480,7 +2480,7 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
     PF_HIP(hipMemcpyAsync(base + obe2, op->ln2_beta, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
     f.ctx = (half_t*)(base + ox16); f.lda_c = D; f.Wot = (half_t*)(base + owot); f.bo = (const float*)(base + obo);
     f.fsmn_v = (half_t*)(base + ov) + 2 * D; f.ldv = 3 * D; f.fsmn_wT = (const float*)(base + owT); f.T = op->T > 0 ? op->T : M;
-    f.ln2_g = (const float*)(base + og2); f.ln2_b = (const float*)(base + obe2); f.xmid = (float*)(base + oxm);
+    f.ln2_g = (const float*)(base + og2); f.ln2_b = (const float*)(base + obe2);
     f.A = nullptr;
   }
   if (x_out) { f.out_x = (float*)(base + oxo); f.ldx = D; }

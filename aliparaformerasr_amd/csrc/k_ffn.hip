@@ -49,11 +49,10 @@ struct FfnDev {
   int M, rot_mask;
   float eps;
   // OP = 1 (attention out-projection in front of the block, one launch for two thirds of an encoder layer):
-  //   x_mid = resid + ctx Wo^T + bo + FSMN(V);  A = LayerNorm_2(x_mid) never leaves LDS;  x = x_mid + FFN(A)
+  //   x_mid = resid + ctx Wo^T + bo + FSMN(V);  A = LayerNorm_2(x_mid) never leaves LDS, x_mid goes back into the accumulators;  x = x_mid + FFN(A)
   const half_t* ctx; const half_t* Wot; const float* bo;      // ctx [M,512] f16 (row stride lda_c), Wo in fragment order, bias
   const half_t* fsmn_v; const float* fsmn_wT;                 // V slice [M, ldv] f16, taps [11][512]
   const float* ln2_g; const float* ln2_b;                     // norm2
-  float* xmid;                                                // fp32 [M,512] scratch for x_mid (row stride 512), re-read by the epilogue
   int lda_c, ldv, T;
 };
 
@@ -276,9 +275,26 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
       }
       if (interior) ff_fsmn<false>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
       else ff_fsmn<true>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+    }
+    // x_mid is the residual of the block's end: instead of a round trip through HBM it goes back into the ACCUMULATORS — the
+    // second product then accumulates on top of it (rows -> LDS fp32 tile -> D^T fragments, the dump above in reverse)
+    ff_lds_barrier();                                              // every wave has its rows of the fp32 tile in registers
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int r = 0; r < 8; ++r)
-        if (mb + r < p.M) *reinterpret_cast<float4*>(p.xmid + (size_t)(mb + r) * FF_D + col) = xv[h][r];
+        *reinterpret_cast<float4a*>(smem + (size_t)(r0 + r) * FF_XROW + (h * 256 + 4 * lane) * 4) = xv[h][r];
+    ff_lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* rowp = smem + (size_t)(i * 32 + l31) * FF_XROW + (wave * 64 + 4 * lh) * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 t = *reinterpret_cast<const float4a*>(rowp + (j * 32 + 8 * g) * 4);
+          yacc[i][j][4 * g + 0] = t.x; yacc[i][j][4 * g + 1] = t.y; yacc[i][j][4 * g + 2] = t.z; yacc[i][j][4 * g + 3] = t.w;
+        }
     }
     // LayerNorm norm2 of the complete rows -> f16 -> the block's operand tile (swizzled k-block layout)
     float4 g4[2], be4[2];
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
                       ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
       rstd[r] = 1.0f / sqrtf(ff_wave_sum(q) * (1.0f / FF_D) + p.eps);
     }
-    ff_lds_barrier();                                              // every wave has its rows of the fp32 tile in registers
+    ff_lds_barrier();                                              // every wave has read its fragments of x_mid back
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int row = r0 + r;
@@ -433,8 +449,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (OP) {                                            // x_mid, written by this very lane in P2
-        if (mb + r < p.M) xv[h][r] = *reinterpret_cast<const float4*>(p.xmid + (size_t)(mb + r) * FF_D + h * 256 + 4 * lane_e);
+      if (OP) {                                            // x_mid is already inside the accumulators
       } else if (p.resid && mb + r < p.M) {
         xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane_e);
       }
@@ -577,10 +592,10 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
   d.lda = a.lda; d.ldr = a.ldr; d.ldx = a.ldx; d.ldn16 = a.ldn16; d.ldn32 = a.ldn32;
   d.M = a.M; d.eps = a.eps;
   d.ctx = a.ctx; d.Wot = a.Wot; d.bo = a.bo; d.fsmn_v = a.fsmn_v; d.fsmn_wT = a.fsmn_wT; d.ln2_g = a.ln2_g; d.ln2_b = a.ln2_b;
-  d.xmid = a.xmid; d.lda_c = a.lda_c; d.ldv = a.ldv; d.T = a.T > 0 ? a.T : a.M;
+  d.lda_c = a.lda_c; d.ldv = a.ldv; d.T = a.T > 0 ? a.T : a.M;
   const bool op = a.ctx != nullptr;
-  PF_CHECK(!op || (a.Wot && a.bo && a.fsmn_v && a.fsmn_wT && a.ln2_g && a.ln2_b && a.xmid && a.lda_c % 8 == 0 && a.ldv % 4 == 0 && d.T >= 8),
-           PF_ERR_INVALID_ARG, "ffn_fused: the out-projection form needs ctx, Wo, bias, the V slice, FSMN taps, norm2 and the x_mid scratch");
+  PF_CHECK(!op || (a.Wot && a.bo && a.fsmn_v && a.fsmn_wT && a.ln2_g && a.ln2_b && a.lda_c % 8 == 0 && a.ldv % 4 == 0 && d.T >= 8),
+           PF_ERR_INVALID_ARG, "ffn_fused: the out-projection form needs ctx, Wo, bias, the V slice, FSMN taps and norm2");
   PF_CHECK(op || a.A, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
   static std::mutex init_mu;
   static bool attr_set[64] = {false};

@@ -144,12 +144,12 @@ struct FfnFusedArgs {
   const float* ln_g; const float* ln_b; float eps;
   half_t* out_n16; int ldn16; float* out_n32; int ldn32;
   // ctx != null: the attention out-projection runs in front of the block in the same launch (A is ignored):
-  //   x_mid = resid + ctx Wo^T + bo + FSMN(V) -> xmid;  the block's operand = LayerNorm(x_mid; ln2) stays in LDS;  x = x_mid + FFN(.)
+  //   x_mid = resid + ctx Wo^T + bo + FSMN(V) (kept on chip);  the block's operand = LayerNorm(x_mid; ln2) stays in LDS;  x = x_mid + FFN(.)
   const half_t* ctx; int lda_c;                  // attention context [M,512] f16
   const half_t* Wot; const float* bo;            // launch_ffn_retile_out image of Wo [512,512]; bias [512]
   const half_t* fsmn_v; int ldv; const float* fsmn_wT; int T;   // V slice (f16, row stride ldv), taps [11][512], utterances = runs of T rows (T >= 8)
   const float* ln2_g; const float* ln2_b;        // norm2
-  float* xmid;                                   // fp32 [M,512] scratch (row stride 512); resid may be null (first layer)
+  // (resid may be null: the first layer)
 };
 bool ffn_fused_applicable(int D, int F);
 size_t ffn_outproj_weight_bytes();
