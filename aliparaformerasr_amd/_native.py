@@ -211,7 +211,8 @@ def load() -> C.CDLL:
 class PfAttnFfnDesc(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("M", C.c_int32), ("T", C.c_int32), ("reserved", C.c_int32)] + \
                [(n, C.POINTER(C.c_float)) for n in ("ctx", "wo", "bo", "v", "fsmn_w", "ln2_gamma", "ln2_beta", "resid",
-                                                    "w1", "b1", "w2", "b2", "ln_gamma", "ln_beta")]
+                                                    "w1", "b1", "w2", "b2", "ln_gamma", "ln_beta",
+                                                    "wqkv", "bqkv", "q_out", "k_out", "v_out")]
 
 
 class PfError(RuntimeError):

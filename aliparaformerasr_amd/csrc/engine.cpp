@@ -63,6 +63,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_FFN_FUSED"); if (e && e[0]) ffn_fused_ = e[0] != '0'; }   // A/B: the whole FFN block in one launch (k_ffn.hip)
   { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
   { const char* e = getenv("PF_ATTN_FFN"); if (e && e[0]) attn_ffn_ = e[0] != '0'; }
+  { const char* e = getenv("PF_QKV_TAIL"); if (e && e[0]) qkv_tail_ = e[0] != '0'; }
 
   // host-only validation BEFORE anything is uploaded (a bad am.mvn must not cost a 0.9 GB upload per retry)
   std::vector<float> shift, scale;
@@ -335,6 +336,12 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       if (attn_ffn_ && L.out.w && L.out.bias && mc_.kernel == 11) {
         L.out_wt = (half_t*)dalloc(ffn_outproj_weight_bytes());
         launch_ffn_retile_out(stream_, L.out.w, L.out.Kpad, L.out_wt);
+        if (qkv_tail_ && L.qkv_p && L.qkv.Kpad == D && L.qkv.bias) {
+          L.qkv_t = (half_t*)dalloc(3 * ffn_outproj_weight_bytes());
+          for (int part = 0; part < 3; ++part)
+            launch_ffn_retile_out(stream_, L.qkv.w + (size_t)part * D * L.qkv.Kpad, L.qkv.Kpad,
+                                  L.qkv_t + (size_t)part * (ffn_outproj_weight_bytes() / 2));
+        }
       }
     }
     return L;
@@ -934,12 +941,19 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
   const int qt = 8 * cdiv(M, 256);
   const bool split = rc && L.qkv_p && qt >= qkv_split_min_tiles_ && qt * 100 >= qkv_split_min_fill_ * (int)round_up(qt, cus_) &&
                      gemm_qkvp_applicable(M, L.qkv.Kpad, lda, L.qkv.Kpad, D);
+  const bool pre = qkv_done_;                                  // written by the previous layer's launch (its Q | K | V tail)
+  qkv_done_ = false;
+  PF_CHECK(!pre || split, PF_ERR_DEVICE, "encoder: a projected Q | K | V without its consumer");
+  const int64_t Mp = round_up((int64_t)M, 128) + 128;          // rows of every encoder buffer (>= round_up(M, 256))
+  // two V buffers: the fused launch of layer l reads V_l (FSMN window: rows of NEIGHBOURING tiles too) and writes V_{l+1}
+  half_t* const vbufs[2] = {qkv16_ + (size_t)Mp * 2 * D, h16_};
   if (split) {
-    const int64_t Mp = round_up((int64_t)M, 128) + 128;        // rows of every encoder buffer (>= round_up(M, 256))
-    half_t* vbuf = qkv16_ + (size_t)Mp * 2 * D;
-    prof_begin("gemm_qkv", 2.0 * M * (double)L.qkv.N * L.qkv.K);
-    launch_gemm_qkvp(stream_, xn16_, lda, L.qkv_p, L.qkv.Kpad, L.qkv_bias_p, M, L.qkv.Kpad, qscale, qkv16_, vbuf, D);
-    prof_end("gemm_qkv");
+    half_t* vbuf = vbufs[v_pp_];
+    if (!pre) {
+      prof_begin("gemm_qkv", 2.0 * M * (double)L.qkv.N * L.qkv.K);
+      launch_gemm_qkvp(stream_, xn16_, lda, L.qkv_p, L.qkv.Kpad, L.qkv_bias_p, M, L.qkv.Kpad, qscale, qkv16_, vbuf, D);
+      prof_end("gemm_qkv");
+    }
     a.q = qkv16_; a.k = qkv16_; a.qk_blocked = 1; a.blk_groups = 2 * D / 8; a.blk_brows = T; a.blk_kgrp = D / 8;
     a.v = vbuf; a.v_bstride = (int64_t)T * D; a.v_rstride = D;
     v16 = vbuf; ldv = D;
@@ -958,9 +972,19 @@ void Engine::enc_layer(const EncLayer& L, int first, const float* speech_dev, in
     f.Wt = L.ffn_wt; f.b1 = L.w1.bias; f.b2 = L.w2.bias; f.M = M;
     f.resid = first ? nullptr : x_; f.ldr = D; f.out_x = nx.keep_x ? x_ : nullptr; f.ldx = D;
     f.ln_g = nx.ln.g; f.ln_b = nx.ln.b; f.eps = 1e-12f; f.out_n16 = nx.n16; f.ldn16 = D; f.out_n32 = nx.n32; f.ldn32 = D;
-    prof_begin("gemm_outffn", 2.0 * M * (double)D * D + 4.0 * M * (double)D * F);
+    // the NEXT layer's Q | K | V projection behind the block when that layer would take the same (blocked-layout) path on
+    // the same rows: LayerNorm_next(x) then never visits HBM either
+    const bool tail = split && nx.next && nx.next->qkv_t && nx.next->ffn_wt && nx.next->out_wt && nx.n16 == xn16_ && !nx.n32;
+    double flops = 2.0 * M * (double)D * D + 4.0 * M * (double)D * F;
+    if (tail) {
+      f.Wqt = nx.next->qkv_t; f.bq = nx.next->qkv.bias; f.out_qk = qkv16_; f.out_v = vbufs[v_pp_ ^ 1]; f.ldvo = D; f.qscale = qscale;
+      f.out_n16 = nullptr;
+      flops += 2.0 * M * 3.0 * D * D;
+    }
+    prof_begin("gemm_outffn", flops);
     launch_ffn_fused(stream_, f);
     prof_end("gemm_outffn");
+    if (tail) { qkv_done_ = true; v_pp_ ^= 1; }
     return;
   }
   if (rc) {
@@ -1043,9 +1067,10 @@ void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
 
   // the LayerNorm that FOLLOWS layer i's FFN-down is the next layer's norm1, or after_norm behind the last one
   const bool has_tp = !tp_.empty();
+  qkv_done_ = false; v_pp_ = 0;
   for (size_t i = 0; i < enc_.size(); ++i) {
     EncNext nx;
-    if (i + 1 < enc_.size()) { nx.ln = enc_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; }
+    if (i + 1 < enc_.size()) { nx.ln = enc_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; nx.next = &enc_[i + 1]; }
     else if (has_tp) { nx.ln = enc_after_; nx.n32 = x_; nx.keep_x = false; }     // after_norm output = the tp residual stream
     else { nx.ln = enc_after_; nx.n16 = H16_; nx.n32 = H32_; nx.keep_x = false; }
     enc_layer(enc_[i], i == 0 ? (pre_encoded ? 2 : 1) : 0, speech_dev, B, T, nx);
@@ -1056,7 +1081,7 @@ void Engine::encoder(const float* speech_dev, int B, int T, bool pre_encoded) {
     prof_end("layernorm");
     for (size_t i = 0; i < tp_.size(); ++i) {
       EncNext nx;
-      if (i + 1 < tp_.size()) { nx.ln = tp_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; }
+      if (i + 1 < tp_.size()) { nx.ln = tp_[i + 1].norm1; nx.n16 = xn16_; nx.keep_x = true; nx.next = &tp_[i + 1]; }
       else { nx.ln = tp_norm_; nx.n16 = H16_; nx.n32 = H32_; nx.keep_x = false; }
       enc_layer(tp_[i], 0, nullptr, B, T, nx);
     }
@@ -2445,6 +2470,9 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
   // out-projection form: Wo (f16 + its image), bias, the V slice inside a [M, 3 D] QKV-shaped buffer, taps, norm2, x_mid scratch
   const size_t owo = carve((size_t)D * D * 2), owot = carve(ffn_outproj_weight_bytes()), obo = carve((size_t)D * 4);
   const size_t ov = carve((size_t)(Mp + 128) * 3 * D * 2), owT = carve((size_t)11 * D * 4), og2 = carve((size_t)D * 4), obe2 = carve((size_t)D * 4);
+  const bool tail = op && op->wqkv;
+  const size_t owq = carve((size_t)3 * D * D * 2), owqt = carve(3 * ffn_outproj_weight_bytes()), obq = carve((size_t)3 * D * 4);
+  const size_t oqk = carve((size_t)Mp * 2 * D * 2), ovo = carve((size_t)Mp * D * 2);
   const size_t oxm = carve((size_t)Mp * D * 4);
   ensure(ws_tmp_, off);
   char* base = (char*)ws_tmp_.p;
@@ -2483,6 +2511,16 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
     f.ln2_g = (const float*)(base + og2); f.ln2_b = (const float*)(base + obe2);
     f.A = nullptr;
   }
+  if (tail) {
+    PF_CHECK(op->bqkv && g, PF_ERR_INVALID_ARG, "attn_ffn_fused: the Q | K | V tail needs its bias and the LayerNorm in front of it");
+    up16(op->wqkv, 3 * D, D, owq, D);
+    for (int part = 0; part < 3; ++part)
+      launch_ffn_retile_out(stream_, (half_t*)(base + owq) + (size_t)part * D * D, D,
+                            (half_t*)(base + owqt) + (size_t)part * (ffn_outproj_weight_bytes() / 2));
+    PF_HIP(hipMemcpyAsync(base + obq, op->bqkv, (size_t)3 * D * 4, hipMemcpyHostToDevice, stream_));
+    f.Wqt = (half_t*)(base + owqt); f.bq = (const float*)(base + obq); f.out_qk = (half_t*)(base + oqk); f.out_v = (half_t*)(base + ovo);
+    f.ldvo = D; f.qscale = 1.0f / std::sqrt(128.0f);
+  }
   if (x_out) { f.out_x = (float*)(base + oxo); f.ldx = D; }
   if (g) {
     PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
@@ -2506,6 +2544,19 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
   PF_HIP(hipStreamSynchronize(stream_));
   if (f.out_n16)
     for (size_t i = 0; i < n16.size(); ++i) n16_out[i] = (float)n16[i];
+  if (tail) {
+    std::vector<half_t> qk((size_t)Mp * 2 * D), vv((size_t)M * D);
+    PF_HIP(hipMemcpy(qk.data(), base + oqk, qk.size() * 2, hipMemcpyDeviceToHost));
+    PF_HIP(hipMemcpy(vv.data(), base + ovo, vv.size() * 2, hipMemcpyDeviceToHost));
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < 2 * D; ++n) {                       // blocked [Mpad, 1024]: ((m / 32 * 128 + n / 8) * 32 + m % 32) * 8 + n % 8
+        const float val = (float)qk[(((size_t)(m >> 5) * 128 + (n >> 3)) * 32 + (m & 31)) * 8 + (n & 7)];
+        float* dst = n < D ? op->q_out : op->k_out;
+        if (dst) dst[(size_t)m * D + (n & (D - 1))] = val;
+      }
+    if (op->v_out)
+      for (size_t i = 0; i < vv.size(); ++i) op->v_out[i] = (float)vv[i];
+  }
 }
 
 // Encoder FSMN exactly as enc_layer() launches it: the f16 V slice of a [M, 3D] QKV buffer (row stride 3D).

@@ -60,6 +60,7 @@ struct EncLayer {
   LNp norm1, norm2; Lin qkv, out, w1, w2; float* fsmn_wT = nullptr; int d_in = 512;
   half_t* qkv_p = nullptr; float* qkv_bias_p = nullptr;   // qkv weight rows / bias in the tile order of gemm_qkvp_kernel (null: not built)
   half_t* ffn_wt = nullptr;                               // W1 | W2 in the fragment order of ffn_fused_kernel (k_ffn.hip; null: not built)
+  half_t* qkv_t = nullptr;                                // the [Q | K | V] weight in that order too (three 512-row images): the PREVIOUS layer's launch runs this projection
   half_t* out_wt = nullptr;                               // the attention out-projection weight in the same kernel's fragment order
 };
 struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
@@ -180,7 +181,9 @@ class Engine {
   void build_pe(int T);
   void encoder(const float* speech_dev, int B, int T, bool pre_encoded = false);
   // the LayerNorm applied to the residual stream right after a layer's FFN-down, and where its results go
-  struct EncNext { LNp ln; half_t* n16 = nullptr; float* n32 = nullptr; bool keep_x = true; };
+  struct EncNext { LNp ln; half_t* n16 = nullptr; float* n32 = nullptr; bool keep_x = true; const EncLayer* next = nullptr; };
+  bool qkv_done_ = false;            // the previous layer's launch has already written this layer's Q | K (blocked) and V
+  int v_pp_ = 0;                     // which of the two V buffers the current layer reads (the fused launch writes the other)
   // first: 0 = not the first layer, 1 = first (x sqrt(d) + position encoding fused into norm1), 2 = first, input already encoded
   void enc_layer(const EncLayer& L, int first, const float* speech_dev, int B, int T, const EncNext& nx);
   void predictor_and_decoder(int B, int T, bool want_logits);
@@ -240,6 +243,7 @@ class Engine {
   size_t ts_copy_floats_ = 0;
   void join_ts();
   bool no_rc_ = false, rc_ffn2_ = true, lstm_steps_ = false;
+  bool qkv_tail_ = true;             // PF_QKV_TAIL: the next layer's Q | K | V projection behind the fused block, same launch
   bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
   int ffn_fused_min_rows_ = 2048;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels win

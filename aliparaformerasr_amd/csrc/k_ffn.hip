@@ -54,6 +54,10 @@ struct FfnDev {
   const half_t* fsmn_v; const float* fsmn_wT;                 // V slice [M, ldv] f16, taps [11][512]
   const float* ln2_g; const float* ln2_b;                     // norm2
   int lda_c, ldv, T;
+  // QK = 1 (behind the block, same launch): the NEXT layer's fused Q | K | V projection of n = LayerNorm_next(x), which then
+  // never visits HBM either: Q (scaled) and K leave in the blocked [Mpad, 1024] layout, V row-major [Mpad, ldvo] (k_gemm_qkv.hip's)
+  const half_t* Wqt; const float* bq; half_t* out_qk; half_t* out_v;
+  int ldvo; float qscale;
 };
 
 constexpr int FF_BM = 64, FF_D = 512, FF_F = 2048, FF_HC = 256, FF_NC = FF_F / FF_HC;   // 8 chunks
@@ -132,7 +136,7 @@ __device__ __forceinline__ void ff_fsmn(float4 (&x)[8], const h4 (&win)[18], con
 // XD: how many k-steps ahead of their MFMAs the LDS fragment reads are issued (ring of XD + 1 fragment pairs)
 // OP: 1 = the attention out-projection (+ bias + residual + FSMN memory + LayerNorm norm2) runs in front of the block on the
 // same 64 rows: its result is the block's LDS operand tile and never visits HBM as f16
-template <int PF, int ABL = 0, int XD = 2, int OP = 0>
+template <int PF, int ABL = 0, int XD = 2, int OP = 0, int QK = 0>
 __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -503,16 +507,22 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
                     ((xv[1][r].x * xv[1][r].x + xv[1][r].y * xv[1][r].y) + (xv[1][r].z * xv[1][r].z + xv[1][r].w * xv[1][r].w));
     rstd[r] = 1.0f / sqrtf(ff_wave_sum(q) * (1.0f / FF_D) + p.eps);
   }
+  h4 yh[QK ? 2 : 1][QK ? 8 : 1];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int m = mb + r;
-    if (m < p.M) {
+    if (QK || m < p.M) {
       const float k = rstd[r];
       const float4 d0 = xv[0][r], d1 = xv[1][r];
       const float4 y0 = make_float4(d0.x * k * g4[0].x + be4[0].x, d0.y * k * g4[0].y + be4[0].y,
                                     d0.z * k * g4[0].z + be4[0].z, d0.w * k * g4[0].w + be4[0].w);
       const float4 y1 = make_float4(d1.x * k * g4[1].x + be4[1].x, d1.y * k * g4[1].y + be4[1].y,
                                     d1.z * k * g4[1].z + be4[1].z, d1.w * k * g4[1].w + be4[1].w);
+      if (QK) {
+        yh[0][r] = h4{(half_t)y0.x, (half_t)y0.y, (half_t)y0.z, (half_t)y0.w};
+        yh[1][r] = h4{(half_t)y1.x, (half_t)y1.y, (half_t)y1.z, (half_t)y1.w};
+      }
+      if (m >= p.M) continue;
       if (p.out_n16) {
         half_t* o = p.out_n16 + (size_t)m * p.ldn16 + 4 * lane_e;
         *reinterpret_cast<h4*>(o) = h4{(half_t)y0.x, (half_t)y0.y, (half_t)y0.z, (half_t)y0.w};
@@ -522,6 +532,126 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         float* o = p.out_n32 + (size_t)m * p.ldn32 + 4 * lane_e;
         *reinterpret_cast<float4*>(o) = y0;
         *reinterpret_cast<float4*>(o + 256) = y1;
+      }
+    }
+  }
+  if constexpr (QK != 0) {
+    if (!p.Wqt) return;
+    // ---- the next layer's Q | K | V projection of these 64 rows: n -> LDS operand tile, three passes of 64 output columns per
+    //      wave (Q, K, V: 3 x 8 x 64 = 1536), each the out-projection's loop over K = 512 with Wq fragments from their image
+    ff_lds_barrier();                                      // every wave has read its rows of the fp32 tile
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = r0 + r, c = h * 256 + 4 * lane_e;
+        *reinterpret_cast<h4*>(smem + (c >> 6) * 8192 + row * 128 + ((((c & 63) >> 3) ^ swz(row)) << 4) + (c & 7) * 2) = yh[h][r];
+      }
+    unsigned xq[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss) {
+        const int ra = i * 32 + l31_e;
+        xq[i][ss] = (unsigned)(ra * 128 + (((2 * ss + lh_e) ^ swz(ra)) << 4));
+      }
+    const unsigned lane16e = (unsigned)lane_e * 16u;
+    // bq (1536 floats) -> the LDS place of b1 (dead by now): a global load used right behind its issue would drain the stream
+    if (wave < 6) ff_glds16(reinterpret_cast<const char*>(p.bq) + wave * 1024 + lane_e * 16, smem + FF_B_OFF + wave * 1024);
+    // ONE weight stream over the three passes (192 fragments of this wave), PF ahead across the pass ends
+    const half_t* wqu = p.Wqt + (size_t)wave * (64 * 512);
+    auto wqload = [&](int gp) __attribute__((always_inline)) -> h8 {      // gp = pass * 64 + pos
+      return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(wqu + (size_t)(gp >> 6) * (8 * 64 * 512) + (gp & 63) * 512) + lane16e);
+    };
+    h8 qring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) qring[i] = wqload(i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ff_lds_barrier();                                      // the operand tile and the bias are complete
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+      // accumulators start as the bias of this wave's 64 columns
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4a*>(smem + FF_B_OFF + (pass * 512 + wave * 64 + 4 * lh_e + j * 32 + 8 * g) * 4);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { yacc[i][j][4 * g + 0] = b4.x; yacc[i][j][4 * g + 1] = b4.y; yacc[i][j][4 * g + 2] = b4.z; yacc[i][j][4 * g + 3] = b4.w; }
+        }
+      {
+        constexpr int XR = XD + 1;
+        h8 xf[XR][2];
+#pragma unroll
+        for (int s0 = 0; s0 < XD; ++s0)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) xf[s0][i] = *reinterpret_cast<const h8*>(smem + xq[i][s0 & 3] + (s0 >> 2) * 8192);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          if (s + XD < 32) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[(s + XD) % XR][i] = *reinterpret_cast<const h8*>(smem + xq[i][(s + XD) & 3] + ((s + XD) >> 2) * 8192);
+          }
+          h8 wq[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int gp = pass * 64 + 2 * s + j;
+            wq[j] = qring[gp % PF];
+            if (gp + PF < 192) qring[gp % PF] = wqload(gp + PF);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) yacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[j], xf[s % XR][i], yacc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (pass < 2) {
+        // Q (scaled) | K: 32 x 8 blocks of the blocked [M, 1024] matrix, 8-byte stores straight from the accumulators
+        const int qk0 = pass * 512 + wave * 64;
+        char* ob = reinterpret_cast<char*>(p.out_qk) + ((size_t)(m0 >> 5) * 128 + (size_t)(qk0 >> 3)) * 512 + l31_e * 16 + lh_e * 8;
+        constexpr size_t rb_stride = (size_t)128 * 512;
+        const float sc = pass == 0 ? p.qscale : 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              f2v lo2 = {yacc[i][j][4 * g + 0], yacc[i][j][4 * g + 1]}, hi2 = {yacc[i][j][4 * g + 2], yacc[i][j][4 * g + 3]};
+              lo2 *= sc; hi2 *= sc;
+              const h2v l = __builtin_convertvector(lo2, h2v), hh = __builtin_convertvector(hi2, h2v);
+              const h4 hv = {l[0], l[1], hh[0], hh[1]};
+              asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(ob + i * rb_stride + (size_t)(j * 4 + g) * 512), "v"(hv) : "memory");
+            }
+      } else {
+        // V: row-major [M, ldvo]; lanes l / l + 32 hold columns 8g + 0..3 / 8g + 4..7 of row l: after v_permlane32_swap lane l
+        // holds the 8 columns of group 2gp, lane l + 32 those of group 2gp + 1 (k_gemm_qkv.hip)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          half_t* vrow = p.out_v + (size_t)(m0 + i * 32 + l31_e) * p.ldvo + wave * 64;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              unsigned x[2], y[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const f2v xa = {yacc[i][j][8 * gp + 2 * e + 0], yacc[i][j][8 * gp + 2 * e + 1]};
+                const f2v ya = {yacc[i][j][8 * gp + 4 + 2 * e + 0], yacc[i][j][8 * gp + 4 + 2 * e + 1]};
+                x[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(xa, h2v));
+                y[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(ya, h2v));
+              }
+#pragma unroll
+              for (int e = 0; e < 2; ++e) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[e]), "+v"(y[e]));
+              const h4 lo_ = __builtin_bit_cast(h4, (unsigned long long)x[0] | ((unsigned long long)x[1] << 32));
+              const h4 hi_ = __builtin_bit_cast(h4, (unsigned long long)y[0] | ((unsigned long long)y[1] << 32));
+              const h8 hv = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);
+              asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(vrow + j * 32 + 16 * gp + 8 * lh_e), "v"(hv) : "memory");
+            }
+        }
       }
     }
   }
@@ -593,7 +723,10 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
   d.M = a.M; d.eps = a.eps;
   d.ctx = a.ctx; d.Wot = a.Wot; d.bo = a.bo; d.fsmn_v = a.fsmn_v; d.fsmn_wT = a.fsmn_wT; d.ln2_g = a.ln2_g; d.ln2_b = a.ln2_b;
   d.lda_c = a.lda_c; d.ldv = a.ldv; d.T = a.T > 0 ? a.T : a.M;
+  d.Wqt = a.Wqt; d.bq = a.bq; d.out_qk = a.out_qk; d.out_v = a.out_v; d.ldvo = a.ldvo; d.qscale = a.qscale;
   const bool op = a.ctx != nullptr;
+  PF_CHECK(!a.Wqt || (op && a.bq && a.out_qk && a.out_v && a.ldvo % 8 == 0 && a.ln_g), PF_ERR_INVALID_ARG,
+           "ffn_fused: the Q | K | V tail needs the out-projection form, the next LayerNorm, bias and both outputs");
   PF_CHECK(!op || (a.Wot && a.bo && a.fsmn_v && a.fsmn_wT && a.ln2_g && a.ln2_b && a.lda_c % 8 == 0 && a.ldv % 4 == 0 && d.T >= 8),
            PF_ERR_INVALID_ARG, "ffn_fused: the out-projection form needs ctx, Wo, bias, the V slice, FSMN taps and norm2");
   PF_CHECK(op || a.A, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
@@ -610,6 +743,7 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
       PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
       PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<12, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
       PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
       if (const char* e = getenv("PF_FFN_ROT")) rot_mask = atoi(e) & 7;      // 0 | 1 | 3 | 7: chunk-order rotation period - 1
       if (const char* e = getenv("PF_FFN_ABL")) abl = atoi(e);
       if (const char* e = getenv("PF_FFN_XD")) xd = atoi(e);                 // LDS fragment reads 1 | 2 | 3 k-steps ahead
@@ -640,6 +774,12 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
   }
 #endif
   (void)abl;
+  if (op && a.Wqt) {
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1, 1>");
+    hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 1, 1>), grid, dim3(512), FF_LDS, s, d);
+    PF_HIP(hipGetLastError());
+    return;
+  }
   if (op) {
     note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1>");
     hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 1>), grid, dim3(512), FF_LDS, s, d);

@@ -150,6 +150,10 @@ struct FfnFusedArgs {
   const half_t* fsmn_v; int ldv; const float* fsmn_wT; int T;   // V slice (f16, row stride ldv), taps [11][512], utterances = runs of T rows (T >= 8)
   const float* ln2_g; const float* ln2_b;        // norm2
   // (resid may be null: the first layer)
+  // Wqt != null (needs ctx and ln_g): the NEXT layer's fused Q | K | V projection of LayerNorm(x; ln_g, ln_b) behind the block,
+  // same launch: Wqt = three launch_ffn_retile_out images ([Q | K | V] weight rows 0-511, 512-1023, 1024-1535), bq [1536];
+  // Q (x qscale) and K -> blocked [Mpad, 1024] out_qk, V -> row-major out_v (row stride ldvo); out_n16 / out_n32 stay optional
+  const half_t* Wqt; const float* bq; half_t* out_qk; half_t* out_v; int ldvo; float qscale;
 };
 bool ffn_fused_applicable(int D, int F);
 size_t ffn_outproj_weight_bytes();

@@ -389,9 +389,10 @@ class Engine:
                                           _fp(be) if be is not None else None, M, _fp(xo), _fp(no) if no is not None else None))
         return xo, no
 
-    def op_attn_ffn_fused(self, ctx, wo, bo, v, fsmn_w, T, ln2, w1, b1, w2, b2, resid=None, ln=None):
+    def op_attn_ffn_fused(self, ctx, wo, bo, v, fsmn_w, T, ln2, w1, b1, w2, b2, resid=None, ln=None, qkv=None):
         """Out-projection + FSMN + norm2 + the FFN block + the next LayerNorm as the ONE launch the pipeline runs
-        (k_ffn.hip, OP = 1): returns (x_out, n16_out or None)."""
+        (k_ffn.hip, OP = 1): returns (x_out, n16_out or None); with qkv = (wqkv [1536,512], bqkv) also the next layer's
+        Q | K | V projection in the same launch: returns (x_out, n16_out, q, k, v)."""
         arrs = {k: _f32(a) for k, a in dict(ctx=ctx, wo=wo, bo=bo, v=v, fsmn_w=fsmn_w, ln2_gamma=ln2[0], ln2_beta=ln2[1],
                                              w1=w1, b1=b1, w2=w2, b2=b2).items()}
         if resid is not None:
@@ -405,8 +406,14 @@ class Engine:
             setattr(d, k, _fp(a))
         xo = np.zeros((M, 512), np.float32)
         no = np.zeros((M, 512), np.float32) if ln is not None else None
+        outs = []
+        if qkv is not None:
+            keep = (_f32(qkv[0]), _f32(qkv[1]))
+            d.wqkv, d.bqkv = _fp(keep[0]), _fp(keep[1])
+            outs = [np.zeros((M, 512), np.float32) for _ in range(3)]
+            d.q_out, d.k_out, d.v_out = [_fp(o) for o in outs]
         N.check(self._lib.pf_op_attn_ffn_fused(self._h, C.byref(d), _fp(xo), _fp(no) if no is not None else None))
-        return xo, no
+        return (xo, no, *outs) if outs else (xo, no)
 
     def op_fsmn_enc(self, v, w) -> np.ndarray:
         v, w = _f32(v), _f32(w)

@@ -336,6 +336,10 @@ typedef struct pf_attn_ffn_desc {
   const float* ln2_gamma; const float* ln2_beta; const float* resid;
   const float* w1; const float* b1; const float* w2; const float* b2;
   const float* ln_gamma; const float* ln_beta;
+  /* optional tail, as the pipeline runs it between two encoder layers: the NEXT layer's fused Q | K | V projection of
+     LayerNorm(x_out; ln_gamma, ln_beta) in the same launch: wqkv [1536,512] = [Q | K | V] rows, bqkv [1536]; q_out (scaled by
+     1/sqrt(128)), k_out, v_out [M,512] = the stored f16 values widened to fp32 (each may be NULL) */
+  const float* wqkv; const float* bqkv; float* q_out; float* k_out; float* v_out;
 } pf_attn_ffn_desc;
 int pf_op_attn_ffn_fused(pf_engine* e, const pf_attn_ffn_desc* d, float* x_out, float* n16_out);
 /* Encoder FSMN kernel (f16 V slice of a [B*T, 3D] buffer in, fp32 out): y = dwconv_k(v) + v. */

@@ -217,6 +217,15 @@ def test_attn_out_ffn_fused_kernel(eng, B, T):
     np.testing.assert_allclose(got_x[rows], ref, rtol=3e-4, atol=4e-3)
     assert np.abs(got_x[rows] - ref).mean() < 2e-4
     np.testing.assert_allclose(got_n[rows], ln_(ref, g, be), rtol=3e-3, atol=3e-3)
+    # ... and with the NEXT layer's Q | K | V projection behind it in the same launch (Q scaled, Q | K through the blocked
+    # layout, V row-major): the products of the f16 LayerNorm result the launch returns
+    wqkv = (rng.standard_normal((3 * D, D)) / np.sqrt(D)).astype(np.float32)
+    bqkv = (0.1 * rng.standard_normal(3 * D)).astype(np.float32)
+    gx, gn, gq, gk, gv = eng.op_attn_ffn_fused(ctx, wo, bo, v, fw, T, (g2, be2), w1, b1, w2, b2, resid=resid, ln=(g, be), qkv=(wqkv, bqkv))
+    np.testing.assert_array_equal(gx, got_x)
+    qkv_ref = got_n[rows].astype(np.float64) @ h16(wqkv).T.astype(np.float64) + bqkv
+    qkv_ref[:, :D] *= np.float32(1.0 / np.sqrt(128.0))
+    np.testing.assert_allclose(np.concatenate([gq[rows], gk[rows], gv[rows]], 1), qkv_ref, rtol=2e-3, atol=2e-3)
     # no residual (the first encoder layer)
     got0, _ = eng.op_attn_ffn_fused(ctx, wo, bo, v, fw, T, (g2, be2), w1, b1, w2, b2)
     xmid0 = xmid - resid[rows]
