@@ -257,6 +257,7 @@ class Engine {
   int cus_ = 256;                    // compute units the persistent kernels size their grids for (cu_limit)
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
+  bool x3_attn_f32_ = true;
   bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs
   std::map<const float*, half_t*> x3w_;   // fp32 weight -> its [lo' | hi] f16 pair image (built on first use)
   DevBuf ws_x3a_, ws_x3t_, ws_x3h_;

@@ -215,6 +215,138 @@ void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs,
   PF_HIP(hipGetLastError());
 }
 
+// The same flash attention on the f16 matrix cores with "x3" operands (math_mode 3): every fp32 operand as the pair
+// hi = f16(x), lo' = f16((x - hi) * 2^11) (22 mantissa bits) and every product as hi hi + 2^-11 (hi lo' + lo' hi), the cross terms in
+// an accumulator of their own.  S^T = K Q^T: 8 k-steps x 3 v_mfma_f32_32x32x16_f16 per 32 keys x 32 queries instead of 64 fp32
+// MFMAs at 1/16 of the rate; O^T = V^T P^T: 4 d-blocks x 2 k-steps x 3.  Q pairs live in registers, K pairs in LDS as rows, V
+// pairs in LDS TRANSPOSED (keys contiguous per d: the k index of an MFMA operand is contiguous per lane); the P operand of k-step
+// t is the lane's own probabilities 8 t .. 8 t + 7 (D layout keys 16 t + 8 (e >> 2) + 4 kh + (e & 3)), V^T fragments follow that
+// key order (two 8-byte reads).  fp32 softmax as above.
+typedef _Float16 x3h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x3h4 __attribute__((ext_vector_type(4)));
+constexpr int AX_LDK = 136, AX_LDV = 36;                       // halves per K row (272 B) / per V^T row (72 B): conflict-free reads
+__device__ __forceinline__ void x3_split(float v, half_t& hi, half_t& lo) {
+  hi = (half_t)v;
+  lo = (half_t)((v - (float)hi) * 2048.0f);
+}
+__global__ __launch_bounds__(256) void attn_x3_kernel(const float* __restrict__ q, int64_t q_bs, int q_rs, const float* __restrict__ k,
+                                                      int64_t k_bs, int k_rs, const float* __restrict__ v, int64_t v_bs, int v_rs,
+                                                      float* __restrict__ o, int64_t o_bs, int o_rs, int H, int Lq, int Lk) {
+  __shared__ __attribute__((aligned(16))) half_t Kh[32 * AX_LDK], Kl[32 * AX_LDK], Vh[128 * AX_LDV], Vl[128 * AX_LDV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qrow = min(q0 + l31, Lq - 1);
+  const float* qp = q + (size_t)b * q_bs + (size_t)qrow * q_rs + h * 128;
+  x3h8 qh[8], ql[8];                                            // B operand of k-step s: d = 16 s + 8 kh + 0..7
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * kh), t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * kh + 4);
+    const float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { half_t a, c; x3_split(f[e], a, c); qh[s][e] = a; ql[s][e] = c; }
+  }
+  f16x om[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) om[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* kb = k + (size_t)b * k_bs + h * 128;
+  const float* vb = v + (size_t)b * v_bs + h * 128;
+  for (int k0 = 0; k0 < Lk; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + it * 256, r = e >> 5, c4 = e & 31;
+      const int kr = min(k0 + r, Lk - 1);
+      const float4 kf = *reinterpret_cast<const float4*>(kb + (size_t)kr * k_rs + 4 * c4);
+      const float4 vf = *reinterpret_cast<const float4*>(vb + (size_t)kr * v_rs + 4 * c4);
+      x3h4 a, c;
+      { half_t x, y; x3_split(kf.x, x, y); a[0] = x; c[0] = y; x3_split(kf.y, x, y); a[1] = x; c[1] = y;
+        x3_split(kf.z, x, y); a[2] = x; c[2] = y; x3_split(kf.w, x, y); a[3] = x; c[3] = y; }
+      *reinterpret_cast<x3h4*>(&Kh[r * AX_LDK + 4 * c4]) = a;
+      *reinterpret_cast<x3h4*>(&Kl[r * AX_LDK + 4 * c4]) = c;
+      const float vv[4] = {vf.x, vf.y, vf.z, vf.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { half_t x, y; x3_split(vv[j], x, y); Vh[(4 * c4 + j) * AX_LDV + r] = x; Vl[(4 * c4 + j) * AX_LDV + r] = y; }
+    }
+    __syncthreads();
+    f16x sm, sc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { sm[e] = 0.f; sc[e] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const x3h8 ah = *reinterpret_cast<const x3h8*>(&Kh[l31 * AX_LDK + 16 * s + 8 * kh]);
+      const x3h8 al = *reinterpret_cast<const x3h8*>(&Kl[l31 * AX_LDK + 16 * s + 8 * kh]);
+      sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], sm, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], sc, 0, 0, 0);
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], sc, 0, 0, 0);
+    }
+    float p[16];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = k0 + 8 * (e >> 2) + 4 * kh + (e & 3);
+      p[e] = key < Lk ? sm[e] + sc[e] * (1.0f / 2048.0f) : -INFINITY;
+      mt = fmaxf(mt, p[e]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { p[e] = expf(p[e] - m_new); ls += p[e]; }
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+    x3h8 ph[2], pl[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { half_t a, c; x3_split(p[e], a, c); ph[e >> 3][e & 7] = a; pl[e >> 3][e & 7] = c; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      f16x oc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { om[d][e] *= alpha; oc[e] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // A operand: lane (d = 32 d + l31, kh): keys 16 t + 4 kh + 0..3 and 16 t + 8 + 4 kh + 0..3
+        const half_t* vhp = &Vh[(d * 32 + l31) * AX_LDV + 16 * t + 4 * kh];
+        const half_t* vlp = &Vl[(d * 32 + l31) * AX_LDV + 16 * t + 4 * kh];
+        const x3h4 h0 = *reinterpret_cast<const x3h4*>(vhp), h1 = *reinterpret_cast<const x3h4*>(vhp + 8);
+        const x3h4 l0 = *reinterpret_cast<const x3h4*>(vlp), l1 = *reinterpret_cast<const x3h4*>(vlp + 8);
+        const x3h8 vhf = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), vlf = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        om[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, ph[t], om[d], 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, pl[t], oc, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlf, ph[t], oc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) om[d][e] += oc[e] * (1.0f / 2048.0f);
+    }
+  }
+  if (q0 + l31 >= Lq) return;
+  const float inv = 1.0f / l_run;
+  float* op = o + (size_t)b * o_bs + (size_t)(q0 + l31) * o_rs + h * 128;
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * kh) =
+          make_float4(om[d][4 * g + 0] * inv, om[d][4 * g + 1] * inv, om[d][4 * g + 2] * inv, om[d][4 * g + 3] * inv);
+}
+
+void launch_attention_x3(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
+                         const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk) {
+  if (B == 0 || Lq == 0 || Lk == 0) return;
+  const bool aligned = ((q_rs | k_rs | v_rs | o_rs) % 4 == 0) && (q_bs % 4 == 0) && (k_bs % 4 == 0) && (v_bs % 4 == 0) && (o_bs % 4 == 0) &&
+                       ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0);
+  if (!aligned) { launch_attention_f32(s, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk); return; }
+  hipLaunchKernelGGL(attn_x3_kernel, dim3((unsigned)cdiv(Lq, 128), (unsigned)(B * H)), dim3(256), 0, s, q, q_bs, q_rs, k, k_bs, k_rs,
+                     v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
+  PF_HIP(hipGetLastError());
+}
+
 // ---- "x3" products (math_mode 3): an fp32 value as TWO f16 numbers, hi = f16(x) and lo' = f16((x - hi) * 2^11) — 22 bits of
 // mantissa, the low part kept in the normal range by the scaling — so that x y = hi_x hi_y + 2^-11 (hi_x lo'_y + lo'_x hi_y)
 // up to 2^-22 relative: three f16 MFMA products (16x the fp32 matrix rate each) with fp32 accumulation.

@@ -169,6 +169,9 @@ void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs,
                           const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk);
 // x [rows, K] fp32 -> out [rows, 2 Kp] f16 = hi | lo' (swap: lo' | hi), lo' = f16((x - hi) * 2^11); Kp % 4 == 0, pad columns zeroed
 void launch_split_x3(hipStream_t s, const float* x, int64_t rows, int K, int ldx, half_t* out, int ldo, int Kp, int swap);
+// the same attention with x3 operands (22-bit pairs on the f16 matrix cores): math_mode 3
+void launch_attention_x3(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
+                         const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk);
 void launch_im2col_f32(hipStream_t s, const float* H, int B, int T, int D, int l_order, int r_order, float* out);
 void launch_add_f32(hipStream_t s, float* x, const float* y, int64_t n);     // x += y
 void launch_posenc_f32(hipStream_t s, const float* x, const float* pe, int B, int T, int F, float xscale, float* out);
