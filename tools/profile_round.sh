@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun): bench lines of every config, rocprofv3 kernel stats of the headline
 # command, PMC traffic (separate passes, per the MI355X guide) of the dominant kernels.  Everything lands in gpurun_out/$TAG.
-TAG=${1:-round4}
+TAG=${1:-round5}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -10,6 +10,9 @@ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-via-recognizer --in
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-via-recognizer --accuracy int8 > $OUT/bench_int8.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --model seaco --accuracy int8 > $OUT/bench_seaco_int8.json 2>> $OUT/bench.err
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-via-recognizer --accuracy fp32 > $OUT/bench_fp32.json 2>> $OUT/bench.err
+python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-via-recognizer --accuracy exact > $OUT/bench_exact.json 2>> $OUT/bench.err
+python bench.py --via recognizer --steps 32 --callers 4 > $OUT/bench_via_recognizer_4callers.json 2>> $OUT/bench.err
+python bench.py --via recognizer --steps 24 --callers 2 --in-flight 2 > $OUT/bench_via_recognizer_2callers.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --model sensevoice > $OUT/bench_sensevoice.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --model seaco > $OUT/bench_seaco.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --batch 128 > $OUT/bench_batch128.json 2>> $OUT/bench.err
@@ -35,7 +38,7 @@ ls -la $OUT
 tail -3 $OUT/bench.err
 python -c "
 import json
-for f in ('bench','bench_one_in_flight','bench_sensevoice','bench_seaco','bench_batch128','bench_int8','bench_seaco_int8','bench_fp32'):
+for f in ('bench','bench_one_in_flight','bench_sensevoice','bench_seaco','bench_batch128','bench_int8','bench_seaco_int8','bench_fp32','bench_exact','bench_via_recognizer_4callers','bench_via_recognizer_2callers'):
     try:
         d=json.load(open('$OUT/'+f+'.json')); print(f, round(d['ms_per_step'],3), round(d['value']), d['roofline']['frac'], d.get('cpu_baseline',{}).get('value'))
     except Exception as e: print(f, 'FAILED', e)

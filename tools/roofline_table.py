@@ -33,7 +33,7 @@ def main():
         ("CIF im2col", "cif_im2col_kernel", None, (M * D * 2 + M * 3 * D * 2) / 1e6),
         ("CIF weighted gather", "cif_gather_kernel", None, (M * D * 4 + Md * D * 4) / 1e6),
     ]
-    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 4)\n")
+    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 5)\n")
     print("Source: `%s` (rocprofv3 --kernel-trace, average kernel duration) and the HIP-event class times of "
           "`bench.py` (`class_ms_per_step`).  L = %d.  Peaks: HBM 8 TB/s spec (6.3 TB/s achievable), dense f16 MFMA 2.5 PFLOP/s.\n" % (trace.split("/")[-1], L))
     print("## HBM-bound kernels\n\n| kernel | avg µs | launches/step | algorithmic MB | achieved TB/s | of 8 TB/s | of 6.3 TB/s |\n|---|---|---|---|---|---|---|")
@@ -53,8 +53,10 @@ def main():
         if v.get("tflops"):
             print("| %s | %d | %.3f | %.0f | %.0f %% |" % (cls, v["launches"], v["ms"], v["tflops"], 100 * v["tflops"] / MFMA_PEAK))
     r = bench["roofline"]
-    print("\nDominant kernel (`bench.py` roofline object, timed inside the timed steps): %s — %.0f TFLOP/s = %.3f of peak; "
-          "PMC traffic %s bytes/launch vs %d algorithmic.\n" % (r["kernel"], r["achieved"], r["frac"], r.get("traffic"), r.get("algorithmic_bytes_per_launch", 0)))
+    print("\nDominant kernel (`bench.py` roofline object, timed inside the timed steps): %s — bound: %s, %.0f %s = %.3f of peak "
+          "(%.3f of the MFMA peak, %.3f of the HBM peak; %.0f FLOP/B against a machine balance of %.0f); PMC traffic %s bytes/launch vs %d algorithmic.\n"
+          % (r["kernel"], r["bound"], r["achieved"], r["unit"], r["frac"], r.get("frac_of_mfma_peak", 0), r.get("frac_of_hbm_peak", 0),
+             r.get("intensity_flop_per_byte", 0), r.get("machine_balance_flop_per_byte", 0), r.get("traffic"), r.get("algorithmic_bytes_per_launch", 0)))
     print("Whole path: %.2f ms/step, RTFx %.0f, %.0f TFLOP/s algorithmic over the wall time.\n" % (bench["ms_per_step"], bench["value"], bench["whole_path_tflops_per_gpu"]))
 
 main()
