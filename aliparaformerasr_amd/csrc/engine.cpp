@@ -53,7 +53,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   // math_mode 3 keeps the fp32-MFMA attention by default: with x3 operands in the attention too (PF_X3_ATTN=1: 47.0 instead of
   // 50.8 ms per 32 x 30 s) 2 of the 5344 ids of the benchmark batch leave the fp32 oracle's — scores are exponentiated, and a
   // 22-bit product is 4x an fp32 product's error; the Linears tolerate it (identity holds), the softmax does not
-  { const char* e = getenv("PF_X3_ATTN"); x3_attn_f32_ = !(e && e[0] == '1'); }
+  { const char* e = getenv("PF_X3_ATTN"); if (e && e[0]) x3_attn_ = atoi(e); }
   int8_mode_ = cfg.math_mode == 2;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
@@ -1695,6 +1695,15 @@ enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
 // (hi | lo') pair by the product's epilogue and `out` is not touched; kX3InPair — A is that pair (the `A` pointer is ignored in
 // mode 3).  Mode 1 ignores both flags.  resid2: a second fp32 addend with the row stride of resid (the FSMN memory beside the
 // residual stream).
+// attention of the fp32 graph: math_mode 1 on the fp32 matrix path; math_mode 3: PF_X3_ATTN = 0 the same, 1 = x3 operands
+// throughout, 2 = fp32 scores (what is exponentiated stays exact) + x3 operands for P V
+void Engine::attention32(const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs, const float* v, int64_t v_bs,
+                         int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk) {
+  if (x3_mode_ && x3_attn_ == 1) launch_attention_x3(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, false);
+  else if (x3_mode_ && x3_attn_ == 2) launch_attention_x3(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, true);
+  else launch_attention_f32(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk);
+}
+
 void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
                     const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
   const bool x3 = x3_mode_ && M >= 64 && ldw == K && (scale_cols == 0 || scale_cols >= N) && (ldc % 4) == 0 && (!resid || ldr % 4 == 0);
@@ -1775,7 +1784,7 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
   gemm32(f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
   gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
   launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
-  (x3_mode_ && !x3_attn_f32_ ? launch_attention_x3 : launch_attention_f32)(stream_, f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
+  attention32(f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
                        (int64_t)T * D, D, B, mc_.heads, T, T);
   if (first) {
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
@@ -1894,7 +1903,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
     launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
     gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, Md, D, D, qd, D, nullptr, 0, false, D, qscale);
     gemm32(H32_, D, Lr.kv32.w32, D, Lr.kv32.bias, M, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
-    (x3_mode_ && !x3_attn_f32_ ? launch_attention_x3 : launch_attention_f32)(stream_, qd, (int64_t)L * D, D, kv, (int64_t)T * 2 * D, 2 * D, kv + D, (int64_t)T * 2 * D, 2 * D, cx,
+    attention32(qd, (int64_t)L * D, D, kv, (int64_t)T * 2 * D, 2 * D, kv + D, (int64_t)T * 2 * D, 2 * D, cx,
                          (int64_t)L * D, D, B, mc_.heads, L, T);
     gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, Md, D, D, xd, D, xd, D, false, 0, 1.f);
   }
@@ -2007,7 +2016,7 @@ void Engine::seaco_head_fp32(int B, int L, const float* e0, const float* hid_asr
     launch_layernorm(stream_, xs, R, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
     gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, R, D, D, qd, D, nullptr, 0, false, D, qscale);
     gemm32(bias_embed, D, Lr.kv32.w32, D, Lr.kv32.bias, NJ, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
-    (x3_mode_ && !x3_attn_f32_ ? launch_attention_x3 : launch_attention_f32)(stream_, qd, (int64_t)L * D, D, kv, 0, 2 * D, kv + D, 0, 2 * D, cx, (int64_t)L * D, D, 2 * B, mc_.heads, L, NJ);
+    attention32(qd, (int64_t)L * D, D, kv, 0, 2 * D, kv + D, 0, 2 * D, cx, (int64_t)L * D, D, 2 * B, mc_.heads, L, NJ);
     gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, R, D, D, xs, D, xs, D, false, 0, 1.f);
   }
   ffn_dec(seaco_final_norm1_, seaco_final_w1_, seaco_final_ffn_norm_, seaco_final_w2_);

@@ -257,7 +257,9 @@ class Engine {
   int cus_ = 256;                    // compute units the persistent kernels size their grids for (cu_limit)
   unsigned* lstm_err_ = nullptr;     // device time-out word of the last persistent LSTM launch (checked at the next result sync)
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
-  bool x3_attn_f32_ = true;
+  int x3_attn_ = 0;                  // PF_X3_ATTN (math_mode 3): 0 = fp32-MFMA attention, 1 = x3 operands throughout, 2 = fp32 scores + x3 P V
+  void attention32(const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs, const float* v, int64_t v_bs, int v_rs,
+                   float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk);
   bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs
   std::map<const float*, half_t*> x3w_;   // fp32 weight -> its [lo' | hi] f16 pair image (built on first use)
   DevBuf ws_x3a_, ws_x3t_, ws_x3h_;

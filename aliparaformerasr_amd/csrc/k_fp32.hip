@@ -229,23 +229,35 @@ __device__ __forceinline__ void x3_split(float v, half_t& hi, half_t& lo) {
   hi = (half_t)v;
   lo = (half_t)((v - (float)hi) * 2048.0f);
 }
+// SF32: the SCORES on the fp32 matrix path (exact fp32 products: what is exponentiated), only P V with x3 operands
+template <bool SF32>
 __global__ __launch_bounds__(256) void attn_x3_kernel(const float* __restrict__ q, int64_t q_bs, int q_rs, const float* __restrict__ k,
                                                       int64_t k_bs, int k_rs, const float* __restrict__ v, int64_t v_bs, int v_rs,
                                                       float* __restrict__ o, int64_t o_bs, int o_rs, int H, int Lq, int Lk) {
-  __shared__ __attribute__((aligned(16))) half_t Kh[32 * AX_LDK], Kl[32 * AX_LDK], Vh[128 * AX_LDV], Vl[128 * AX_LDV];
+  __shared__ __attribute__((aligned(16))) half_t Kh[SF32 ? 8 : 32 * AX_LDK], Kl[SF32 ? 8 : 32 * AX_LDK], Vh[128 * AX_LDV], Vl[128 * AX_LDV];
+  __shared__ __attribute__((aligned(16))) float Kf[SF32 ? AF_KT * AF_LDK : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int qrow = min(q0 + l31, Lq - 1);
   const float* qp = q + (size_t)b * q_bs + (size_t)qrow * q_rs + h * 128;
-  x3h8 qh[8], ql[8];                                            // B operand of k-step s: d = 16 s + 8 kh + 0..7
+  x3h8 qh[SF32 ? 1 : 8], ql[SF32 ? 1 : 8];                      // B operand of k-step s: d = 16 s + 8 kh + 0..7
+  float qf[SF32 ? 64 : 1];                                      // SF32: fp32 k-step 4 g + e <-> d = 8 g + 4 kh + e (attn_f32_mfma_kernel)
+  if constexpr (SF32) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + 8 * g + 4 * kh);
+      qf[4 * g + 0] = t.x; qf[4 * g + 1] = t.y; qf[4 * g + 2] = t.z; qf[4 * g + 3] = t.w;
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * kh), t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * kh + 4);
     const float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) { half_t a, c; x3_split(f[e], a, c); qh[s][e] = a; ql[s][e] = c; }
+  }
   }
   f16x om[4];
 #pragma unroll
@@ -263,11 +275,15 @@ __global__ __launch_bounds__(256) void attn_x3_kernel(const float* __restrict__ 
       const int kr = min(k0 + r, Lk - 1);
       const float4 kf = *reinterpret_cast<const float4*>(kb + (size_t)kr * k_rs + 4 * c4);
       const float4 vf = *reinterpret_cast<const float4*>(vb + (size_t)kr * v_rs + 4 * c4);
-      x3h4 a, c;
-      { half_t x, y; x3_split(kf.x, x, y); a[0] = x; c[0] = y; x3_split(kf.y, x, y); a[1] = x; c[1] = y;
-        x3_split(kf.z, x, y); a[2] = x; c[2] = y; x3_split(kf.w, x, y); a[3] = x; c[3] = y; }
-      *reinterpret_cast<x3h4*>(&Kh[r * AX_LDK + 4 * c4]) = a;
-      *reinterpret_cast<x3h4*>(&Kl[r * AX_LDK + 4 * c4]) = c;
+      if constexpr (SF32) {
+        *reinterpret_cast<float4*>(&Kf[r * AF_LDK + 4 * c4]) = kf;
+      } else {
+        x3h4 a, c;
+        { half_t x, y; x3_split(kf.x, x, y); a[0] = x; c[0] = y; x3_split(kf.y, x, y); a[1] = x; c[1] = y;
+          x3_split(kf.z, x, y); a[2] = x; c[2] = y; x3_split(kf.w, x, y); a[3] = x; c[3] = y; }
+        *reinterpret_cast<x3h4*>(&Kh[r * AX_LDK + 4 * c4]) = a;
+        *reinterpret_cast<x3h4*>(&Kl[r * AX_LDK + 4 * c4]) = c;
+      }
       const float vv[4] = {vf.x, vf.y, vf.z, vf.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) { half_t x, y; x3_split(vv[j], x, y); Vh[(4 * c4 + j) * AX_LDV + r] = x; Vl[(4 * c4 + j) * AX_LDV + r] = y; }
@@ -276,6 +292,16 @@ __global__ __launch_bounds__(256) void attn_x3_kernel(const float* __restrict__ 
     f16x sm, sc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { sm[e] = 0.f; sc[e] = 0.f; }
+    if constexpr (SF32) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float4 kf = *reinterpret_cast<const float4*>(&Kf[l31 * AF_LDK + 8 * g + 4 * kh]);
+        sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[4 * g + 0], sm, 0, 0, 0);
+        sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[4 * g + 1], sm, 0, 0, 0);
+        sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[4 * g + 2], sm, 0, 0, 0);
+        sm = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[4 * g + 3], sm, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const x3h8 ah = *reinterpret_cast<const x3h8*>(&Kh[l31 * AX_LDK + 16 * s + 8 * kh]);
@@ -283,6 +309,7 @@ __global__ __launch_bounds__(256) void attn_x3_kernel(const float* __restrict__ 
       sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], sm, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], sc, 0, 0, 0);
       sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], sc, 0, 0, 0);
+    }
     }
     float p[16];
     float mt = -INFINITY;
@@ -337,13 +364,17 @@ __global__ __launch_bounds__(256) void attn_x3_kernel(const float* __restrict__ 
 }
 
 void launch_attention_x3(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
-                         const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk) {
+                         const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk, bool scores_f32) {
   if (B == 0 || Lq == 0 || Lk == 0) return;
   const bool aligned = ((q_rs | k_rs | v_rs | o_rs) % 4 == 0) && (q_bs % 4 == 0) && (k_bs % 4 == 0) && (v_bs % 4 == 0) && (o_bs % 4 == 0) &&
                        ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0);
   if (!aligned) { launch_attention_f32(s, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk); return; }
-  hipLaunchKernelGGL(attn_x3_kernel, dim3((unsigned)cdiv(Lq, 128), (unsigned)(B * H)), dim3(256), 0, s, q, q_bs, q_rs, k, k_bs, k_rs,
-                     v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
+  if (scores_f32)
+    hipLaunchKernelGGL(attn_x3_kernel<true>, dim3((unsigned)cdiv(Lq, 128), (unsigned)(B * H)), dim3(256), 0, s, q, q_bs, q_rs, k, k_bs, k_rs,
+                       v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
+  else
+    hipLaunchKernelGGL(attn_x3_kernel<false>, dim3((unsigned)cdiv(Lq, 128), (unsigned)(B * H)), dim3(256), 0, s, q, q_bs, q_rs, k, k_bs, k_rs,
+                       v, v_bs, v_rs, o, o_bs, o_rs, H, Lq, Lk);
   PF_HIP(hipGetLastError());
 }
 

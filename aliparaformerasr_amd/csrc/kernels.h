@@ -171,7 +171,7 @@ void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs,
 void launch_split_x3(hipStream_t s, const float* x, int64_t rows, int K, int ldx, half_t* out, int ldo, int Kp, int swap);
 // the same attention with x3 operands (22-bit pairs on the f16 matrix cores): math_mode 3
 void launch_attention_x3(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
-                         const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk);
+                         const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk, bool scores_f32 = false);
 void launch_im2col_f32(hipStream_t s, const float* H, int B, int T, int D, int l_order, int r_order, float* out);
 void launch_add_f32(hipStream_t s, float* x, const float* y, int64_t n);     // x += y
 void launch_posenc_f32(hipStream_t s, const float* x, const float* pe, int B, int T, int F, float xscale, float* out);
