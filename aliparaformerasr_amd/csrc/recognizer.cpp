@@ -472,6 +472,7 @@ void Recognizer::audio_free(float* p, size_t bytes) {
 void Recognizer::upload(float* dst, const float* src, size_t bytes) {
   CopyLane& ln = lanes_[next_lane_.fetch_add(1) % lanes_.size()];
   std::lock_guard<std::mutex> lk(ln.mu);
+  if (disposed_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");     // (Dispose destroys the lanes under this lock)
   PF_HIP(hipSetDevice(device_));
   if (!ln.s) PF_HIP(hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
   PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ln.s));
