@@ -246,7 +246,7 @@ class Engine {
   bool qkv_tail_ = true;             // PF_QKV_TAIL: the next layer's Q | K | V projection behind the fused block, same launch
   bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
-  int ffn_fused_min_rows_ = 2048;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels win
+  int ffn_fused_min_rows_ = 1200;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels tie or win (tools/mid_rows.py)
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)
   int dec_fuse_ = 1;                 // bit 1: FSMN + norm3, bit 2: out-projection + next norm1, bit 4: FFN-down + norm2 (row-complete GEMM)
