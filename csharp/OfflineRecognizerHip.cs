@@ -67,6 +67,11 @@ namespace AliParaformerAsr.Hip
                                                                       modelebFilePath ?? "", hotwordFilePath ?? "", batchSize,
                                                                       threadsNum, device, out _r));
 
+        /// <summary>Engines of this recognizer's pool (round 5).  GetResults holds no lock in the reference
+        /// (OfflineRecognizer.cs:110-198), so a server calls it from several threads; here every call takes a free engine of the
+        /// pool (same device, one copy of the weights) — created on demand up to $PF_RECOGNIZER_ENGINES (default 2).</summary>
+        public int NumEngines { get { int n = ParaformerHip.pf_recognizer_num_engines(_r); ParaformerHip.Check(n < 0 ? n : 0); return n; } }
+
         public OfflineStream CreateOfflineStream()
         {
             ParaformerHip.Check(ParaformerHip.pf_recognizer_create_stream(_r, out IntPtr s));
