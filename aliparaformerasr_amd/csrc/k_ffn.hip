@@ -1,4 +1,7 @@
-// k_ffn.hip — the encoder's WHOLE position-wise feed-forward block in one launch (round 5):
+// k_ffn.hip — the tail of a SAN-M encoder layer in ONE launch per 64-row tile (round 5).  Core: the WHOLE position-wise
+// feed-forward block; template options put the attention out-projection (+ bias + residual + FSMN memory + LayerNorm norm2) in
+// FRONT of it (OP) and the next layer's fused Q | K | V projection BEHIND it (QK), so that an encoder layer is attention + this
+// launch and neither LayerNorm result, nor the 2048-wide hidden, nor x_mid ever visits HBM.
 //
 //   h = relu(xn W1^T + b1)                     xn [M,512] f16 (LayerNorm norm2 of the residual stream), W1 [2048,512]
 //   x = x + h W2^T + b2                        W2 [512,2048]; x fp32 residual stream
