@@ -118,6 +118,7 @@ SIGNATURES = {
     "pf_op_gemm_rc": (C.c_int, [_vp, _P(PfGemmRcDesc), _f, _f, _f, _f, _f]),
     "pf_op_ffn": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_ffn_fused": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int32, _f, _f]),
+    "pf_op_dec_ffn_fused": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f]),
     "pf_op_attn_ffn_fused": (C.c_int, [_vp, _vp, _f, _f]),
     "pf_op_fsmn_enc": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn_dec": (C.c_int, [_vp, _f, _f, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),

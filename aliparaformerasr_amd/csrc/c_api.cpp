@@ -534,6 +534,19 @@ int pf_op_ffn_fused(pf_engine* h, const float* x, const float* w1, const float* 
   return PF_OK;
   PF_CATCH
 }
+int pf_op_dec_ffn_fused(pf_engine* h, const float* x, const float* w1, const float* b1, const float* gamma_f, const float* beta_f,
+                        const float* w2, const float* g, const float* be, int32_t M, int32_t splits, float* t_out, float* n_out) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(x); NEED(w1); NEED(b1); NEED(gamma_f); NEED(beta_f); NEED(w2);
+  PF_CHECK(t_out || n_out, PF_ERR_INVALID_ARG, "dec_ffn_fused: no output requested");
+  PF_CHECK((g != nullptr) == (be != nullptr) && (g || !n_out), PF_ERR_INVALID_ARG, "dec_ffn_fused: the LayerNorm output needs gamma and beta");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_dec_ffn_fused(x, w1, b1, gamma_f, beta_f, w2, g, be, M, splits, t_out, n_out);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_attn_ffn_fused(pf_engine* h, const pf_attn_ffn_desc* d, float* x_out, float* n16_out) {
   PF_TRY
   std::shared_ptr<Engine> eh_ = E(h);

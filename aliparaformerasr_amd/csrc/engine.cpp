@@ -66,6 +66,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_RC_FFN2"); if (e && e[0]) rc_ffn2_ = e[0] != '0'; }   // A/B switch for tools/: the unfused encoder sequence
   { const char* e = getenv("PF_FFN_FUSED"); if (e && e[0]) ffn_fused_ = e[0] != '0'; }   // A/B: the whole FFN block in one launch (k_ffn.hip)
   { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
+  { const char* e = getenv("PF_DEC_FFN"); if (e && e[0]) dec_ffn_fused_ = e[0] != '0'; }
   { const char* e = getenv("PF_ATTN_FFN"); if (e && e[0]) attn_ffn_ = e[0] != '0'; }
   { const char* e = getenv("PF_QKV_TAIL"); if (e && e[0]) qkv_tail_ = e[0] != '0'; }
 
@@ -493,6 +494,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       PF_HIP(hipMemcpyAsync(kvb + (size_t)i * 2 * D, kvbias.dev, 2 * D * 4, hipMemcpyDeviceToDevice, stream_));
       L.kv32.w32 = kvw.dev; L.kv32.bias = kvbias.dev; L.kv32.N = 2 * D; L.kv32.K = D;
       L.kv32.w = dec_kv_all_.w + (size_t)i * 2 * D * D; L.kv32.Kpad = D;
+      L.ffn_img = make_dec_ffn_image(L.w1, L.ffn_norm, L.w2);
       dec_.push_back(L);
     }
   }
@@ -501,6 +503,7 @@ void Engine::load_weights(const pf_engine_config& cfg) {
   dec_final_ffn_norm_ = make_ln("decoder.final.ffn.norm", dec_final_w1_.N);
   dec_final_w2_ = make_lin("decoder.final.ffn.w2", false);
   dec_after_ = make_ln("decoder.after_norm", D);
+  dec_final_img_ = make_dec_ffn_image(dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
   dec_out_ = make_lin("decoder.output", true);
   PF_CHECK(dec_out_.N == mc_.vocab && dec_out_.K == D && dec_final_w1_.K == D && dec_final_w1_.N == mc_.ffn &&
                dec_final_w2_.N == D && dec_final_w2_.K == dec_final_w1_.N,
@@ -574,6 +577,17 @@ void Engine::load_weights(const pf_engine_config& cfg) {
     PF_CHECK(seaco_out_.N == mc_.vocab, PF_ERR_FORMAT, "weights: seaco.output rows != vocab");
   }
   PF_HIP(hipStreamSynchronize(stream_));
+}
+
+// The decoder's FFN block for the split form of ffn_fused_kernel (k_ffn.hip): W1, gamma_F (.) W2 (from the fp32 tensor, one
+// rounding), b1, colsum(gamma_F (.) W2), W2 beta_F.  Null when the form does not apply (mode, shape).
+half_t* Engine::make_dec_ffn_image(const Lin& w1, const LNp& fn, const Lin& w2) {
+  if (!dec_ffn_fused_ || !ffn_fused_ || fp32_mode_ || int8_mode_ || !ffn_fused_applicable(w1.K, w1.N) || w2.N != w1.K || w2.K != w1.N ||
+      !w1.w || !w1.bias || !w2.w32 || w2.bias || w1.Kpad != w1.K || fn.D != w1.N)
+    return nullptr;
+  half_t* img = (half_t*)dalloc(ffn_dec_image_bytes());
+  launch_ffn_dec_retile(stream_, w1.w, w1.Kpad, w2.w32, fn.g, fn.b, w1.bias, img);
+  return img;
 }
 
 Lin Engine::make_lin(const std::string& prefix, bool bias) {
@@ -1207,7 +1221,25 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   bool have_n1 = false;                                // xdn16 already holds norm1(xd) of the coming block
   // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or
   // post(t) in n32 / n16
-  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const LNp& post, float* n32, half_t* n16) {
+  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const half_t* img, const LNp& post, float* n32, half_t* n16) {
+    if (img && !dsmall) {
+      // norm1 | the whole block in the split form of the fused FFN kernel + its finishing pass (LayerNorm over the hidden
+      // applied from row statistics, then `post`): 2 launches for FFN-up | LayerNorm(2048) | FFN-down | LayerNorm
+      if (!have_n1) {
+        prof_begin("layernorm", 0);
+        launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
+        prof_end("layernorm");
+      }
+      have_n1 = false;
+      ensure(ws_decffn_, ffn_dec_workspace_bytes(Md));
+      FfnDecArgs f{};
+      f.A = xdn16; f.lda = D; f.img = img; f.ws = ws_decffn_.p; f.M = Md; f.eps_hidden = 1e-12f;
+      f.ln_g = post.g; f.ln_b = post.b; f.eps = 1e-12f; f.n32 = n32; f.ldn32 = D; f.n16 = n16; f.ldn16 = D;
+      prof_begin("gemm_dec_ffn", 4.0 * Md * (double)D * F);
+      launch_ffn_dec(stream_, f);
+      prof_end("gemm_dec_ffn");
+      return;
+    }
     if (dsmall) {
       // short inputs: norm1 | FFN-up | LayerNorm(2048) in place | FFN-down partials | their sum + the LayerNorm behind it
       prof_begin("layernorm", 0);
@@ -1246,7 +1278,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
 
   for (int i = 0; i < nd; ++i) {
     const DecLayer& Lr = dec_[i];
-    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2, Lr.norm2, tn32, nullptr);
+    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2, Lr.ffn_img, Lr.norm2, tn32, nullptr);
     bool fused = false;
     if (f_fsmn) {
       prof_begin("fsmn", 0);
@@ -1285,7 +1317,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
       gemm("gemm_dec_out", Lr.out, ctxd16, D, Md, xd, D, nullptr, 0, xd, D, nullptr, 0, false, 0, 1.f);
     }
   }
-  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_, dec_after_, hid32, xdn16);
+  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_, dec_final_img_, dec_after_, hid32, xdn16);
   logits_ld_ = (int)round_up(V, 4);                 // fp32 rows stay 16-byte aligned for any vocabulary size
   gemm("gemm_vocab", dec_out_, xdn16, D, Md, logits_, logits_ld_, nullptr, 0, nullptr, 0, nullptr, 0, false, 0, 1.f);
   prof_begin("argmax", 0);
@@ -2466,6 +2498,60 @@ void Engine::op_ffn(const float* x, const float* w1, const float* b1, const floa
 }
 
 // The encoder FFN block as enc_layer() launches it for long inputs: retile W1 / W2, then ONE launch of ffn_fused_kernel.
+// The decoder's FFN block in the split form of the fused kernel (k_ffn.hip), standalone: t = LN_F(relu(f16(x) W1^T + b1)) W2^T,
+// n = LayerNorm(t).  x is the block's already normalised input.
+void Engine::op_dec_ffn_fused(const float* x, const float* w1, const float* b1, const float* gf, const float* bf, const float* w2,
+                              const float* g, const float* be, int M, int splits, float* t_out, float* n_out) {
+  PF_HIP(hipSetDevice(device_));
+  const int D = 512, F = 2048;
+  PF_CHECK(M > 0, PF_ERR_INVALID_ARG, "dec_ffn_fused: M must be positive");
+  PF_CHECK(splits == 0 || splits == 1 || splits == 2 || splits == 3 || splits == 4 || splits == 8, PF_ERR_INVALID_ARG,
+           "dec_ffn_fused: splits must be 0 (automatic) | 1 | 2 | 3 | 4 | 8");
+  const int64_t Mp = round_up(M, 256) + 128;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * D, (int64_t)F * D) * 4);
+  const size_t ox16 = carve((size_t)Mp * D * 2), ow1 = carve((size_t)F * D * 2), ow2 = carve((size_t)D * F * 4);
+  const size_t oimg = carve(ffn_dec_image_bytes()), ows = carve(ffn_dec_workspace_bytes(M, splits));
+  const size_t ob1 = carve((size_t)F * 4), ogf = carve((size_t)F * 4), obf = carve((size_t)F * 4), og = carve((size_t)D * 4), obe = carve((size_t)D * 4);
+  const size_t ot = carve((size_t)M * D * 4), on = carve((size_t)M * D * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));
+  auto up16 = [&](const float* src, int rows, int cols, size_t dst, int ldo) {
+    PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
+    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), ldo);
+    PF_HIP(hipStreamSynchronize(stream_));
+  };
+  up16(x, M, D, ox16, D); up16(w1, F, D, ow1, D);
+  PF_HIP(hipMemcpyAsync(base + ow2, w2, (size_t)D * F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ogf, gf, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + obf, bf, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
+  if (g) {
+    PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+    PF_HIP(hipMemcpyAsync(base + obe, be, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+  }
+  launch_ffn_dec_retile(stream_, (const half_t*)(base + ow1), D, (const float*)(base + ow2), (const float*)(base + ogf),
+                        (const float*)(base + obf), (const float*)(base + ob1), (half_t*)(base + oimg));
+  FfnDecArgs f{};
+  f.A = (const half_t*)(base + ox16); f.lda = D; f.img = (const half_t*)(base + oimg); f.ws = base + ows; f.M = M; f.splits = splits;
+  f.eps_hidden = 1e-12f; f.eps = 1e-12f;
+  if (t_out) { f.t32 = (float*)(base + ot); f.ldt = D; }
+  if (g) { f.ln_g = (const float*)(base + og); f.ln_b = (const float*)(base + obe); }
+  if (n_out) { f.n32 = (float*)(base + on); f.ldn32 = D; }
+  const char* rep = getenv("PF_OP_REPEAT");                        // tools/: repeated launches, timed as class "gemm_op_warm"
+  const int reps = rep ? std::max(1, atoi(rep)) : 1;
+  for (int r = 0; r < reps; ++r) {
+    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F);
+    launch_ffn_dec(stream_, f);
+    prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
+  }
+  if (t_out) PF_HIP(hipMemcpyAsync(t_out, base + ot, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  if (n_out) PF_HIP(hipMemcpyAsync(n_out, base + on, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+}
+
 void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
                           const float* g, const float* be, int M, float* x_out, float* n16_out, const pf_attn_ffn_desc* op) {
   PF_HIP(hipSetDevice(device_));

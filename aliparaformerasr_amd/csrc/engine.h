@@ -63,7 +63,10 @@ struct EncLayer {
   half_t* qkv_t = nullptr;                                // the [Q | K | V] weight in that order too (three 512-row images): the PREVIOUS layer's launch runs this projection
   half_t* out_wt = nullptr;                               // the attention out-projection weight in the same kernel's fragment order
 };
-struct DecLayer { LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr; };   // kv32: fp32 pointers only
+struct DecLayer {
+  LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr;   // kv32: fp32 pointers only
+  half_t* ffn_img = nullptr;   // (W1, gamma_F (.) W2, b1, colsum, W2 beta_F) in the fragment order of the split FFN form (k_ffn.hip; null: not built)
+};
 
 struct DevBuf {       // grow-only device allocation
   void* p = nullptr;
@@ -131,6 +134,8 @@ class Engine {
   // activations [M, K], {a_scale, a_zp}, the uint8 weights [N, K] and their per-channel scale / zero point
   void op_qlinear(const float* x, const float* W, const float* bias, int M, int N, int K, int relu, int x_is_f16, float* y,
                   uint8_t* xq_out, float* aparams_out, uint8_t* wq_out, float* wscale_out, int32_t* wzp_out);
+  void op_dec_ffn_fused(const float* x, const float* w1, const float* b1, const float* gf, const float* bf, const float* w2,
+                        const float* g, const float* be, int M, int splits, float* t_out, float* n_out);
   void op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
                     const float* g, const float* be, int M, float* x_out, float* n16_out, const pf_attn_ffn_desc* op = nullptr);
   void op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
@@ -173,6 +178,7 @@ class Engine {
   const Tensor* tensor_u8(const std::string& name) const;       // nullptr when absent
   bool has_tensor(const std::string& name) const { return tensors_.count(name) != 0; }
   Lin make_lin(const std::string& prefix, bool bias);
+  half_t* make_dec_ffn_image(const Lin& w1, const LNp& fn, const Lin& w2);
   LNp make_ln(const std::string& prefix, int width);
   void release();
   float* make_fsmn_wT(const std::string& name, int K = 0);
@@ -246,6 +252,7 @@ class Engine {
   bool qkv_tail_ = true;             // PF_QKV_TAIL: the next layer's Q | K | V projection behind the fused block, same launch
   bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
+  bool dec_ffn_fused_ = true;        // PF_DEC_FFN: the decoder's FFN block (with its LayerNorm over the hidden) as the split form of the same kernel
   int ffn_fused_min_rows_ = 1200;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels tie or win (tools/mid_rows.py)
   bool no_small_fuse_ = false;
   bool dec_h32_ = false;             // PF_DEC_H32=1: decoder FFN hidden through fp32 (A/B switch)
@@ -293,6 +300,7 @@ class Engine {
   std::vector<DecLayer> dec_;
   LNp enc_after_, tp_norm_, dec_final_norm1_, dec_final_ffn_norm_, dec_after_;
   Lin cif_conv_, dec_kv_all_, dec_final_w1_, dec_final_w2_, dec_out_, ctc_;
+  half_t* dec_final_img_ = nullptr;  // the final block's image for the split FFN form (DecLayer::ffn_img)
   const float* cif_out_w_ = nullptr;
   const float* cif_out_b_ = nullptr;
   struct LstmLayer { Lin ih; half_t* whh = nullptr; };
@@ -321,7 +329,7 @@ class Engine {
   float* small_ws_ = nullptr;        // short-input GEMM: split partials
   float* cif_conv_w32_ = nullptr;    // fp32 mode: the CIF conv as a [D][taps*D] GEMM operand
   float* ts_up_w32_ = nullptr;       // fp32 mode: the transposed conv as a [(j, out)][in] GEMM operand
-  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_kv_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_, ws_seaco_hw_;
+  DevBuf ws_audio_, ws_meta_, ws_fbank_, ws_speech_, ws_enc_, ws_dec_, ws_decffn_, ws_kv_, ws_pe_, ws_tmp_, ws_ts_, ws_seaco_, ws_seaco_in_, ws_seaco_hw_;
   bool seaco_hw_valid_ = false;     // ws_seaco_hw_ holds the embedder output / K,V rows of the CURRENT hot-word list (f16 path)
   int pe_T_ = 0;
   // encoder views (valid after encoder())

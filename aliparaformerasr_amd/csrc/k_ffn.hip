@@ -61,6 +61,10 @@ struct FfnDev {
   // never visits HBM either: Q (scaled) and K leave in the blocked [Mpad, 1024] layout, V row-major [Mpad, ldvo] (k_gemm_qkv.hip's)
   const half_t* Wqt; const float* bq; half_t* out_qk; half_t* out_v;
   int ldvo; float qscale;
+  // SP > 0 (decoder form): the hidden range is split over S workgroups per tile, SP chunks each; a workgroup leaves
+  // its partial product rows (fp32, no bias) and the row sums / sums of squares of ITS part of the hidden
+  float* part; float* stats;                                   // [S][Mp][512], [S][Mp][2]
+  int S, Mp;
 };
 
 constexpr int FF_BM = 64, FF_D = 512, FF_F = 2048, FF_HC = 256, FF_NC = FF_F / FF_HC;   // 8 chunks
@@ -139,14 +143,23 @@ __device__ __forceinline__ void ff_fsmn(float4 (&x)[8], const h4 (&win)[18], con
 // XD: how many k-steps ahead of their MFMAs the LDS fragment reads are issued (ring of XD + 1 fragment pairs)
 // OP: 1 = the attention out-projection (+ bias + residual + FSMN memory + LayerNorm norm2) runs in front of the block on the
 // same 64 rows: its result is the block's LDS operand tile and never visits HBM as f16
-template <int PF, int ABL = 0, int XD = 2, int OP = 0, int QK = 0>
+// SP: 0 = the encoder form (all 8 chunks, bias + residual + LayerNorm epilogue); > 0 = the decoder form: this workgroup walks SP
+// chunks of the hidden starting at chunk (blockIdx % S) * SP (the weight images carry a ninth, all-zero chunk so that 3 x 3 covers
+// 8), collects sum / sum of squares of its relu'd hidden rows on the way and leaves raw partial rows: the LayerNorm over the
+// 2048 hidden columns that sits between the decoder's two products is applied AFTERWARDS (ffn_dec_finish_kernel) as
+//   LN(h) W2^T = rstd (h (gamma (.) W2)^T - mean colsum(gamma (.) W2)) + beta W2^T
+template <int PF, int ABL = 0, int XD = 2, int OP = 0, int QK = 0, int SP = 0>
 __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
+  static_assert(SP == 0 || (OP == 0 && QK == 0), "the split form has no prologue / tail");
+  constexpr int NCH = SP ? SP : FF_NC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, l31 = lane & 31;
-  const int m0 = blockIdx.x * FF_BM;
-  const int rot = (int)(blockIdx.x >> 3) & p.rot_mask;     // chunk order rotated per workgroup (spreads the L2 lines in time)
+  const int tile = SP ? (int)blockIdx.x / p.S : (int)blockIdx.x;
+  const int c_begin = SP ? ((int)blockIdx.x - tile * p.S) * SP : 0;
+  const int m0 = tile * FF_BM;
+  const int rot = SP ? 0 : (int)(blockIdx.x >> 3) & p.rot_mask;     // chunk order rotated per workgroup (spreads the L2 lines in time)
   auto swz = [](int row) __attribute__((always_inline)) -> int { return (row >> 1) & 7; };
 
   // ---- weight stream: position gp = c * 64 + pos; pos 0..31 = W1 fragment of k-step pos, 32..63 = W2 fragment (t, j) = ((pos - 32) / 2, pos & 1)
@@ -156,11 +169,11 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
   const unsigned lane16 = (unsigned)lane * 16u;
   auto wload = [&](int gp) __attribute__((always_inline)) -> h8 {
     const int c = gp >> 6, pos = gp & 63;
-    const int cc = (c + rot) & (FF_NC - 1);
+    const int cc = SP ? c_begin + c : (c + rot) & (FF_NC - 1);
     const half_t* b = (pos < 32 ? w1u : w2u) + (size_t)cc * (8 * 32 * 512) + (pos & 31) * 512;
     return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(b) + lane16);
   };
-  constexpr int NPOS = FF_NC * 64;
+  constexpr int NPOS = NCH * 64;
   h8 ring[PF];
   if (!OP) {
 #pragma unroll
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     // b1 (2048 floats) as it is: read back per chunk with ds_read — a global load used right behind its issue would make
     // the compiler wait for vmcnt(0), i.e. drain the weight stream
     if (!OP) ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
+    if (SP && wave == 0) ff_glds16(reinterpret_cast<const char*>(p.b1) + 8192 + lane * 16, smem + FF_B_OFF + 8192);   // the zero chunk's bias
   }
   // fragment read offsets of the xn tile: row half i, 16-byte k-group (2 ss + lh) of a k-block
   unsigned xo[2][4];
@@ -351,9 +365,10 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     __builtin_amdgcn_s_barrier();
   }
 
+  float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};          // SP: sum / sum of squares of the hidden, rows i * 32 + l31, this lane's share
 #pragma unroll
-  for (int c = 0; c < FF_NC; ++c) {
-    const int cc = (c + rot) & (FF_NC - 1);
+  for (int c = 0; c < NCH; ++c) {
+    const int cc = SP ? c_begin + c : (c + rot) & (FF_NC - 1);
     // ---- U: hidden^T[32 x 64] of this wave, accumulators start as the bias
     f16x hacc[2];
 #pragma unroll
@@ -438,6 +453,17 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
             if (!(ABL & 4)) yacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[j], hf[t % XR][i], yacc[i][j], 0, 0, 0);
             else { yacc[i][j][0] += (float)w2[j][0]; yacc[i][j][1] += (float)hf[t % XR][i][0]; }
           }
+        if (SP && (t & 7) == wave) {
+          // every wave reads every cell of the hidden: wave w keeps the statistics of k-steps w and w + 8 (exact f16 products, fp32 sums)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const h2 pr = {hf[t % XR][i][2 * q], hf[t % XR][i][2 * q + 1]};
+              st_s[i] = __builtin_amdgcn_fdot2(pr, h2{(_Float16)1.f, (_Float16)1.f}, st_s[i], false);
+              st_q[i] = __builtin_amdgcn_fdot2(pr, pr, st_q[i], false);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -471,6 +497,33 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4a*>(rowp + (j * 32 + 8 * g) * 4) =
             make_float4(yacc[i][j][4 * g + 0], yacc[i][j][4 * g + 1], yacc[i][j][4 * g + 2], yacc[i][j][4 * g + 3]);
+  }
+  if constexpr (SP != 0) {
+    // the 16 (wave, lane half) shares of the row statistics -> the place of b1 (dead by now): [wave][lh][64 rows] float2
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float2*>(smem + FF_B_OFF + (((wave * 2 + lh_e) * 64 + i * 32 + l31_e) << 3)) = make_float2(st_s[i], st_q[i]);
+    __syncthreads();
+    const int split = c_begin / SP;
+    if (wave == 0 && m0 + lane_e < p.M) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float2 v = *reinterpret_cast<const float2*>(smem + FF_B_OFF + ((k * 64 + lane_e) << 3));
+        s += v.x; q += v.y;
+      }
+      *reinterpret_cast<float2*>(p.stats + ((size_t)split * p.Mp + m0 + lane_e) * 2) = make_float2(s, q);
+    }
+    float* prow = p.part + ((size_t)split * p.Mp + mb) * FF_D + 4 * lane_e;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (mb + r >= p.M) break;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<float4*>(prow + (size_t)r * FF_D + h * 256) =
+            *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * FF_XROW + (h * 256 + 4 * lane_e) * 4);
+    }
+    return;
   }
   __syncthreads();
 #pragma unroll
@@ -695,6 +748,197 @@ __global__ void ffn_retile_out_kernel(const half_t* __restrict__ Wo, int ldw, ha
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = src[e];
   *reinterpret_cast<h8*>(Wot + (size_t)pc * 8) = v;
+}
+
+
+// ---- decoder form (SP > 0) -----------------------------------------------------------------------------------------
+// The decoder's position-wise block is  t = LN_F(relu(xn W1^T + b1)) W2^T  (LayerNorm over the 2048 hidden columns between the
+// products, W2 without bias: the w_1 / norm / w_2 nodes of the decoder graph behind AliParaformerAsr/OfflineProjOfParaformer.cs:68).
+// With h = relu(..) (f16, as the unfused path stores it), mean / rstd its row statistics:
+//   t = rstd (h W2g^T - mean c) + d,   W2g = gamma (.) W2 (rounded to f16 ONCE, from the fp32 tensor),  c = colsum(W2g) (of the
+//   rounded values: the subtraction then cancels exactly what the product accumulated),  d = W2 beta
+// so the chunked kernel applies unchanged and the statistics are only needed at the end.  Image layout (f16 unless noted):
+//   W1t [9 chunks][8 waves][32 steps][512]  |  W2gt [9][8][32][512]  |  b1p fp32 [2304]  |  c fp32 [512]  |  d fp32 [512]
+// chunk 8 = zeros (3 splits x 3 chunks).
+constexpr size_t FFD_W = (size_t)9 * 16384 * 8;            // halves per weight image
+size_t ffn_dec_image_bytes() { return 2 * FFD_W * 2 + (2304 + 512 + 512) * 4; }
+
+__global__ void ffn_dec_retile_kernel(const half_t* __restrict__ W1, int ldw1, const float* __restrict__ W2, const float* __restrict__ gamma,
+                                      const float* __restrict__ b1, half_t* __restrict__ img) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NP = 9 * 16384;
+  if (idx < 2 * NP) {
+    const int which = idx >= NP, pc = which ? idx - NP : idx;
+    const int l = pc & 63, piece = (pc >> 6) & 31, w = (pc >> 11) & 7, c = pc >> 14;
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+    if (c < 8) {
+      if (which == 0) {
+        const half_t* src = W1 + (size_t)(c * 256 + w * 32 + (l & 31)) * ldw1 + 16 * piece + 8 * (l >> 5);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[e];
+      } else {
+        const int t = piece >> 1, j = piece & 1;
+        const int k0 = c * 256 + 16 * t + 4 * (l >> 5);
+        const float* src = W2 + (size_t)(w * 64 + j * 32 + (l & 31)) * FF_F + k0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (_Float16)(src[8 * (q >> 2) + (q & 3)] * gamma[k0 + 8 * (q >> 2) + (q & 3)]);
+      }
+    }
+    *reinterpret_cast<h8*>(img + (which ? FFD_W : 0) + (size_t)pc * 8) = v;
+  } else if (idx < 2 * NP + 2304) {
+    const int k = idx - 2 * NP;
+    reinterpret_cast<float*>(img + 2 * FFD_W)[k] = k < FF_F ? b1[k] : 0.f;
+  }
+}
+// c[n] = sum_k float(f16(gamma_k W2[n][k])), d[n] = sum_k beta_k W2[n][k]; one 256-thread workgroup per n, sums in double
+__global__ void ffn_dec_colsum_kernel(const float* __restrict__ W2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      half_t* __restrict__ img) {
+  __shared__ double sc[256], sd[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  double c = 0.0, d = 0.0;
+  for (int k = tid; k < FF_F; k += 256) {
+    const float w = W2[(size_t)n * FF_F + k];
+    c += (double)(float)(_Float16)(w * gamma[k]);
+    d += (double)w * (double)beta[k];
+  }
+  sc[tid] = c; sd[tid] = d;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { sc[tid] += sc[tid + o]; sd[tid] += sd[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float* f = reinterpret_cast<float*>(img + 2 * FFD_W) + 2304;
+    f[n] = (float)sc[0];
+    f[512 + n] = (float)sd[0];
+  }
+}
+
+void launch_ffn_dec_retile(hipStream_t s, const half_t* W1, int ldw1, const float* W2_f32, const float* gamma, const float* beta,
+                           const float* b1, half_t* img) {
+  constexpr int n = 2 * 9 * 16384 + 2304;
+  hipLaunchKernelGGL(ffn_dec_retile_kernel, dim3((n + 255) / 256), dim3(256), 0, s, W1, ldw1, W2_f32, gamma, b1, img);
+  PF_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ffn_dec_colsum_kernel, dim3(FF_D), dim3(256), 0, s, W2_f32, gamma, beta, img);
+  PF_HIP(hipGetLastError());
+}
+
+// Finishing pass of the decoder form: one wave per row.  t = rstd (sum_s part_s - mean c) + d with the row statistics of the
+// whole hidden (sum over the S shares; variance in double: E[h^2] - mean^2 of 2048 non-negative values), then the LayerNorm
+// behind the block (norm2 / after_norm): two-pass statistics on DPP wave sums -> fp32 and / or f16.
+__global__ __launch_bounds__(256) void ffn_dec_finish_kernel(const float* __restrict__ part, const float* __restrict__ stats, int S, int Mp, int M,
+                                                             const float* __restrict__ cd, float eps_f, const float* __restrict__ g,
+                                                             const float* __restrict__ b, float eps, float* __restrict__ t32, int ldt,
+                                                             float* __restrict__ n32, int ldn32, half_t* __restrict__ n16, int ldn16) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  float s = 0.f, q = 0.f;
+  for (int sp = 0; sp < S; ++sp) {
+    const float* r = part + ((size_t)sp * Mp + m) * FF_D + 4 * lane;
+    const float4 v0 = *reinterpret_cast<const float4*>(r), v1 = *reinterpret_cast<const float4*>(r + 256);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    const float2 st = *reinterpret_cast<const float2*>(stats + ((size_t)sp * Mp + m) * 2);
+    s += st.x; q += st.y;
+  }
+  const double mu_d = (double)s * (1.0 / FF_F);
+  double var = (double)q * (1.0 / FF_F) - mu_d * mu_d;
+  var = var > 0.0 ? var : 0.0;
+  const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps_f));
+  const float4 c0 = *reinterpret_cast<const float4*>(cd + 4 * lane), c1 = *reinterpret_cast<const float4*>(cd + 256 + 4 * lane);
+  const float4 d0 = *reinterpret_cast<const float4*>(cd + 512 + 4 * lane), d1 = *reinterpret_cast<const float4*>(cd + 768 + 4 * lane);
+  float4 y0 = make_float4(rs * (a0.x - mu * c0.x) + d0.x, rs * (a0.y - mu * c0.y) + d0.y, rs * (a0.z - mu * c0.z) + d0.z, rs * (a0.w - mu * c0.w) + d0.w);
+  float4 y1 = make_float4(rs * (a1.x - mu * c1.x) + d1.x, rs * (a1.y - mu * c1.y) + d1.y, rs * (a1.z - mu * c1.z) + d1.z, rs * (a1.w - mu * c1.w) + d1.w);
+  if (t32) {
+    *reinterpret_cast<float4*>(t32 + (size_t)m * ldt + 4 * lane) = y0;
+    *reinterpret_cast<float4*>(t32 + (size_t)m * ldt + 256 + 4 * lane) = y1;
+  }
+  if (!g) return;
+  const float mean = ff_wave_sum(((y0.x + y0.y) + (y0.z + y0.w)) + ((y1.x + y1.y) + (y1.z + y1.w))) * (1.0f / FF_D);
+  y0.x -= mean; y0.y -= mean; y0.z -= mean; y0.w -= mean; y1.x -= mean; y1.y -= mean; y1.z -= mean; y1.w -= mean;
+  const float k = 1.0f / sqrtf(ff_wave_sum(((y0.x * y0.x + y0.y * y0.y) + (y0.z * y0.z + y0.w * y0.w)) +
+                                            ((y1.x * y1.x + y1.y * y1.y) + (y1.z * y1.z + y1.w * y1.w))) * (1.0f / FF_D) + eps);
+  const float4 g0 = *reinterpret_cast<const float4*>(g + 4 * lane), g1 = *reinterpret_cast<const float4*>(g + 256 + 4 * lane);
+  const float4 b0 = *reinterpret_cast<const float4*>(b + 4 * lane), b1 = *reinterpret_cast<const float4*>(b + 256 + 4 * lane);
+  const float4 z0 = make_float4(y0.x * k * g0.x + b0.x, y0.y * k * g0.y + b0.y, y0.z * k * g0.z + b0.z, y0.w * k * g0.w + b0.w);
+  const float4 z1 = make_float4(y1.x * k * g1.x + b1.x, y1.y * k * g1.y + b1.y, y1.z * k * g1.z + b1.z, y1.w * k * g1.w + b1.w);
+  if (n32) {
+    *reinterpret_cast<float4*>(n32 + (size_t)m * ldn32 + 4 * lane) = z0;
+    *reinterpret_cast<float4*>(n32 + (size_t)m * ldn32 + 256 + 4 * lane) = z1;
+  }
+  if (n16) {
+    *reinterpret_cast<h4*>(n16 + (size_t)m * ldn16 + 4 * lane) = h4{(half_t)z0.x, (half_t)z0.y, (half_t)z0.z, (half_t)z0.w};
+    *reinterpret_cast<h4*>(n16 + (size_t)m * ldn16 + 256 + 4 * lane) = h4{(half_t)z1.x, (half_t)z1.y, (half_t)z1.z, (half_t)z1.w};
+  }
+}
+
+// how many workgroups share a tile's hidden range: the form with the shortest critical path on 256 CUs (a workgroup = one CU:
+// 140 KB of LDS).  Measured at M = 5344 (profiles/round5_dec_ffn.txt): 17 us of fixed work + 4.3 us per chunk per round, a
+// second round of a few workgroups costs about half a round; the finishing pass ~7 us + 1.2 us per share it sums.
+int ffn_dec_splits(int M) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("PF_DEC_FFN_SPLITS"); forced = e ? atoi(e) : 0; }
+  if (forced == 1 || forced == 2 || forced == 3 || forced == 4 || forced == 8) return forced;
+  const int tiles = cdiv(M, FF_BM);
+  const int cand[5] = {1, 2, 3, 4, 8}, nch[5] = {8, 4, 3, 2, 1};
+  int best = 1; double bt = 1e30;
+  for (int i = 0; i < 5; ++i) {
+    const int wgs = tiles * cand[i], rounds = cdiv(wgs, 256);
+    const double last = (wgs - (rounds - 1) * 256) / 256.0;            // how full the last round is
+    const double t = (17.0 + 4.3 * nch[i]) * (rounds - 1 + (rounds > 1 ? 0.5 + 0.5 * last : 1.0)) + 1.2 * cand[i];
+    if (t < bt - 0.5) { bt = t; best = cand[i]; }
+  }
+  return best;
+}
+size_t ffn_dec_workspace_bytes(int M, int splits) {        // partial rows + statistics of every split
+  const size_t Mp = (size_t)round_up(M, 64);
+  return (size_t)(splits > 0 ? splits : ffn_dec_splits(M)) * Mp * (FF_D + 2) * 4;
+}
+
+void launch_ffn_dec(hipStream_t s, const FfnDecArgs& a) {
+  PF_CHECK(a.M > 0 && a.A && a.img && a.ws, PF_ERR_INVALID_ARG, "ffn_dec: missing operand");
+  PF_CHECK(a.lda % 8 == 0 && (!a.t32 || a.ldt % 4 == 0) && (!a.n32 || a.ldn32 % 4 == 0) && (!a.n16 || a.ldn16 % 4 == 0), PF_ERR_INVALID_ARG,
+           "ffn_dec: leading dimensions must keep 16-byte (8-byte for f16) row alignment");
+  PF_CHECK(!a.ln_g == !a.ln_b && (a.ln_g || (!a.n16 && !a.n32)) && (a.t32 || a.n16 || a.n32), PF_ERR_INVALID_ARG, "ffn_dec: outputs");
+  const int S = a.splits > 0 ? a.splits : ffn_dec_splits(a.M);
+  PF_CHECK(S == 1 || S == 2 || S == 3 || S == 4 || S == 8, PF_ERR_INVALID_ARG, "ffn_dec: splits must be 1 | 2 | 3 | 4 | 8");
+  const int Mp = (int)round_up(a.M, 64);
+  FfnDev d{};
+  d.A = a.A; d.lda = a.lda; d.W1t = a.img; d.W2t = a.img + FFD_W; d.b1 = reinterpret_cast<const float*>(a.img + 2 * FFD_W);
+  d.M = a.M; d.S = S; d.Mp = Mp;
+  d.part = reinterpret_cast<float*>(a.ws); d.stats = d.part + (size_t)S * Mp * FF_D;
+  static std::mutex init_mu;
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!attr_set[dev & 63]) {
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
+      attr_set[dev & 63] = true;
+    }
+  }
+  const dim3 grid((unsigned)(cdiv(a.M, FF_BM) * S));
+  switch (S) {
+    case 1: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 8>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 8>), grid, dim3(512), FF_LDS + 1024, s, d); break;
+    case 2: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 4>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 4>), grid, dim3(512), FF_LDS + 1024, s, d); break;
+    case 3: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 3>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 3>), grid, dim3(512), FF_LDS + 1024, s, d); break;
+    case 4: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 2>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 2>), grid, dim3(512), FF_LDS + 1024, s, d); break;
+    default: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 1>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 1>), grid, dim3(512), FF_LDS + 1024, s, d); break;
+  }
+  PF_HIP(hipGetLastError());
+  hipLaunchKernelGGL(ffn_dec_finish_kernel, dim3((unsigned)cdiv(a.M, 4)), dim3(256), 0, s, d.part, d.stats, S, Mp, a.M,
+                     reinterpret_cast<const float*>(a.img + 2 * FFD_W) + 2304, a.eps_hidden, a.ln_g, a.ln_b, a.eps, a.t32, a.ldt, a.n32, a.ldn32,
+                     a.n16, a.ldn16);
+  PF_HIP(hipGetLastError());
 }
 
 size_t ffn_fused_weight_bytes() { return (size_t)2 * 131072 * 16; }      // W1t | W2t: 2 MiB each

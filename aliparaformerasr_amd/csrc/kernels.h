@@ -162,6 +162,27 @@ size_t ffn_fused_weight_bytes();
 void launch_ffn_retile(hipStream_t s, const half_t* W1, int ldw1, const half_t* W2, int ldw2, half_t* Wt);
 void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a);
 
+// The decoder's position-wise block  t = LN_F(relu(A W1^T + b1)) W2^T  [, n = LayerNorm(t; ln_g, ln_b)]  (k_ffn.hip, split form):
+// the same chunked kernel, the hidden range of a 64-row tile shared by 1 | 2 | 3 | 4 | 8 workgroups (ffn_dec_splits: the decoder
+// has few rows), LN_F applied afterwards from row statistics collected on the way.  D = 512, F = 2048 only.
+struct FfnDecArgs {
+  const half_t* A; int lda;                      // norm1(x) as f16 [M,512]
+  const half_t* img;                             // launch_ffn_dec_retile image of (W1, gamma_F (.) W2, b1, colsum, W2 beta_F)
+  void* ws;                                      // ffn_dec_workspace_bytes(M)
+  int M;
+  int splits;                                    // 0 = ffn_dec_splits(M); 1 | 2 | 3 | 4 | 8 forces the form (ws must then hold that many)
+  float eps_hidden;                              // epsilon of LN_F
+  float* t32; int ldt;                           // t, fp32 [M,512] or null
+  const float* ln_g; const float* ln_b; float eps;
+  float* n32; int ldn32; half_t* n16; int ldn16; // LayerNorm(t) or null
+};
+size_t ffn_dec_image_bytes();
+size_t ffn_dec_workspace_bytes(int M, int splits = 0);
+int ffn_dec_splits(int M);
+void launch_ffn_dec_retile(hipStream_t s, const half_t* W1, int ldw1, const float* W2_f32, const float* gamma, const float* beta,
+                           const float* b1, half_t* img);
+void launch_ffn_dec(hipStream_t s, const FfnDecArgs& a);
+
 // ---------------------------------------------------------------- fp32 parity mode (k_fp32.hip) ----
 void launch_gemm_f32(hipStream_t s, const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
                      float* out, int ldc, const float* resid, int ldr, bool relu, int scale_cols, float scale);

@@ -389,6 +389,23 @@ class Engine:
                                           _fp(be) if be is not None else None, M, _fp(xo), _fp(no) if no is not None else None))
         return xo, no
 
+    def op_dec_ffn_fused(self, x, w1, b1, ln_hidden, w2, ln=None, splits=0):
+        """The decoder's FFN block (LayerNorm over the 2048 hidden columns between the products, w2 without bias) in the split
+        form of the fused kernel (k_ffn.hip): returns (t, LayerNorm(t; ln) or None).  x = the block's normalised input;
+        ln_hidden = (gamma, beta) [2048]; splits: 0 = the pipeline's choice for the row count, or 1 | 2 | 3 | 4 | 8."""
+        x, w1, b1, w2 = map(_f32, (x, w1, b1, w2))
+        gf, bf = _f32(ln_hidden[0]), _f32(ln_hidden[1])
+        M, D = x.shape
+        assert D == 512 and w1.shape == (2048, 512) and w2.shape == (512, 2048) and gf.shape == (2048,) and bf.shape == (2048,)
+        g = _f32(ln[0]) if ln is not None else None
+        be = _f32(ln[1]) if ln is not None else None
+        t = np.zeros((M, D), np.float32)
+        n = np.zeros((M, D), np.float32) if ln is not None else None
+        N.check(self._lib.pf_op_dec_ffn_fused(self._h, _fp(x), _fp(w1), _fp(b1), _fp(gf), _fp(bf), _fp(w2),
+                                              _fp(g) if g is not None else None, _fp(be) if be is not None else None, M, int(splits),
+                                              _fp(t), _fp(n) if n is not None else None))
+        return t, n
+
     def op_attn_ffn_fused(self, ctx, wo, bo, v, fsmn_w, T, ln2, w1, b1, w2, b2, resid=None, ln=None, qkv=None):
         """Out-projection + FSMN + norm2 + the FFN block + the next LayerNorm as the ONE launch the pipeline runs
         (k_ffn.hip, OP = 1): returns (x_out, n16_out or None); with qkv = (wqkv [1536,512], bqkv) also the next layer's

@@ -180,6 +180,43 @@ def test_ffn_fused_kernel(eng, M):
         np.testing.assert_allclose(got_x, eng.op_ffn(x, w1, b1, w2, b2, resid), rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("M,splits", [(5344, 0), (5344, 1), (5344, 2), (5344, 4), (5344, 8), (21376, 0), (1300, 0), (777, 3), (64, 8), (5, 0)])
+def test_dec_ffn_fused_kernel(eng, M, splits):
+    """The decoder's FFN block — w_1 + ReLU, LayerNorm over the 2048 hidden columns, w_2 without bias — and the LayerNorm behind
+    it, as the split form of the fused FFN kernel + its finishing pass (k_ffn.hip): the hidden LayerNorm is
+    applied AFTER the second product from row statistics collected on the way.  Row counts: the benchmark's decoder (32 x 167),
+    batch 128, short and ragged ones; every split count.  Reference: fp64 products of the f16-rounded operands, the hidden
+    rounded to f16 where the kernel rounds it (after bias + ReLU), the exact LayerNorm on it, gamma (.) W2 rounded to f16."""
+    rng = np.random.default_rng(300 + M % 11 + splits)
+    D, F = 512, 2048
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    gf = (1 + 0.2 * rng.standard_normal(F)).astype(np.float32)
+    bf = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    rows = np.unique(np.concatenate([np.arange(min(M, 96)), rng.integers(0, M, 256), np.arange(max(0, M - 70), M)]))
+    xs = h16(x[rows]).astype(np.float64)
+    h = h16(np.maximum(xs @ h16(w1).T.astype(np.float64) + b1, 0).astype(np.float32)).astype(np.float64)
+    mu = h.mean(-1, keepdims=True)
+    hn = (h - mu) / np.sqrt(((h - mu) ** 2).mean(-1, keepdims=True) + 1e-12)
+    # the kernel multiplies the un-normalised hidden with f16(gamma (.) W2): the same sum, rounded at a different place
+    ref = (hn * gf) @ w2.T.astype(np.float64) + bf.astype(np.float64) @ w2.T.astype(np.float64)
+    ref16 = hn @ h16(w2 * gf[None, :]).T.astype(np.float64) + bf.astype(np.float64) @ w2.T.astype(np.float64)
+    m2 = ref16.mean(-1, keepdims=True)
+    ln = (ref16 - m2) / np.sqrt(((ref16 - m2) ** 2).mean(-1, keepdims=True) + 1e-12) * g + be
+    t, n = eng.op_dec_ffn_fused(x, w1, b1, (gf, bf), w2, ln=(g, be), splits=splits)
+    np.testing.assert_allclose(t[rows], ref16, rtol=2e-4, atol=2e-3)
+    assert np.abs(t[rows] - ref16).mean() < 1e-4
+    np.testing.assert_allclose(t[rows], ref, rtol=2e-3, atol=2e-2)              # against unrounded gamma (.) W2: f16 weight rounding only
+    np.testing.assert_allclose(n[rows], ln, rtol=1e-3, atol=1e-3)
+    t2, none = eng.op_dec_ffn_fused(x, w1, b1, (gf, bf), w2, splits=splits)
+    assert none is None
+    np.testing.assert_array_equal(t2, t)                                        # deterministic: fixed summation order of the shares
+
+
 @pytest.mark.parametrize("B,T", [(32, 500), (64, 170), (5, 83 + 40), (3, 9)])
 def test_attn_out_ffn_fused_kernel(eng, B, T):
     """Two thirds of an encoder layer in ONE launch (k_ffn.hip, OP = 1): out-projection + bias + residual + FSMN memory of
