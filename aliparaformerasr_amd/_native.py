@@ -118,7 +118,7 @@ SIGNATURES = {
     "pf_op_gemm_rc": (C.c_int, [_vp, _P(PfGemmRcDesc), _f, _f, _f, _f, _f]),
     "pf_op_ffn": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_ffn_fused": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int32, _f, _f]),
-    "pf_op_dec_ffn_fused": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, _f, _f]),
+    "pf_op_dec_ffn_fused": (C.c_int, [_vp, C.c_void_p, _f, _f, _f]),
     "pf_op_attn_ffn_fused": (C.c_int, [_vp, _vp, _f, _f]),
     "pf_op_fsmn_enc": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn_dec": (C.c_int, [_vp, _f, _f, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
@@ -214,6 +214,12 @@ class PfAttnFfnDesc(C.Structure):
                [(n, C.POINTER(C.c_float)) for n in ("ctx", "wo", "bo", "v", "fsmn_w", "ln2_gamma", "ln2_beta", "resid",
                                                     "w1", "b1", "w2", "b2", "ln_gamma", "ln_beta",
                                                     "wqkv", "bqkv", "q_out", "k_out", "v_out")]
+
+
+class PfDecFfnDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("M", C.c_int32), ("splits", C.c_int32), ("reserved", C.c_int32)] + \
+               [(n, C.POINTER(C.c_float)) for n in ("x", "w1", "b1", "gamma_f", "beta_f", "w2", "ln_gamma", "ln_beta",
+                                                    "ctx", "wo", "bo", "resid", "ln1_gamma", "ln1_beta")]
 
 
 class PfError(RuntimeError):

@@ -534,16 +534,21 @@ int pf_op_ffn_fused(pf_engine* h, const float* x, const float* w1, const float* 
   return PF_OK;
   PF_CATCH
 }
-int pf_op_dec_ffn_fused(pf_engine* h, const float* x, const float* w1, const float* b1, const float* gamma_f, const float* beta_f,
-                        const float* w2, const float* g, const float* be, int32_t M, int32_t splits, float* t_out, float* n_out) {
+int pf_op_dec_ffn_fused(pf_engine* h, const pf_dec_ffn_desc* d, float* t_out, float* n_out, float* x_out) {
   PF_TRY
   std::shared_ptr<Engine> eh_ = E(h);
   Engine* e = eh_.get();
-  NEED(x); NEED(w1); NEED(b1); NEED(gamma_f); NEED(beta_f); NEED(w2);
+  NEED(d);
+  PF_CHECK(d->struct_size == (int32_t)sizeof(pf_dec_ffn_desc), PF_ERR_INVALID_ARG, "pf_dec_ffn_desc.struct_size mismatch");
+  PF_CHECK(d->reserved == 0, PF_ERR_INVALID_ARG, "pf_dec_ffn_desc.reserved must be 0");
+  NEED(d->w1); NEED(d->b1); NEED(d->gamma_f); NEED(d->beta_f); NEED(d->w2);
+  if (d->ctx) { NEED(d->wo); NEED(d->bo); NEED(d->resid); NEED(d->ln1_gamma); NEED(d->ln1_beta); }
+  else { NEED(d->x); PF_CHECK(!x_out, PF_ERR_INVALID_ARG, "dec_ffn_fused: x_out needs the out-projection form (ctx)"); }
   PF_CHECK(t_out || n_out, PF_ERR_INVALID_ARG, "dec_ffn_fused: no output requested");
-  PF_CHECK((g != nullptr) == (be != nullptr) && (g || !n_out), PF_ERR_INVALID_ARG, "dec_ffn_fused: the LayerNorm output needs gamma and beta");
+  PF_CHECK((d->ln_gamma != nullptr) == (d->ln_beta != nullptr) && (d->ln_gamma || !n_out), PF_ERR_INVALID_ARG,
+           "dec_ffn_fused: the LayerNorm output needs gamma and beta");
   std::lock_guard<std::mutex> lk(e->mutex());
-  e->op_dec_ffn_fused(x, w1, b1, gamma_f, beta_f, w2, g, be, M, splits, t_out, n_out);
+  e->op_dec_ffn_fused(*d, t_out, n_out, x_out);
   return PF_OK;
   PF_CATCH
 }

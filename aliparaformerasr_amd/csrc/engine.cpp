@@ -67,6 +67,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_FFN_FUSED"); if (e && e[0]) ffn_fused_ = e[0] != '0'; }   // A/B: the whole FFN block in one launch (k_ffn.hip)
   { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
   { const char* e = getenv("PF_DEC_FFN"); if (e && e[0]) dec_ffn_fused_ = e[0] != '0'; }
+  { const char* e = getenv("PF_DEC_OUT_CHAIN"); if (e && e[0]) dec_out_chain_ = e[0] != '0'; }
   { const char* e = getenv("PF_ATTN_FFN"); if (e && e[0]) attn_ffn_ = e[0] != '0'; }
   { const char* e = getenv("PF_QKV_TAIL"); if (e && e[0]) qkv_tail_ = e[0] != '0'; }
 
@@ -495,6 +496,10 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       L.kv32.w32 = kvw.dev; L.kv32.bias = kvbias.dev; L.kv32.N = 2 * D; L.kv32.K = D;
       L.kv32.w = dec_kv_all_.w + (size_t)i * 2 * D * D; L.kv32.Kpad = D;
       L.ffn_img = make_dec_ffn_image(L.w1, L.ffn_norm, L.w2);
+      if (L.ffn_img && dec_out_chain_ && L.out.w && L.out.bias && L.out.Kpad == D) {
+        L.out_wt = (half_t*)dalloc(ffn_outproj_weight_bytes());
+        launch_ffn_retile_out(stream_, L.out.w, L.out.Kpad, L.out_wt);
+      }
       dec_.push_back(L);
     }
   }
@@ -1182,9 +1187,11 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   const size_t o_x = carve(Mdp * D * 4), o_xn = carve(Mdp * D * 2);
   const size_t o_h32 = carve(Mdp * F * 4), o_h16 = carve(Mdp * F * 2), o_t = carve(Mdp * D * 4), o_tn = carve(Mdp * D * 4);
   const size_t o_q = carve(Mdp * D * 2), o_ctx = carve(Mdp * D * 2), o_lg = carve((size_t)Mdp * round_up(V, 4) * 4), o_ids = carve((size_t)Md * 8);
+  const size_t o_x2 = carve(Mdp * D * 4);
   ensure(ws_dec_, off);
   char* base = (char*)ws_dec_.p;
   float* xd = (float*)(base + o_x); half_t* xdn16 = (half_t*)(base + o_xn);
+  float* xd_alt = (float*)(base + o_x2);               // the residual stream ping-pongs when the out-projection rides in front of the next FFN launch
   float* hd32 = (float*)(base + o_h32); half_t* hd16 = (half_t*)(base + o_h16);
   float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
   half_t* qd16 = (half_t*)(base + o_q); half_t* ctxd16 = (half_t*)(base + o_ctx);
@@ -1219,13 +1226,18 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   }
   const bool f_fsmn = (dec_fuse_ & 1) != 0, f_out = (dec_fuse_ & 2) != 0 && !dsmall, f_ffn2 = (dec_fuse_ & 4) != 0;
   bool have_n1 = false;                                // xdn16 already holds norm1(xd) of the coming block
+  // out-projection chain (k_ffn.hip, OP = 2): layer i's cross-attention out-projection + residual + the next norm1 run in
+  // front of the NEXT block's split FFN launch; `pend` = the layer whose context (ctxd16) still waits for its projection
+  bool chain = dec_out_chain_ && !dsmall && dec_final_img_ != nullptr;
+  for (int i = 0; i < nd && chain; ++i) chain = dec_[i].ffn_img && dec_[i].out_wt;
+  const DecLayer* pend = nullptr;
   // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or
   // post(t) in n32 / n16
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const half_t* img, const LNp& post, float* n32, half_t* n16) {
     if (img && !dsmall) {
       // norm1 | the whole block in the split form of the fused FFN kernel + its finishing pass (LayerNorm over the hidden
       // applied from row statistics, then `post`): 2 launches for FFN-up | LayerNorm(2048) | FFN-down | LayerNorm
-      if (!have_n1) {
+      if (!have_n1 && !pend) {
         prof_begin("layernorm", 0);
         launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, xdn16, D, nullptr, 0);
         prof_end("layernorm");
@@ -1235,9 +1247,14 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
       FfnDecArgs f{};
       f.A = xdn16; f.lda = D; f.img = img; f.ws = ws_decffn_.p; f.M = Md; f.eps_hidden = 1e-12f;
       f.ln_g = post.g; f.ln_b = post.b; f.eps = 1e-12f; f.n32 = n32; f.ldn32 = D; f.n16 = n16; f.ldn16 = D;
-      prof_begin("gemm_dec_ffn", 4.0 * Md * (double)D * F);
+      if (pend) {
+        f.A = nullptr; f.ctx = ctxd16; f.lda_c = D; f.Wot = pend->out_wt; f.bo = pend->out.bias;
+        f.resid = xd; f.ldr = D; f.out_x = xd_alt; f.ldx = D; f.ln1_g = n1.g; f.ln1_b = n1.b; f.eps1 = 1e-12f;
+      }
+      prof_begin("gemm_dec_ffn", 4.0 * Md * (double)D * F + (pend ? 2.0 * Md * (double)D * D : 0.0));
       launch_ffn_dec(stream_, f);
       prof_end("gemm_dec_ffn");
+      if (pend) { std::swap(xd, xd_alt); pend = nullptr; }
       return;
     }
     if (dsmall) {
@@ -1303,7 +1320,9 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
     prof_begin("attn_cross", 4.0 * B * (double)L * T * D);
     launch_attention(stream_, a);
     prof_end("attn_cross");
-    if (f_out) {
+    if (chain) {
+      pend = &Lr;
+    } else if (f_out) {
       const LNp& nxt = i + 1 < nd ? dec_[i + 1].norm1 : dec_final_norm1_;
       GemmRcArgs g{};
       g.A = ctxd16; g.lda = D; g.W = Lr.out.w; g.ldw = Lr.out.Kpad; g.bias = Lr.out.bias; g.M = Md; g.K = Lr.out.Kpad;
@@ -2499,14 +2518,15 @@ void Engine::op_ffn(const float* x, const float* w1, const float* b1, const floa
 
 // The encoder FFN block as enc_layer() launches it for long inputs: retile W1 / W2, then ONE launch of ffn_fused_kernel.
 // The decoder's FFN block in the split form of the fused kernel (k_ffn.hip), standalone: t = LN_F(relu(f16(x) W1^T + b1)) W2^T,
-// n = LayerNorm(t).  x is the block's already normalised input.
-void Engine::op_dec_ffn_fused(const float* x, const float* w1, const float* b1, const float* gf, const float* bf, const float* w2,
-                              const float* g, const float* be, int M, int splits, float* t_out, float* n_out) {
+// n = LayerNorm(t); x = the block's normalised input, or (ds.ctx) LayerNorm norm1 of x_out = resid + ctx Wo^T + bo computed by
+// the same launch.
+void Engine::op_dec_ffn_fused(const pf_dec_ffn_desc& ds, float* t_out, float* n_out, float* x_out) {
   PF_HIP(hipSetDevice(device_));
-  const int D = 512, F = 2048;
+  const int D = 512, F = 2048, M = ds.M, splits = ds.splits;
   PF_CHECK(M > 0, PF_ERR_INVALID_ARG, "dec_ffn_fused: M must be positive");
   PF_CHECK(splits == 0 || splits == 1 || splits == 2 || splits == 3 || splits == 4 || splits == 8, PF_ERR_INVALID_ARG,
            "dec_ffn_fused: splits must be 0 (automatic) | 1 | 2 | 3 | 4 | 8");
+  const bool op = ds.ctx != nullptr;
   const int64_t Mp = round_up(M, 256) + 128;
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
@@ -2515,6 +2535,8 @@ void Engine::op_dec_ffn_fused(const float* x, const float* w1, const float* b1, 
   const size_t oimg = carve(ffn_dec_image_bytes()), ows = carve(ffn_dec_workspace_bytes(M, splits));
   const size_t ob1 = carve((size_t)F * 4), ogf = carve((size_t)F * 4), obf = carve((size_t)F * 4), og = carve((size_t)D * 4), obe = carve((size_t)D * 4);
   const size_t ot = carve((size_t)M * D * 4), on = carve((size_t)M * D * 4);
+  const size_t owo = carve((size_t)D * D * 2), owot = carve(ffn_outproj_weight_bytes()), obo = carve((size_t)D * 4);
+  const size_t og1 = carve((size_t)D * 4), obe1 = carve((size_t)D * 4), oxr = carve((size_t)Mp * D * 4), oxo = carve((size_t)Mp * D * 4);
   ensure(ws_tmp_, off);
   char* base = (char*)ws_tmp_.p;
   PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));
@@ -2523,32 +2545,38 @@ void Engine::op_dec_ffn_fused(const float* x, const float* w1, const float* b1, 
     launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), ldo);
     PF_HIP(hipStreamSynchronize(stream_));
   };
-  up16(x, M, D, ox16, D); up16(w1, F, D, ow1, D);
-  PF_HIP(hipMemcpyAsync(base + ow2, w2, (size_t)D * F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ogf, gf, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + obf, bf, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
-  if (g) {
-    PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-    PF_HIP(hipMemcpyAsync(base + obe, be, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-  }
+  auto up = [&](const float* src, size_t n, size_t dst) { PF_HIP(hipMemcpyAsync(base + dst, src, n * 4, hipMemcpyHostToDevice, stream_)); };
+  up16(op ? ds.ctx : ds.x, M, D, ox16, D); up16(ds.w1, F, D, ow1, D);
+  up(ds.w2, (size_t)D * F, ow2); up(ds.b1, F, ob1); up(ds.gamma_f, F, ogf); up(ds.beta_f, F, obf);
+  if (ds.ln_gamma) { up(ds.ln_gamma, D, og); up(ds.ln_beta, D, obe); }
   launch_ffn_dec_retile(stream_, (const half_t*)(base + ow1), D, (const float*)(base + ow2), (const float*)(base + ogf),
                         (const float*)(base + obf), (const float*)(base + ob1), (half_t*)(base + oimg));
   FfnDecArgs f{};
   f.A = (const half_t*)(base + ox16); f.lda = D; f.img = (const half_t*)(base + oimg); f.ws = base + ows; f.M = M; f.splits = splits;
   f.eps_hidden = 1e-12f; f.eps = 1e-12f;
+  if (op) {
+    up16(ds.wo, D, D, owo, D);
+    launch_ffn_retile_out(stream_, (const half_t*)(base + owo), D, (half_t*)(base + owot));
+    up(ds.bo, D, obo); up(ds.ln1_gamma, D, og1); up(ds.ln1_beta, D, obe1);
+    PF_HIP(hipMemsetAsync(base + oxr, 0, (size_t)Mp * D * 4, stream_));
+    up(ds.resid, (size_t)M * D, oxr);
+    f.A = nullptr; f.ctx = (const half_t*)(base + ox16); f.lda_c = D; f.Wot = (const half_t*)(base + owot); f.bo = (const float*)(base + obo);
+    f.resid = (const float*)(base + oxr); f.ldr = D; f.out_x = (float*)(base + oxo); f.ldx = D;
+    f.ln1_g = (const float*)(base + og1); f.ln1_b = (const float*)(base + obe1); f.eps1 = 1e-12f;
+  }
   if (t_out) { f.t32 = (float*)(base + ot); f.ldt = D; }
-  if (g) { f.ln_g = (const float*)(base + og); f.ln_b = (const float*)(base + obe); }
+  if (ds.ln_gamma) { f.ln_g = (const float*)(base + og); f.ln_b = (const float*)(base + obe); }
   if (n_out) { f.n32 = (float*)(base + on); f.ldn32 = D; }
   const char* rep = getenv("PF_OP_REPEAT");                        // tools/: repeated launches, timed as class "gemm_op_warm"
   const int reps = rep ? std::max(1, atoi(rep)) : 1;
   for (int r = 0; r < reps; ++r) {
-    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F);
+    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F + (op ? 2.0 * M * (double)D * D : 0.0));
     launch_ffn_dec(stream_, f);
     prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
   }
   if (t_out) PF_HIP(hipMemcpyAsync(t_out, base + ot, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
   if (n_out) PF_HIP(hipMemcpyAsync(n_out, base + on, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  if (x_out && op) PF_HIP(hipMemcpyAsync(x_out, base + oxo, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
   PF_HIP(hipStreamSynchronize(stream_));
 }
 

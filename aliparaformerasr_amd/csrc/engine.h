@@ -66,6 +66,7 @@ struct EncLayer {
 struct DecLayer {
   LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr;   // kv32: fp32 pointers only
   half_t* ffn_img = nullptr;   // (W1, gamma_F (.) W2, b1, colsum, W2 beta_F) in the fragment order of the split FFN form (k_ffn.hip; null: not built)
+  half_t* out_wt = nullptr;    // the cross-attention out-projection weight in that kernel's fragment order: the NEXT block's launch runs it
 };
 
 struct DevBuf {       // grow-only device allocation
@@ -134,8 +135,7 @@ class Engine {
   // activations [M, K], {a_scale, a_zp}, the uint8 weights [N, K] and their per-channel scale / zero point
   void op_qlinear(const float* x, const float* W, const float* bias, int M, int N, int K, int relu, int x_is_f16, float* y,
                   uint8_t* xq_out, float* aparams_out, uint8_t* wq_out, float* wscale_out, int32_t* wzp_out);
-  void op_dec_ffn_fused(const float* x, const float* w1, const float* b1, const float* gf, const float* bf, const float* w2,
-                        const float* g, const float* be, int M, int splits, float* t_out, float* n_out);
+  void op_dec_ffn_fused(const pf_dec_ffn_desc& ds, float* t_out, float* n_out, float* x_out);
   void op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
                     const float* g, const float* be, int M, float* x_out, float* n16_out, const pf_attn_ffn_desc* op = nullptr);
   void op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
@@ -252,6 +252,7 @@ class Engine {
   bool qkv_tail_ = true;             // PF_QKV_TAIL: the next layer's Q | K | V projection behind the fused block, same launch
   bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
+  bool dec_out_chain_ = true;        // PF_DEC_OUT_CHAIN: a decoder layer's out-projection + the next norm1 in front of the next FFN launch
   bool dec_ffn_fused_ = true;        // PF_DEC_FFN: the decoder's FFN block (with its LayerNorm over the hidden) as the split form of the same kernel
   int ffn_fused_min_rows_ = 1200;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels tie or win (tools/mid_rows.py)
   bool no_small_fuse_ = false;

@@ -143,6 +143,9 @@ __device__ __forceinline__ void ff_fsmn(float4 (&x)[8], const h4 (&win)[18], con
 // XD: how many k-steps ahead of their MFMAs the LDS fragment reads are issued (ring of XD + 1 fragment pairs)
 // OP: 1 = the attention out-projection (+ bias + residual + FSMN memory + LayerNorm norm2) runs in front of the block on the
 // same 64 rows: its result is the block's LDS operand tile and never visits HBM as f16
+// OP: 2 (split form only) = the decoder's cross-attention out-projection of the PREVIOUS layer in front of the block:
+// x = resid + ctx Wo^T + bo (written by the tile's first share; out_x must not alias resid: the other shares read it),
+// operand = LayerNorm norm1(x); no FSMN, nothing returns into the accumulators (the decoder block has no residual)
 // SP: 0 = the encoder form (all 8 chunks, bias + residual + LayerNorm epilogue); > 0 = the decoder form: this workgroup walks SP
 // chunks of the hidden starting at chunk (blockIdx % S) * SP (the weight images carry a ninth, all-zero chunk so that 3 x 3 covers
 // 8), collects sum / sum of squares of its relu'd hidden rows on the way and leaves raw partial rows: the LayerNorm over the
@@ -150,7 +153,7 @@ __device__ __forceinline__ void ff_fsmn(float4 (&x)[8], const h4 (&win)[18], con
 //   LN(h) W2^T = rstd (h (gamma (.) W2)^T - mean colsum(gamma (.) W2)) + beta W2^T
 template <int PF, int ABL = 0, int XD = 2, int OP = 0, int QK = 0, int SP = 0>
 __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
-  static_assert(SP == 0 || (OP == 0 && QK == 0), "the split form has no prologue / tail");
+  static_assert((SP == 0 && OP != 2) || (SP != 0 && OP != 1 && QK == 0), "the split form: optional plain out-projection prologue (OP = 2), no tail");
   constexpr int NCH = SP ? SP : FF_NC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     // b1 (2048 floats) as it is: read back per chunk with ds_read — a global load used right behind its issue would make
     // the compiler wait for vmcnt(0), i.e. drain the weight stream
     if (!OP) ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
-    if (SP && wave == 0) ff_glds16(reinterpret_cast<const char*>(p.b1) + 8192 + lane * 16, smem + FF_B_OFF + 8192);   // the zero chunk's bias
+    if (SP && !OP && wave == 0) ff_glds16(reinterpret_cast<const char*>(p.b1) + 8192 + lane * 16, smem + FF_B_OFF + 8192);   // the zero chunk's bias
   }
   // fragment read offsets of the xn tile: row half i, 16-byte k-group (2 ss + lh) of a k-block
   unsigned xo[2][4];
@@ -260,17 +263,19 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         xv[h][r] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.resid && mb + r < p.M) xv[h][r] = *reinterpret_cast<const float4*>(p.resid + (size_t)(mb + r) * p.ldr + h * 256 + 4 * lane);
       }
-    h4 vwin[2][18];
-    const int t_first = mb % p.T;
-    const bool interior = t_first >= 5 && t_first + 7 + 5 < p.T && mb + 7 + 5 < p.M;
+    h4 vwin[2][OP == 1 ? 18 : 1];
+    const int t_first = OP == 1 ? mb % p.T : 0;
+    const bool interior = OP == 1 && t_first >= 5 && t_first + 7 + 5 < p.T && mb + 7 + 5 < p.M;
+    if constexpr (OP == 1) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int s = 0; s < 18; ++s) {
-        int mm = mb - 5 + s;
-        mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);
-        vwin[h][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + h * 256 + 4 * lane);
-      }
+        for (int s = 0; s < 18; ++s) {
+          int mm = mb - 5 + s;
+          mm = mm < 0 ? 0 : (mm >= p.M ? p.M - 1 : mm);
+          vwin[h][s] = *reinterpret_cast<const h4*>(p.fsmn_v + (size_t)mm * p.ldv + h * 256 + 4 * lane);
+        }
+    }
     ff_lds_barrier();                                              // every wave has finished reading the context tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -294,11 +299,20 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * FF_XROW + col * 4);
         xv[h][r].x += v.x + b4.x; xv[h][r].y += v.y + b4.y; xv[h][r].z += v.z + b4.z; xv[h][r].w += v.w + b4.w;
       }
-      if (interior) ff_fsmn<false>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
-      else ff_fsmn<true>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+      if constexpr (OP == 1) {
+        if (interior) ff_fsmn<false>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+        else ff_fsmn<true>(xv[h], vwin[h], p.fsmn_wT + col, mb, t_first, p.T, p.M);
+      } else {
+        if (c_begin == 0) {                                        // the tile's first share writes the residual stream
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[h][r];
+        }
+      }
     }
     // x_mid is the residual of the block's end: instead of a round trip through HBM it goes back into the ACCUMULATORS — the
     // second product then accumulates on top of it (rows -> LDS fp32 tile -> D^T fragments, the dump above in reverse)
+    if constexpr (OP == 1) {
     ff_lds_barrier();                                              // every wave has its rows of the fp32 tile in registers
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -316,6 +330,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
           const float4 t = *reinterpret_cast<const float4a*>(rowp + (j * 32 + 8 * g) * 4);
           yacc[i][j][4 * g + 0] = t.x; yacc[i][j][4 * g + 1] = t.y; yacc[i][j][4 * g + 2] = t.z; yacc[i][j][4 * g + 3] = t.w;
         }
+    }
     }
     // LayerNorm norm2 of the complete rows -> f16 -> the block's operand tile (swizzled k-block layout)
     float4 g4[2], be4[2];
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     // b1 -> LDS now (its place was inside the fp32 tile's footprint? no: behind it — but the DMA is cheapest here, off the
     // critical path), then the block's first weight fragments
     ff_glds16(reinterpret_cast<const char*>(p.b1) + wave * 1024 + lane * 16, smem + FF_B_OFF + wave * 1024);
+    if (SP && wave == 0) ff_glds16(reinterpret_cast<const char*>(p.b1) + 8192 + lane * 16, smem + FF_B_OFF + 8192);
 #pragma unroll
     for (int i = 0; i < PF; ++i) ring[i] = wload(i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -900,40 +916,89 @@ size_t ffn_dec_workspace_bytes(int M, int splits) {        // partial rows + sta
 }
 
 void launch_ffn_dec(hipStream_t s, const FfnDecArgs& a) {
-  PF_CHECK(a.M > 0 && a.A && a.img && a.ws, PF_ERR_INVALID_ARG, "ffn_dec: missing operand");
+  PF_CHECK(a.M > 0 && a.img && a.ws, PF_ERR_INVALID_ARG, "ffn_dec: missing operand");
   PF_CHECK(a.lda % 8 == 0 && (!a.t32 || a.ldt % 4 == 0) && (!a.n32 || a.ldn32 % 4 == 0) && (!a.n16 || a.ldn16 % 4 == 0), PF_ERR_INVALID_ARG,
            "ffn_dec: leading dimensions must keep 16-byte (8-byte for f16) row alignment");
   PF_CHECK(!a.ln_g == !a.ln_b && (a.ln_g || (!a.n16 && !a.n32)) && (a.t32 || a.n16 || a.n32), PF_ERR_INVALID_ARG, "ffn_dec: outputs");
   const int S = a.splits > 0 ? a.splits : ffn_dec_splits(a.M);
   PF_CHECK(S == 1 || S == 2 || S == 3 || S == 4 || S == 8, PF_ERR_INVALID_ARG, "ffn_dec: splits must be 1 | 2 | 3 | 4 | 8");
   const int Mp = (int)round_up(a.M, 64);
+  const bool op = a.ctx != nullptr;
+  PF_CHECK(op || a.A, PF_ERR_INVALID_ARG, "ffn_dec: missing operand");
+  PF_CHECK(!op || (a.Wot && a.bo && a.resid && a.out_x && a.out_x != a.resid && a.ln1_g && a.ln1_b && a.lda_c % 8 == 0 && a.ldr % 4 == 0 &&
+                   a.ldx % 4 == 0),
+           PF_ERR_INVALID_ARG, "ffn_dec: the out-projection form needs ctx, Wo, bias, the residual, a separate x output and norm1");
   FfnDev d{};
   d.A = a.A; d.lda = a.lda; d.W1t = a.img; d.W2t = a.img + FFD_W; d.b1 = reinterpret_cast<const float*>(a.img + 2 * FFD_W);
   d.M = a.M; d.S = S; d.Mp = Mp;
   d.part = reinterpret_cast<float*>(a.ws); d.stats = d.part + (size_t)S * Mp * FF_D;
+  d.ctx = a.ctx; d.lda_c = a.lda_c; d.Wot = a.Wot; d.bo = a.bo; d.resid = a.resid; d.ldr = a.ldr; d.out_x = a.out_x; d.ldx = a.ldx;
+  d.ln2_g = a.ln1_g; d.ln2_b = a.ln1_b; d.eps = a.eps1;
   static std::mutex init_mu;
   static bool attr_set[64] = {false};
   int dev = 0;
   PF_HIP(hipGetDevice(&dev));
+  constexpr int LDSB = FF_LDS + 1024;
   {
     std::lock_guard<std::mutex> lk(init_mu);
     if (!attr_set[dev & 63]) {
-      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
-      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
-      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
-      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
-      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + 1024));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 2, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 2, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 2, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      PF_HIP(hipFuncSetAttribute((const void*)ffn_fused_kernel<8, 0, 2, 2, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
       attr_set[dev & 63] = true;
     }
   }
   const dim3 grid((unsigned)(cdiv(a.M, FF_BM) * S));
-  switch (S) {
-    case 1: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 8>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 8>), grid, dim3(512), FF_LDS + 1024, s, d); break;
-    case 2: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 4>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 4>), grid, dim3(512), FF_LDS + 1024, s, d); break;
-    case 3: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 3>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 3>), grid, dim3(512), FF_LDS + 1024, s, d); break;
-    case 4: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 2>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 2>), grid, dim3(512), FF_LDS + 1024, s, d); break;
-    default: note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 1>"); hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 0, 0, 1>), grid, dim3(512), FF_LDS + 1024, s, d); break;
+#ifdef PF_FFN_ABLATIONS
+  if (const char* e = getenv("PF_DEC_ABL")) {              // tools/dec_ffn_abl.sh: garbage results, only the times matter (S = 3 forms)
+    const int abl = atoi(e);
+    auto go = [&](auto kern) {
+      PF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      hipLaunchKernelGGL(kern, grid, dim3(512), LDSB, s, d);
+    };
+    if (abl && S == 3) {
+      switch (abl) {
+        case 1: op ? go(ffn_fused_kernel<8, 1, 2, 2, 0, 3>) : go(ffn_fused_kernel<8, 1, 2, 0, 0, 3>); break;
+        case 3: op ? go(ffn_fused_kernel<8, 3, 2, 2, 0, 3>) : go(ffn_fused_kernel<8, 3, 2, 0, 0, 3>); break;
+        case 7: op ? go(ffn_fused_kernel<8, 7, 2, 2, 0, 3>) : go(ffn_fused_kernel<8, 7, 2, 0, 0, 3>); break;
+        case 15: op ? go(ffn_fused_kernel<8, 15, 2, 2, 0, 3>) : go(ffn_fused_kernel<8, 15, 2, 0, 0, 3>); break;
+        default: PF_CHECK(false, PF_ERR_INVALID_ARG, "PF_DEC_ABL: 1 | 3 | 7 | 15");
+      }
+      PF_HIP(hipGetLastError());
+      return;                                              // no finishing pass: the split kernel alone
+    }
   }
+#endif
+#define PF_DEC_GO(OPV, SPV)                                                                            \
+  do {                                                                                                 \
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, " #OPV ", 0, " #SPV ">");                              \
+    hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, OPV, 0, SPV>), grid, dim3(512), LDSB, s, d);         \
+  } while (0)
+  if (op) {
+    switch (S) {
+      case 1: PF_DEC_GO(2, 8); break;
+      case 2: PF_DEC_GO(2, 4); break;
+      case 3: PF_DEC_GO(2, 3); break;
+      case 4: PF_DEC_GO(2, 2); break;
+      default: PF_DEC_GO(2, 1); break;
+    }
+  } else {
+    switch (S) {
+      case 1: PF_DEC_GO(0, 8); break;
+      case 2: PF_DEC_GO(0, 4); break;
+      case 3: PF_DEC_GO(0, 3); break;
+      case 4: PF_DEC_GO(0, 2); break;
+      default: PF_DEC_GO(0, 1); break;
+    }
+  }
+#undef PF_DEC_GO
   PF_HIP(hipGetLastError());
   hipLaunchKernelGGL(ffn_dec_finish_kernel, dim3((unsigned)cdiv(a.M, 4)), dim3(256), 0, s, d.part, d.stats, S, Mp, a.M,
                      reinterpret_cast<const float*>(a.img + 2 * FFD_W) + 2304, a.eps_hidden, a.ln_g, a.ln_b, a.eps, a.t32, a.ldt, a.n32, a.ldn32,

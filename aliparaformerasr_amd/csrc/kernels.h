@@ -166,7 +166,12 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a);
 // the same chunked kernel, the hidden range of a 64-row tile shared by 1 | 2 | 3 | 4 | 8 workgroups (ffn_dec_splits: the decoder
 // has few rows), LN_F applied afterwards from row statistics collected on the way.  D = 512, F = 2048 only.
 struct FfnDecArgs {
-  const half_t* A; int lda;                      // norm1(x) as f16 [M,512]
+  const half_t* A; int lda;                      // norm1(x) as f16 [M,512] (ignored when ctx != null)
+  // ctx != null: the PREVIOUS layer's cross-attention out-projection in front of the block, same launch:
+  //   x = resid + ctx Wo^T + bo -> out_x (fp32, must NOT alias resid);  the block's operand = LayerNorm(x; ln1_g, ln1_b), kept in LDS
+  const half_t* ctx; int lda_c; const half_t* Wot; const float* bo;      // Wot: launch_ffn_retile_out image of Wo [512,512]
+  const float* resid; int ldr; float* out_x; int ldx;
+  const float* ln1_g; const float* ln1_b; float eps1;
   const half_t* img;                             // launch_ffn_dec_retile image of (W1, gamma_F (.) W2, b1, colsum, W2 beta_F)
   void* ws;                                      // ffn_dec_workspace_bytes(M)
   int M;

@@ -389,22 +389,34 @@ class Engine:
                                           _fp(be) if be is not None else None, M, _fp(xo), _fp(no) if no is not None else None))
         return xo, no
 
-    def op_dec_ffn_fused(self, x, w1, b1, ln_hidden, w2, ln=None, splits=0):
+    def op_dec_ffn_fused(self, x, w1, b1, ln_hidden, w2, ln=None, splits=0, out_proj=None):
         """The decoder's FFN block (LayerNorm over the 2048 hidden columns between the products, w2 without bias) in the split
         form of the fused kernel (k_ffn.hip): returns (t, LayerNorm(t; ln) or None).  x = the block's normalised input;
-        ln_hidden = (gamma, beta) [2048]; splits: 0 = the pipeline's choice for the row count, or 1 | 2 | 3 | 4 | 8."""
-        x, w1, b1, w2 = map(_f32, (x, w1, b1, w2))
-        gf, bf = _f32(ln_hidden[0]), _f32(ln_hidden[1])
-        M, D = x.shape
-        assert D == 512 and w1.shape == (2048, 512) and w2.shape == (512, 2048) and gf.shape == (2048,) and bf.shape == (2048,)
-        g = _f32(ln[0]) if ln is not None else None
-        be = _f32(ln[1]) if ln is not None else None
-        t = np.zeros((M, D), np.float32)
-        n = np.zeros((M, D), np.float32) if ln is not None else None
-        N.check(self._lib.pf_op_dec_ffn_fused(self._h, _fp(x), _fp(w1), _fp(b1), _fp(gf), _fp(bf), _fp(w2),
-                                              _fp(g) if g is not None else None, _fp(be) if be is not None else None, M, int(splits),
-                                              _fp(t), _fp(n) if n is not None else None))
-        return t, n
+        ln_hidden = (gamma, beta) [2048]; splits: 0 = the pipeline's choice for the row count, or 1 | 2 | 3 | 4 | 8.
+        out_proj = (ctx, wo, bo, resid, (g1, b1)): the previous layer's cross-attention out-projection in front of the block
+        in the same launch (x is ignored): returns (t, n, x_out) with x_out = resid + ctx wo^T + bo, the block's input =
+        LayerNorm(x_out; g1, b1)."""
+        arrs = dict(w1=_f32(w1), b1=_f32(b1), gamma_f=_f32(ln_hidden[0]), beta_f=_f32(ln_hidden[1]), w2=_f32(w2))
+        if out_proj is None:
+            arrs["x"] = _f32(x)
+            M = arrs["x"].shape[0]
+        else:
+            ctx, wo, bo, resid, ln1 = out_proj
+            arrs.update(ctx=_f32(ctx), wo=_f32(wo), bo=_f32(bo), resid=_f32(resid), ln1_gamma=_f32(ln1[0]), ln1_beta=_f32(ln1[1]))
+            M = arrs["ctx"].shape[0]
+        assert arrs["w1"].shape == (2048, 512) and arrs["w2"].shape == (512, 2048) and arrs["gamma_f"].shape == (2048,)
+        if ln is not None:
+            arrs["ln_gamma"], arrs["ln_beta"] = _f32(ln[0]), _f32(ln[1])
+        d = N.PfDecFfnDesc()
+        d.struct_size, d.M, d.splits = C.sizeof(N.PfDecFfnDesc), M, int(splits)
+        for k, a in arrs.items():
+            setattr(d, k, _fp(a))
+        t = np.zeros((M, 512), np.float32)
+        n = np.zeros((M, 512), np.float32) if ln is not None else None
+        xo = np.zeros((M, 512), np.float32) if out_proj is not None else None
+        N.check(self._lib.pf_op_dec_ffn_fused(self._h, C.byref(d), _fp(t), _fp(n) if n is not None else None,
+                                              _fp(xo) if xo is not None else None))
+        return (t, n, xo) if out_proj is not None else (t, n)
 
     def op_attn_ffn_fused(self, ctx, wo, bo, v, fsmn_w, T, ln2, w1, b1, w2, b2, resid=None, ln=None, qkv=None):
         """Out-projection + FSMN + norm2 + the FFN block + the next LayerNorm as the ONE launch the pipeline runs

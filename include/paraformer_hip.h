@@ -327,13 +327,24 @@ int pf_op_ffn(pf_engine* e, const float* x, const float* w1, const float* b1, co
 int pf_op_ffn_fused(pf_engine* e, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                     const float* resid, const float* ln_gamma, const float* ln_beta, int32_t M, float* x_out, float* n16_out);
 /* The decoder's position-wise block as the pipeline runs it since round 5 (k_ffn.hip, split form; d_model 512, hidden 2048):
-   t = LayerNorm_F(relu(x w1^T + b1); gamma_f, beta_f) w2^T  (the w_1 / norm / w_2 nodes of a decoder layer, w2 without bias;
-   x = the block's normalised input, rounded to f16 like every f16-mode operand), n = LayerNorm(t; ln_gamma, ln_beta).
-   splits: how many workgroups share a 64-row tile's hidden range, 0 = the pipeline's choice for M, or 1 | 2 | 3 | 4 | 8.
-   t_out / n_out [M,512] fp32, either may be NULL (n_out needs ln_gamma / ln_beta). */
-int pf_op_dec_ffn_fused(pf_engine* e, const float* x, const float* w1, const float* b1, const float* gamma_f, const float* beta_f,
-                        const float* w2, const float* ln_gamma, const float* ln_beta, int32_t M, int32_t splits, float* t_out,
-                        float* n_out);
+   t = LayerNorm_F(relu(x w1^T + b1); gamma_f, beta_f) w2^T  (the w_1 / norm / w_2 nodes of a decoder layer, w2 without bias),
+   n = LayerNorm(t; ln_gamma, ln_beta).  x [M,512] = the block's normalised input (rounded to f16 like every f16-mode operand) —
+   or, with ctx != NULL, the PREVIOUS layer's cross-attention out-projection runs in front of the block in the same launch:
+   x_out = resid + ctx wo^T + bo, the block's input = LayerNorm(x_out; ln1_gamma, ln1_beta) (x is then ignored).
+   splits: how many workgroups share a 64-row tile's hidden range, 0 = the pipeline's choice for M, or 1 | 2 | 3 | 4 | 8. */
+typedef struct pf_dec_ffn_desc {
+  int32_t struct_size;           /* sizeof(pf_dec_ffn_desc) */
+  int32_t M, splits, reserved;   /* reserved = 0 */
+  const float* x;                /* [M,512] or NULL with ctx */
+  const float* w1; const float* b1;            /* [2048,512], [2048] */
+  const float* gamma_f; const float* beta_f;   /* [2048] */
+  const float* w2;                             /* [512,2048] */
+  const float* ln_gamma; const float* ln_beta; /* [512] or NULL */
+  const float* ctx; const float* wo; const float* bo; const float* resid;   /* [M,512], [512,512], [512], [M,512] or all NULL */
+  const float* ln1_gamma; const float* ln1_beta;                           /* [512], with ctx */
+} pf_dec_ffn_desc;
+/* t_out / n_out / x_out [M,512] fp32, each may be NULL (n_out needs ln_gamma / ln_beta, x_out needs ctx). */
+int pf_op_dec_ffn_fused(pf_engine* e, const pf_dec_ffn_desc* d, float* t_out, float* n_out, float* x_out);
 /* The same launch with the attention out-projection in front of the block, as the pipeline runs two thirds of an encoder
    layer since round 5: x_mid = resid + ctx wo^T + bo + FSMN(v) (11 taps, utterances = runs of T rows);
    x_out = x_mid + W2 relu(W1 LayerNorm(x_mid; ln2) + b1) + b2; n16_out = f16 LayerNorm(x_out; ln_gamma, ln_beta).

@@ -217,6 +217,50 @@ def test_dec_ffn_fused_kernel(eng, M, splits):
     np.testing.assert_array_equal(t2, t)                                        # deterministic: fixed summation order of the shares
 
 
+@pytest.mark.parametrize("M,splits", [(5344, 0), (5344, 1), (5344, 2), (5344, 8), (1300, 0), (777, 3), (200, 4), (5, 0)])
+def test_dec_out_ffn_fused_kernel(eng, M, splits):
+    """The same launch with the previous decoder layer's cross-attention out-projection in front (k_ffn.hip, OP = 2):
+    x = resid + ctx Wo^T + bo (written by the tile's first share), LayerNorm norm1 of it stays in LDS as the block's operand.
+    Reference: fp64 products of the f16-rounded operands, the norm1 result and the hidden rounded to f16 where the kernel
+    rounds them."""
+    rng = np.random.default_rng(400 + M % 13 + splits)
+    D, F = 512, 2048
+    ctx = rng.standard_normal((M, D)).astype(np.float32)
+    wo = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    bo = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    resid = (2 * rng.standard_normal((M, D))).astype(np.float32)
+    g1 = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    be1 = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    w1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    gf = (1 + 0.2 * rng.standard_normal(F)).astype(np.float32)
+    bf = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    rows = np.unique(np.concatenate([np.arange(min(M, 96)), rng.integers(0, M, 256), np.arange(max(0, M - 70), M)]))
+    xr = h16(ctx[rows]).astype(np.float64) @ h16(wo).T.astype(np.float64) + bo + resid[rows]
+    m1 = xr.mean(-1, keepdims=True)
+    xn = h16(((xr - m1) / np.sqrt(((xr - m1) ** 2).mean(-1, keepdims=True) + 1e-12) * g1 + be1).astype(np.float32)).astype(np.float64)
+    h = h16(np.maximum(xn @ h16(w1).T.astype(np.float64) + b1, 0).astype(np.float32)).astype(np.float64)
+    mu = h.mean(-1, keepdims=True)
+    hn = (h - mu) / np.sqrt(((h - mu) ** 2).mean(-1, keepdims=True) + 1e-12)
+    ref = hn @ h16(w2 * gf[None, :]).T.astype(np.float64) + bf.astype(np.float64) @ w2.T.astype(np.float64)
+    m2 = ref.mean(-1, keepdims=True)
+    ln = (ref - m2) / np.sqrt(((ref - m2) ** 2).mean(-1, keepdims=True) + 1e-12) * g + be
+    t, n, xo = eng.op_dec_ffn_fused(None, w1, b1, (gf, bf), w2, ln=(g, be), splits=splits, out_proj=(ctx, wo, bo, resid, (g1, be1)))
+    np.testing.assert_allclose(xo[rows], xr, rtol=1e-5, atol=2e-5)
+    # norm1 values on an f16 rounding boundary may round the other way: each flips one operand of the first product by 2^-11
+    np.testing.assert_allclose(t[rows], ref, rtol=2e-3, atol=1e-2)
+    assert np.abs(t[rows] - ref).mean() < 3e-4
+    np.testing.assert_allclose(n[rows], ln, rtol=5e-3, atol=5e-3)
+    # the operand tile equals what the two-step path feeds the block: same result as the plain form on LayerNorm(x_out)
+    m1a = xo.astype(np.float64).mean(-1, keepdims=True)
+    xa = ((xo - m1a) / np.sqrt(((xo - m1a) ** 2).mean(-1, keepdims=True) + 1e-12) * g1 + be1).astype(np.float32)
+    t2, _ = eng.op_dec_ffn_fused(xa, w1, b1, (gf, bf), w2, splits=splits)
+    np.testing.assert_allclose(t, t2, rtol=2e-3, atol=1e-2)
+
+
 @pytest.mark.parametrize("B,T", [(32, 500), (64, 170), (5, 83 + 40), (3, 9)])
 def test_attn_out_ffn_fused_kernel(eng, B, T):
     """Two thirds of an encoder layer in ONE launch (k_ffn.hip, OP = 1): out-projection + bias + residual + FSMN memory of
