@@ -121,6 +121,8 @@ SIGNATURES = {
     "pf_op_dec_ffn_fused": (C.c_int, [_vp, C.c_void_p, _f, _f, _f]),
     "pf_op_attn_ffn_fused": (C.c_int, [_vp, _vp, _f, _f]),
     "pf_op_fsmn_enc": (C.c_int, [_vp, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_linear32": (C.c_int, [_vp, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
+    "pf_op_ffn32": (C.c_int, [_vp, _f, _f, _f, _f, _f, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_fsmn_dec": (C.c_int, [_vp, _f, _f, _i32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]),
     "pf_op_logsoftmax_argmax": (C.c_int, [_vp, _f, C.c_int64, C.c_int32, _f, _i64]),
     "pf_op_layernorm": (C.c_int, [_vp, _f, _f, _f, C.c_int64, C.c_int32, _f]),

@@ -578,6 +578,30 @@ int pf_op_fsmn_enc(pf_engine* h, const float* v, const float* w, int32_t B, int3
   return PF_OK;
   PF_CATCH
 }
+int pf_op_linear32(pf_engine* h, const float* x, const float* W, const float* bias, const float* resid, int32_t M, int32_t N,
+                   int32_t K, int32_t relu, float* y) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(x); NEED(W); NEED(y);
+  PF_CHECK(M > 0 && N > 0 && K > 0, PF_ERR_INVALID_ARG, "linear32: bad shape");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_linear32(x, W, bias, resid, M, N, K, relu != 0, y);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_op_ffn32(pf_engine* h, const float* x, const float* W1, const float* b1, const float* W2, const float* b2, int32_t M,
+                int32_t D, int32_t F, float* y) {
+  PF_TRY
+  std::shared_ptr<Engine> eh_ = E(h);
+  Engine* e = eh_.get();
+  NEED(x); NEED(W1); NEED(b1); NEED(W2); NEED(b2); NEED(y);
+  PF_CHECK(M > 0 && D > 0 && F > 0, PF_ERR_INVALID_ARG, "ffn32: bad shape");
+  std::lock_guard<std::mutex> lk(e->mutex());
+  e->op_ffn32(x, W1, b1, W2, b2, M, D, F, y);
+  return PF_OK;
+  PF_CATCH
+}
 int pf_op_fsmn_dec(pf_engine* h, const float* tn, const float* w, const int32_t* token_num, int32_t B, int32_t L,
                    int32_t D, int32_t k, float* x) {
   PF_TRY

@@ -54,6 +54,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   // 50.8 ms per 32 x 30 s) 2 of the 5344 ids of the benchmark batch leave the fp32 oracle's — scores are exponentiated, and a
   // 22-bit product is 4x an fp32 product's error; the Linears tolerate it (identity holds), the softmax does not
   { const char* e = getenv("PF_X3_ATTN"); if (e && e[0]) x3_attn_ = atoi(e); }
+  { const char* e = getenv("PF_X3_FUSE"); if (e && e[0] == '0') x3_fuse_ = false; }
   int8_mode_ = cfg.math_mode == 2;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
@@ -1749,10 +1750,34 @@ enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
 // attention of the fp32 graph: math_mode 1 on the fp32 matrix path; math_mode 3: PF_X3_ATTN = 0 the same, 1 = x3 operands
 // throughout, 2 = fp32 scores (what is exponentiated stays exact) + x3 operands for P V
 void Engine::attention32(const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs, const float* v, int64_t v_bs,
-                         int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk) {
+                         int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk, bool only_operand) {
+  // only_operand: o [B * Lq, H * 128] (dense rows) is nothing but the A operand of the gemm32 that follows — in math_mode 3 the
+  // fp32-MFMA kernel's epilogue writes it as that product's (hi | lo') pair (no fp32 context, no split pass)
+  const int Dm = H * 128, M = B * Lq;
+  if (only_operand && x3_mode_ && x3_fuse_ && x3_attn_ == 0 && o_rs == Dm && o_bs == (int64_t)Lq * Dm && Dm % 64 == 0 && M > gemm_small_max_rows()) {
+    const int64_t Mp = round_up(M, 256) + 128;
+    ensure(ws_x3a_, (size_t)Mp * 2 * Dm * 2);
+    half_t* a2 = (half_t*)ws_x3a_.p;
+    if (launch_attention_f32_pair(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, a2, (int64_t)Lq * 2 * Dm, 2 * Dm, Dm, B, H, Lq, Lk)) {
+      x3a_src_ = o; x3a_M_ = M; x3a_K_ = Dm; x3a_ld_ = Dm; x3a_buf_ = a2; x3a_pair_only_ = true;
+      return;
+    }
+  }
   if (x3_mode_ && x3_attn_ == 1) launch_attention_x3(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, false);
   else if (x3_mode_ && x3_attn_ == 2) launch_attention_x3(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, true);
   else launch_attention_f32(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk);
+}
+
+void Engine::layernorm32(const float* x, int M, int D, const LNp& ln, float* xn) {
+  if (x3_mode_ && x3_fuse_ && D == 512 && M > gemm_small_max_rows()) {
+    const int64_t Mp = round_up(M, 256) + 128;
+    ensure(ws_x3a_, (size_t)Mp * 2 * D * 2);
+    half_t* a2 = (half_t*)ws_x3a_.p;
+    launch_layernorm_pair(stream_, x, M, ln.g, ln.b, a2, 2 * D, D);
+    x3a_src_ = xn; x3a_M_ = M; x3a_K_ = D; x3a_ld_ = D; x3a_buf_ = a2; x3a_pair_only_ = true;
+    return;
+  }
+  launch_layernorm(stream_, x, M, D, ln.g, ln.b, nullptr, 0, xn, D);
 }
 
 void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
@@ -1761,6 +1786,7 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
   const bool pair_ok = x3 && M > gemm_small_max_rows();
   if (!x3) {
     PF_CHECK(!(flags & kX3InPair) || !x3_pair_live_, PF_ERR_UNSUPPORTED, "gemm32: operand pair without its consumer");
+    PF_CHECK(!(x3a_pair_only_ && x3a_src_ == A), PF_ERR_UNSUPPORTED, "gemm32: the operand exists only as an x3 pair, but this product does not take the x3 form");
     launch_gemm_f32(stream_, A, lda, W, ldw, bias, M, N, K, out, ldc, resid, ldr, relu, scale_cols, scale);
     if (resid2) {
       PF_CHECK(ldc == N && ldr == N, PF_ERR_UNSUPPORTED, "gemm32: a second addend needs contiguous rows");
@@ -1785,13 +1811,15 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
   if ((flags & kX3InPair) && x3_pair_live_) {
     PF_CHECK(x3_pair_M_ == M && x3_pair_K_ == K, PF_ERR_INVALID_ARG, "gemm32: operand pair of another shape");
     a2 = (half_t*)ws_x3h_.p;                                          // written by the producing product's epilogue
-    x3_pair_live_ = false; x3a_src_ = nullptr;
+    x3_pair_live_ = false; x3a_src_ = nullptr; x3a_pair_only_ = false;
   } else {
     ensure(ws_x3a_, (size_t)Mp * 2 * Kp * 2);
     a2 = (half_t*)ws_x3a_.p;
     // kX3SameInput: the caller states that A is the (unchanged) operand of its previous gemm32 call — Q, K and V share one
-    const bool same = (flags & kX3SameInput) && x3a_src_ == A && x3a_M_ == M && x3a_K_ == K && x3a_ld_ == lda && x3a_buf_ == a2;
-    if (!same) launch_split_x3(stream_, A, M, K, lda, a2, 2 * Kp, Kp, 0);   // rows = [hi_x | lo'_x]
+    // (or the producer wrote the pair itself: layernorm32 / attention32 — then there is no fp32 form to split)
+    const bool same = ((flags & kX3SameInput) || x3a_pair_only_) && x3a_src_ == A && x3a_M_ == M && x3a_K_ == K && x3a_ld_ == lda && x3a_buf_ == a2;
+    PF_CHECK(same || !(x3a_pair_only_ && x3a_src_ == A), PF_ERR_UNSUPPORTED, "gemm32: the operand pair in the arena is not the one this product names");
+    if (!same) { launch_split_x3(stream_, A, M, K, lda, a2, 2 * Kp, Kp, 0); x3a_pair_only_ = false; }   // rows = [hi_x | lo'_x]
     x3a_src_ = A; x3a_M_ = M; x3a_K_ = K; x3a_ld_ = lda; x3a_buf_ = a2;
   }
   const bool out_pair = (flags & kX3OutPair) && pair_ok && N % 64 == 0;
@@ -1799,6 +1827,27 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
   if (out_pair) {
     ensure(ws_x3h_, (size_t)Mp * 2 * Np64 * 2);
     PF_CHECK((void*)ws_x3h_.p != (void*)a2, PF_ERR_UNSUPPORTED, "gemm32: chained operand pairs");
+  }
+  static int x3_one = -1;                              // PF_X3_ONE=0: the two-launch form of round 5's first version (A/B)
+  if (x3_one < 0) { const char* e = getenv("PF_X3_ONE"); x3_one = (e && e[0] == '0') ? 0 : 1; }
+  if (x3_one && pair_ok) {
+    // ONE launch: the K loop walks the cross terms first ([hi_x | lo'_x] x [lo'_W | hi_W], depth 2 Kp), scales the accumulators
+    // by 2^-11, steps the cursors back (A to hi_x, W to hi_W) and adds hi_x hi_W^T (depth Kp) on top — small terms first, one
+    // fp32 accumulator, no [M, N] intermediate written and read back (FFN-up: 2 x 131 MB per layer), half the launches
+    GemmArgs c{};
+    c.A = a2; c.lda = 2 * Kp; c.W = wcat; c.ldw = 2 * Kp; c.bias = bias; c.M = M; c.N = N; c.K = 3 * Kp;
+    c.k_wrap = 2 * Kp / 64; c.a_wrap = 2 * Kp; c.w_wrap = Kp; c.wrap_scale = 1.0f / 2048.0f;
+    if (out_pair) {
+      c.out_f16 = (half_t*)ws_x3h_.p; c.ldc16 = 2 * Np64; c.f16_lo_off = Np64;
+      x3_pair_live_ = true; x3_pair_M_ = M; x3_pair_K_ = N;
+    } else {
+      c.out_f32 = out; c.ldc32 = ldc;
+    }
+    c.scale_cols = scale_cols ? (int)round_up(N, 64) : 0; c.scale = scale;
+    c.add2 = resid2; c.ld2 = ldr; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
+    c.out_padded = 1; c.small_ws = small_ws_;
+    launch_gemm(stream_, c);                                          // out = (x W^T + bias) [* scale] [+ resid2] [+ resid]; ReLU
+    return;
   }
   GemmArgs g{};
   g.A = a2; g.lda = 2 * Kp; g.W = wcat + Kp; g.ldw = 2 * Kp; g.bias = bias; g.M = M; g.N = N; g.K = Kp;
@@ -1828,7 +1877,7 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
     launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), f[F_T]);
     launch_layernorm(stream_, f[F_T], M, Fd, L.norm1.g, L.norm1.b, nullptr, 0, f[F_XN], Fd);
   } else {
-    launch_layernorm(stream_, f[F_X], M, D, L.norm1.g, L.norm1.b, nullptr, 0, f[F_XN], D);
+    layernorm32(f[F_X], M, D, L.norm1, f[F_XN]);
   }
   const float* Wq = L.qkv.w32;
   gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
@@ -1836,7 +1885,7 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
   gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
   launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
   attention32(f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
-                       (int64_t)T * D, D, B, mc_.heads, T, T);
+                       (int64_t)T * D, D, B, mc_.heads, T, T, true);
   if (first) {
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
   } else {
@@ -1844,7 +1893,7 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
     // product's epilogue as (lin + fsmn) + x up to one rounding of the association
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_X], D, false, 0, 1.f, 0, f[F_FS]);
   }
-  launch_layernorm(stream_, f[F_X], M, D, L.norm2.g, L.norm2.b, nullptr, 0, f[F_XN], D);
+  layernorm32(f[F_X], M, D, L.norm2, f[F_XN]);
   gemm32(f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f, kX3OutPair);
   gemm32(f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f, kX3InPair);
 }
@@ -1871,6 +1920,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
   plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
 
+  x3_pair_live_ = false; x3a_src_ = nullptr; x3a_pair_only_ = false;      // (a forward that threw may have left an operand pair announced)
   for (size_t i = 0; i < enc_.size(); ++i) enc_layer_fp32(enc_[i], i == 0, speech_dev, B, T, f);
   if (tp_.empty()) {
     launch_layernorm(stream_, f[F_X], M, D, enc_after_.g, enc_after_.b, nullptr, 0, H32_, D);
@@ -1941,7 +1991,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   }
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
-    launch_layernorm(stream_, xd, Md, D, n1.g, n1.b, nullptr, 0, xn, D);
+    layernorm32(xd, Md, D, n1, xn);
     gemm32(xn, D, w1.w32, D, w1.bias, Md, F, D, hd, F, nullptr, 0, true, 0, 1.f);
     launch_layernorm(stream_, hd, Md, F, fn.g, fn.b, nullptr, 0, hn, F);
     gemm32(hn, F, w2.w32, F, nullptr, Md, D, F, t32, D, nullptr, 0, false, 0, 1.f);
@@ -1951,11 +2001,11 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
     ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
     launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
     launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
-    launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
+    layernorm32(xd, Md, D, Lr.norm3, xn);
     gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, Md, D, D, qd, D, nullptr, 0, false, D, qscale);
     gemm32(H32_, D, Lr.kv32.w32, D, Lr.kv32.bias, M, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
     attention32(qd, (int64_t)L * D, D, kv, (int64_t)T * 2 * D, 2 * D, kv + D, (int64_t)T * 2 * D, 2 * D, cx,
-                         (int64_t)L * D, D, B, mc_.heads, L, T);
+                         (int64_t)L * D, D, B, mc_.heads, L, T, true);
     gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, Md, D, D, xd, D, xd, D, false, 0, 1.f);
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
@@ -2299,6 +2349,69 @@ void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, i
     PF_HIP(hipMemcpyAsync(C, base + oC, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
     PF_HIP(hipStreamSynchronize(stream_));
   }
+}
+
+void Engine::x3_forget(const float* W) {
+  auto it = x3w_.find(W);
+  if (it == x3w_.end()) return;
+  for (size_t i = 0; i < owned_.size(); ++i)
+    if (owned_[i] == (void*)it->second) { owned_.erase(owned_.begin() + i); break; }
+  hipFree(it->second);
+  x3w_.erase(it);
+}
+
+// A Linear / the FFN block of the fp32 graph exactly as enc_layer_fp32() launches them (gemm32: math_mode 1 on the fp32
+// matrix path, math_mode 3 as x3 products with the K-loop wrap and, in the block, the operand-pair epilogue).
+void Engine::op_linear32(const float* x, const float* W, const float* bias, const float* resid, int M, int N, int K, bool relu, float* y) {
+  PF_CHECK(fp32_mode_, PF_ERR_UNSUPPORTED, "linear32: the engine was not created with math_mode 1 or 3");
+  PF_HIP(hipSetDevice(device_));
+  const int ldc = (int)round_up(N, 4);
+  const int64_t Mp = round_up(M, 256) + 128, Np = round_up(N, 256);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t ox = carve((size_t)Mp * K * 4), oW = carve((size_t)Np * K * 4), ob = carve((size_t)Np * 4), orr = carve((size_t)Mp * ldc * 4),
+               oy = carve((size_t)Mp * ldc * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base, 0, off, stream_));
+  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
+  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
+  if (resid) PF_HIP(hipMemcpy2DAsync(base + orr, (size_t)ldc * 4, resid, (size_t)N * 4, (size_t)N * 4, M, hipMemcpyHostToDevice, stream_));
+  gemm32((const float*)(base + ox), K, (const float*)(base + oW), K, bias ? (const float*)(base + ob) : nullptr, M, N, K, (float*)(base + oy), ldc,
+         resid ? (const float*)(base + orr) : nullptr, ldc, relu, 0, 1.f);
+  PF_HIP(hipMemcpy2DAsync(y, (size_t)N * 4, base + oy, (size_t)ldc * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  x3_forget((const float*)(base + oW));
+  x3a_src_ = nullptr;
+}
+
+void Engine::op_ffn32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, int M, int D, int F, float* y) {
+  PF_CHECK(fp32_mode_, PF_ERR_UNSUPPORTED, "ffn32: the engine was not created with math_mode 1 or 3");
+  PF_CHECK(D % 4 == 0 && F % 4 == 0, PF_ERR_INVALID_ARG, "ffn32: D and F must be multiples of 4");
+  PF_HIP(hipSetDevice(device_));
+  const int64_t Mp = round_up(M, 256) + 128, Dp = round_up(D, 256), Fp = round_up(F, 256);
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
+  const size_t ox = carve((size_t)Mp * D * 4), o1 = carve((size_t)Fp * D * 4), ob1 = carve((size_t)Fp * 4), o2 = carve((size_t)Dp * F * 4),
+               ob2 = carve((size_t)Dp * 4), oh = carve((size_t)Mp * F * 4), oy = carve((size_t)Mp * D * 4);
+  ensure(ws_tmp_, off);
+  char* base = (char*)ws_tmp_.p;
+  PF_HIP(hipMemsetAsync(base, 0, off, stream_));
+  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + o1, W1, (size_t)F * D * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + o2, W2, (size_t)D * F * 4, hipMemcpyHostToDevice, stream_));
+  PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
+  const float* xd = (const float*)(base + ox);
+  gemm32(xd, D, (const float*)(base + o1), D, (const float*)(base + ob1), M, F, D, (float*)(base + oh), F, nullptr, 0, true, 0, 1.f, kX3OutPair);
+  gemm32((const float*)(base + oh), F, (const float*)(base + o2), F, (const float*)(base + ob2), M, D, F, (float*)(base + oy), D, xd, D, false, 0, 1.f,
+         kX3InPair);
+  PF_HIP(hipMemcpyAsync(y, base + oy, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
+  PF_HIP(hipStreamSynchronize(stream_));
+  x3_forget((const float*)(base + o1));
+  x3_forget((const float*)(base + o2));
+  x3a_src_ = nullptr;
 }
 
 // GEMM exactly as the pipeline launches it: kernel kind (fp32 / f16 row-major / f16 blocked result), tile height,

@@ -130,6 +130,8 @@ class Engine {
   void op_argmax(const float* x, int64_t rows, int V, int64_t* ids);
   void op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C);
   void op_gemm_ex(const pf_gemm_desc& d, const float* A, const float* W, float* C);
+  void op_linear32(const float* x, const float* W, const float* bias, const float* resid, int M, int N, int K, bool relu, float* y);
+  void op_ffn32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, int M, int D, int F, float* y);
   void op_gemm_rc(const pf_gemm_rc_desc& d, const float* A, const float* W, float* x_out, float* n16_out, float* n32_out);
   // DynamicQuantizeLinear(x) + MatMulInteger + rescale (+ bias) (+ ReLU) on the int8 MFMA; optional outputs: the uint8
   // activations [M, K], {a_scale, a_zp}, the uint8 weights [N, K] and their per-channel scale / zero point
@@ -267,8 +269,14 @@ class Engine {
   void check_async_errors();         // after a stream sync: raises what a kernel of the finished forward reported through a flag word
   int x3_attn_ = 0;                  // PF_X3_ATTN (math_mode 3): 0 = fp32-MFMA attention, 1 = x3 operands throughout, 2 = fp32 scores + x3 P V
   void attention32(const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs, const float* v, int64_t v_bs, int v_rs,
-                   float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk);
+                   float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk, bool only_operand = false);
+  // LayerNorm of the fp32 graph whose result is ONLY the A operand of gemm32 calls that follow (xn names it): in math_mode 3
+  // (D = 512, above the short-input threshold) it is written as that operand pair and xn is not touched
+  void layernorm32(const float* x, int M, int D, const LNp& ln, float* xn);
+  bool x3_fuse_ = true;              // PF_X3_FUSE=0: LayerNorm / attention write fp32 and gemm32 splits (A/B)
+  bool x3a_pair_only_ = false;       // x3a_src_ exists ONLY as the pair in ws_x3a_ (its fp32 form was never written)
   bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs
+  void x3_forget(const float* W);          // drops W's cached pair image (stand-alone ops: their weights live in a scratch arena)
   std::map<const float*, half_t*> x3w_;   // fp32 weight -> its [lo' | hi] f16 pair image (built on first use)
   DevBuf ws_x3a_, ws_x3t_, ws_x3h_;
   bool x3_pair_live_ = false; int x3_pair_M_ = 0, x3_pair_K_ = 0;   // ws_x3h_ holds the (hi | lo') pair the next gemm32 consumes

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const float* __restrict__
 constexpr int AF_KT = 32, AF_LDK = 132;
 __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restrict__ q, int64_t q_bs, int q_rs, const float* __restrict__ k,
                                                             int64_t k_bs, int k_rs, const float* __restrict__ v, int64_t v_bs, int v_rs,
-                                                            float* __restrict__ o, int64_t o_bs, int o_rs, int H, int Lq, int Lk) {
+                                                            float* __restrict__ o, int64_t o_bs, int o_rs, int H, int Lq, int Lk,
+                                                            half_t* __restrict__ opair = nullptr, int p_lo = 0) {
   __shared__ __attribute__((aligned(16))) float Ks[AF_KT * AF_LDK], Vs[AF_KT * AF_LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
@@ -188,6 +189,24 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
   }
   if (q0 + l31 >= Lq) return;
   const float inv = 1.0f / l_run;
+  if (opair) {
+    // math_mode 3: the context is only the A operand of the out-projection — it leaves as that product's (hi | lo') pair
+    // (o_bs / o_rs then index the pair matrix, p_lo = column offset of the lo' half)
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    half_t* pp = opair + (size_t)b * o_bs + (size_t)(q0 + l31) * o_rs + h * 128;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = oacc[d][4 * g + 0] * inv, v1 = oacc[d][4 * g + 1] * inv, v2 = oacc[d][4 * g + 2] * inv, v3 = oacc[d][4 * g + 3] * inv;
+        const h4 hv = h4{(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+        *reinterpret_cast<h4*>(pp + d * 32 + 8 * g + 4 * kh) = hv;
+        *reinterpret_cast<h4*>(pp + p_lo + d * 32 + 8 * g + 4 * kh) =
+            h4{(half_t)((v0 - (float)hv[0]) * 2048.f), (half_t)((v1 - (float)hv[1]) * 2048.f), (half_t)((v2 - (float)hv[2]) * 2048.f),
+               (half_t)((v3 - (float)hv[3]) * 2048.f)};
+      }
+    return;
+  }
   float* op = o + (size_t)b * o_bs + (size_t)(q0 + l31) * o_rs + h * 128;
 #pragma unroll
   for (int d = 0; d < 4; ++d)
@@ -195,6 +214,20 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(op + d * 32 + 8 * g + 4 * kh) =
           make_float4(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+}
+
+// The MFMA form with the context written as an x3 operand pair (hi at pair[b * p_bs + q * p_rs + h * 128 + d], lo' p_lo columns on).
+// Returns false when the MFMA form does not apply (alignment): the caller then keeps the fp32 result + split.
+bool launch_attention_f32_pair(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
+                               const float* v, int64_t v_bs, int v_rs, half_t* pair, int64_t p_bs, int p_rs, int p_lo, int B, int H, int Lq, int Lk) {
+  if (B * H == 0 || Lq == 0) return true;
+  const bool aligned = ((q_rs | k_rs | v_rs | p_rs | p_lo) % 4 == 0) && (q_bs % 4 == 0) && (k_bs % 4 == 0) && (v_bs % 4 == 0) && (p_bs % 4 == 0) &&
+                       ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0) && (((uintptr_t)pair & 7) == 0);
+  if (!aligned || Lk <= 0) return false;
+  hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3((unsigned)cdiv(Lq, 128), (unsigned)(B * H)), dim3(256), 0, s, q, q_bs, q_rs, k, k_bs, k_rs,
+                     v, v_bs, v_rs, (float*)nullptr, p_bs, p_rs, H, Lq, Lk, pair, p_lo);
+  PF_HIP(hipGetLastError());
+  return true;
 }
 
 void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,

@@ -69,6 +69,8 @@ struct GemmDev {
   int out_padded;
   int out_blocked, a_blocked;
   int f16_lo_off;            // > 0: out_f16 receives the result as an x3 pair: hi at column n, lo' = f16((v - hi) * 2^11) at n + f16_lo_off
+  int k_wrap, a_wrap, w_wrap;    // K-loop wrap (kernels.h): k-step index, cursor steps back in BYTES; 0 = none
+  float wrap_scale;
   // int8 variant (gemm_i8_pp3): A / W hold SIGNED bytes a' = a_q - 128, w' = w_q - 128 (K counted in bytes);
   // acc = sum a' w' is corrected to sum (a_q - a_zp)(w_q - w_zp[n]) with the row / column sums and dequantised
   const int32_t* q_rowsum;   // [M]  sum_k a'[m,k]
@@ -215,6 +217,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
     if (--is_left > 0) {
       is_a += p.a_blocked ? (BK / 8) * 512 : BK * 2; is_w += BK * 2;
       if (++is_kt == nk) { is_kt = 0; is_tile += G; set_issue_tile(); }
+      else if (is_kt == p.k_wrap) { is_a -= p.a_wrap; is_w -= p.w_wrap; }      // (k_wrap = 0 never matches: is_kt >= 1 here)
     }
   };
   auto issue_step = [&]() __attribute__((always_inline)) {
@@ -527,8 +530,14 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
           }
         }
         if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc32 + n) = v;
-        if (p.out_f16)
-          *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+        if (p.out_f16) {
+          const h4 hv = h4{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+          *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + n) = hv;
+          if (p.f16_lo_off > 0)        // math_mode 3: the next product's operand pair (as in the direct epilogue)
+            *reinterpret_cast<h4*>(p.out_f16 + (size_t)m * p.ldc16 + n + p.f16_lo_off) =
+                h4{(half_t)((v.x - (float)hv[0]) * 2048.f), (half_t)((v.y - (float)hv[1]) * 2048.f),
+                   (half_t)((v.z - (float)hv[2]) * 2048.f), (half_t)((v.w - (float)hv[3]) * 2048.f)};
+        }
         if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 chunks of loads in flight (VGPRs)
       }
     }
@@ -623,6 +632,19 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
     else { if (fast0 && ep_tile + G < total_tiles) fetch_bias(ep_tile + G); }
   };
 
+  // K-loop wrap: the partial sum so far (the x3 cross terms, carried 2^11 too large) is brought to the scale of the terms that follow
+  auto wrap_scale_acc = [&]() __attribute__((always_inline)) {
+    if constexpr (KIND == 2 && !I8) {
+      const float ws = p.wrap_scale;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] *= ws;
+    }
+  };
+
   // 16 MFMAs with the step's DMA pieces slotted between them; `mid` (counted wait + phase barrier)
   // runs after 12 MFMAs so the matrix pipe does not drain at the phase boundary
   auto burst = [&](int pass_idx, auto&& mid) __attribute__((always_inline)) {      // pass_idx < 0: no pass this step
@@ -686,6 +708,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < n_my; ++t) {
       for (int kt = 0; kt < nk; ++kt, ++k) {
+        if (KIND == 2 && !I8 && kt == p.k_wrap && kt) wrap_scale_acc();
         const int sA = pend > 0 ? 1 : 0;
         const int pidx = sA ? 4 * MI - pend : -1;
         pend -= sA;
@@ -714,6 +737,7 @@ __device__ __forceinline__ void gemm_pp3_impl(const GemmDev& p) {
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < n_my; ++t) {
       for (int kt = 0; kt < nk; ++kt, ++k) {
+        if (KIND == 2 && !I8 && kt == p.k_wrap && kt) wrap_scale_acc();
         const int sB = pend > 0 ? 1 : 0;
         const int pidx = sB ? 4 * MI - pend : -1;
         pend -= sB;
@@ -792,8 +816,12 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   d.out_padded = a.out_padded;
   d.out_blocked = a.out_blocked; d.a_blocked = a.a_blocked;
   d.f16_lo_off = a.f16_lo_off;
-  PF_CHECK(a.f16_lo_off == 0 || (a.out_f16 && a.add2 && !a.out_blocked && a.f16_lo_off % 4 == 0 && a.M > gemm_small_max_rows()),
-           PF_ERR_INVALID_ARG, "gemm: the x3 pair output is an option of the fp32-kind epilogue (add2 given, M above the short-input threshold)");
+  PF_CHECK(a.f16_lo_off == 0 || (a.out_f16 && !a.out_blocked && a.f16_lo_off % 4 == 0 && a.M > gemm_small_max_rows()),
+           PF_ERR_INVALID_ARG, "gemm: the x3 pair output is an option of the fp32-kind epilogue (M above the short-input threshold)");
+  d.k_wrap = a.k_wrap; d.a_wrap = a.a_wrap * 2; d.w_wrap = a.w_wrap * 2; d.wrap_scale = a.wrap_scale;
+  PF_CHECK(a.k_wrap == 0 || (a.k_wrap > 0 && a.k_wrap < a.K / 64 && a.a_wrap % 64 == 0 && a.w_wrap % 64 == 0 && a.a_wrap <= a.k_wrap * 64 &&
+                             a.w_wrap <= a.k_wrap * 64 && !a.a_blocked && !a.out_blocked && a.M > gemm_small_max_rows()),
+           PF_ERR_INVALID_ARG, "gemm: K-loop wrap needs 0 < k_wrap < K / 64, cursor steps of whole k-steps inside the range walked so far, row-major operands, M above the short-input threshold");
   PF_CHECK(!a.out_blocked || (a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && a.N % 64 == 0),
            PF_ERR_INVALID_ARG, "gemm: blocked output needs an f16-only padded result with N % 64 == 0");
   PF_CHECK(!a.a_blocked || a.K % 64 == 0, PF_ERR_INVALID_ARG, "gemm: blocked A operand needs K % 64 == 0");
@@ -866,7 +894,8 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   if (total == 0) return;
   int grid = cus[dev];
   if (grid > total) grid = total;
-  const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && ((a.ldc16 & 7) == 0 || a.out_blocked);
+  const bool f16_only = a.out_f16 && !a.out_f32 && !a.resid && !a.add2 && a.out_padded && ((a.ldc16 & 7) == 0 || a.out_blocked) &&
+                        a.f16_lo_off == 0 && a.k_wrap == 0;     // (pair output and the K-loop wrap live in the fp32-kind kernel)
   const int lds = gemm_lds_bytes(mi);
   note_gemm_kernel(f16_only && a.out_blocked ? (mi == 2 ? "gemm_f16_pp3<3, 2>" : "gemm_f16_pp3<3, 1>")
                    : f16_only ? (mi == 2 ? "gemm_f16_pp3<1, 2>" : "gemm_f16_pp3<1, 1>")

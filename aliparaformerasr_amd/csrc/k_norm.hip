@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <int R>
 __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int64_t rows,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           half_t* __restrict__ out16, int ld16, float* __restrict__ out32, int ld32) {
+                                                           half_t* __restrict__ out16, int ld16, float* __restrict__ out32, int ld32,
+                                                           int lo_off = 0) {
   constexpr int D = 512;
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -179,8 +180,17 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
     }
     if (out16) {
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-      reinterpret_cast<h4*>(out16 + row * (int64_t)ld16)[lane] = h4{(half_t)ya.x, (half_t)ya.y, (half_t)ya.z, (half_t)ya.w};
-      reinterpret_cast<h4*>(out16 + row * (int64_t)ld16)[lane + 64] = h4{(half_t)yb.x, (half_t)yb.y, (half_t)yb.z, (half_t)yb.w};
+      const h4 ha = h4{(half_t)ya.x, (half_t)ya.y, (half_t)ya.z, (half_t)ya.w}, hb = h4{(half_t)yb.x, (half_t)yb.y, (half_t)yb.z, (half_t)yb.w};
+      reinterpret_cast<h4*>(out16 + row * (int64_t)ld16)[lane] = ha;
+      reinterpret_cast<h4*>(out16 + row * (int64_t)ld16)[lane + 64] = hb;
+      if (lo_off > 0) {                     // math_mode 3: the normalised row leaves as the (hi, lo') operand pair of an x3 product
+        reinterpret_cast<h4*>(out16 + row * (int64_t)ld16 + lo_off)[lane] =
+            h4{(half_t)((ya.x - (float)ha[0]) * 2048.f), (half_t)((ya.y - (float)ha[1]) * 2048.f), (half_t)((ya.z - (float)ha[2]) * 2048.f),
+               (half_t)((ya.w - (float)ha[3]) * 2048.f)};
+        reinterpret_cast<h4*>(out16 + row * (int64_t)ld16 + lo_off)[lane + 64] =
+            h4{(half_t)((yb.x - (float)hb[0]) * 2048.f), (half_t)((yb.y - (float)hb[1]) * 2048.f), (half_t)((yb.z - (float)hb[2]) * 2048.f),
+               (half_t)((yb.w - (float)hb[3]) * 2048.f)};
+      }
     }
   }
 }
@@ -214,6 +224,16 @@ static void ln_dispatch(hipStream_t s, const float* x, int64_t rows, int D, cons
     default: throw Error(PF_ERR_INVALID_ARG, "layernorm: width too large");
   }
 #undef LN_CASE
+  PF_HIP(hipGetLastError());
+}
+
+// LayerNorm(512) whose result leaves ONLY as the operand pair of an x3 product (math_mode 3): hi = f16(y) at out[row, 0:512],
+// lo' = f16((y - hi) 2^11) at out[row, lo_off : lo_off + 512] — what launch_layernorm + launch_split_x3 produce, one pass
+void launch_layernorm_pair(hipStream_t s, const float* x, int64_t rows, const float* gamma, const float* beta, half_t* out, int ldo, int lo_off) {
+  PF_CHECK(ldo % 4 == 0 && lo_off % 4 == 0 && lo_off >= 512, PF_ERR_INVALID_ARG, "layernorm_pair: bad layout");
+  if (rows == 0) return;
+  hipLaunchKernelGGL(layernorm512_kernel<2>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, x, rows, gamma, beta, out, ldo, (float*)nullptr, 0,
+                     lo_off);
   PF_HIP(hipGetLastError());
 }
 

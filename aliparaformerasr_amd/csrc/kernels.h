@@ -30,8 +30,14 @@ struct GemmArgs {
   int a_blocked;
   float* small_ws;               // scratch of the short-input kernel (k_gemm_small.hip, gemm_small_ws_bytes() bytes, one per
                                  // stream); null = never dispatch to it
-  int f16_lo_off;                // > 0 (fp32-kind epilogue only: add2 given): out_f16 receives the result as the operand pair of an
+  int f16_lo_off;                // > 0 (selects the fp32-kind epilogue): out_f16 receives the result as the operand pair of an
                                  // "x3" product (math_mode 3): hi = f16(v) at column n, lo' = f16((v - hi) * 2^11) at n + f16_lo_off
+  // K-loop wrap (math_mode 3: the three partial products of an x3 Linear in ONE accumulation).  k_wrap > 0: after k_wrap
+  // k-steps (of 64 columns) the accumulators are multiplied by wrap_scale and the operand cursors step BACK by a_wrap / w_wrap
+  // columns, then the loop runs on to K / 64 steps in total:  A = [hi_x | lo'_x], W = [lo'_W | hi_W] (both 2 Kp wide),
+  // K = 3 Kp, k_wrap = 2 Kp / 64, a_wrap = 2 Kp, w_wrap = Kp, wrap_scale = 2^-11  gives
+  //   (hi_x lo'_W^T + lo'_x hi_W^T) 2^-11 + hi_x hi_W^T   — the small terms first, one fp32 accumulator, no intermediate in HBM.
+  int k_wrap, a_wrap, w_wrap; float wrap_scale;
   int force_mi;                  // 0 = choose by shape; 1 / 2 = 128- / 256-row tiles of gemm_f16_pp3, 4 = the short-input kernel, 5 = the persistent 256 x 256 kernel (blocked result)
                                  // (stand-alone op tests; 4 / 5 fail when that kernel does not apply)
 };
@@ -193,6 +199,8 @@ void launch_gemm_f32(hipStream_t s, const float* A, int lda, const float* W, int
                      float* out, int ldc, const float* resid, int ldr, bool relu, int scale_cols, float scale);
 void launch_attention_f32(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
                           const float* v, int64_t v_bs, int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk);
+bool launch_attention_f32_pair(hipStream_t s, const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs,
+                               const float* v, int64_t v_bs, int v_rs, half_t* pair, int64_t p_bs, int p_rs, int p_lo, int B, int H, int Lq, int Lk);
 // x [rows, K] fp32 -> out [rows, 2 Kp] f16 = hi | lo' (swap: lo' | hi), lo' = f16((x - hi) * 2^11); Kp % 4 == 0, pad columns zeroed
 void launch_split_x3(hipStream_t s, const float* x, int64_t rows, int K, int ldx, half_t* out, int ldo, int Kp, int swap);
 // the same attention with x3 operands (22-bit pairs on the f16 matrix cores): math_mode 3
@@ -225,6 +233,8 @@ void launch_pad_sentinel(hipStream_t s, const float* feats, const int64_t* feat_
 void launch_posenc_ln_tab(hipStream_t s, const float* speech, int B, int T, int F, float xscale, const float* pe,
                       const float* gamma, const float* beta, half_t* out, int ldo);
 // LayerNorm rows of width D (512 or 2048, or generic) : fp32 in -> f16 and/or fp32 out
+void launch_layernorm_pair(hipStream_t s, const float* x, int64_t rows, const float* gamma, const float* beta, half_t* out, int ldo,
+                           int lo_off);     // D = 512; result as the (hi | lo') operand pair of an x3 product only (k_norm.hip)
 void launch_layernorm(hipStream_t s, const float* x, int64_t rows, int D, const float* gamma,
                       const float* beta, half_t* out16, int ld16, float* out32, int ld32);
 

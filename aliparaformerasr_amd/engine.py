@@ -451,6 +451,27 @@ class Engine:
         N.check(self._lib.pf_op_fsmn_enc(self._h, _fp(v), _fp(w), B, T, D, w.shape[1], _fp(y)))
         return y
 
+    def op_linear32(self, x, W, bias=None, resid=None, relu=False) -> np.ndarray:
+        """A Linear of the fp32 graph as math_mode 1 / 3 runs it (pf_op_linear32)."""
+        x, W = _f32(x), _f32(W)
+        M, K = x.shape
+        Nn = W.shape[0]
+        b = _f32(bias) if bias is not None else None
+        r = _f32(resid) if resid is not None else None
+        y = np.zeros((M, Nn), np.float32)
+        N.check(self._lib.pf_op_linear32(self._h, _fp(x), _fp(W), _fp(b) if b is not None else None,
+                                         _fp(r) if r is not None else None, M, Nn, K, 1 if relu else 0, _fp(y)))
+        return y
+
+    def op_ffn32(self, x, W1, b1, W2, b2) -> np.ndarray:
+        """x + relu(x W1^T + b1) W2^T + b2 as math_mode 1 / 3 runs the FFN block (pf_op_ffn32)."""
+        x, W1, b1, W2, b2 = _f32(x), _f32(W1), _f32(b1), _f32(W2), _f32(b2)
+        M, D = x.shape
+        F = W1.shape[0]
+        y = np.zeros((M, D), np.float32)
+        N.check(self._lib.pf_op_ffn32(self._h, _fp(x), _fp(W1), _fp(b1), _fp(W2), _fp(b2), M, D, F, _fp(y)))
+        return y
+
     def op_fsmn_dec(self, tn, w, token_num, x) -> np.ndarray:
         tn, w, x = _f32(tn), _f32(w), _f32(x).copy()
         B, L, D = tn.shape

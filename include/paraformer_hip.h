@@ -361,6 +361,17 @@ typedef struct pf_attn_ffn_desc {
   const float* wqkv; const float* bqkv; float* q_out; float* k_out; float* v_out;
 } pf_attn_ffn_desc;
 int pf_op_attn_ffn_fused(pf_engine* e, const pf_attn_ffn_desc* d, float* x_out, float* n16_out);
+/* A Linear of the fp32 graph as the engine's math_mode runs it (engines created with math_mode 1 or 3 only):
+     y [M,N] = x [M,K] W[N,K]^T + bias [+ resid [M,N]] [ReLU]
+   math_mode 3 ("exact"): operands as (hi, lo') f16 pairs, the three partial products in ONE accumulation of the pipeline's
+   f16 MFMA kernel (K-loop wrap, csrc/kernels.h) — the stand-alone counterpart of Engine::gemm32.  bias / resid may be NULL. */
+int pf_op_linear32(pf_engine* e, const float* x, const float* W, const float* bias, const float* resid, int32_t M, int32_t N,
+                   int32_t K, int32_t relu, float* y);
+/* The FFN block of the fp32 graph as math_mode 1 / 3 runs it: y [M,D] = x + relu(x W1^T + b1) W2^T + b2, W1 [F,D], W2 [D,F].
+   In math_mode 3 above the short-input threshold the hidden never exists in fp32: the first product's epilogue writes it as
+   the (hi, lo') operand pair of the second (what the encoder layers do). */
+int pf_op_ffn32(pf_engine* e, const float* x, const float* W1, const float* b1, const float* W2, const float* b2, int32_t M,
+                int32_t D, int32_t F, float* y);
 /* Encoder FSMN kernel (f16 V slice of a [B*T, 3D] buffer in, fp32 out): y = dwconv_k(v) + v. */
 int pf_op_fsmn_enc(pf_engine* e, const float* v, const float* w, int32_t B, int32_t T, int32_t D, int32_t k, float* y);
 /* Decoder FSMN kernel: x += (dwconv_k(tn*m) + tn*m)*m, m = (l < token_num[b]); x in/out [B,L,D]. */

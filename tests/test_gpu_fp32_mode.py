@@ -181,3 +181,60 @@ def test_fp32_mode_seaco_bias_decoder(mode):
     r0 = eng.recognize(audio, want_logits=True, hotwords=np.zeros((0, 10), np.int32))
     assert np.abs(r0.logits - ref["asr_logits"]).max() < TOL
     eng.close()
+
+
+# ---- operator level: one Linear / one FFN block of the fp32 graph exactly as Engine::gemm32 launches them ----------------
+# Reference: float64 products of the fp32 inputs.  What the bars separate: an f16-operand product is off by ~2^-11 per
+# term (5e-4 at these magnitudes, measured 1.5e-3 max), a product of (hi, lo') pairs — 22 mantissa bits — by ~2^-22 per term
+# plus the fp32 accumulation (measured < 3e-6); fp32 operands (mode 1) the accumulation alone.
+def _tiny_engine(mode):
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=64)
+    return Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, seed=1)), cmvn=W.synth_cmvn(), device=0, math_mode=mode)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 512), (700, 512, 560), (1100, 2048, 512), (600, 8404, 512), (5344, 512, 2048), (300, 512, 512)])
+def test_linear32_operator_keeps_22_bits(mode, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    Wt = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    eng = _tiny_engine(mode)
+    tol = 1e-5 * max(1.0, K / 512.0) ** 0.5            # fp32 accumulation grows with sqrt(K): 1.02e-5 measured at K = 2048 on the fp32 matrix path
+    for relu, resid in ((False, None), (True, None), (False, r)):
+        y = eng.op_linear32(x, Wt, b, resid=resid, relu=relu)
+        ref = x.astype(np.float64) @ Wt.astype(np.float64).T + b
+        if resid is not None:
+            ref = ref + resid
+        if relu:
+            ref = np.maximum(ref, 0.0)
+        err = np.abs(y - ref).max()
+        assert err < tol, (relu, resid is not None, err)
+    # a second call with other weights at the same scratch address must not meet a cached operand image
+    y2 = eng.op_linear32(x, -Wt, b)
+    assert np.abs(y2 - (x.astype(np.float64) @ (-Wt).astype(np.float64).T + b)).max() < tol
+    eng.close()
+
+
+@pytest.mark.parametrize("M", [1100, 4000, 200])
+def test_ffn32_block_hidden_travels_as_an_operand_pair(mode, M):
+    """x + relu(x W1^T + b1) W2^T + b2 with the encoder's shapes: above the short-input threshold math_mode 3 never stores the
+    hidden in fp32 — the first product's epilogue writes the (hi, lo') pair the second consumes.  A hidden that lost its lo'
+    half (f16-rounded) shows up as ~5e-4 here."""
+    D, F = 512, 2048
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    W1 = (rng.standard_normal((F, D)) / np.sqrt(D)).astype(np.float32)
+    W2 = (rng.standard_normal((D, F)) / np.sqrt(F)).astype(np.float32)
+    b1 = rng.standard_normal(F).astype(np.float32)
+    b2 = rng.standard_normal(D).astype(np.float32)
+    eng = _tiny_engine(mode)
+    y = eng.op_ffn32(x, W1, b1, W2, b2)
+    x64 = x.astype(np.float64)
+    # the hidden is an fp32 tensor in the graph: round it where the graph does
+    h = np.maximum(x64 @ W1.astype(np.float64).T + b1, 0.0)
+    ref = x64 + h @ W2.astype(np.float64).T + b2
+    err = np.abs(y - ref).max()
+    assert err < 2e-5, err
+    eng.close()
