@@ -55,6 +55,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   // 22-bit product is 4x an fp32 product's error; the Linears tolerate it (identity holds), the softmax does not
   { const char* e = getenv("PF_X3_ATTN"); if (e && e[0]) x3_attn_ = atoi(e); }
   { const char* e = getenv("PF_X3_FUSE"); if (e && e[0] == '0') x3_fuse_ = false; }
+  { const char* e = getenv("PF_X3_ONE"); if (e && e[0] == '0') x3_one_ = false; }
   int8_mode_ = cfg.math_mode == 2;
   { const char* e = getenv("PF_NO_RC"); no_rc_ = e && e[0] == '1'; }
   { const char* e = getenv("PF_LSTM_STEPS"); lstm_steps_ = e && e[0] == '1'; }
@@ -1782,7 +1783,10 @@ void Engine::layernorm32(const float* x, int M, int D, const LNp& ln, float* xn)
 
 void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
                     const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
-  const bool x3 = x3_mode_ && M >= 64 && ldw == K && (scale_cols == 0 || scale_cols >= N) && (ldc % 4) == 0 && (!resid || ldr % 4 == 0);
+  // (a q-scale on the leading columns only — the fused Q | K | V product — is an option of the one-launch form's epilogue)
+  const bool part_scale = scale_cols > 0 && scale_cols < N;
+  const bool x3 = x3_mode_ && M >= 64 && ldw == K && (!part_scale || (x3_one_ && scale_cols % 64 == 0 && M > gemm_small_max_rows())) &&
+                  (ldc % 4) == 0 && (!resid || ldr % 4 == 0);
   const bool pair_ok = x3 && M > gemm_small_max_rows();
   if (!x3) {
     PF_CHECK(!(flags & kX3InPair) || !x3_pair_live_, PF_ERR_UNSUPPORTED, "gemm32: operand pair without its consumer");
@@ -1796,12 +1800,12 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
   }
   const int Kp = (int)round_up(K, 64);
   const int64_t Np = round_up(N, 256), Mp = round_up(M, 256) + 128;
-  auto it = x3w_.find(W);
+  auto it = x3w_.find(std::make_pair(W, N));
   if (it == x3w_.end()) {
     half_t* wc = (half_t*)dalloc((size_t)Np * 2 * Kp * 2);
     PF_HIP(hipMemsetAsync(wc, 0, (size_t)Np * 2 * Kp * 2, stream_));
     launch_split_x3(stream_, W, N, K, ldw, wc, 2 * Kp, Kp, 1);        // rows = [lo'_W | hi_W]
-    it = x3w_.emplace(W, wc).first;
+    it = x3w_.emplace(std::make_pair(W, N), wc).first;
   }
   const half_t* wcat = it->second;
   const int ldt = (int)round_up(N, 4);
@@ -1828,9 +1832,7 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
     ensure(ws_x3h_, (size_t)Mp * 2 * Np64 * 2);
     PF_CHECK((void*)ws_x3h_.p != (void*)a2, PF_ERR_UNSUPPORTED, "gemm32: chained operand pairs");
   }
-  static int x3_one = -1;                              // PF_X3_ONE=0: the two-launch form of round 5's first version (A/B)
-  if (x3_one < 0) { const char* e = getenv("PF_X3_ONE"); x3_one = (e && e[0] == '0') ? 0 : 1; }
-  if (x3_one && pair_ok) {
+  if (x3_one_ && pair_ok) {
     // ONE launch: the K loop walks the cross terms first ([hi_x | lo'_x] x [lo'_W | hi_W], depth 2 Kp), scales the accumulators
     // by 2^-11, steps the cursors back (A to hi_x, W to hi_W) and adds hi_x hi_W^T (depth Kp) on top — small terms first, one
     // fp32 accumulator, no [M, N] intermediate written and read back (FFN-up: 2 x 131 MB per layer), half the launches
@@ -1843,7 +1845,7 @@ void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const floa
     } else {
       c.out_f32 = out; c.ldc32 = ldc;
     }
-    c.scale_cols = scale_cols ? (int)round_up(N, 64) : 0; c.scale = scale;
+    c.scale_cols = part_scale ? scale_cols : (scale_cols ? (int)round_up(N, 64) : 0); c.scale = scale;
     c.add2 = resid2; c.ld2 = ldr; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
     c.out_padded = 1; c.small_ws = small_ws_;
     launch_gemm(stream_, c);                                          // out = (x W^T + bias) [* scale] [+ resid2] [+ resid]; ReLU
@@ -1880,12 +1882,24 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
     layernorm32(f[F_X], M, D, L.norm1, f[F_XN]);
   }
   const float* Wq = L.qkv.w32;
+  // math_mode 3 above the short-input threshold: Q | K | V as ONE x3 product of N = 3 D (the weight is stored [Q | K | V] rows;
+  // q-scale on the first D columns) into the three consecutive buffers read as one [M, 3 D] matrix
+  const bool qkv_one = x3_mode_ && x3_one_ && x3_fuse_ && M > gemm_small_max_rows() && mc_.kernel == 11 && D % 64 == 0 &&
+                       f[F_K] == f[F_Q] + (size_t)M * D && f[F_V] == f[F_K] + (size_t)M * D;
+  if (qkv_one) {
+    float* qkv = f[F_Q];
+    gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, 3 * D, din, qkv, 3 * D, nullptr, 0, false, D, qscale);
+    launch_fsmn_f32_ld(stream_, qkv + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, f[F_FS]);
+    attention32(qkv, (int64_t)T * 3 * D, 3 * D, qkv + D, (int64_t)T * 3 * D, 3 * D, qkv + 2 * D, (int64_t)T * 3 * D, 3 * D, f[F_CTX],
+                (int64_t)T * D, D, B, mc_.heads, T, T, true);
+  } else {
   gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
   gemm32(f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
   gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
   launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
   attention32(f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
                        (int64_t)T * D, D, B, mc_.heads, T, T, true);
+  }
   if (first) {
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
   } else {
@@ -2352,12 +2366,13 @@ void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, i
 }
 
 void Engine::x3_forget(const float* W) {
-  auto it = x3w_.find(W);
-  if (it == x3w_.end()) return;
-  for (size_t i = 0; i < owned_.size(); ++i)
-    if (owned_[i] == (void*)it->second) { owned_.erase(owned_.begin() + i); break; }
-  hipFree(it->second);
-  x3w_.erase(it);
+  for (auto it = x3w_.begin(); it != x3w_.end();) {
+    if (it->first.first != W) { ++it; continue; }
+    for (size_t i = 0; i < owned_.size(); ++i)
+      if (owned_[i] == (void*)it->second) { owned_.erase(owned_.begin() + i); break; }
+    hipFree(it->second);
+    it = x3w_.erase(it);
+  }
 }
 
 // A Linear / the FFN block of the fp32 graph exactly as enc_layer_fp32() launches them (gemm32: math_mode 1 on the fp32

@@ -273,11 +273,13 @@ class Engine {
   // LayerNorm of the fp32 graph whose result is ONLY the A operand of gemm32 calls that follow (xn names it): in math_mode 3
   // (D = 512, above the short-input threshold) it is written as that operand pair and xn is not touched
   void layernorm32(const float* x, int M, int D, const LNp& ln, float* xn);
+  bool x3_one_ = true;               // PF_X3_ONE=0: an x3 Linear as two launches with an [M, N] fp32 intermediate (round 5's first form; A/B)
   bool x3_fuse_ = true;              // PF_X3_FUSE=0: LayerNorm / attention write fp32 and gemm32 splits (A/B)
   bool x3a_pair_only_ = false;       // x3a_src_ exists ONLY as the pair in ws_x3a_ (its fp32 form was never written)
   bool x3_mode_ = false;             // math_mode 3: the fp32 graph with every large Linear as three f16 MFMA products of (hi, lo') operand pairs
   void x3_forget(const float* W);          // drops W's cached pair image (stand-alone ops: their weights live in a scratch arena)
-  std::map<const float*, half_t*> x3w_;   // fp32 weight -> its [lo' | hi] f16 pair image (built on first use)
+  std::map<std::pair<const float*, int>, half_t*> x3w_;   // (fp32 weight, rows N) -> its [lo' | hi] f16 pair image (built on first use; the fused
+                                                          // Q | K | V product and the three separate ones name the same first row)
   DevBuf ws_x3a_, ws_x3t_, ws_x3h_;
   bool x3_pair_live_ = false; int x3_pair_M_ = 0, x3_pair_K_ = 0;   // ws_x3h_ holds the (hi | lo') pair the next gemm32 consumes
   enum { kX3OutPair = 1, kX3InPair = 2, kX3SameInput = 4 };

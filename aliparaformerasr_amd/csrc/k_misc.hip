@@ -303,7 +303,7 @@ void launch_fsmn_dec_stream(hipStream_t s, const float* tn, const float* wT, con
 // (identity term first, taps 0 .. K-1) — the same roundings, a third of the time (that form re-reads every row K times
 // through L1 with one L2 round trip per tap: 38 us for 2 x 32 MB at the benchmark shape).
 template <int K>
-__global__ __launch_bounds__(256) void fsmn_f32_win_kernel(const float* __restrict__ v, const float* __restrict__ wT, int B, int T, int D,
+__global__ __launch_bounds__(256) void fsmn_f32_win_kernel(const float* __restrict__ v, int ldv, const float* __restrict__ wT, int B, int T, int D,
                                                            float* __restrict__ out) {
   const int cq = D >> 2;
   const int tb = (T + FS_ROWS - 1) / FS_ROWS;
@@ -314,13 +314,13 @@ __global__ __launch_bounds__(256) void fsmn_f32_win_kernel(const float* __restri
   const int t0 = (int)(r % tb) * FS_ROWS;
   const int b = (int)(r / tb);
   constexpr int left = (K - 1) / 2, NR = FS_ROWS + K - 1;
-  const float* vb = v + (int64_t)b * T * D + c4;
+  const float* vb = v + (int64_t)b * T * ldv + c4;
   float4 x[NR];
 #pragma unroll
   for (int s = 0; s < NR; ++s) {
     int tt = t0 - left + s;
     tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);               // clamped reads; rows outside [0, T) are skipped below
-    x[s] = *reinterpret_cast<const float4*>(vb + (int64_t)tt * D);
+    x[s] = *reinterpret_cast<const float4*>(vb + (int64_t)tt * ldv);
   }
   float4 w[K];
 #pragma unroll
@@ -341,16 +341,20 @@ __global__ __launch_bounds__(256) void fsmn_f32_win_kernel(const float* __restri
   }
 }
 
+// v rows with stride ldv (the V third of a fused [M, 3 D] Q | K | V result), no mask, k = 11, v and y distinct
+void launch_fsmn_f32_ld(hipStream_t s, const float* v, int ldv, const float* wT, int B, int T, int D, int k, float* y) {
+  PF_CHECK(k == 11 && ldv % 4 == 0 && D % 4 == 0, PF_ERR_UNSUPPORTED, "fsmn_f32_ld: kernel size 11, 16-byte rows");
+  const int64_t tot = (int64_t)B * ((T + FS_ROWS - 1) / FS_ROWS) * (D / 4);
+  if (tot == 0) return;
+  hipLaunchKernelGGL(fsmn_f32_win_kernel<11>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, v, ldv, wT, B, T, D, y);
+  PF_HIP(hipGetLastError());
+}
+
 void launch_fsmn_f32(hipStream_t s, const float* v, const float* wT, const float* mask, int B, int T, int D,
                      int k, float* y) {
   const int64_t total = (int64_t)B * T * (D / 4);
   if (total == 0) return;
-  if (!mask && k == 11 && v != y) {
-    const int64_t tot = (int64_t)B * ((T + FS_ROWS - 1) / FS_ROWS) * (D / 4);
-    hipLaunchKernelGGL(fsmn_f32_win_kernel<11>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, v, wT, B, T, D, y);
-    PF_HIP(hipGetLastError());
-    return;
-  }
+  if (!mask && k == 11 && v != y) { launch_fsmn_f32_ld(s, v, D, wT, B, T, D, k, y); return; }
   hipLaunchKernelGGL(fsmn_f32_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, wT, mask,
                      (const int32_t*)nullptr, B, T, D, k, 0, y);
   PF_HIP(hipGetLastError());

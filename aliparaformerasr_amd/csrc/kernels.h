@@ -272,6 +272,7 @@ bool launch_fsmn_dec_ln(hipStream_t s, const float* tn, const float* w, const in
 void launch_fsmn_dec_stream(hipStream_t s, const float* tn, const float* wT, const int32_t* len, const float* cache_in,
                             int B, int L, int D, int k, float* x, float* cache_out);
 // generic fp32 FSMN for the stand-alone op (mask [B,T] floats or null)
+void launch_fsmn_f32_ld(hipStream_t s, const float* v, int ldv, const float* wT, int B, int T, int D, int k, float* y);
 void launch_fsmn_f32(hipStream_t s, const float* v, const float* w, const float* mask, int B, int T, int D,
                      int k, float* y);
 // CIF: im2col of H (f16) for the k=3 conv: [B*T, 3*D]

@@ -14,7 +14,12 @@ The fbank itself lives in ManySpeech.SpeechFeatures 1.1.7 (kaldi-native-fbank),
 which is NOT in /root/reference; `kaldi_fbank` restates the published kaldi
 algorithm (feature-window.cc / mel-computations.cc / feature-fbank.cc) with
 the options the C# passes (dither, snip_edges, window_type, sample_rate,
-num_bins; everything else = knf defaults).  Parity unpinned for that function.
+num_bins; everything else = knf defaults).  Parity unpinned for that function:
+the reference holds no vector of its dependency.  What exists instead (round 5):
+agreement with a second, independently written restatement of the same published
+algorithm — `transformers.audio_utils.spectrogram` with the Kaldi options — to
+8e-5 on log-energies (tests/test_oracle_golden.py::
+test_fbank_oracle_agrees_with_an_independent_kaldi_restatement).
 """
 from __future__ import annotations
 

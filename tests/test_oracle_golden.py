@@ -120,6 +120,53 @@ def test_fbank_frame_counts_and_reference_values():
     assert abs(int(np.argmax(fb[50])) - int(np.argmin(np.abs(centres - mel(1000.0))))) <= 1
 
 
+@pytest.mark.parametrize("window", ["hamming", "povey"])
+def test_fbank_oracle_agrees_with_an_independent_kaldi_restatement(window):
+    """The fbank lives in ManySpeech.SpeechFeatures (kaldi-native-fbank), absent from the reference tree, and the reference holds
+    no vector for it.  What CAN be checked here: `transformers.audio_utils.spectrogram` with the Kaldi options (HuggingFace's
+    numpy restatement of Kaldi's fbank — DC removal, pre-emphasis with the first-sample rule, window, power spectrum, mel banks
+    triangular in mel space, log with the FLT_EPSILON floor; their own tests hold it against torchaudio.compliance.kaldi) was
+    written by other people from the same published algorithm.  Agreement pins the oracle's restatement to a second
+    independent one — not to the reference's binary dependency, which stays unpinned.  snip_edges = true only: their framing
+    without centring is Kaldi's; their centring (numpy reflect) is not Kaldi's mirror."""
+    au = pytest.importorskip("transformers.audio_utils")
+    mf = au.mel_filter_bank(num_frequency_bins=257, num_mel_filters=80, min_frequency=20, max_frequency=8000, sampling_rate=16000,
+                            norm=None, mel_scale="kaldi", triangularize_in_mel_space=True)
+    win = au.window_function(400, window, periodic=False)
+    np.testing.assert_allclose(fe.window_function(window), win, atol=1e-7)
+    rng = np.random.default_rng(7)
+    t = np.arange(16000 * 2) / 16000.0
+    signals = {
+        "noise": (rng.standard_normal(16000 * 3) * 0.1).astype(np.float32),
+        "sweep": (0.3 * np.sin(2 * np.pi * (100 + 1800 * t) * t)).astype(np.float32),
+        "loud_clipped": np.clip(rng.standard_normal(9000), -1, 1).astype(np.float32),
+        "quiet": (rng.standard_normal(5000) * 1e-4).astype(np.float32),
+        "silence": np.zeros(4000, np.float32),
+        "one_frame": (rng.standard_normal(400) * 0.05).astype(np.float32),
+    }
+    conf = fe.FrontendConf(dither=0.0, snip_edges=True, window=window)
+    for name, x in signals.items():
+        a = fe.kaldi_fbank(x, conf)
+        b = au.spectrogram((x * np.float32(32768.0)).astype(np.float64), win, frame_length=400, hop_length=160, fft_length=512, power=2.0,
+                           center=False, preemphasis=0.97, mel_filters=mf, log_mel="log", mel_floor=1.192092955078125e-07,
+                           remove_dc_offset=True).T
+        assert a.shape == (fe.num_frames(x.shape[0], True), 80) and b.shape[0] >= a.shape[0], (name, a.shape, b.shape)
+        # float32 (oracle, as kaldi computes) against float64 (theirs).  Log-energies of magnitude ~20 agree to 8e-5 wherever a
+        # bin holds signal; a bin at the leakage floor of a pure tone under the povey window (1e-9 of the frame's peak) holds
+        # float32 rounding noise in the oracle — as it does in kaldi — so the comparison is on energies relative to the frame's
+        # peak, and on logs for every bin above 1e-6 of it
+        b = b[: a.shape[0]]
+        if a.size == 0:
+            continue
+        ea, eb = np.exp(a.astype(np.float64)), np.exp(b.astype(np.float64))
+        peak = eb.max(axis=1, keepdims=True)
+        assert (np.abs(ea - eb) / peak).max() < 2e-5, (name, (np.abs(ea - eb) / peak).max())
+        loud = eb > 1e-6 * peak
+        assert loud.mean() > (0.05 if name == "sweep" else 0.5) or name == "silence", (name, loud.mean())     # a tone fills few bins
+        assert np.abs(a - b)[loud].max() < 5e-4, (name, np.abs(a - b)[loud].max())
+    assert np.all(fe.kaldi_fbank(signals["silence"], conf) == np.log(np.float32(1.1920929e-07)))
+
+
 def test_mel_banks_shape_and_partition():
     w = fe.mel_banks(80, 16000)
     assert w.shape == (80, 256)
