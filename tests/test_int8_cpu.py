@@ -60,3 +60,19 @@ def test_qlinear_is_matmulinteger_plus_rescale():
             ref[m, n] = np.float32(np.float32(acc) * np.float32(xs * ws[n])) + b[n]
     np.testing.assert_array_equal(y, ref)
     assert np.abs(y - (x @ w.T + b)).max() < 0.15
+
+
+def test_matmulinteger_onnx_vector_through_qlinear():
+    """The ONNX backend test of MatMulInteger (onnx/backend/test/case/node/matmulinteger.py): A uint8 [4, 3] with
+    a_zero_point 12, B uint8 [3, 2] with b_zero_point 0 -> Y int32.  Fed through the oracle's public Linear: float rows
+    x = A - 12 plus one row that pins the dynamic range to [-12, 243], so that DynamicQuantizeLinear returns scale 1, zero
+    point 12 and the codes A themselves; unit weight scales then make y the published integers."""
+    A = np.array([[11, 7, 3], [10, 6, 2], [9, 5, 1], [8, 4, 0]], np.int32)
+    B = np.array([[1, 4], [2, 5], [3, 6]], np.int32)
+    Y = np.array([[-38, -83], [-44, -98], [-50, -113], [-56, -128]], np.int32)
+    x = np.concatenate([A - 12, np.array([[243, -12, 0]], np.int32)]).astype(np.float32)
+    xq, xs, xz = q8.quantize_activation(x)
+    assert xs == 1.0 and xz == 12
+    np.testing.assert_array_equal(xq[:4], A)
+    y = q8.qlinear(x, B.T.copy(), np.ones(2, np.float32), np.zeros(2, np.int32))
+    np.testing.assert_array_equal(y[:4], Y.astype(np.float32))
