@@ -37,10 +37,25 @@ typedef float f16x __attribute__((ext_vector_type(16)));
 #ifndef ATT_ABL
 #define ATT_ABL 0
 #endif
+#ifndef ATT_DMA
+#define ATT_DMA 0
+#endif
 #define ATT_BQ 128
 #define ATT_BK 64
 #define ATT_TILE_BYTES (ATT_BK * ATT_DK * 2)      // 16 KiB
 #define ATT_STAGE_BYTES (2 * ATT_TILE_BYTES)      // one ring stage: K tile | V tile
+
+// -DATT_TIMING (tools/attn_timing.sh; timing experiments only): every wave sums, per phase of the tile loop, the shader-clock time
+// it spent there (s_memtime differences, scalar) and leaves the sums in att_tm[workgroup][wave][phase]:
+//   0 counted DMA wait | 1 workgroup barrier | 2 issue of the next tile's DMA | 3 S^T = K Q^T issue (+ K fragment reads) |
+//   4 tile-tail mask + online softmax (first use of S: includes the wait for the MFMAs) | 5 O^T += V^T P^T (V reads, issue) |
+//   6 prologue (Q fragments, first stages) | 7 whole kernel
+#ifdef ATT_TIMING
+__device__ unsigned long long att_tm[1024 * 8 * 8];
+#define ATT_TS(i) { const unsigned long long t_ = __builtin_readcyclecounter(); tm_acc[i] += (unsigned)(t_ - t_prev); t_prev = t_; }
+#else
+#define ATT_TS(i)
+#endif
 
 struct AttnDev {
   const half_t* q; const half_t* k; const half_t* v; half_t* o;
@@ -77,6 +92,11 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, lc = lane & 31;
+#ifdef ATT_TIMING
+  unsigned tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  unsigned long long t_prev = t_begin;
+#endif
   // XCD-aware block order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; remap
   // so that the query tiles of one (batch, head) — which stream the same K/V — are consecutive on ONE
   // XCD and share its L2 (otherwise every K/V byte is fetched from HBM once per query tile)
@@ -261,20 +281,35 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
       else __builtin_amdgcn_s_waitcnt(((2 * PIECES) & 15) | (7 << 4) | (15 << 8) | (((2 * PIECES) >> 4) << 14));
     }
     asm volatile("" ::: "memory");
+    ATT_TS(0)
     __builtin_amdgcn_s_barrier();                                   // ... everybody's; slot (kt - 1) % NS is free
     asm volatile("" ::: "memory");
-    if (!(ATT_ABL & 8)) {
-      if (kt + NS - 1 < nkt) {
-        constexpr int ns = slot == 0 ? NS - 1 : slot - 1;           // (kt + NS - 1) % NS
-        stage_k(ns, kt + NS - 1);
-        stage_v(ns, kt + NS - 1);
-      }
+    ATT_TS(1)
+    // The next tile's LDS-DMA pieces: 32 KB per workgroup and tile through the CU's 64 B / clk vector-memory path = 512 clocks
+    // during which a wave that issues all its pieces in one burst sits at issue (tools/attn_timing.sh: 9 % of the kernel).
+    // ATT_DMA = 1: K pieces here, V pieces behind the S^T MFMAs (they then drain beside the matrix pipe); 0 (default): one burst.
+    // Measured (tools/attn_ab.sh, profiles/round5_attn_timing.txt): 1.497 -> 1.516 ms per step of self-attention, i.e. no gain — an
+    // in-order wave that stalls on its V pieces behind the MFMAs starts its softmax that much later
+    // (256-query workgroups only: the 128-query form runs at its register limit, and holding the V offsets across the S^T MFMAs spills)
+    constexpr int ns_next = slot == 0 ? NS - 1 : slot - 1;          // (kt + NS - 1) % NS
+    constexpr bool dma_split = ATT_DMA != 0 && NW == 8;
+    const bool more = !(ATT_ABL & 8) && kt + NS - 1 < nkt;
+    if (more) {
+      stage_k(ns_next, kt + NS - 1);
+      if (!dma_split || wave_idle) stage_v(ns_next, kt + NS - 1);
     }
+    ATT_TS(2)
     // a wave whose 32 queries all lie beyond Lq (the last query tile of a short sequence: decoder L = 167 -> waves 2, 3 of
     // the second 128-query tile; SenseVoice T = 171 -> waves 6, 7 of a 256-query tile) only stages and keeps the barriers:
     // its matrix / VALU slots go to the other waves of its SIMD
     if (wave_idle) return;
     if (!(ATT_ABL & 4)) qk(sb, s_cur);
+    if (dma_split && more) {
+      __builtin_amdgcn_sched_barrier(0);
+      stage_v(ns_next, kt + NS - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ATT_TS(3)
 
     // first V^T fragments (d block 0)
     fp4 va[8], vb2[8];
@@ -336,6 +371,10 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
       }
     const f2 ps = (psum4[0] + psum4[1]) + (psum4[2] + psum4[3]);
     l_run += ps.x + ps.y;
+#ifdef ATT_TIMING
+    asm volatile("" :: "v"(pf[0][0]), "v"(pf[1][1]), "v"(l_run));    // the softmax results exist before the stamp
+#endif
+    ATT_TS(4)
 
     // ---- O^T += V^T P^T : fragments of d block db+1 are requested before the MFMAs of block db
 #if !(ATT_ABL & 2)
@@ -353,11 +392,13 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
 #else
     o_acc[0][0] += (float)pf[0][0][0] + (float)pf[1][1][7] + (float)pf[0][1][3] + (float)pf[1][0][5];
 #endif
+    ATT_TS(5)
   };
 
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st)
     if (st < nkt) { stage_k(st, st); stage_v(st, st); }
+  ATT_TS(6)
 
   for (int kt = 0; kt < nkt; kt += NS) {
     tile(kt, att_ic<0>{});
@@ -411,7 +452,21 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
     if (wg == 0)                                        // the consumer folds 256 pairs whatever this grid was
       for (int i = total + tid; i < 256; i += 64 * NW) { p.range[2 * i] = 0.f; p.range[2 * i + 1] = 0.f; }
   }
+#ifdef ATT_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tm_acc[7] = (unsigned)(__builtin_readcyclecounter() - t_begin);
+  if (lane == 0 && lid < 512)                          // 256-query workgroups in the first half, 128-query ones (cross-attention) in the second
+    for (int i = 0; i < 8; ++i) att_tm[(((NW == 8 ? 0 : 512) + lid) * 8 + (wave & 7)) * 8 + i] = tm_acc[i];
+#endif
 }
+
+#ifdef ATT_TIMING
+}  // namespace pf
+extern "C" int pf_debug_attn_timing(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::att_tm), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+namespace pf {
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Ping-pong form for 256-query workgroups (round 4).  Counters on attn_kernel<8> (profiles/round4_feed_gap.md): matrix

@@ -1087,28 +1087,28 @@ void launch_ffn_fused(hipStream_t s, const FfnFusedArgs& a) {
 #endif
   (void)abl;
   if (op && a.Wqt) {
-    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1, 1>");
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1, 1, 0>");
     hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 1, 1>), grid, dim3(512), FF_LDS, s, d);
     PF_HIP(hipGetLastError());
     return;
   }
   if (op) {
-    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1>");
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 1, 0, 0>");
     hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2, 1>), grid, dim3(512), FF_LDS, s, d);
     PF_HIP(hipGetLastError());
     return;
   }
   if (pf >= 12) {                                       // 12 fragments in flight, LDS reads one k-step ahead
-    note_gemm_kernel("ffn_fused_kernel<12, 0, 1>");
+    note_gemm_kernel("ffn_fused_kernel<12, 0, 1, 0, 0, 0>");
     hipLaunchKernelGGL((ffn_fused_kernel<12, 0, 1>), grid, dim3(512), FF_LDS, s, d);
   } else if (xd >= 3) {
-    note_gemm_kernel("ffn_fused_kernel<8, 0, 3>");
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 3, 0, 0, 0>");
     hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 3>), grid, dim3(512), FF_LDS, s, d);
   } else if (xd == 2) {
-    note_gemm_kernel("ffn_fused_kernel<8, 0, 2>");
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 2, 0, 0, 0>");
     hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 2>), grid, dim3(512), FF_LDS, s, d);
   } else {
-    note_gemm_kernel("ffn_fused_kernel<8, 0, 1>");
+    note_gemm_kernel("ffn_fused_kernel<8, 0, 1, 0, 0, 0>");
     hipLaunchKernelGGL((ffn_fused_kernel<8, 0, 1>), grid, dim3(512), FF_LDS, s, d);
   }
   PF_HIP(hipGetLastError());

@@ -778,8 +778,8 @@ def main():
             # (+ 6 M D^2 FLOPs, Q | K | V out instead of the f16 LayerNorm result); the figures below are per AVERAGE launch
             tail_share = (n_dom - args_steps_timed) / float(n_dom) if n_dom else 0.0
             dom_rows = int(round(fpl_dom / (4.0 * Nn * Kk + 2.0 * 512 * 512 + tail_share * 6.0 * 512 * 512)))
-            if "1, 1>" not in dom_kernel and tail_share > 0.5:
-                dom_kernel = dom_kernel.replace("1>", "1, 1>") + " [%d of %d launches per step; the last layer's runs without the Q|K|V tail]" % (
+            if "2, 1, 1, 0>" not in dom_kernel and tail_share > 0.5:          # (template arguments: PF, ABL, XD, OP, QK, SP — as rocprofv3 prints them)
+                dom_kernel = dom_kernel.replace("2, 1, 0, 0>", "2, 1, 1, 0>") + " [%d of %d launches per step; the last layer's runs without the Q|K|V tail]" % (
                     round(tail_share * n_dom / max(args_steps_timed, 1)), n_dom // max(args_steps_timed, 1))
         else:
             dom_rows = int(round(fpl_dom / ((4.0 if dominant == "gemm_ffn" else 2.0) * Nn * Kk)))
