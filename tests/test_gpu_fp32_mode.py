@@ -90,6 +90,45 @@ def test_fp32_mode_full_depth_is_closer_than_f16_mode(mode):
     assert agree > 0.99
 
 
+def test_fp32_mode_above_the_short_input_threshold(mode, sv_embed):
+    """Row counts above the short-input threshold (M > 512 for encoder AND decoder): where math_mode 3 takes its one-launch
+    products (K-loop wrap), the fused Q | K | V product, LayerNorm / attention writing operand pairs and the pair epilogue of the
+    FFN hidden — the forms the benchmark runs, on models small enough for the oracle to follow here.  Same bars as the small
+    models."""
+    from aliparaformerasr_amd.engine import Engine
+    cmvn = W.synth_cmvn()
+    cfg = W.paraformer_large_config(enc_layers=3, dec_layers=2, vocab=515)
+    w = W.synth_weights(cfg, seed=35)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=mode)
+    audio = [W.synth_audio(n, 15 + u) for u, n in enumerate((480000, 470000, 400000, 480000, 333000, 480000))]
+    speech = _speech(audio, cmvn)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32", fast=True).paraformer(speech)
+    res = eng.forward_feats(speech, want_logits=True)
+    assert speech.shape[0] * speech.shape[1] > 2048 and res.token_ids.shape[0] * res.token_ids.shape[1] > 512
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    err = np.abs(res.logits - ref["logits"]).max()
+    assert err < 5e-4, err                           # (fast=True: torch kernels, a second summation order)
+    _ids_match(res, ref["logits"])
+    eng.close()
+    # SenseVoice: prompt rows in front, two encoder stacks, CTC head over every frame
+    cfg = W.sensevoice_small_config(enc_layers=3, tp_layers=2, vocab=403)
+    w = W.synth_weights(cfg, seed=9)
+    w["embed.weight"] = sv_embed.astype(np.float32)
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=mode)
+    conf = fe.FrontendConf(dither=0.0)
+    audio = [W.synth_audio(n, 70 + u) for u, n in enumerate((160000, 150000, 160000, 120000, 160000, 160000, 99000, 160000))]
+    feats = [glue.sensevoice_prepend(fe.wav_frontend(a, conf, cmvn[0], cmvn[1]), sv_embed, use_itn=True) for a in audio]
+    T = max(f.shape[0] for f in feats)
+    speech = fe.pad_sequence(feats).reshape(len(audio), T, 560)
+    assert speech.shape[0] * T > 1200
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32", fast=True).sensevoice(speech)
+    res = eng.forward_feats(speech, want_logits=True)
+    err = np.abs(res.logits - ref["logits"]).max()
+    assert err < 5e-4, err
+    _ids_match(res, ref["logits"])
+    eng.close()
+
+
 def test_fp32_mode_sensevoice(sv_embed, mode):
     from aliparaformerasr_amd.engine import Engine
     cfg = W.sensevoice_small_config(enc_layers=3, tp_layers=2, vocab=403)
