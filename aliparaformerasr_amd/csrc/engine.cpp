@@ -130,8 +130,9 @@ void Engine::release() {
   owned_.clear();
   DevBuf* bufs[] = {&ws_f32_, &ws_audio_, &ws_meta_, &ws_fbank_, &ws_speech_, &ws_enc_, &ws_dec_, &ws_kv_, &ws_pe_, &ws_tmp_,
                     &ws_ts_, &ws_seaco_, &ws_seaco_in_, &ws_seaco_hw_, &ws_q_, &ws_qf_, &ws_seaco_q_, &ws_x3a_, &ws_x3t_, &ws_x3h_};
-  x3_pair_live_ = false; x3a_src_ = nullptr;
+  x3_pair_live_ = false; x3a_src_ = nullptr; x3a_pair_only_ = false;
   x3w_.clear();
+  ts_whh_x3_ = nullptr;
   seaco_hw_valid_ = false;
   for (DevBuf* b : bufs)
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
@@ -2057,6 +2058,10 @@ void Engine::timestamp_head_fp32(int B, int T) {
   const size_t o_up = carve((size_t)M3 * D * 4), o_xg = carve((size_t)M3 * 4 * D * 4), o_ho = carve((size_t)M3 * 2 * D * 4);
   const size_t o_g = carve((size_t)B * 4 * D * 4), o_h = carve((size_t)B * D * 4), o_c = carve((size_t)B * D * 4);
   const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4);
+  // math_mode 3: the recurrence as ONE persistent launch with (hi, lo') pair operands (k_bicif.hip, lstm_ring_kernel<true>): room for
+  // both directions' input gates, the four pair slots of h and the sync words
+  const bool x3_rec = x3_mode_ && x3_fuse_ && !lstm_steps_ && D == 512 && (D / 8) * 2 * ((B + 31) / 32) <= cus_;
+  const size_t o_xg2 = x3_rec ? carve((size_t)(M3 + 256) * 8 * D * 4) : 0, o_hs = x3_rec ? carve((size_t)2 * 4 * B * 2 * D * 2) : 0, o_sw = x3_rec ? carve(256) : 0;
   ensure(ws_ts_, off);
   char* base = (char*)ws_ts_.p;
   float* up32 = (float*)(base + o_up); float* xg = (float*)(base + o_xg); float* hout = (float*)(base + o_ho);
@@ -2066,6 +2071,24 @@ void Engine::timestamp_head_fp32(int B, int T) {
   // [M, 3D] row-major IS [3M, D]
   gemm32(H32_, D, ts_up_w32_, D, ts_up_.bias, M, up * D, D, up32, up * D, nullptr, 0, false, 0, 1.f);
   const char* sfx[2] = {"", "_reverse"};
+  bool done = false;
+  if (x3_rec) {
+    if (!ts_whh_x3_) {                                   // [2 dir][4D][hi (D) | lo' (D)], built once from the fp32 tensors
+      ts_whh_x3_ = (half_t*)dalloc((size_t)2 * 4 * D * 2 * D * 2);
+      for (int d = 0; d < 2; ++d)
+        launch_split_x3(stream_, tensor(std::string("predictor.blstm.weight_hh") + sfx[d]).dev, 4 * D, D, D, ts_whh_x3_ + (size_t)d * 4 * D * 2 * D, 2 * D, D, 0);
+    }
+    float* xg2 = (float*)(base + o_xg2);
+    for (int d = 0; d < 2; ++d)                          // input half of the gates, both directions side by side: [M3, 8D]
+      gemm32(up32, D, tensor(std::string("predictor.blstm.weight_ih") + sfx[d]).dev, D, ts_ih_.bias + (size_t)d * 4 * D, (int)M3, 4 * D, D,
+             xg2 + (size_t)d * 4 * D, 8 * D, nullptr, 0, false, 0, 1.f, d == 1 ? kX3SameInput : 0);
+    LstmArgs a{};
+    a.whh = ts_whh_x3_; a.xg = xg2; a.hstate = (half_t*)(base + o_hs); a.cstate = nullptr; a.hout = hout; a.B = B; a.T3 = T3; a.D = D; a.ndir = 2;
+    unsigned* sw = (unsigned*)(base + o_sw);
+    done = launch_lstm_persistent_x3(stream_, a, sw);
+    if (done) lstm_err_ = sw + 63;
+  }
+  if (!done)
   for (int d = 0; d < 2; ++d)
     lstm_fp32(up32, B, T3, tensor(std::string("predictor.blstm.weight_ih") + sfx[d]).dev,
               tensor(std::string("predictor.blstm.weight_hh") + sfx[d]).dev, ts_ih_.bias + (size_t)d * 4 * D, d == 1, xg, gates, hb,
@@ -2728,7 +2751,6 @@ void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, cons
   const bool tail = op && op->wqkv;
   const size_t owq = carve((size_t)3 * D * D * 2), owqt = carve(3 * ffn_outproj_weight_bytes()), obq = carve((size_t)3 * D * 4);
   const size_t oqk = carve((size_t)Mp * 2 * D * 2), ovo = carve((size_t)Mp * D * 2);
-  const size_t oxm = carve((size_t)Mp * D * 4);
   ensure(ws_tmp_, off);
   char* base = (char*)ws_tmp_.p;
   PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));

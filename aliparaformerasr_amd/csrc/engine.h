@@ -324,6 +324,7 @@ class Engine {
   int n_hotwords_ = 0;
   Lin ts_up_, ts_ih_;               // BiCIF: ConvTranspose1d as [3D, D], W_ih of both directions [8D, D]
   half_t* ts_whh_ = nullptr;        // [2][4D][D]
+  half_t* ts_whh_x3_ = nullptr;     // math_mode 3: [2][4D][hi (D) | lo' (D)] pair rows of the fp32 W_hh (built at first use)
   const float* ts_out_w_ = nullptr;
   const float* ts_out_b_ = nullptr;
   std::vector<float> embed_host_;

@@ -220,24 +220,36 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(LstmArgs a, unsign
 // operations of a wave retire in order).  A granule is written by one 16-byte store of one lane (observed untorn on
 // gfx950; the poison test reads its first word).  Bounded spins + the error word as in the counter form.
 // hstate: [ndir][4][B][D], slot 0 zero, slots 1-3 poison.
+// X3 (math_mode 3, the exact mode's timestamp head): W_hh and h travel as (hi, lo') f16 pairs — 22 mantissa bits — and a step's
+// product is hi_W lo'_h + lo'_W hi_h (16 MFMAs), the accumulators x 2^-11, + hi_W hi_h (8 MFMAs) in one fp32 accumulator, as the
+// Linears of that mode.  whh rows are then [hi (D) | lo' (D)] (launch_split_x3), a slot row of hstate
+// likewise: a producer publishes TWO 16-byte granules per utterance (hi at column ub * 8, lo' at D + ub * 8), each poisoned and
+// polled like the single granule of the f16 form (the argument in the header holds per granule: both poison stores of a step
+// precede the counted wait, both value stores follow it).
+template <bool X3>
 __global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __restrict__ err) {
   const int D = a.D;
+  const int RS = X3 ? 2 * D : D;                            // row stride of whh and of a slot row (f16 elements)
   const int ub = blockIdx.x, dir = blockIdx.y, bt = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kg = lane >> 5;
   __shared__ float red[4][16][64];
   __shared__ _Float16 hx[32][8];
+  __shared__ _Float16 hxl[X3 ? 32 : 1][8];                  // X3: the lo' halves of the new slice
   __shared__ float hf[32][8];                               // the same slice in fp32 for hout
   __shared__ int s_abort;
   // wave 4 is the STORE wave: poison, h and hout stores are its only memory operations, so the compute waves' polls
   // (s_waitcnt vmcnt(0) each) never sit behind the acknowledgement of a write-through store
   const bool storer = wave == 4;
   const int cw = storer ? 0 : wave;                          // K slice index of a compute wave
-  const half_t* wrow = a.whh + ((size_t)dir * 4 * D + (size_t)(r & 3) * D + ub * 8 + (r >> 2)) * D;
+  const half_t* wrow = a.whh + ((size_t)dir * 4 * D + (size_t)(r & 3) * D + ub * 8 + (r >> 2)) * RS;
   const int kspan = D / 4;
-  h8v av[8];
+  h8v av[8], avl[X3 ? 8 : 1];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const h8v*>(wrow + cw * kspan + s * 16 + kg * 8);
+  for (int s = 0; s < 8; ++s) {
+    av[s] = *reinterpret_cast<const h8v*>(wrow + cw * kspan + s * 16 + kg * 8);
+    if constexpr (X3) avl[s] = *reinterpret_cast<const h8v*>(wrow + D + cw * kspan + s * 16 + kg * 8);
+  }
   const int bb = min(bt * 32 + r, a.B - 1);
   const int uq = ub * 8 + 2 * cw + kg;
   float c = 0.f;
@@ -246,21 +258,26 @@ __global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __
   h8v poison;
 #pragma unroll
   for (int e = 0; e < 8; ++e) poison[e] = __builtin_bit_cast(_Float16, (unsigned short)0xFFFFu);
-  half_t* const slots = a.hstate + (size_t)dir * 4 * a.B * D;
+  half_t* const slots = a.hstate + (size_t)dir * 4 * a.B * RS;
   for (int step = 0; step < a.T3; ++step) {
     const int t = dir == 0 ? step : a.T3 - 1 - step;
     const int si = step & 3, so = (step + 1) & 3, sp = (step + 3) & 3;
     if (storer) {
       __syncthreads();                                         // (1) the workgroup holds all of h_{step-1}
       if (s_abort) return;
-      if (lane < 32 && bt * 32 + lane < a.B)                   // re-arm this workgroup's granules of the slot read one step ago
-        st16_sc1(slots + ((size_t)sp * a.B + bt * 32 + lane) * D + ub * 8, poison);
+      if (lane < 32 && bt * 32 + lane < a.B) {                 // re-arm this workgroup's granules of the slot read one step ago
+        st16_sc1(slots + ((size_t)sp * a.B + bt * 32 + lane) * RS + ub * 8, poison);
+        if constexpr (X3) st16_sc1(slots + ((size_t)sp * a.B + bt * 32 + lane) * RS + D + ub * 8, poison);
+      }
       __syncthreads();                                         // (2) hx / hf hold the new slice
-      // the poison store of the PREVIOUS step must have completed before this step's h becomes visible (see above): of
-      // this wave's stores only {poison(step), hout(step-1), h(step-1)} may still be in flight
-      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      if (lane < 32 && bt * 32 + lane < a.B)
-        st16_sc1(slots + ((size_t)so * a.B + bt * 32 + lane) * D + ub * 8, *reinterpret_cast<const h8v*>(&hx[lane][0]));
+      // the poison stores of the PREVIOUS step must have completed before this step's h becomes visible (see above): of
+      // this wave's stores only {poison(step), hout(step-1), h(step-1)} may still be in flight (X3: two granules each)
+      if constexpr (X3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (lane < 32 && bt * 32 + lane < a.B) {
+        st16_sc1(slots + ((size_t)so * a.B + bt * 32 + lane) * RS + ub * 8, *reinterpret_cast<const h8v*>(&hx[lane][0]));
+        if constexpr (X3) st16_sc1(slots + ((size_t)so * a.B + bt * 32 + lane) * RS + D + ub * 8, *reinterpret_cast<const h8v*>(&hxl[lane][0]));
+      }
       const int ob = bt * 32 + (lane >> 1);
       if (ob < a.B)
         *reinterpret_cast<float4*>(a.hout + ((size_t)ob * a.T3 + t) * (size_t)(a.ndir * D) + (size_t)dir * D + ub * 8 + (lane & 1) * 4) =
@@ -269,35 +286,39 @@ __global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __
     }
     const float* xgp = a.xg + ((size_t)bb * a.T3 + t) * (size_t)(a.ndir * 4 * D) + (size_t)dir * 4 * D + uq;
     const float xi = xgp[0], xf = xgp[D], xc = xgp[2 * D], xo = xgp[3 * D];
-    const half_t* hrow = slots + ((size_t)si * a.B + bb) * D + wave * kspan + kg * 8;
-    h8v bv[8];
+    const half_t* hrow = slots + ((size_t)si * a.B + bb) * RS + wave * kspan + kg * 8;
+    h8v bv[8], bvl[X3 ? 8 : 1];
     unsigned spins = 0;
     // cheap poll first: lane j < 16 watches the first word of producer (wave * 16 + j)'s granule for the tile's first
     // utterance (64 bytes per wave and poll; polling with the eight full loads — 8 KB per wave — kept 4 MB per round in
     // flight on the fabric and made a step 7 us instead of 4.2); the full loads follow and are re-checked
-    const unsigned* watch = reinterpret_cast<const unsigned*>(slots + ((size_t)si * a.B + bt * 32) * D + wave * kspan + (lane & 15) * 8);
+    const unsigned* watch = reinterpret_cast<const unsigned*>(slots + ((size_t)si * a.B + bt * 32) * RS + wave * kspan + (lane & 15) * 8);
+    auto load_all = [&]() __attribute__((always_inline)) -> bool {      // true = some granule is still poison
+      ld8x16_sc1(hrow, bv);
+      bool bad = false;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bad |= (__builtin_bit_cast(uint4, bv[s]).x == 0xFFFFFFFFu);
+      if constexpr (X3) {
+        ld8x16_sc1(hrow + D, bvl);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bad |= (__builtin_bit_cast(uint4, bvl[s]).x == 0xFFFFFFFFu);
+      }
+      return __any(bad);
+    };
     // the workgroups run in lockstep, so the others' h_{step-1} becomes visible about one store latency after this
     // workgroup published its own: wait that long (a.step x 64 clocks), then ask for the real thing at once — when it is
     // there the step has ONE load round trip after arrival instead of two (successful cheap poll + the full loads)
     bool got = false;
     if (step > 0 && a.step > 0) {
       for (int z = 0; z < a.step; ++z) __builtin_amdgcn_s_sleep(2);
-      ld8x16_sc1(hrow, bv);
-      bool bad = false;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) bad |= (__builtin_bit_cast(uint4, bv[s]).x == 0xFFFFFFFFu);
-      got = !__any(bad);
+      got = !load_all();
     }
     while (!got) {
       unsigned w0;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w0) : "v"(watch) : "memory");
-      bool bad = w0 == 0xFFFFFFFFu;
+      const bool bad = w0 == 0xFFFFFFFFu;
       if (!__any(bad)) {
-        ld8x16_sc1(hrow, bv);
-        bad = false;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) bad |= (__builtin_bit_cast(uint4, bv[s]).x == 0xFFFFFFFFu);
-        if (!__any(bad)) break;
+        if (!load_all()) break;
       }
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 22) || (lane == 0 && (spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -308,6 +329,15 @@ __global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __
     f16v acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if constexpr (X3) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bvl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[s], bv[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] *= (1.0f / 2048.0f);
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s], bv[s], acc, 0, 0, 0);
 #pragma unroll
@@ -321,7 +351,9 @@ __global__ __launch_bounds__(320) void lstm_ring_kernel(LstmArgs a, unsigned* __
     const float gi = g[0] + xi, gf = g[1] + xf, gg = g[2] + xc, go = g[3] + xo;
     c = sigmoidf_(gf) * c + sigmoidf_(gi) * tanhf(gg);
     const float h = sigmoidf_(go) * tanhf(c);
-    hx[r][2 * wave + kg] = (_Float16)h;
+    const _Float16 hh = (_Float16)h;
+    hx[r][2 * wave + kg] = hh;
+    if constexpr (X3) hxl[r][2 * wave + kg] = (_Float16)((h - (float)hh) * 2048.0f);
     hf[r][2 * wave + kg] = h;
     __syncthreads();                                           // (2)
   }
@@ -350,12 +382,36 @@ bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_wor
     const size_t slot = (size_t)a.B * a.D * 2;
     PF_HIP(hipMemsetAsync(a.hstate, 0xFF, (size_t)a.ndir * 4 * slot, s));
     for (int d = 0; d < a.ndir; ++d) PF_HIP(hipMemsetAsync(reinterpret_cast<char*>(a.hstate) + (size_t)d * 4 * slot, 0, slot, s));
-    hipLaunchKernelGGL(lstm_ring_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(320), 0, s, b, sync_words + 63);
+    hipLaunchKernelGGL(lstm_ring_kernel<false>, dim3(a.D / 8, a.ndir, tiles), dim3(320), 0, s, b, sync_words + 63);
   } else {
     PF_HIP(hipMemsetAsync(a.hstate, 0, (size_t)a.ndir * 2 * a.B * a.D * 2, s));
     b.step = var;
     hipLaunchKernelGGL(lstm_persistent_kernel, dim3(a.D / 8, a.ndir, tiles), dim3(256), 0, s, b, sync_words, sync_words + 63);
   }
+  PF_HIP(hipGetLastError());
+  return true;
+}
+
+// The ring form with (hi, lo') pair operands (math_mode 3): a.whh = [ndir][4D][2D] pair rows (launch_split_x3), a.hstate has room for
+// [ndir][4][B][2D] f16 and is initialised here (slot 0 zero, slots 1-3 poison).  false = not applicable (as above).
+bool launch_lstm_persistent_x3(hipStream_t s, const LstmArgs& a, unsigned* sync_words) {
+  if (a.D != 512 || (a.ndir != 1 && a.ndir != 2)) return false;
+  const int tiles = cdiv(a.B, 32);
+  const int wgs = (a.D / 8) * a.ndir * tiles;
+  int dev = 0;
+  PF_HIP(hipGetDevice(&dev));
+  int cus = 0;
+  PF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (wgs > cus || a.ndir * tiles > 60) return false;
+  PF_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
+  LstmArgs b = a;
+  static int delay = -1;
+  if (delay < 0) { const char* e = getenv("PF_LSTM_DELAY"); delay = e ? atoi(e) : 13; }
+  b.step = delay;
+  const size_t slot = (size_t)a.B * 2 * a.D * 2;
+  PF_HIP(hipMemsetAsync(a.hstate, 0xFF, (size_t)a.ndir * 4 * slot, s));
+  for (int d = 0; d < a.ndir; ++d) PF_HIP(hipMemsetAsync(reinterpret_cast<char*>(a.hstate) + (size_t)d * 4 * slot, 0, slot, s));
+  hipLaunchKernelGGL(lstm_ring_kernel<true>, dim3(a.D / 8, a.ndir, tiles), dim3(320), 0, s, b, sync_words + 63);
   PF_HIP(hipGetLastError());
   return true;
 }

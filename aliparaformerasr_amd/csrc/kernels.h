@@ -311,6 +311,8 @@ void launch_lstm_step(hipStream_t s, const LstmArgs& a);
 // state lives in registers).  sync_words: >= 64 device words (arrival counters + [63] = time-out flag, zeroed here).
 // false = not applicable (more workgroups than CUs): use launch_lstm_step per step.
 bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_words);
+// the same recurrence with (hi, lo') pair operands (math_mode 3): whh = [ndir][4D][2D] pair rows, hstate [ndir][4][B][2D]
+bool launch_lstm_persistent_x3(hipStream_t s, const LstmArgs& a, unsigned* sync_words);
 void launch_us_alpha(hipStream_t s, const float* hout, int64_t rows, int W, const float* w, const float* b0,
                      float smooth, float noise, float* out);
 void launch_us_peak(hipStream_t s, float* alphas, const int32_t* token_num, int B, int T3, float thr, float* peak);
