@@ -290,7 +290,10 @@ WavData decode_wav_file(const std::string& path) {
   }
   PF_CHECK(data && w.channels > 0 && w.sample_rate > 0 && block_align > 0, PF_ERR_FORMAT, "wav: missing fmt/data chunk: " + path);
   const int bps = bits / 8;
-  PF_CHECK((fmt_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) || (fmt_tag == 3 && bits == 32),
+  // PCM 8 / 16 / 24 / 32, IEEE float 32 / 64, G.711 A-law (6) and mu-law (7): what NAudio's AudioFileReader turns into float samples
+  // for a RIFF/WAVE file (the G.711 forms through a codec that expands them to 16-bit PCM first)
+  PF_CHECK((fmt_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) || (fmt_tag == 3 && (bits == 32 || bits == 64)) ||
+               ((fmt_tag == 6 || fmt_tag == 7) && bits == 8),
            PF_ERR_UNSUPPORTED, "wav: unsupported sample format");
   const size_t n = data_bytes / bps;
   w.samples.resize(n);
@@ -298,7 +301,16 @@ WavData decode_wav_file(const std::string& path) {
   for (size_t i = 0; i < n; ++i) {
     const unsigned char* q = d + i * bps;
     float v;
-    if (fmt_tag == 3) { std::memcpy(&v, q, 4); }
+    if (fmt_tag == 7) {                                  // ITU-T G.711 mu-law: ~byte = sign | exponent (3) | mantissa (4)
+      const int u = (~q[0]) & 0xFF;
+      const int mag = ((((u & 0x0F) << 3) + 0x84) << ((u >> 4) & 7)) - 0x84;
+      v = (float)((u & 0x80) ? -mag : mag) / 32768.0f;
+    } else if (fmt_tag == 6) {                           // A-law: byte ^ 0x55, sign bit set = positive
+      const int a = q[0] ^ 0x55, e = (a >> 4) & 7, m = a & 0x0F;
+      const int mag = e == 0 ? (m << 4) + 8 : ((m << 4) + 0x108) << (e - 1);
+      v = (float)((a & 0x80) ? mag : -mag) / 32768.0f;
+    } else if (fmt_tag == 3 && bits == 64) { double d; std::memcpy(&d, q, 8); v = (float)d; }
+    else if (fmt_tag == 3) { std::memcpy(&v, q, 4); }
     else if (bits == 16) { int16_t x; std::memcpy(&x, q, 2); v = x / 32768.0f; }
     else if (bits == 24) { int32_t x = (int32_t)((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)(int8_t)q[2] << 16)); v = x / 8388608.0f; }
     else if (bits == 32) { int32_t x; std::memcpy(&x, q, 4); v = x / 2147483648.0f; }

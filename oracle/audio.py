@@ -3,7 +3,9 @@
 Reference: AliParaformerAsr.Examples/Utils/AudioHelper.cs — GetFileSample (:12-32), Resample with channel
 down-mix (:223-279), IsAudioByHeader / IsWavHeader (:286-340).  NAudio's AudioFileReader (external NuGet
 package) converts every PCM width to IEEE float; the conversions restated here are NAudio's published
-sample providers: PCM8 b/128-1, PCM16 /32768, PCM24 /8388608, PCM32 /2147483648, float32 unchanged."""
+sample providers: PCM8 b/128-1, PCM16 /32768, PCM24 /8388608, PCM32 /2147483648, float32 unchanged.  G.711 files
+(WAVE_FORMAT_ALAW 6 / MULAW 7, 8 bits) reach AudioFileReader through a codec that expands them to 16-bit PCM first: the ITU-T
+G.711 tables (restated as their closed forms below), then /32768; IEEE float64 narrows to float32."""
 import struct
 
 import numpy as np
@@ -28,7 +30,18 @@ def decode_wav(data: bytes):
             break
         pos += 8 + sz + (sz & 1)
     tag, ch, sr, align, bits = fmt
-    if tag == 3:
+    if tag == 7 and bits == 8:                       # mu-law (G.711): ~byte = sign | exponent (3) | mantissa (4)
+        u = (~np.frombuffer(payload, np.uint8)).astype(np.int32) & 0xFF
+        mag = ((((u & 0x0F) << 3) + 0x84) << ((u >> 4) & 7)) - 0x84
+        x = (np.where(u & 0x80, -mag, mag).astype(F32) / F32(32768.0)).astype(F32)
+    elif tag == 6 and bits == 8:                     # A-law (G.711): byte ^ 0x55, sign bit SET = positive
+        a = np.frombuffer(payload, np.uint8).astype(np.int32) ^ 0x55
+        e, m = (a >> 4) & 7, a & 0x0F
+        mag = np.where(e == 0, (m << 4) + 8, ((m << 4) + 0x108) << np.maximum(e - 1, 0))
+        x = (np.where(a & 0x80, mag, -mag).astype(F32) / F32(32768.0)).astype(F32)
+    elif tag == 3 and bits == 64:
+        x = np.frombuffer(payload[: len(payload) // 8 * 8], "<f8").astype(F32)
+    elif tag == 3:
         x = np.frombuffer(payload[: len(payload) // 4 * 4], "<f4").astype(F32)
     elif bits == 16:
         x = (np.frombuffer(payload[: len(payload) // 2 * 2], "<i2").astype(F32) / F32(32768.0)).astype(F32)

@@ -17,7 +17,11 @@ def lib():
 
 
 def _wav(path, sr, ch, bits, data, tag=1):
-    if bits == 16:
+    if tag in (6, 7):
+        payload = np.asarray(data, np.uint8).tobytes()
+    elif tag == 3 and bits == 64:
+        payload = np.asarray(data, "<f8").tobytes()
+    elif bits == 16:
         payload = np.asarray(data, "<i2").tobytes()
     elif bits == 8:
         payload = np.asarray(data, np.uint8).tobytes()
@@ -81,6 +85,9 @@ def test_wav_decode_formats(lib, tmp_path):
         ("p32.wav", 8000, 2, 32, 1, rng.integers(-(1 << 31), (1 << 31) - 1, 1600)),
         ("p8.wav", 22050, 1, 8, 1, rng.integers(0, 255, 2205)),
         ("f32.wav", 48000, 2, 32, 3, rng.uniform(-1, 1, 9600)),
+        ("f64.wav", 16000, 1, 64, 3, rng.uniform(-1, 1, 500)),
+        ("ulaw.wav", 8000, 1, 8, 7, np.arange(256)),                         # every G.711 code
+        ("alaw.wav", 8000, 2, 8, 6, np.arange(256)),
     ]
     for name, sr, ch, bits, tag, data in cases:
         blob = _wav(tmp_path / name, sr, ch, bits, data, tag)
@@ -89,6 +96,13 @@ def test_wav_decode_formats(lib, tmp_path):
         assert (gsr, gch) == (sr, ch)
         assert abs(gdur - rdur) < 1e-9
         assert got.shape == ref.shape and np.array_equal(got, ref), name
+    # ITU-T G.711 corner codes (16-bit expansions): mu-law 0x00 / 0x80 = -/+32124, 0x7F / 0xFF = 0; A-law 0x2A / 0xAA = -/+32256, 0x55 / 0xD5 = -/+8
+    _wav(tmp_path / "u.wav", 16000, 1, 8, [0x00, 0x80, 0x7F, 0xFF, 0x8F], tag=7)
+    got, *_ = _read(lib, tmp_path / "u.wav")
+    assert list(got * 32768) == [-32124.0, 32124.0, 0.0, 0.0, 16764.0]
+    _wav(tmp_path / "a.wav", 16000, 1, 8, [0x2A, 0xAA, 0x55, 0xD5], tag=6)
+    got, *_ = _read(lib, tmp_path / "a.wav")
+    assert list(got * 32768) == [-32256.0, 32256.0, -8.0, 8.0]
     # hand-evaluated PCM16 values
     _wav(tmp_path / "k.wav", 16000, 1, 16, [0, 16384, -32768, 32767])
     got, *_ = _read(lib, tmp_path / "k.wav")
