@@ -184,6 +184,27 @@ def test_fp32_mode_bicif_timestamp_head(mode):
     eng.close()
 
 
+def test_exact_mode_timestamp_recurrence_with_two_utterance_tiles():
+    """math_mode 3 runs the BiCIF head's BiLSTM as ONE persistent launch with (hi, lo') pair operands (lstm_ring_kernel<true>).  40
+    utterances = two tiles of 32 per direction (256 workgroups: the whole device, the last tile ragged): token counts identical and
+    peaks within the fp32 mode's bar of the fp32 oracle's."""
+    from aliparaformerasr_amd.engine import Engine
+    cfg = W.paraformer_large_config(enc_layers=1, dec_layers=1, vocab=128, timestamp_head=True)
+    w = W.synth_weights(cfg, seed=4)
+    cmvn = W.synth_cmvn()
+    eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0, math_mode=3)
+    audio = [W.synth_audio(9000 + 700 * (u % 7), 40 + u) for u in range(40)]
+    speech = _speech(audio, cmvn)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp32").paraformer(speech)
+    res = eng.recognize(audio)
+    np.testing.assert_array_equal(res.token_num, ref["token_num"])
+    thr = np.float32(np.float32(1.0) - np.float32(1e-4))
+    d = np.abs(res.cif_peak - ref["us_cif_peak"])
+    d = np.minimum(d, np.abs(d - thr))
+    assert d.max() < 2e-4, d.max()
+    eng.close()
+
+
 def test_fp32_mode_seaco_bias_decoder(mode):
     """configs[4]'s SeACo branch in fp32: hotword embedder (Embedding + 2 x LSTM), the bias decoder on [CIF embeds ;
     decoder hidden], hotword_output_layer, NO-BIAS merge — merged log-probs within 2e-4 of the fp32 oracle on every
