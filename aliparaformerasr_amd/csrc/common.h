@@ -37,6 +37,9 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // PF_CU_CAP=n: limits PERSISTENT grid sizes (and their tile-shape rules) to n compute units.  It does not partition the
 // device: the hardware still places those workgroups where it likes, and the non-persistent kernels (attention, the
 // row-complete and short-input GEMMs) ignore it (tools/: the two-engine overlap experiment of round 4)
+// An integer knob read from the environment.  Call sites keep the result in a function-local `static const`, whose
+// initialisation C++11 makes thread-safe: launchers run concurrently from the recognizer pool's caller threads.
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
 inline int cu_limit(int cus) {
   static const int cap = [] { const char* e = getenv("PF_CU_CAP"); return e ? atoi(e) : 0; }();   // thread-safe initialiser
   return cap > 0 && cap < cus ? cap : cus;

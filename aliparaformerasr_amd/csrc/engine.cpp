@@ -1354,8 +1354,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
 // Needs ev_enc_ (encoder output) and ev_scan_ (token_num) recorded on stream_.
 void Engine::start_timestamp_head(int B, int T) {
   {
-    static int ts_side = -1;
-    if (ts_side < 0) { const char* e = getenv("PF_TS_STREAM"); ts_side = e ? atoi(e) : 1; }
+    static const int ts_side = env_int("PF_TS_STREAM", 1);
     if (ts_side && !lstm_steps_) {
       // beside the decoder, on its own stream: everything timestamp_head enqueues (two GEMMs, the persistent recurrence,
       // the peaks and their copy to the host) goes to ts_stream_, which waits for the CIF scan (= the encoder too)

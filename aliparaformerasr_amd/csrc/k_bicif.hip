@@ -372,11 +372,9 @@ bool launch_lstm_persistent(hipStream_t s, const LstmArgs& a, unsigned* sync_wor
   if (wgs > cus || a.ndir * tiles > 60) return false;       // every workgroup must be resident: one per CU at most
   PF_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
   LstmArgs b = a;
-  static int var = -1;                                       // PF_LSTM_VAR: 2 = ring form (default), 0 / 1 = arrival-counter form
-  if (var < 0) { const char* e = getenv("PF_LSTM_VAR"); var = e ? atoi(e) : 2; }
+  static const int var = env_int("PF_LSTM_VAR", 2);          // PF_LSTM_VAR: 2 = ring form (default), 0 / 1 = arrival-counter form
   if (var == 2) {
-    static int delay = -1;                                   // PF_LSTM_DELAY: x 2 x 64 clocks before the first (full) load of a step
-    if (delay < 0) { const char* e = getenv("PF_LSTM_DELAY"); delay = e ? atoi(e) : 13; }
+    static const int delay = env_int("PF_LSTM_DELAY", 13);   // PF_LSTM_DELAY: x 2 x 64 clocks before the first (full) load of a step
     b.step = delay;
     // hstate [ndir][4][B][D]: slot 0 = h_{-1} = 0, slots 1 to 3 poison
     const size_t slot = (size_t)a.B * a.D * 2;
@@ -405,8 +403,7 @@ bool launch_lstm_persistent_x3(hipStream_t s, const LstmArgs& a, unsigned* sync_
   if (wgs > cus || a.ndir * tiles > 60) return false;
   PF_HIP(hipMemsetAsync(sync_words, 0, 64 * sizeof(unsigned), s));
   LstmArgs b = a;
-  static int delay = -1;
-  if (delay < 0) { const char* e = getenv("PF_LSTM_DELAY"); delay = e ? atoi(e) : 13; }
+  static const int delay = env_int("PF_LSTM_DELAY", 13);
   b.step = delay;
   const size_t slot = (size_t)a.B * 2 * a.D * 2;
   PF_HIP(hipMemsetAsync(a.hstate, 0xFF, (size_t)a.ndir * 4 * slot, s));

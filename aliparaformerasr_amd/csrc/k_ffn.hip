@@ -896,8 +896,7 @@ __global__ __launch_bounds__(256) void ffn_dec_finish_kernel(const float* __rest
 // 140 KB of LDS).  Measured at M = 5344 (profiles/round5_dec_ffn.txt): 17 us of fixed work + 4.3 us per chunk per round, a
 // second round of a few workgroups costs about half a round; the finishing pass ~7 us + 1.2 us per share it sums.
 int ffn_dec_splits(int M) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("PF_DEC_FFN_SPLITS"); forced = e ? atoi(e) : 0; }
+  static const int forced = env_int("PF_DEC_FFN_SPLITS", 0);
   if (forced == 1 || forced == 2 || forced == 3 || forced == 4 || forced == 8) return forced;
   const int tiles = cdiv(M, FF_BM);
   const int cand[5] = {1, 2, 3, 4, 8}, nch[5] = {8, 4, 3, 2, 1};

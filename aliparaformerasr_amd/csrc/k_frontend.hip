@@ -375,14 +375,11 @@ void launch_fbank(hipStream_t s, const FbankTables* tb, const float* audio, cons
   const int64_t blocks = (total_frames + 3) / 4;
   // the persistent grid = exactly the workgroups that are resident at once (the occupancy the registers and the LDS
   // allow: 4 per CU at 114 VGPRs); a grid of 5 per CU ran its fifth workgroups as a second round: 156 vs 131 us
-  static int per_cu = -1;
-  if (per_cu < 0) {
-    const char* e = getenv("PF_FBANK_WGS");
-    int occ = 0;
-    if (e) occ = atoi(e);
-    else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fbank_kernel, 256, 0) != hipSuccess) occ = 4;
-    per_cu = std::max(1, std::min(occ, 8));
-  }
+  static const int per_cu = [] {
+    int occ = env_int("PF_FBANK_WGS", 0);
+    if (occ <= 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fbank_kernel, 256, 0) != hipSuccess) occ = 4;
+    return std::max(1, std::min(occ, 8));
+  }();
   hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)std::min<int64_t>(blocks, (int64_t)cus * per_cu)), dim3(256), 0, s, p);
   PF_HIP(hipGetLastError());
 }

@@ -847,7 +847,8 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   // from different host threads (one engine per GPU, include/paraformer_hip.h pf_group_*)
   static std::mutex init_mu;
   static int cus[64] = {0};
-  static float mi_x = -1.f;                          // PF_GEMM_MI_X: tuning knob for tools/ (tiles < x * CUs -> 128-row tiles)
+  // PF_GEMM_MI_X: tuning knob for tools/ (tiles < x * CUs -> 128-row tiles)
+  static const float mi_x = [] { const char* e = getenv("PF_GEMM_MI_X"); return e ? (float)atof(e) : 0.6f; }();
   {
     std::lock_guard<std::mutex> lk(init_mu);
     if (!cus[dev]) {
@@ -861,12 +862,10 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
       PF_HIP(hipFuncSetAttribute((const void*)gemm_f16_pp3<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1)));
       cus[dev] = cu_limit(prop.multiProcessorCount);
     }
-    if (mi_x < 0.f) { const char* e = getenv("PF_GEMM_MI_X"); mi_x = e ? (float)atof(e) : 0.6f; }
   }
   {
     // blocked-layout results (FFN-up): the persistent 256 x 256-tile kernel (k_gemm_big.hip); PF_BIGP=0 keeps this file's kernel
-    static int use_bigp = -1;
-    if (use_bigp < 0) { const char* e = getenv("PF_BIGP"); use_bigp = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }   // 2: whenever it applies and fills the chip once
+    static const int use_bigp = [] { const char* e = getenv("PF_BIGP"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();   // 2: whenever it applies and fills the chip once
     const bool can = gemm_bigp_applicable(a);
     PF_CHECK(a.force_mi != 5 || can, PF_ERR_INVALID_ARG, "gemm: the persistent 256 x 256 kernel does not apply to this problem");
     // by rounds: a 256 x 256 tile costs ~1.9 tiles of this file's kernel; whichever schedule has less idle tail wins
@@ -881,8 +880,7 @@ void launch_gemm(hipStream_t s, const GemmArgs& a) {
   // tile height by rounds: a 128-row tile costs ~0.58 of a 256-row one (half the MFMAs, two thirds of the operand
   // bytes); whichever schedule has the shorter last round wins (decoder FFN-up, M = 5344: 336 tiles = 2 rounds vs
   // 672 = 3 x 0.58).  PF_GEMM_ROUNDS=0 keeps the tile-count rule alone.
-  static int by_rounds = -1;
-  if (by_rounds < 0) { const char* e = getenv("PF_GEMM_ROUNDS"); by_rounds = (e && e[0] == '0') ? 0 : 1; }
+  static const int by_rounds = [] { const char* e = getenv("PF_GEMM_ROUNDS"); return (e && e[0] == '0') ? 0 : 1; }();
   const int t2 = cdiv(d.M, 256) * cdiv(d.N, GEMM_BN), t1 = cdiv(d.M, 128) * cdiv(d.N, GEMM_BN);
   const bool few = (float)t2 < mi_x * cus[dev];
   const bool rounds1 = by_rounds && 0.58 * cdiv(t1, cus[dev]) < (double)cdiv(t2, cus[dev]);

@@ -308,8 +308,7 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(ReduceDev p) {
 
 // rows up to which the pipeline prefers this kernel (PF_SMALL_M overrides; 0 disables)
 int gemm_small_max_rows() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PF_SMALL_M"); v = e ? atoi(e) : 512; if (v > 512) v = 512; }   // workspace rows; measured:
+  static const int v = std::min(env_int("PF_SMALL_M", 512), 512);   // workspace rows; measured:
   // M = 664 (8 x 5 s) ties with the persistent kernel (5.51 vs 5.44 ms), M = 1000 (2 x 30 s) loses (6.56 vs 6.06 ms)
   return v;
 }

@@ -201,8 +201,7 @@ static void ln_dispatch(hipStream_t s, const float* x, int64_t rows, int D, cons
   PF_CHECK(D % 4 == 0 && D <= 64 * 4 * 8, PF_ERR_INVALID_ARG, "layernorm: unsupported width");
   if (rows == 0) return;
   if (!POSENC && D == 512 && rows >= 4096 && (!out16 || ld16 == D)) {
-    static int rows_per_wave = -1;                             // PF_LN_ROWS: 1 keeps the one-row kernel (A/B switch)
-    if (rows_per_wave < 0) { const char* e = getenv("PF_LN_ROWS"); rows_per_wave = e ? atoi(e) : 2; }
+    static const int rows_per_wave = env_int("PF_LN_ROWS", 2);   // PF_LN_ROWS: 1 keeps the one-row kernel (A/B switch)
     if (rows_per_wave == 2 || rows_per_wave == 4) {
       const int R = rows_per_wave;
       const dim3 g2((unsigned)((rows + 4 * R - 1) / (4 * R))), b2(256);

@@ -241,19 +241,26 @@ void Stream::AddSamples(const float* samples, int64_t n) {
   if (!has_speech && !device_form && owner->device_streams()) {
     // first call: the samples go to the device and stay there; SpeechLength is what GetFbank + LfrCmvn would return
     // (OfflineStream.cs:40-41) — a function of the sample count
+    // Device memory for a backlog of streams can run out where the reference never fails: then this stream simply takes the
+    // host form below (features computed now and kept on the host, as in rounds 1-4) — ADVICE r5
     size_t got = 0;
-    float* d = n > 0 ? owner->audio_alloc((size_t)n * 4, &got) : nullptr;
+    float* d = nullptr;
+    bool on_device = true;
     try {
-      if (n > 0) owner->upload(d, samples, (size_t)n * 4);
-    } catch (...) {
+      if (n > 0) { d = owner->audio_alloc((size_t)n * 4, &got); owner->upload(d, samples, (size_t)n * 4); }
+    } catch (const Error& ex) {
       if (d) owner->audio_free(d, got);
-      throw;
+      if (ex.code == PF_ERR_DISPOSED) throw;
+      (void)hipGetLastError();                                      // clear the sticky out-of-memory status
+      on_device = false;
     }
-    dev_audio = d; dev_bytes = got; dev_n = n;
-    device_form = true;
-    has_speech = true;
-    SpeechLength = owner->feature_floats(n);
-    return;
+    if (on_device) {
+      dev_audio = d; dev_bytes = got; dev_n = n;
+      device_form = true;
+      has_speech = true;
+      SpeechLength = owner->feature_floats(n);
+      return;
+    }
   }
   materialize();                                                   // a second call appends to the FEATURES (:43-54)
   Recognizer::Lease e = owner->acquire();
@@ -343,31 +350,32 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
     read_binary_file(model_path_.c_str(), file);
     PF_CHECK(file.size() >= 16, PF_ERR_FORMAT, "weights: image too small");
     PF_HIP(hipSetDevice(device_));
-    PF_HIP(hipMalloc(&image_, file.size()));
+    void* img = nullptr;
+    PF_HIP(hipMalloc(&img, file.size()));
+    const int dev = device_;
+    image_ = std::shared_ptr<void>(img, [dev](void* p) { hipSetDevice(dev); hipFree(p); });
     image_bytes_ = (int64_t)file.size();
-    if (hipMemcpy(image_, file.data(), file.size(), hipMemcpyHostToDevice) != hipSuccess) {
-      hipFree(image_); image_ = nullptr;
-      throw Error(PF_ERR_DEVICE, "weights: upload failed");
-    }
+    if (hipMemcpy(img, file.data(), file.size(), hipMemcpyHostToDevice) != hipSuccess)
+      throw Error(PF_ERR_DEVICE, "weights: upload failed");       // (image_ frees itself)
   }
-  ec.weights_device = image_;
+  ec.weights_device = image_.get();
   ec.weights_bytes = image_bytes_;
-  try {
-    engines_.push_back(std::make_shared<Engine>(ec));
-  } catch (...) {
-    hipFree(image_); image_ = nullptr;
-    throw;
-  }
+  { const char* e = getenv("PF_RECOGNIZER_AUDIO_CACHE_MB"); if (e && e[0]) audio_cache_cap_ = (size_t)std::max(0, atoi(e)) << 20; }
+  engines_.push_back(make_engine());
   busy_.push_back(0);
   engine_kind_ = engines_[0]->model().kind;
   sv_device_prompt_ = engines_[0]->has_device_prompt();
+  if (engine_kind_ == "sensevoicesmall") { sv_embed_ = engines_[0]->embed_table(); sv_use_itn_ = engines_[0]->model().use_itn; }
   feat_m_ = (conf_.lfr_m != 1 || conf_.lfr_n != 1) ? conf_.lfr_m : 1;
   // the device form of a stream needs the batched front-end to compute exactly what AddSamples + PadSequence would
   device_streams_ = device_streams_ && engines_[0]->staged_frontend_matches_host();
   uid_ = register_recognizer();
 }
 
-std::shared_ptr<Engine> Recognizer::make_engine() { return std::make_shared<Engine>(ec_); }
+std::shared_ptr<Engine> Recognizer::make_engine() {
+  std::shared_ptr<void> img = image_;                // the engine points into the image: it must outlive the engine
+  return std::shared_ptr<Engine>(new Engine(ec_), [img](Engine* e) { delete e; });
+}
 
 int Recognizer::feature_floats(int64_t n) {
   std::shared_ptr<Engine> e = engine();
@@ -399,10 +407,19 @@ Recognizer::Lease Recognizer::acquire() {
   std::unique_lock<std::mutex> lk(mu_);
   for (;;) {
     if (disposed_ || engines_.empty()) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
-    int idx = -1;
-    for (size_t i = 0; i < engines_.size(); ++i)
-      if (!busy_[i]) { idx = (int)i; break; }
-    if (idx < 0 && (int)engines_.size() + creating_ < max_engines_) {
+    // a free engine whose mutex is free too: users of pf_recognizer_engine lock engine 0 without a lease, and a call must
+    // not queue behind them while another engine idles or the pool may still grow
+    int idx = -1, held = -1;
+    std::unique_lock<std::mutex> elk;
+    for (size_t i = 0; i < engines_.size(); ++i) {
+      if (busy_[i]) continue;
+      std::unique_lock<std::mutex> t(engines_[i]->mutex(), std::try_to_lock);
+      if (t.owns_lock()) { idx = (int)i; elk = std::move(t); break; }
+      if (held < 0) held = (int)i;
+    }
+    const bool may_grow = (int)engines_.size() + creating_ < max_engines_;
+    if (idx < 0 && held >= 0 && !may_grow) idx = held;          // nothing else to take: queue on that engine's mutex below
+    if (idx < 0 && may_grow) {
       // every engine is busy and the pool may grow: build one outside the lock (weight conversion takes ~1 s)
       ++creating_;
       lk.unlock();
@@ -418,6 +435,7 @@ Recognizer::Lease Recognizer::acquire() {
       }
       lk.lock();
       --creating_;
+      cv_.notify_all();                   // Dispose() waits for creating_ == 0 (this branch used to leave it asleep)
       if (disposed_) { lk.unlock(); ne.reset(); lk.lock(); continue; }
       engines_.push_back(ne);
       busy_.push_back(0);
@@ -428,7 +446,8 @@ Recognizer::Lease Recognizer::acquire() {
       Lease l;
       l.r_ = this; l.idx_ = idx; l.e_ = engines_[(size_t)idx];
       lk.unlock();
-      l.lk_ = std::unique_lock<std::mutex>(l.e_->mutex());          // also serialises with users of pf_recognizer_engine
+      if (elk.owns_lock()) l.lk_ = std::move(elk);
+      else l.lk_ = std::unique_lock<std::mutex>(l.e_->mutex());     // also serialises with users of pf_recognizer_engine
       return l;
     }
     cv_.wait(lk);
@@ -459,7 +478,7 @@ void Recognizer::audio_free(float* p, size_t bytes) {
   if (!p) return;
   {
     std::lock_guard<std::mutex> lk(mu_);
-    if (!disposed_ && audio_cached_bytes_ + bytes <= ((size_t)1 << 30)) {        // keep up to 1 GiB for re-use
+    if (!disposed_ && audio_cached_bytes_ + bytes <= audio_cache_cap_) {          // keep up to 1 GiB (PF_RECOGNIZER_AUDIO_CACHE_MB) for re-use
       audio_cache_[bytes].push_back(p);
       audio_cached_bytes_ += bytes;
       return;
@@ -509,11 +528,20 @@ void Recognizer::Dispose() {
   hipSetDevice(device_);
   for (auto& kv : cache)
     for (float* p : kv.second) hipFree(p);
+  free_device_side();
+}
+
+void Recognizer::free_device_side() {
+  hipSetDevice(device_);
+  for (auto& kv : audio_cache_)
+    for (float* p : kv.second) hipFree(p);
+  audio_cache_.clear();
+  audio_cached_bytes_ = 0;
   for (CopyLane& ln : lanes_) {
     std::lock_guard<std::mutex> lk(ln.mu);
     if (ln.s) { hipStreamDestroy(ln.s); ln.s = nullptr; }
   }
-  if (image_) { hipFree(image_); image_ = nullptr; }
+  image_.reset();                                  // freed when the last engine that adopted it is gone
 }
 
 void Recognizer::Forward(const std::vector<Stream*>& streams) {
@@ -608,9 +636,8 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
         // quirk Q8 on the device form: the reference has prepended the query rows to Speech IN PLACE, and a stream whose
         // chunk RemoveChunk keeps (at most two ids) carries them into its next call: give it the host form with them
         s->materialize();
-        Lease l2 = acquire();
-        const std::vector<float>& emb = l2->embed_table();
-        const int order[4] = {l2->model().use_itn ? 14 : 15, 1, 2, 15};
+        const std::vector<float>& emb = sv_embed_;
+        const int order[4] = {sv_use_itn_ ? 14 : 15, 1, 2, 15};
         std::vector<float> sp((size_t)4 * W + s->Speech.size());
         for (int r = 0; r < 4; ++r) std::memcpy(&sp[(size_t)r * W], &emb[(size_t)order[r] * W], (size_t)W * 4);
         std::memcpy(sp.data() + (size_t)4 * W, s->Speech.data(), s->Speech.size() * 4);
@@ -626,6 +653,9 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
 }
 
 Recognizer::~Recognizer() {
+  // never disposed (or the constructor threw after the image was uploaded): nobody else can reach this object any more,
+  // so the engines, the audio cache, the copy lanes and the image go here (~0.9 GB used to leak)
+  if (!disposed_.exchange(true)) { engines_.clear(); busy_.clear(); free_device_side(); }
   std::lock_guard<std::mutex> lk(g_live_mu);
   g_live.erase(uid_);
 }

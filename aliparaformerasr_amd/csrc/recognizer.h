@@ -134,7 +134,13 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   pf_engine_config ec_{};                                     // template for further engines (strings owned below)
   std::string model_path_, mvn_path_, window_;
   std::vector<float> cmvn_shift_, cmvn_scale_;
-  void* image_ = nullptr; int64_t image_bytes_ = 0;           // the PFW image on the device, shared by every engine
+  // the PFW image on the device, adopted in place by every engine of the pool.  Shared ownership: each engine's deleter holds
+  // a reference, so a caller of pf_recognizer_engine that still holds its shared_ptr<Engine> across Dispose() keeps the
+  // weights it points into alive (Dispose used to hipFree it under such a caller)
+  std::shared_ptr<void> image_; int64_t image_bytes_ = 0;
+  void free_device_side();                                    // audio cache + copy lanes + our image reference (Dispose, ~Recognizer)
+  std::vector<float> sv_embed_; bool sv_use_itn_ = false;     // SenseVoice prompt table, cached so quirk Q8 needs no engine lease
+  size_t audio_cache_cap_ = (size_t)1 << 30;                  // PF_RECOGNIZER_AUDIO_CACHE_MB
   std::map<size_t, std::vector<float*>> audio_cache_; size_t audio_cached_bytes_ = 0;
   struct CopyLane { std::mutex mu; hipStream_t s = nullptr; };
   std::array<CopyLane, 4> lanes_;

@@ -435,3 +435,41 @@ def test_dispose_waits_for_calls_in_flight_and_pool_survives_errors(model_dir, m
     assert not errs, errs
     with pytest.raises(ObjectDisposedException):
         r.CreateOfflineStream()
+
+
+@pytest.mark.timeout(300)
+def test_dispose_while_the_pool_is_growing_does_not_hang(mid_model_dir, monkeypatch):
+    """Dispose() waits for `creating_ == 0`; a caller that finishes building an engine AFTER disposed_ was set
+    used to leave without waking it.  Two callers start together on a one-engine pool (the second one's first call finds the
+    engine busy and builds another, ~0.3-1 s of weight conversion) and Dispose lands inside that window; it must return,
+    and both callers must end with the reference's ObjectDisposedException / recognition failure — not hang."""
+    import threading
+    import time
+    from aliparaformerasr_amd.offline_recognizer import ObjectDisposedException, OfflineRecognizer, RecognizerException
+    monkeypatch.setenv("PF_RECOGNIZER_ENGINES", "2")
+    p = mid_model_dir
+    audio = [W.synth_audio(20 * 16000, 60 + u) for u in range(8)]
+    for delay in (0.0, 0.05, 0.2, 0.5):
+        r = OfflineRecognizer(p["model"], p["config"], p["mvn"], p["tokens"])
+        errs = []
+
+        def loop():
+            try:
+                for _ in range(200):
+                    _batch_ids(r, audio)
+            except (ObjectDisposedException, RecognizerException):
+                pass
+            except BaseException as ex:               # noqa: BLE001
+                errs.append(ex)
+        th = [threading.Thread(target=loop) for _ in range(2)]
+        for x in th:
+            x.start()
+        time.sleep(delay)
+        t0 = time.perf_counter()
+        r.Dispose()
+        took = time.perf_counter() - t0
+        for x in th:
+            x.join(60)
+            assert not x.is_alive(), "a caller hangs after Dispose (delay %.2f s)" % delay
+        assert not errs, errs
+        assert took < 30, took
