@@ -150,6 +150,13 @@ SIGNATURES = {
     "pf_result_timestamp": (C.c_int, [_vp, C.c_int32, C.c_int32, _P(_i32), _i32]),
     "pf_result_num_timestamps": (C.c_int, [_vp, C.c_int32, _i32]),
     "pf_stream_tokens": (C.c_int, [_vp, _P(_i64), _i32]),
+    "pf_stream_create": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_char_p, _P(_vp)]),
+    "pf_stream_set_tokens": (C.c_int, [_vp, _i64, C.c_int32]),
+    "pf_stream_num_timestamps": (C.c_int, [_vp, _i32]),
+    "pf_stream_timestamp": (C.c_int, [_vp, C.c_int32, _P(_i32), _i32]),
+    "pf_stream_set_timestamps": (C.c_int, [_vp, _i32, _i32, C.c_int32]),
+    "pf_stream_get_speech": (C.c_int, [_vp, _f, C.c_int64, _i32]),
+    "pf_stream_set_speech": (C.c_int, [_vp, _f, C.c_int32, C.c_int32]),
     "pf_online_recognizer_create": (C.c_int, [C.c_char_p] * 5 + [C.c_int32, C.c_int32, _P(_vp)]),
     "pf_online_recognizer_dispose": (None, [_vp]),
     "pf_online_recognizer_free": (None, [_vp]),

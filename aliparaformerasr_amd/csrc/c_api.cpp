@@ -765,10 +765,31 @@ int pf_recognizer_create_stream(pf_recognizer* h, pf_stream** out) {
   PF_CATCH
 }
 
+int pf_stream_create(const char* mvn_path, int32_t fs, int32_t n_mels, int32_t lfr_m, int32_t lfr_n, int32_t snip_edges,
+                     float dither, const char* window, pf_stream** out) {
+  PF_TRY
+  NEED(out);
+  *out = nullptr;
+  ConfEntity c;                                     // FrontendConfEntity defaults where the caller passes 0 / NULL
+  if (fs > 0) c.fs = fs;
+  if (n_mels > 0) c.n_mels = n_mels;
+  if (lfr_m > 0) c.lfr_m = lfr_m;
+  if (lfr_n > 0) c.lfr_n = lfr_n;
+  c.snip_edges = snip_edges != 0;
+  c.dither = dither;
+  if (window && window[0]) c.window = window;
+  std::shared_ptr<Stream> s = std::make_shared<Stream>(std::string(mvn_path ? mvn_path : ""), c);
+  pf_stream* sh = stream_shells().get();
+  sh->s = s;
+  *out = sh;
+  return PF_OK;
+  PF_CATCH
+}
+
 int pf_stream_add_samples(pf_stream* h, const float* samples, int64_t n) {
   PF_TRY
   Stream* s = S(h);
-  PF_CHECK(!s->owner->disposed(), PF_ERR_DISPOSED, "OfflineRecognizer");
+  PF_CHECK(!s->owner || !s->owner->disposed(), PF_ERR_DISPOSED, "OfflineRecognizer");
   s->AddSamples(samples, n);
   return PF_OK;
   PF_CATCH
@@ -893,6 +914,83 @@ int pf_stream_tokens(pf_stream* h, const int64_t** ids, int32_t* n) {
   Stream* s = S(h);
   if (ids) *ids = s->Tokens.data();
   if (n) *n = (int32_t)s->Tokens.size();
+  return PF_OK;
+  PF_CATCH
+}
+
+int pf_stream_set_tokens(pf_stream* h, const int64_t* ids, int32_t n) {
+  PF_TRY
+  Stream* s = S(h);
+  PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "negative token count");
+  if (n > 0) NEED(ids);
+  s->Tokens.assign(ids, ids + n);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_stream_num_timestamps(pf_stream* h, int32_t* n) {
+  PF_TRY
+  NEED(n);
+  *n = (int32_t)S(h)->Timestamps.size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_stream_timestamp(pf_stream* h, int32_t j, const int32_t** ints, int32_t* n_ints) {
+  PF_TRY
+  Stream* s = S(h);
+  PF_CHECK(j >= 0 && j < (int32_t)s->Timestamps.size(), PF_ERR_INVALID_ARG, "timestamp index out of range");
+  if (ints) *ints = s->Timestamps[(size_t)j].data();
+  if (n_ints) *n_ints = (int32_t)s->Timestamps[(size_t)j].size();
+  return PF_OK;
+  PF_CATCH
+}
+int pf_stream_set_timestamps(pf_stream* h, const int32_t* ints, const int32_t* lens, int32_t n) {
+  PF_TRY
+  Stream* s = S(h);
+  PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "negative timestamp count");
+  std::vector<std::vector<int32_t>> ts;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    NEED(lens);
+    PF_CHECK(lens[i] >= 0, PF_ERR_INVALID_ARG, "negative timestamp length");
+    if (lens[i] > 0) NEED(ints);
+    ts.emplace_back(ints + off, ints + off + lens[i]);
+    off += (size_t)lens[i];
+  }
+  s->Timestamps.swap(ts);
+  return PF_OK;
+  PF_CATCH
+}
+int pf_stream_get_speech(pf_stream* h, float* out, int64_t cap, int32_t* n_floats) {
+  PF_TRY
+  Stream* s = S(h);
+  NEED(n_floats);
+  if (!s->has_speech) { *n_floats = -1; return PF_OK; }            // OfflineInputEntity.Speech == null
+  PF_CHECK(s->owner != nullptr || s->pending.empty(), PF_ERR_UNSUPPORTED,
+           "OfflineInputEntity.Speech of a stream no recognizer has adopted yet: its features are computed at the first GetResults");
+  if (s->device_form) {
+    PF_CHECK(!s->owner->disposed(), PF_ERR_DISPOSED, "OfflineRecognizer");
+    s->materialize();                                               // device form -> host form (features read back)
+  }
+  *n_floats = (int32_t)s->Speech.size();
+  PF_CHECK((int64_t)s->Speech.size() <= cap, PF_ERR_CAPACITY, "speech buffer too small");
+  if (!s->Speech.empty()) { NEED(out); std::memcpy(out, s->Speech.data(), s->Speech.size() * 4); }
+  return PF_OK;
+  PF_CATCH
+}
+int pf_stream_set_speech(pf_stream* h, const float* speech, int32_t n_floats, int32_t speech_length) {
+  PF_TRY
+  Stream* s = S(h);
+  s->drop_device_audio();
+  s->pending.clear();
+  if (n_floats < 0) {                                               // Speech = null
+    std::vector<float>().swap(s->Speech);
+    s->has_speech = false;
+  } else {
+    if (n_floats > 0) NEED(speech);
+    s->Speech.assign(speech, speech + n_floats);
+    s->has_speech = true;
+  }
+  s->SpeechLength = speech_length;
   return PF_OK;
   PF_CATCH
 }

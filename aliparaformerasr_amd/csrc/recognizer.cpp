@@ -211,10 +211,19 @@ static uint64_t register_recognizer() {
 
 // ------------------------------------------------------------------ Stream ----------------
 Stream::Stream(std::shared_ptr<Recognizer> r) : owner(std::move(r)) {}
+Stream::Stream(const std::string& mvn_path, const ConfEntity& conf) : uconf(conf) {
+  if (!mvn_path.empty()) parse_mvn_text(read_text_file(mvn_path.c_str()), ushift, uscale);   // WavFrontend.cs:19 LoadCmvn
+}
 Stream::~Stream() { drop_device_audio(); }
 
+// frames GetFbank + LfrCmvn return for one AddSamples call of n samples (WavFrontend.cs:31-111; kaldi frame count)
+static int conf_lfr_frames(const ConfEntity& c, int64_t n) {
+  const int t80 = c.snip_edges ? (n < 400 ? 0 : (int)(1 + (n - 400) / 160)) : (int)((n + 80) / 160);
+  return (c.lfr_m == 1 && c.lfr_n == 1) ? t80 : t80 / c.lfr_n;
+}
+
 void Stream::drop_device_audio() {
-  if (dev_audio) owner->audio_free(dev_audio, dev_bytes);
+  if (dev_audio && owner) owner->audio_free(dev_audio, dev_bytes);
   dev_audio = nullptr; dev_bytes = 0; dev_n = 0;
   device_form = false;
 }
@@ -236,8 +245,15 @@ void Stream::materialize() {
 void Stream::AddSamples(const float* samples, int64_t n) {
   if (disposed) throw Error(PF_ERR_DISPOSED, "OfflineStream");
   if (!samples) throw Error(PF_ERR_NULL_SAMPLES, "source");       // ArgumentNullException("source")
-  if (owner->disposed()) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
   PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "negative sample count");
+  if (!owner) {                                                    // public-constructor stream: replayed at adoption
+    pending.emplace_back(samples, samples + n);
+    const int m = (uconf.lfr_m != 1 || uconf.lfr_n != 1) ? uconf.lfr_m : 1;
+    has_speech = true;
+    SpeechLength += conf_lfr_frames(uconf, n) * m * uconf.n_mels;
+    return;
+  }
+  if (owner->disposed()) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
   if (!has_speech && !device_form && owner->device_streams()) {
     // first call: the samples go to the device and stay there; SpeechLength is what GetFbank + LfrCmvn would return
     // (OfflineStream.cs:40-41) — a function of the sample count
@@ -503,6 +519,24 @@ std::shared_ptr<Stream> Recognizer::CreateOfflineStream() {
   return std::make_shared<Stream>(shared_from_this());
 }
 
+void Recognizer::adopt(Stream* s) {
+  if (s->owner) return;
+  const ConfEntity& a = s->uconf; const ConfEntity& b = conf_;
+  const bool same = a.fs == b.fs && a.n_mels == b.n_mels && a.lfr_m == b.lfr_m && a.lfr_n == b.lfr_n &&
+                    a.snip_edges == b.snip_edges && a.dither == b.dither && a.window == b.window &&
+                    s->ushift == cmvn_shift_ && s->uscale == cmvn_scale_;
+  PF_CHECK(same, PF_ERR_UNSUPPORTED,
+           "OfflineStream(mvnFilePath, confEntity): the stream's front-end differs from the recognizer's (am.mvn values or "
+           "frontend_conf); create it with CreateOfflineStream or with the recognizer's own files");
+  s->owner = shared_from_this();
+  std::vector<std::vector<float>> calls;
+  calls.swap(s->pending);
+  s->has_speech = false;
+  s->SpeechLength = 0;
+  static const float kNone = 0.f;
+  for (auto& c : calls) s->AddSamples(c.empty() ? &kNone : c.data(), (int64_t)c.size());
+}
+
 void Recognizer::Dispose() {
   std::vector<std::shared_ptr<Engine>> es;
   std::map<size_t, std::vector<float*>> cache;
@@ -548,6 +582,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
   if (streams.empty()) return;                                      // :120-123
   try {
     if (disposed_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");
+    for (Stream* s : streams) adopt(s);
     // the fast form needs every stream in the device form; otherwise every stream is brought to the host form first
     bool all_dev = device_streams_;
     for (Stream* s : streams) all_dev = all_dev && s->device_form;

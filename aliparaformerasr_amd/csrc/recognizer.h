@@ -53,7 +53,15 @@ class Recognizer;
 class Stream {
  public:
   explicit Stream(std::shared_ptr<Recognizer> r);
+  // The reference's PUBLIC constructor, new OfflineStream(mvnFilePath, confEntity) (OfflineStream.cs:20-28): a stream that
+  // belongs to no recognizer yet.  It owns no engine, so AddSamples keeps the samples on the host (SpeechLength is a function
+  // of the sample counts) and the first GetResults that receives it adopts it (Recognizer::adopt): the pending calls are
+  // replayed there.  Its front-end must be the adopting recognizer's (same am.mvn values, same frontend_conf) — the reference
+  // would compute the features with the stream's own files; anything else answers PF_ERR_UNSUPPORTED instead of guessing.
+  Stream(const std::string& mvn_path, const ConfEntity& conf);
   ~Stream();
+  ConfEntity uconf; std::vector<float> ushift, uscale;        // unbound form only
+  std::vector<std::vector<float>> pending;                    // AddSamples calls not yet replayed
   void AddSamples(const float* samples, int64_t n);          // OfflineStream.cs:36-57
   void Dispose();                                             // OfflineStream.cs:81-121: drops the buffers
   std::vector<float> Speech;                                  // OfflineInputEntity.Speech (host form)
@@ -80,6 +88,7 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
              int threads_num, int device);
   ~Recognizer();
   std::shared_ptr<Stream> CreateOfflineStream();              // OfflineRecognizer.cs:92-100
+  void adopt(Stream* s);                                      // binds a stream built with the public constructor (see Stream)
   // GetResults (:110-116).  The result list belongs to the CALLING THREAD until its next GetResults on this
   // recognizer (the reference returns a fresh List per call; concurrent callers must not share one).
   void GetResults(const std::vector<Stream*>& streams);

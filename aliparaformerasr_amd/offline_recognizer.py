@@ -64,11 +64,52 @@ class OfflineRecognizerResultEntity:
     Timestamps: List[List[int]] = field(default_factory=list)
 
 
+@dataclass
+class FrontendConfEntity:
+    """Model/FrontendConfEntity.cs:6-28 (defaults included)."""
+    fs: int = 16000
+    window: str = "hamming"
+    n_mels: int = 80
+    frame_length: int = 25
+    frame_shift: int = 10
+    dither: float = 1.0
+    lfr_m: int = 7
+    lfr_n: int = 6
+    snip_edges: bool = False
+
+
+@dataclass
+class ConfEntity:
+    """Model/ConfEntity.cs: only what OfflineStream's constructor reads (frontend_conf)."""
+    frontend_conf: FrontendConfEntity = field(default_factory=FrontendConfEntity)
+
+
+@dataclass
+class OfflineInputEntity:
+    """Model/OfflineInputEntity.cs:6-11."""
+    Speech: Optional[np.ndarray] = None
+    SpeechLength: int = 0
+    Hotwords: Optional[List[List[int]]] = field(default_factory=list)
+
+
 class OfflineStream:
-    def __init__(self, lib, handle, recognizer=None):
-        self._lib = lib
-        self._h = handle
-        self._recognizer = recognizer       # keeps the recognizer wrapper (and its native handle) alive
+    Hyp: List[int] = [0, 0]                 # OfflineStream.cs:24,31 (per instance below)
+
+    def __init__(self, mvnFilePath=None, confEntity=None, *, _lib=None, _handle=None, _recognizer=None):
+        """Public form: OfflineStream(mvnFilePath, confEntity) (OfflineStream.cs:20-28) — a stream that belongs to no
+        recognizer yet; the first GetResults that receives it adopts it.  CreateOfflineStream uses the private form."""
+        self.Hyp = [0, 0]                   # OfflineStream.cs:24,31: never read again by the reference
+        if _handle is not None:
+            self._lib, self._h, self._recognizer = _lib, _handle, _recognizer
+            return
+        self._lib = N.load()
+        self._recognizer = None
+        f = (confEntity or ConfEntity()).frontend_conf
+        h = C.c_void_p()
+        _ck(self._lib.pf_stream_create((mvnFilePath or "").encode("utf-8"), f.fs, f.n_mels, f.lfr_m, f.lfr_n,
+                                       1 if f.snip_edges else 0, float(f.dither), (f.window or "").encode("utf-8"),
+                                       C.byref(h)))
+        self._h = h
 
     def AddSamples(self, samples) -> None:
         if samples is None:
@@ -108,6 +149,59 @@ class OfflineStream:
         _ck(self._lib.pf_stream_tokens(self._h, C.byref(p), n))
         return [p[i] for i in range(n.value)]
 
+    @Tokens.setter
+    def Tokens(self, value: List[int]) -> None:
+        a = (C.c_int64 * max(len(value), 1))(*value)
+        _ck(self._lib.pf_stream_set_tokens(self._h, a, len(value)))
+
+    @property
+    def Timestamps(self) -> List[List[int]]:
+        n = C.c_int32()
+        _ck(self._lib.pf_stream_num_timestamps(self._h, n))
+        out = []
+        for j in range(n.value):
+            p = C.POINTER(C.c_int32)()
+            k = C.c_int32()
+            _ck(self._lib.pf_stream_timestamp(self._h, j, C.byref(p), k))
+            out.append([p[m] for m in range(k.value)])
+        return out
+
+    @Timestamps.setter
+    def Timestamps(self, value: List[List[int]]) -> None:
+        flat = [v for t in value for v in t]
+        ints = (C.c_int32 * max(len(flat), 1))(*flat)
+        lens = (C.c_int32 * max(len(value), 1))(*[len(t) for t in value])
+        _ck(self._lib.pf_stream_set_timestamps(self._h, ints, lens, len(value)))
+
+    @property
+    def OfflineInputEntity(self) -> OfflineInputEntity:
+        n = C.c_int32()
+        rc = self._lib.pf_stream_get_speech(self._h, None, 0, n)
+        speech = None
+        if rc == N.PF_ERR_CAPACITY:
+            speech = np.empty(n.value, np.float32)
+            _ck(self._lib.pf_stream_get_speech(self._h, speech.ctypes.data_as(C.POINTER(C.c_float)), speech.size, n))
+        else:
+            _ck(rc)
+            speech = None if n.value < 0 else np.empty(0, np.float32)
+        return OfflineInputEntity(Speech=speech, SpeechLength=self.SpeechLength, Hotwords=self.Hotwords)
+
+    @OfflineInputEntity.setter
+    def OfflineInputEntity(self, value: OfflineInputEntity) -> None:
+        if value is None or value.Speech is None:
+            _ck(self._lib.pf_stream_set_speech(self._h, None, -1, 0 if value is None else value.SpeechLength))
+        else:
+            x = np.ascontiguousarray(value.Speech, dtype=np.float32)
+            _ck(self._lib.pf_stream_set_speech(self._h, x.ctypes.data_as(C.POINTER(C.c_float)), x.size, value.SpeechLength))
+        self.Hotwords = None if value is None else value.Hotwords
+
+    def GetDecodeChunk(self) -> OfflineInputEntity:        # OfflineStream.cs:58-68
+        return self.OfflineInputEntity
+
+    def RemoveChunk(self) -> None:                         # OfflineStream.cs:69-79
+        if len(self.Tokens) > 2:
+            _ck(self._lib.pf_stream_set_speech(self._h, None, -1, 0))
+
     @property
     def SpeechLength(self) -> int:
         n = C.c_int32()
@@ -144,7 +238,7 @@ class OfflineRecognizer:
     def CreateOfflineStream(self) -> OfflineStream:
         s = C.c_void_p()
         _ck(self._lib.pf_recognizer_create_stream(self._h, C.byref(s)))
-        return OfflineStream(self._lib, s, self)
+        return OfflineStream(_lib=self._lib, _handle=s, _recognizer=self)
 
     def GetResult(self, stream: OfflineStream) -> OfflineRecognizerResultEntity:
         return self.GetResults([stream])[0]

@@ -1,5 +1,5 @@
 // OfflineRecognizerHip.cs — drop-in classes with the public signatures of OfflineRecognizer
-// (AliParaformerAsr/OfflineRecognizer.cs:23,92,102,110,441,468) and OfflineStream (OfflineStream.cs:20,34,36), backed
+// (AliParaformerAsr/OfflineRecognizer.cs:23,92,102,110,441,468) and OfflineStream (OfflineStream.cs:20,30-34,36,58,69,115), backed
 // by the native mirror pf_recognizer_* / pf_stream_*: front-end, model, arg-max, time_stamp_lfr6_onnx and
 // DecodeMulti all run behind the C ABI; only ids, timestamps and text cross it.
 using System;
@@ -10,13 +10,68 @@ using AliParaformerAsr.Native;
 
 namespace AliParaformerAsr.Hip
 {
-    public sealed class OfflineStream : IDisposable
+    public class OfflineStream : IDisposable
     {
         internal IntPtr Handle;
         internal OfflineStream(IntPtr h) { Handle = h; }
 
+        /// <summary>OfflineStream.cs:20-28.  A stream that belongs to no recognizer yet: its AddSamples calls are kept and
+        /// replayed by the first GetResults that receives it (the front-end runs on that recognizer's GPU); the am.mvn values
+        /// and frontend_conf must be that recognizer's.</summary>
+        public OfflineStream(string mvnFilePath, ConfEntity confEntity)
+        {
+            FrontendConfEntity f = confEntity.frontend_conf;
+            ParaformerHip.Check(ParaformerHip.pf_stream_create(mvnFilePath ?? "", f.fs, f.n_mels, f.lfr_m, f.lfr_n, f.snip_edges ? 1 : 0,
+                                                               f.dither, f.window ?? "", out Handle));
+        }
+
         public void AddSamples(float[] samples)
             => ParaformerHip.Check(ParaformerHip.pf_stream_add_samples(Handle, samples, samples == null ? 0 : samples.LongLength));
+
+        /// <summary>OfflineStream.cs:58-68: the entity Forward reads.  A snapshot: features that live on the device are
+        /// computed and read back for it.</summary>
+        public OfflineInputEntity GetDecodeChunk() => OfflineInputEntity;
+
+        /// <summary>OfflineStream.cs:69-79.</summary>
+        public void RemoveChunk()
+        {
+            if (Tokens.Count > 2) ParaformerHip.Check(ParaformerHip.pf_stream_set_speech(Handle, null, -1, 0));
+        }
+
+        /// <summary>OfflineStream.cs:30.  get: a snapshot {Speech, SpeechLength, Hotwords}; set: written through.</summary>
+        public OfflineInputEntity OfflineInputEntity
+        {
+            get
+            {
+                var e = new OfflineInputEntity();
+                ParaformerHip.Check(ParaformerHip.pf_stream_num_feature_floats(Handle, out int len));
+                int rc = ParaformerHip.pf_stream_get_speech(Handle, null, 0, out int n);
+                if (rc == ParaformerHip.PF_ERR_CAPACITY)
+                {
+                    var a = new float[n];
+                    ParaformerHip.Check(ParaformerHip.pf_stream_get_speech(Handle, a, a.LongLength, out n));
+                    e.Speech = a;
+                }
+                else
+                {
+                    ParaformerHip.Check(rc);
+                    e.Speech = n < 0 ? null : new float[0];
+                }
+                e.SpeechLength = len;
+                e.Hotwords = Hotwords;
+                return e;
+            }
+            set
+            {
+                ParaformerHip.Check(ParaformerHip.pf_stream_set_speech(Handle, value?.Speech, value?.Speech == null ? -1 : value.Speech.Length,
+                                                                       value?.SpeechLength ?? 0));
+                Hotwords = value?.Hotwords;
+            }
+        }
+
+        /// <summary>OfflineStream.cs:31.  {blank, blank} from the constructor on; nothing in the reference reads it afterwards
+        /// (Forward works on Tokens), so it stays a managed field.</summary>
+        public Int64[] Hyp { get; set; } = new Int64[] { 0, 0 };
 
         public List<int[]>? Hotwords
         {
@@ -47,12 +102,41 @@ namespace AliParaformerAsr.Hip
                 if (n > 0) Marshal.Copy(p, a, 0, n);
                 return new List<Int64>(a);
             }
+            set
+            {
+                long[] a = value == null ? new long[0] : value.ToArray();
+                ParaformerHip.Check(ParaformerHip.pf_stream_set_tokens(Handle, a, a.Length));
+            }
         }
 
-        public void Dispose()
+        public List<int[]> Timestamps                                           // OfflineStream.cs:33
+        {
+            get
+            {
+                ParaformerHip.Check(ParaformerHip.pf_stream_num_timestamps(Handle, out int n));
+                var r = new List<int[]>(n);
+                for (int j = 0; j < n; j++)
+                {
+                    ParaformerHip.Check(ParaformerHip.pf_stream_timestamp(Handle, j, out IntPtr p, out int k));
+                    var a = new int[k];
+                    if (k > 0) Marshal.Copy(p, a, 0, k);
+                    r.Add(a);
+                }
+                return r;
+            }
+            set
+            {
+                var flat = new List<int>(); var lens = new int[Math.Max(value?.Count ?? 0, 1)];
+                for (int i = 0; i < (value?.Count ?? 0); i++) { flat.AddRange(value![i]); lens[i] = value[i].Length; }
+                ParaformerHip.Check(ParaformerHip.pf_stream_set_timestamps(Handle, flat.ToArray(), lens, value?.Count ?? 0));
+            }
+        }
+
+        protected virtual void Dispose(bool disposing)                          // OfflineStream.cs:81-113
         {   // later calls answer ObjectDisposedException("OfflineStream"); the finaliser releases the handle
             if (Handle != IntPtr.Zero) ParaformerHip.pf_stream_dispose(Handle);
         }
+        public void Dispose() => Dispose(disposing: true);                      // :115 (the finaliser is NOT suppressed: it frees the handle)
         ~OfflineStream() { if (Handle != IntPtr.Zero) { ParaformerHip.pf_stream_free(Handle); Handle = IntPtr.Zero; } }
     }
 

@@ -1,4 +1,4 @@
-// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 5).
+// ParaformerHip.cs — P/Invoke declarations of libparaformer_hip.so (include/paraformer_hip.h, PF_ABI_VERSION 6).
 // Drop into the reference project (AliParaformerAsr/Native/) — see csharp/README.md.  Not compiled in the build
 // image of this repository (no .NET toolchain); the same entry points are exercised through the Python ctypes
 // binding aliparaformerasr_amd/_native.py by tests/.
@@ -23,7 +23,9 @@ namespace AliParaformerAsr.Native
         public int use_itn;
         public int frame_length_ms, frame_shift_ms, dither_seed;
         /// <summary>0 = f16 MFMA (model.onnx semantics, default), 1 = fp32 MFMA parity mode, 2 = dynamic int8 as the
-        /// reference's default model.int8.onnx computes (Examples/Program.cs:98-101): Linear layers on the int8 MFMA.</summary>
+        /// reference's default model.int8.onnx computes (Examples/Program.cs:98-101): Linear layers on the int8 MFMA,
+        /// 3 = "exact" at matrix-core speed (ABI 5): the fp32 graph with every large Linear as three f16 MFMA products of
+        /// (hi, lo) operand pairs — token-identical to fp32 on the benchmark batches.</summary>
         public int math_mode;
         public int reserved0, reserved1, reserved2;
     }
@@ -99,6 +101,15 @@ namespace AliParaformerAsr.Native
         [DllImport(Lib)] internal static extern int pf_stream_get_hotwords(IntPtr s, [Out] int[] ids, int idsCap, [Out] int[] lens, int lensCap, out int nHotwords);
         [DllImport(Lib)] internal static extern int pf_stream_num_feature_floats(IntPtr s, out int n);
         [DllImport(Lib)] internal static extern int pf_stream_tokens(IntPtr s, out IntPtr ids, out int n);
+        // ABI 6: the rest of OfflineStream's public surface (OfflineStream.cs:20-34)
+        [DllImport(Lib)] internal static extern int pf_stream_create([MarshalAs(UnmanagedType.LPUTF8Str)] string mvnPath, int fs, int nMels, int lfrM, int lfrN,
+                                                                    int snipEdges, float dither, [MarshalAs(UnmanagedType.LPUTF8Str)] string window, out IntPtr stream);
+        [DllImport(Lib)] internal static extern int pf_stream_set_tokens(IntPtr s, long[]? ids, int n);
+        [DllImport(Lib)] internal static extern int pf_stream_num_timestamps(IntPtr s, out int n);
+        [DllImport(Lib)] internal static extern int pf_stream_timestamp(IntPtr s, int j, out IntPtr ints, out int nInts);
+        [DllImport(Lib)] internal static extern int pf_stream_set_timestamps(IntPtr s, int[]? ints, int[]? lens, int n);
+        [DllImport(Lib)] internal static extern int pf_stream_get_speech(IntPtr s, [Out] float[]? speech, long cap, out int nFloats);
+        [DllImport(Lib)] internal static extern int pf_stream_set_speech(IntPtr s, float[]? speech, int nFloats, int speechLength);
         [DllImport(Lib)] internal static extern void pf_stream_dispose(IntPtr s);
         [DllImport(Lib)] internal static extern void pf_stream_free(IntPtr s);
         [DllImport(Lib)] internal static extern int pf_recognizer_get_results(IntPtr r, IntPtr[] streams, int nStreams);

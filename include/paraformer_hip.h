@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 5
+#define PF_ABI_VERSION 6
 
 typedef enum pf_status {
   PF_OK = 0,
@@ -458,6 +458,25 @@ int pf_result_timestamp(pf_recognizer* r, int32_t i, int32_t j, const int32_t** 
 int pf_result_num_timestamps(pf_recognizer* r, int32_t i, int32_t* n);
 /* stream.Tokens after Forward (raw ids, OfflineRecognizer.cs:187). */
 int pf_stream_tokens(pf_stream* s, const int64_t** ids, int32_t* n);
+
+/* ABI 6: the rest of OfflineStream's public surface (OfflineStream.cs:20-34).  Only the reference's own Forward touches
+   these members, but "same public signatures" means a caller may.
+   new OfflineStream(mvnFilePath, confEntity) (:20-28): a stream that belongs to no recognizer yet; the arguments are
+   confEntity.frontend_conf's fields (0 / NULL = the FrontendConfEntity default).  Its AddSamples calls are kept on the host
+   and replayed by the first GetResults that receives it; a front-end other than that recognizer's -> PF_ERR_UNSUPPORTED
+   (raised by that GetResults inside Forward's try block: "Offline recognition failed"). */
+int pf_stream_create(const char* mvn_path, int32_t fs, int32_t n_mels, int32_t lfr_m, int32_t lfr_n, int32_t snip_edges,
+                     float dither, const char* window, pf_stream** out);
+int pf_stream_set_tokens(pf_stream* s, const int64_t* ids, int32_t n);          /* Tokens { set; }      :32 */
+int pf_stream_num_timestamps(pf_stream* s, int32_t* n);                          /* Timestamps { get; }  :33 */
+int pf_stream_timestamp(pf_stream* s, int32_t j, const int32_t** ints, int32_t* n_ints);
+int pf_stream_set_timestamps(pf_stream* s, const int32_t* ints, const int32_t* lens, int32_t n);   /* Timestamps { set; } */
+/* OfflineInputEntity { Speech, SpeechLength } (:30; Model/OfflineInputEntity.cs).  get: *n_floats = -1 when Speech is null,
+   else the float count (PF_ERR_CAPACITY with the count reported when cap is smaller); a stream whose samples live on the
+   device is brought to the host form (features computed and read back).  set: n_floats < 0 sets Speech = null;
+   speech_length is stored as given (the reference's two setters are independent). */
+int pf_stream_get_speech(pf_stream* s, float* out, int64_t cap, int32_t* n_floats);
+int pf_stream_set_speech(pf_stream* s, const float* speech, int32_t n_floats, int32_t speech_length);
 
 /* ------------------------------------------------------------------------ */
 /* 7. Streaming path: the reference's OnlineRecognizer / OnlineStream

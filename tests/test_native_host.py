@@ -20,7 +20,7 @@ def lib():
 
 def test_library_is_in_tree_and_loads(lib):
     assert os.path.dirname(N.LIB_PATH) == os.path.join(ROOT, "aliparaformerasr_amd")
-    assert lib.pf_version() == 5
+    assert lib.pf_version() == 6
 
 
 def test_exports_every_declared_symbol(lib):
@@ -215,3 +215,41 @@ def test_header_is_plain_c99_and_cxx11(tmp_path):
                 ["gcc", "-std=c99", "-Wall", "-fsyntax-only", inc, os.path.join(root, "tests", "native", "abi_host_fuzz.c")]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, (cmd, r.stderr[-2000:])
+
+
+def test_public_constructor_stream_without_a_recognizer(tmp_path):
+    """ABI 6: new OfflineStream(mvnFilePath, confEntity) (OfflineStream.cs:20-34) needs no device — the
+    samples wait on the host, SpeechLength follows the sample counts call by call (LFR floor per call, as AddSamples
+    appends the features of each call), Tokens / Timestamps / OfflineInputEntity are plain state."""
+    from aliparaformerasr_amd import weights as W
+    from aliparaformerasr_amd.offline_recognizer import (ArgumentNullException, ConfEntity, FrontendConfEntity,
+                                                         OfflineInputEntity, OfflineStream)
+    from oracle import frontend as fe
+    shift, scale = W.synth_cmvn()
+    mvn = tmp_path / "am.mvn"
+    mvn.write_text(fe.format_mvn_text(shift, scale))
+    s = OfflineStream(str(mvn), ConfEntity(FrontendConfEntity(dither=0.0)))
+    assert s.Tokens == [0, 0] and s.Hyp == [0, 0] and s.Timestamps == [] and s.Hotwords == []
+    assert s.OfflineInputEntity.Speech is None and s.SpeechLength == 0
+    with pytest.raises(ArgumentNullException):
+        s.AddSamples(None)
+    want = 0
+    for n in (16000, 7, 32000 + 159):
+        s.AddSamples(np.zeros(n, np.float32))
+        want += ((n + 80) // 160) // 6 * 560
+        assert s.SpeechLength == want
+    s.Tokens = [5, 6, 7]
+    assert s.Tokens == [5, 6, 7]
+    s.Timestamps = [[0, 60], [60, 120, 120, 180]]
+    assert s.Timestamps == [[0, 60], [60, 120, 120, 180]]
+    s.RemoveChunk()                                  # more than two tokens: Speech = null, SpeechLength = 0 (:69-79)
+    assert s.OfflineInputEntity.Speech is None and s.SpeechLength == 0
+    e = OfflineInputEntity(Speech=np.arange(1120, dtype=np.float32), SpeechLength=1120, Hotwords=[[3, 4], [9]])
+    s.OfflineInputEntity = e
+    got = s.GetDecodeChunk()
+    np.testing.assert_array_equal(got.Speech, e.Speech)
+    assert got.SpeechLength == 1120 and got.Hotwords == [[3, 4], [9]]
+    s.Dispose()
+    from aliparaformerasr_amd.offline_recognizer import ObjectDisposedException
+    with pytest.raises(ObjectDisposedException):
+        s.AddSamples(np.zeros(10, np.float32))
