@@ -1,7 +1,8 @@
-"""Command-line harness mirroring AliParaformerAsr.Examples (offline part).
+"""Command-line harness mirroring AliParaformerAsr.Examples (`-type offline` and `-type online`).
 
     python -m aliparaformerasr_amd.examples -type offline -method batch -base <dir> -model <name> \
         [-accuracy int8] [-threads 2] -files a.wav b.wav
+    python -m aliparaformerasr_amd.examples -type online -method one -base <dir> -model <name> -files a.wav
 
 Mirrors (file:line in /root/reference/AliParaformerAsr.Examples):
   * argument handling and defaults — Program.cs:93-104, ParseArgs :197-252: the MANYSPEECH_BASE / _TYPE / _BATCH / _MODEL /
@@ -13,7 +14,11 @@ Mirrors (file:line in /root/reference/AliParaformerAsr.Examples):
   * sample loading — IsAudioByHeader + GetFileSample (:121-160, Utils/AudioHelper.cs:12-32) through the native
     pf_host_wav_read / pf_host_is_audio; default file list = every *.wav under the model directory;
   * "-method one" / "-method batch" loops, the JSON-ish result line and the timing lines — :169-249 (the timed
-    window includes stream creation, AddSamples, GetResults, printing and Dispose, as upstream)."""
+    window includes stream creation, AddSamples, GetResults, printing and Dispose, as upstream);
+  * `-type online` (Program.cs:290-297) — OnlineAliParaformerAsrRecognizer.cs:8-279: encoder / decoder file selection
+    (:43-63), at most TWO media files (:121-171), 9600-sample chunks (AudioHelper.GetFileChunkSamples :80-127) plus six
+    400-sample silence chunks (:160-163), one AddSamples + GetResult + printed text per chunk (:181-194; only the "one"
+    method exists upstream — the batch loop is commented out there), timing lines :272-279."""
 from __future__ import annotations
 
 import ctypes as C
@@ -159,6 +164,96 @@ def offline_recognizer(method="one", model="paraformer-seaco-large-zh-timestamp-
     return results
 
 
+def select_online_model_files(base: str, model: str, accuracy: str):
+    """OnlineAliParaformerAsrRecognizer.cs:15-84 (the containers here are .pfw instead of .onnx)."""
+    folder = os.path.join(base, model)
+    if not os.path.isdir(folder):
+        print("Error: folder does not exist - %s" % folder)
+        return None
+    names = sorted(f for f in os.listdir(folder) if os.path.isfile(os.path.join(folder, f)))
+    full = lambda f: os.path.join(base, model, f)
+
+    def pick(cands):
+        pref = [f for f in cands if (".%s." % accuracy) in f]
+        return full(pref[-1]) if pref else (full(cands[-1]) if cands else "")
+
+    def last(pred):
+        m = [f for f in names if pred(f)]
+        return full(m[-1]) if m else ""
+    return dict(
+        encoderFilePath=pick([f for f in names if f.startswith("model") or f.startswith("encoder")]),
+        decoderFilePath=pick([f for f in names if f.startswith("decoder")]),
+        configFilePath=last(lambda f: f.startswith("asr") and (f.endswith(".yaml") or f.endswith(".json"))),
+        mvnFilePath=last(lambda f: f.startswith("am") and f.endswith(".mvn")),
+        tokensFilePath=last(lambda f: f.startswith("tokens")),
+    )
+
+
+def get_file_chunk_samples(path: str, chunk: int = 160 * 6 * 10):
+    """AudioHelper.GetFileChunkSamples (:80-127): GetFileSample's samples cut into 9600-sample pieces, the last one shorter."""
+    s, dur = get_file_sample(path)
+    return [s[i: i + chunk] for i in range(0, len(s), chunk)], dur
+
+
+def online_recognizer(method="one", model="speech_paraformer-large_asr_nat-zh-cn-16k-common-vocab8404-online-onnx",
+                      accuracy="int8", threads=2, files=None, base=None, out=sys.stdout):
+    from .online_recognizer import OnlineRecognizer
+    base = base or os.getcwd()
+    if not model:
+        print("Init models failure!", file=out)
+        return None
+    sel = select_online_model_files(base, model, accuracy)
+    if sel is None or not sel["encoderFilePath"] or not sel["tokensFilePath"]:
+        print("Init models failure!", file=out)
+        return None
+    t0 = time.perf_counter()
+    try:
+        rec = OnlineRecognizer(threadsNum=threads, **sel)
+    except Exception as ex:                                 # :97-100
+        print("Error occurred: %s" % ex, file=out)
+        print("Init models failure!", file=out)
+        return None
+    print("init_models_elapsed_milliseconds:%s" % ((time.perf_counter() - t0) * 1e3), file=out)
+    t0 = time.perf_counter()                                # :126: the window opens before the files are read
+    if not files:
+        files = []
+        for d, _dirs, fs in os.walk(os.path.join(base, model)):
+            files += [os.path.join(d, f) for f in sorted(fs) if f.lower().endswith(".wav")]
+    samples_list, total_ms, n = [], 0.0, 0
+    for f in files:
+        if n >= 2:                                          # batchSize = 2 (:129, :152-155)
+            break
+        if not os.path.isfile(f):
+            continue
+        if is_audio_by_header(f):
+            chunks, dur = get_file_chunk_samples(f)
+            if chunks:
+                chunks += [np.zeros(400, np.float32) for _ in range(6)]          # :160-163
+                samples_list.append(chunks)
+                total_ms += dur
+        n += 1
+    if not samples_list:
+        print("No media file is read!", file=out)
+        return None
+    method = method or "batch"
+    texts = []
+    if method == "one":                                     # :176-194 (the only method the reference runs)
+        for chunks in samples_list:
+            st = rec.CreateOnlineStream()
+            for c in chunks:
+                st.AddSamples(c)
+                r = rec.GetResult(st)
+                print(r.Text, file=out)
+                texts.append(r.Text)
+    rec.Dispose()
+    elapsed = (time.perf_counter() - t0) * 1e3
+    print("elapsed_milliseconds:%s" % elapsed, file=out)
+    print("total_duration:%s" % total_ms, file=out)
+    print("rtf:%s" % (elapsed / total_ms if total_ms else float("inf")), file=out)
+    print("Hello, World!", file=out)
+    return texts
+
+
 def parse_args(argv, env=None):
     # environment variables are the defaults, command-line parameters overwrite them (Program.cs:20-28, :93-104)
     env = os.environ if env is None else env
@@ -205,11 +300,16 @@ def main(argv=None):
     except ValueError as ex:
         print("parameter error: %s" % ex)
         return 2
-    if cfg["recognizerType"] != "offline":
-        print("only -type offline is built (the streaming path is out of scope, DESIGN.md §7)")
+    # Program.cs:290-308
+    if cfg["recognizerType"] == "online":
+        online_recognizer(cfg["methodType"], cfg["modelName"], cfg["modelAccuracy"], cfg["threads"], cfg["files"],
+                          cfg["modelBasePath"] or None)
+    elif cfg["recognizerType"] == "offline":
+        offline_recognizer(cfg["methodType"], cfg["modelName"], cfg["modelAccuracy"], cfg["threads"], cfg["files"],
+                           cfg["modelBasePath"] or None)
+    else:
+        print("the recognizer type must be online or offline")
         return 2
-    offline_recognizer(cfg["methodType"], cfg["modelName"], cfg["modelAccuracy"], cfg["threads"], cfg["files"],
-                       cfg["modelBasePath"] or None)
     return 0
 
 

@@ -200,3 +200,33 @@ def test_environment_variables_are_the_defaults_and_flags_overwrite_them():
     assert ex.parse_args(["-type", "offline"], {})["modelAccuracy"] == "int8"        # Program.cs:100 default
     with pytest.raises(ValueError, match="valid integer"):
         ex.parse_args(["-type", "offline"], {"MANYSPEECH_THREADS": "many"})
+
+
+def test_online_harness_file_selection_chunking_and_routing(tmp_path, capsys):
+    """`-type online` (Program.cs:290-297): encoder = `model*` | `encoder*` preferring ".<accuracy>.", decoder = `decoder*`
+    (OnlineAliParaformerAsrRecognizer.cs:43-63); GetFileChunkSamples = 9600-sample pieces (AudioHelper.cs:80-127); an
+    unknown type is refused with the reference's message; a missing model directory ends in "Init models failure!"."""
+    from aliparaformerasr_amd import examples as ex
+    d = tmp_path / "on"
+    d.mkdir()
+    for f in ("encoder.int8.pfw", "encoder.pfw", "decoder.int8.pfw", "decoder.pfw", "asr.yaml", "am.mvn", "tokens.txt", "tokens.json"):
+        (d / f).write_text("x")
+    sel = ex.select_online_model_files(str(tmp_path), "on", "int8")
+    assert sel["encoderFilePath"].endswith("encoder.int8.pfw") and sel["decoderFilePath"].endswith("decoder.int8.pfw")
+    assert sel["tokensFilePath"].endswith("tokens.txt") and sel["mvnFilePath"].endswith("am.mvn")
+    sel = ex.select_online_model_files(str(tmp_path), "on", "fp32")          # no ".fp32." file: the last candidate
+    assert sel["encoderFilePath"].endswith("encoder.pfw") and sel["decoderFilePath"].endswith("decoder.pfw")
+    x = (np.arange(9600 * 2 + 123) % 200 - 100).astype(np.float32) / 32768.0
+    import struct
+    pcm = np.round(x * 32768.0).astype("<i2").tobytes()
+    (tmp_path / "c.wav").write_bytes(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " +
+                                     struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    chunks, dur = ex.get_file_chunk_samples(str(tmp_path / "c.wav"))
+    assert [len(c) for c in chunks] == [9600, 9600, 123] and abs(dur - (9600 * 2 + 123) / 16.0) < 1e-6
+    np.testing.assert_array_equal(np.concatenate(chunks), x)
+    assert ex.main(["-type", "both"]) == 2
+    assert "the recognizer type must be online or offline" in capsys.readouterr().out
+    import io
+    buf = io.StringIO()
+    assert ex.online_recognizer("one", "absent", "int8", 2, None, str(tmp_path), out=buf) is None
+    assert "Init models failure!" in buf.getvalue()
