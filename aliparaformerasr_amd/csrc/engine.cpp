@@ -1752,6 +1752,9 @@ enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
 // throughout, 2 = fp32 scores (what is exponentiated stays exact) + x3 operands for P V
 void Engine::attention32(const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs, const float* v, int64_t v_bs,
                          int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk, bool only_operand) {
+  const char* acls = (q_rs == k_rs && Lq == Lk) ? "attn32_self" : "attn32_cross";
+  prof_begin(acls, 4.0 * B * H * (double)Lq * Lk * 128);
+  struct End { Engine* e; const char* c; ~End() { e->prof_end(c); } } end_{this, acls};
   // only_operand: o [B * Lq, H * 128] (dense rows) is nothing but the A operand of the gemm32 that follows — in math_mode 3 the
   // fp32-MFMA kernel's epilogue writes it as that product's (hi | lo') pair (no fp32 context, no split pass)
   const int Dm = H * 128, M = B * Lq;
@@ -1770,6 +1773,8 @@ void Engine::attention32(const float* q, int64_t q_bs, int q_rs, const float* k,
 }
 
 void Engine::layernorm32(const float* x, int M, int D, const LNp& ln, float* xn) {
+  prof_begin("layernorm", 0);
+  struct End { Engine* e; ~End() { e->prof_end("layernorm"); } } end_{this};
   if (x3_mode_ && x3_fuse_ && D == 512 && M > gemm_small_max_rows()) {
     const int64_t Mp = round_up(M, 256) + 128;
     ensure(ws_x3a_, (size_t)Mp * 2 * D * 2);
@@ -1783,6 +1788,15 @@ void Engine::layernorm32(const float* x, int M, int D, const LNp& ln, float* xn)
 
 void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
                     const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
+  // the class's FLOPs are the fp32 graph's 2 M N K; math_mode 3 executes three times that on the f16 matrix cores
+  const char* cls = cls32_;
+  prof_begin(cls, 2.0 * M * (double)N * K);
+  gemm32_impl(A, lda, W, ldw, bias, M, N, K, out, ldc, resid, ldr, relu, scale_cols, scale, flags, resid2);
+  prof_end(cls);
+}
+
+void Engine::gemm32_impl(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
+                         const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
   // (a q-scale on the leading columns only — the fused Q | K | V product — is an option of the one-launch form's epilogue)
   const bool part_scale = scale_cols > 0 && scale_cols < N;
   const bool x3 = x3_mode_ && M >= 64 && ldw == K && (!part_scale || (x3_one_ && scale_cols % 64 == 0 && M > gemm_small_max_rows())) &&
@@ -1886,10 +1900,13 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
   // q-scale on the first D columns) into the three consecutive buffers read as one [M, 3 D] matrix
   const bool qkv_one = x3_mode_ && x3_one_ && x3_fuse_ && M > gemm_small_max_rows() && mc_.kernel == 11 && D % 64 == 0 &&
                        f[F_K] == f[F_Q] + (size_t)M * D && f[F_V] == f[F_K] + (size_t)M * D;
+  cls32_ = "gemm32_qkv";
   if (qkv_one) {
     float* qkv = f[F_Q];
     gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, 3 * D, din, qkv, 3 * D, nullptr, 0, false, D, qscale);
+    prof_begin("fsmn", 0);
     launch_fsmn_f32_ld(stream_, qkv + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, f[F_FS]);
+    prof_end("fsmn");
     attention32(qkv, (int64_t)T * 3 * D, 3 * D, qkv + D, (int64_t)T * 3 * D, 3 * D, qkv + 2 * D, (int64_t)T * 3 * D, 3 * D, f[F_CTX],
                 (int64_t)T * D, D, B, mc_.heads, T, T, true);
   } else {
@@ -1900,6 +1917,7 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
   attention32(f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
                        (int64_t)T * D, D, B, mc_.heads, T, T, true);
   }
+  cls32_ = "gemm32_out";
   if (first) {
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
   } else {
@@ -1908,8 +1926,11 @@ void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_d
     gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_X], D, false, 0, 1.f, 0, f[F_FS]);
   }
   layernorm32(f[F_X], M, D, L.norm2, f[F_XN]);
+  cls32_ = "gemm32_ffn1";
   gemm32(f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f, kX3OutPair);
+  cls32_ = "gemm32_ffn2";
   gemm32(f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f, kX3InPair);
+  cls32_ = "gemm32_misc";
 }
 
 void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logits) {
@@ -1964,6 +1985,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   }
   // ---- CIF predictor
   launch_im2col_f32(stream_, H32_, B, T, D, mc_.cif_l_order, mc_.cif_r_order, f[F_T]);
+  cls32_ = "gemm32_cif";
   gemm32(f[F_T], taps * D, cif_conv_w32_, taps * D, cif_conv_.bias, M, D, taps * D, f[F_FS], D, nullptr, 0, true, 0, 1.f);
   launch_cif_alpha(stream_, f[F_FS], B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
@@ -2004,6 +2026,7 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
     PF_HIP(hipMemcpyAsync(e0, xd, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
   }
   const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
+  cls32_ = "gemm32_dec";
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
     layernorm32(xd, Md, D, n1, xn);
     gemm32(xn, D, w1.w32, D, w1.bias, Md, F, D, hd, F, nullptr, 0, true, 0, 1.f);
@@ -2024,8 +2047,10 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   }
   ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
   launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
+  cls32_ = "gemm32_vocab";
   gemm32(xn, D, dec_out_.w32, D, dec_out_.bias, Md, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
   launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
+  cls32_ = "gemm32_misc";
   if (bias_branch) seaco_head_fp32(B, L, e0, xn, want_logits);      // xn = the ASR decoder's after_norm hidden
   PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
 }

@@ -284,6 +284,10 @@ class Engine {
   bool x3_pair_live_ = false; int x3_pair_M_ = 0, x3_pair_K_ = 0;   // ws_x3h_ holds the (hi | lo') pair the next gemm32 consumes
   enum { kX3OutPair = 1, kX3InPair = 2, kX3SameInput = 4 };
   const float* x3a_src_ = nullptr; int x3a_M_ = 0, x3a_K_ = 0, x3a_ld_ = 0; half_t* x3a_buf_ = nullptr;   // what ws_x3a_ holds the pair of
+  // profile class of the gemm32 / attention32 calls that follow (bench.py's `exact` roofline; "gemm32_*" / "attn32_*")
+  const char* cls32_ = "gemm32_misc";
+  void gemm32_impl(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
+                   const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2);
   void gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
               const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags = 0, const float* resid2 = nullptr);
   bool fp32_mode_ = false;           // math_mode 1: every GEMM / attention product on the fp32 MFMA path (parity runs)
