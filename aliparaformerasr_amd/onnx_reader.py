@@ -201,8 +201,12 @@ def _node(op, name, ins, outs, attrs=None):
     body += _ld(3, name.encode()) + _ld(4, op.encode())
     for k, v in (attrs or {}).items():
         a = _ld(1, k.encode())
+        if v is None:
+            continue                                   # (tensor / graph attributes the reader does not keep)
         if isinstance(v, str):
             a += _ld(4, v.encode()) + _vi((20 << 3) | 0) + _vi(3)
+        elif isinstance(v, float):
+            a += _vi((2 << 3) | 5) + struct.pack("<f", v) + _vi((20 << 3) | 0) + _vi(1)
         elif isinstance(v, (list, tuple)):
             a += b"".join(_vi((8 << 3) | 0) + _vi(x) for x in v) + _vi((20 << 3) | 0) + _vi(7)
         else:
