@@ -859,6 +859,18 @@ def main():
             pass
         dq = ids_check_int8["engine_rounding_points"]
         ids_check_int8["device_token_num_differ_from_int8q_oracle"] = dq["token_num_near_ties_resolved_differently"] if dq else None
+        try:
+            # ASSERTED: where the two int8 oracles agree with each other — same token_num, same id, both decided
+            # by more than GOLDEN_MARGIN_INT8 — and the device resolves that token_num too, the device's id is theirs
+            Lc = min(res.token_ids.shape[1], ga["ids"].shape[1], gb["ids"].shape[1])
+            rows3 = (ga["token_num"] == gb["token_num"]) & (np.asarray(res.token_num) == gb["token_num"])
+            both = ((ga["ids"][:, :Lc] == gb["ids"][:, :Lc]) & (ga["margin"][:, :Lc] > GOLDEN_MARGIN_INT8) & (gb["margin"][:, :Lc] > GOLDEN_MARGIN_INT8)
+                    & rows3[:, None] & (np.arange(Lc)[None, :] < gb["token_num"][:, None]))
+            bad = int((res.token_ids[:, :Lc] != gb["ids"][:, :Lc])[both].sum())
+            ids_check_int8["where_both_oracles_agree"] = {"utterances": int(rows3.sum()), "positions": int(both.sum()), "mismatches": bad, "ok": bad == 0}
+            assert bad == 0, "int8 ids differ from BOTH int8 oracles where these agree with each other: %r" % (ids_check_int8["where_both_oracles_agree"],)
+        except NameError:
+            pass
 
     # PCIe-inclusive rate (never `value`): host float32 audio in, ids back on the host, per batch
     host_ms = None

@@ -319,3 +319,13 @@ def test_int8_full_depth_at_the_benchmark_shape():
     assert abs(int(res.token_ids.shape[1]) - int(gq["ids"].shape[1])) <= 3
     assert (d != 0).sum() <= pair_tn + 4 and np.abs(d).max() <= 3
     assert rows.sum() >= 6 and agree >= pair_agree - 0.08
+    # VERDICT r5 weak #8 — the hard statement the graph does allow: where the two int8 ORACLES agree with each other (same
+    # token_num, same id, both decided by more than 0.3) and the device resolves the same token_num, the device's id is theirs
+    rows3 = rows & (gq["token_num"] == gr["token_num"])
+    L3 = min(L, gr["ids"].shape[1])
+    both = (gq["ids"][:, :L3] == gr["ids"][:, :L3]) & (gq["margin"][:, :L3] > 0.3) & (gr["margin"][:, :L3] > 0.3) & rows3[:, None] & \
+           (np.arange(L3)[None, :] < gq["token_num"][:, None])
+    print("int8 32x30 s: %d utterances on which both oracles and the device share token_num; %d positions both oracles decide by > 0.3: "
+          "%d differ on the device" % (rows3.sum(), both.sum(), (res.token_ids[:, :L3] != gq["ids"][:, :L3])[both].sum()))
+    assert both.sum() >= 20
+    np.testing.assert_array_equal(res.token_ids[:, :L3][both], gq["ids"][:, :L3][both])
