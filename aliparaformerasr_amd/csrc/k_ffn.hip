@@ -67,6 +67,22 @@ struct FfnDev {
   int S, Mp;
 };
 
+// -DFF_TIMING (tools/ffn_timing.sh; timing experiments only): every wave of the encoder form (OP = 1) stamps the shader clock at the
+// phase boundaries below (ticks since its own start) and leaves them in ff_tm[workgroup][wave][stamp]
+#ifdef FF_TIMING
+__device__ unsigned ff_tm[256 * 8 * 16];
+#define FF_TS(i) { if (OP == 1 && SP == 0) tm_[i] = (unsigned)(__builtin_readcyclecounter() - t_begin_); }
+#else
+#define FF_TS(i)
+#endif
+
+// fragments in flight per wave in the out-projection prologue (PFO) and in the Q | K | V tail (PFQ); the main loop's is the template's PF
+#ifndef FF_PFO
+#define FF_PFO 8
+#endif
+#ifndef FF_PFQ
+#define FF_PFQ 8
+#endif
 constexpr int FF_BM = 64, FF_D = 512, FF_F = 2048, FF_HC = 256, FF_NC = FF_F / FF_HC;   // 8 chunks
 constexpr int FF_A_BYTES = FF_BM * FF_D * 2;              // 64 KiB: 8 k-blocks of [64 rows][128 B]
 constexpr int FF_H_BYTES = FF_BM * FF_HC * 2;             // 32 KiB per hidden buffer (two of them)
@@ -159,6 +175,10 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, l31 = lane & 31;
+#ifdef FF_TIMING
+  unsigned tm_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin_ = __builtin_readcyclecounter();
+#endif
   const int tile = SP ? (int)blockIdx.x / p.S : (int)blockIdx.x;
   const int c_begin = SP ? ((int)blockIdx.x - tile * p.S) * SP : 0;
   const int m0 = tile * FF_BM;
@@ -222,11 +242,13 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     auto woload = [&](int pos) __attribute__((always_inline)) -> h8 {
       return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(wou + pos * 512) + lane16);
     };
-    h8 oring[PF];
+    constexpr int PFO = FF_PFO;
+    h8 oring[PFO];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) oring[i] = woload(i);
+    for (int i = 0; i < PFO; ++i) oring[i] = woload(i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the context tile (and the first PF fragments) have landed
     __builtin_amdgcn_s_barrier();
+    FF_TS(0)
     {
       constexpr int XR = XD + 1;
       h8 xf[XR][2];
@@ -243,8 +265,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         h8 wo[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          wo[j] = oring[(2 * s + j) % PF];
-          if (2 * s + j + PF < 64) oring[(2 * s + j) % PF] = woload(2 * s + j + PF);
+          wo[j] = oring[(2 * s + j) % PFO];
+          if (2 * s + j + PFO < 64) oring[(2 * s + j) % PFO] = woload(2 * s + j + PFO);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -253,6 +275,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    FF_TS(1)
     // ---- P2 (k_gemm_rc.hip's epilogue): the fp32 tile through LDS; wave w owns rows 8w .. 8w+7 completely
     const int r0 = wave * 8, mb = m0 + r0;
     float4 xv[2][8];
@@ -310,6 +333,10 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         }
       }
     }
+#ifdef FF_TIMING
+    asm volatile("" :: "v"(xv[0][0].x), "v"(xv[1][7].w));
+#endif
+    FF_TS(2)
     // x_mid is the residual of the block's end: instead of a round trip through HBM it goes back into the ACCUMULATORS — the
     // second product then accumulates on top of it (rows -> LDS fp32 tile -> D^T fragments, the dump above in reverse)
     if constexpr (OP == 1) {
@@ -376,6 +403,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     for (int i = 0; i < PF; ++i) ring[i] = wload(i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ff_lds_barrier();                                              // the operand tile is complete
+    FF_TS(3)
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the tile (and the first PF weight fragments) have landed
     __builtin_amdgcn_s_barrier();
@@ -485,6 +513,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     }
   }
 
+  FF_TS(4)
   // ---- epilogue (k_gemm_rc.hip's): wave w owns rows 8w .. 8w+7 completely; lane: columns 4 lane and 256 + 4 lane
   // (the lane index is re-derived here with mbcnt: keeping the work-item id alive across the unrolled main loop costs
   //  two spilled registers, i.e. a scratch arena, for nothing)
@@ -493,6 +522,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
   const int r0 = wave * 8;
   const int mb = m0 + r0;
   float4 xv[2][8];
+  float4 xs_[QK ? 2 : 1][QK ? 8 : 1];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -551,12 +581,19 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
       const float4 v = *reinterpret_cast<const float4a*>(smem + (size_t)(r0 + r) * FF_XROW + col * 4);
       xv[h][r].x += v.x + b4.x; xv[h][r].y += v.y + b4.y; xv[h][r].z += v.z + b4.z; xv[h][r].w += v.w + b4.w;
     }
-    if (p.out_x) {
+    if (QK != 0 && p.Wqt) {
+      // with a tail behind it the residual stream is stored at the very END of the kernel: vmcnt retires stores in order with the
+      // loads, so 128 KB of x stores per workgroup issued here would sit in front of every counted wait of the tail's weight stream
+      // (and of the vmcnt(0) that precedes it) until HBM has acknowledged them — 64 registers held instead (round 6: −4 %)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xs_[h][r] = xv[h][r];
+    } else if (p.out_x) {
 #pragma unroll
       for (int r = 0; r < 8; ++r)
         if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + col) = xv[h][r];
     }
   }
+  FF_TS(5)
   if (!p.ln_g) return;
   float4 g4[2], be4[2];
 #pragma unroll
@@ -632,24 +669,38 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     if (wave < 6) ff_glds16(reinterpret_cast<const char*>(p.bq) + wave * 1024 + lane_e * 16, smem + FF_B_OFF + wave * 1024);
     // ONE weight stream over the three passes (192 fragments of this wave), PF ahead across the pass ends
     const half_t* wqu = p.Wqt + (size_t)wave * (64 * 512);
+    // The workgroups of an XCD walk Q, K, V in three different orders (round 6).  Every layer's Wq image is COLD in the XCD's L2
+    // when the tail starts; with one order all 32 CUs run into every first-touch miss together and wait for it together (three
+    // passes 18 + 18 + 15 k cycles for 8 k cycles of MFMA each).  With three orders each third of the image is fetched by one group
+    // while the other two stream something else, and a workgroup's second and third pass find their lines already filled by the
+    // other groups: 14 + 6.6 + 5.3 k cycles, −8 % on the whole launch (profiles/round6_ffn_timeline.md).  The results do not
+    // depend on the order.
+    const int prot = (int)((blockIdx.x >> 3) % 3u);
     auto wqload = [&](int gp) __attribute__((always_inline)) -> h8 {      // gp = pass * 64 + pos
-      return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(wqu + (size_t)(gp >> 6) * (8 * 64 * 512) + (gp & 63) * 512) + lane16e);
+      int pq = (gp >> 6) + prot;
+      pq = pq >= 3 ? pq - 3 : pq;
+      return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(wqu + (size_t)pq * (8 * 64 * 512) + (gp & 63) * 512) + lane16e);
     };
-    h8 qring[PF];
+    constexpr int PFQ = FF_PFQ;
+    h8 qring[PFQ];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) qring[i] = wqload(i);
+    for (int i = 0; i < PFQ; ++i) qring[i] = wqload(i);
+    FF_TS(6)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ff_lds_barrier();                                      // the operand tile and the bias are complete
+    FF_TS(7)
     typedef float f2v __attribute__((ext_vector_type(2)));
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
+      int pr = pass + prot;                               // which of Q | K | V this pass computes
+      pr = pr >= 3 ? pr - 3 : pr;
       // accumulators start as the bias of this wave's 64 columns
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4 b4 = *reinterpret_cast<const float4a*>(smem + FF_B_OFF + (pass * 512 + wave * 64 + 4 * lh_e + j * 32 + 8 * g) * 4);
+          const float4 b4 = *reinterpret_cast<const float4a*>(smem + FF_B_OFF + (pr * 512 + wave * 64 + 4 * lh_e + j * 32 + 8 * g) * 4);
 #pragma unroll
           for (int i = 0; i < 2; ++i) { yacc[i][j][4 * g + 0] = b4.x; yacc[i][j][4 * g + 1] = b4.y; yacc[i][j][4 * g + 2] = b4.z; yacc[i][j][4 * g + 3] = b4.w; }
         }
@@ -670,8 +721,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int gp = pass * 64 + 2 * s + j;
-            wq[j] = qring[gp % PF];
-            if (gp + PF < 192) qring[gp % PF] = wqload(gp + PF);
+            wq[j] = qring[gp % PFQ];
+            if (gp + PFQ < 192) qring[gp % PFQ] = wqload(gp + PFQ);
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -680,12 +731,13 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (pass < 2) {
+      FF_TS(8 + 2 * pass)
+      if (pr < 2) {
         // Q (scaled) | K: 32 x 8 blocks of the blocked [M, 1024] matrix, 8-byte stores straight from the accumulators
-        const int qk0 = pass * 512 + wave * 64;
+        const int qk0 = pr * 512 + wave * 64;
         char* ob = reinterpret_cast<char*>(p.out_qk) + ((size_t)(m0 >> 5) * 128 + (size_t)(qk0 >> 3)) * 512 + l31_e * 16 + lh_e * 8;
         constexpr size_t rb_stride = (size_t)128 * 512;
-        const float sc = pass == 0 ? p.qscale : 1.f;
+        const float sc = pr == 0 ? p.qscale : 1.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -696,7 +748,9 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
               lo2 *= sc; hi2 *= sc;
               const h2v l = __builtin_convertvector(lo2, h2v), hh = __builtin_convertvector(hi2, h2v);
               const h4 hv = {l[0], l[1], hh[0], hh[1]};
-              asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(ob + i * rb_stride + (size_t)(j * 4 + g) * 512), "v"(hv) : "memory");
+              // (plain stores: on gfx950 stores count in vmcnt IN ORDER with the loads, so a write-through (sc1) store's long
+              //  acknowledgement holds up the next pass's counted waits for its weight fragments — round 6 timeline, −0.8 %)
+              asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(ob + i * rb_stride + (size_t)(j * 4 + g) * 512), "v"(hv) : "memory");
             }
       } else {
         // V: row-major [M, ldvo]; lanes l / l + 32 hold columns 8g + 0..3 / 8g + 4..7 of row l: after v_permlane32_swap lane l
@@ -725,9 +779,31 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
             }
         }
       }
+      FF_TS(9 + 2 * pass)
     }
+    if (p.out_x) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (mb + r < p.M) *reinterpret_cast<float4*>(p.out_x + (size_t)(mb + r) * p.ldx + h * 256 + 4 * lane_e) = xs_[h][r];
+    }
+#ifdef FF_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FF_TS(14)
+    if (OP == 1 && SP == 0 && lane_e == 0 && blockIdx.x < 256)
+      for (int i = 0; i < 16; ++i) ff_tm[(blockIdx.x * 8 + wave) * 16 + i] = tm_[i];
+#endif
   }
 }
+
+#ifdef FF_TIMING
+}  // namespace pf
+extern "C" int pf_debug_ffn_timing(unsigned* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::ff_tm), (size_t)n * 4, 0, hipMemcpyDeviceToHost);
+}
+namespace pf {
+#endif
 
 // W1 [2048, ldw1] and W2 [512, ldw2] (f16, K-contiguous) -> the fragment-ordered images the kernel streams:
 //   W1t[((c * 8 + w) * 32 + s) * 512 + l * 8 + e] = W1[c * 256 + w * 32 + (l & 31)][16 s + 8 (l >> 5) + e]
