@@ -71,9 +71,16 @@ struct FfnDev {
 // phase boundaries below (ticks since its own start) and leaves them in ff_tm[workgroup][wave][stamp]
 #ifdef FF_TIMING
 __device__ unsigned ff_tm[256 * 8 * 16];
+#ifdef FF_TIMING_MAIN      // the 16 stamps = end of phase U / end of phase D of the 8 chunks of the main loop instead
+#define FF_TS(i)
+#define FF_TSM(i) { if (OP == 1 && SP == 0) tm_[i] = (unsigned)(__builtin_readcyclecounter() - t_begin_); }
+#else
 #define FF_TS(i) { if (OP == 1 && SP == 0) tm_[i] = (unsigned)(__builtin_readcyclecounter() - t_begin_); }
+#define FF_TSM(i)
+#endif
 #else
 #define FF_TS(i)
+#define FF_TSM(i)
 #endif
 
 // fragments in flight per wave in the out-projection prologue (PFO) and in the Q | K | V tail (PFQ); the main loop's is the template's PF
@@ -239,9 +246,12 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
     // ---- P1: Y^T[64 out columns of this wave x 64 rows] = Wo[wave] ctx^T over K = 512: 32 k-steps of 4 MFMAs, Wo fragments
     //      (2 per step, private to the wave) straight from their fragment-ordered image, ctx fragments from the LDS tile
     const half_t* wou = p.Wot + (size_t)wave * (64 * 512);
+    // (four different K-loop starting points for four groups of workgroups — the tail's remedy against lockstep cold misses — buy
+    //  0.8 k of this phase's 15 k cycles: not kept, profiles/round6_ffn_timeline.md)
     auto woload = [&](int pos) __attribute__((always_inline)) -> h8 {
       return *reinterpret_cast<const h8*>(reinterpret_cast<const char*>(wou + pos * 512) + lane16);
     };
+    auto xblk = [&](int s_) __attribute__((always_inline)) -> int { return (s_ >> 2) * 8192; };
     constexpr int PFO = FF_PFO;
     h8 oring[PFO];
 #pragma unroll
@@ -255,12 +265,12 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
 #pragma unroll
       for (int s0 = 0; s0 < XD; ++s0)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xf[s0][i] = *reinterpret_cast<const h8*>(smem + xo[i][s0 & 3] + (s0 >> 2) * 8192);
+        for (int i = 0; i < 2; ++i) xf[s0][i] = *reinterpret_cast<const h8*>(smem + xo[i][s0 & 3] + xblk(s0));
 #pragma unroll
       for (int s = 0; s < 32; ++s) {
         if (s + XD < 32) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) xf[(s + XD) % XR][i] = *reinterpret_cast<const h8*>(smem + xo[i][(s + XD) & 3] + ((s + XD) >> 2) * 8192);
+          for (int i = 0; i < 2; ++i) xf[(s + XD) % XR][i] = *reinterpret_cast<const h8*>(smem + xo[i][(s + XD) & 3] + xblk(s + XD));
         }
         h8 wo[2];
 #pragma unroll
@@ -444,6 +454,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    FF_TSM(2 * c)
     // relu -> f16 -> the cells of k-steps t = 2 wave, 2 wave + 1 of the second product
     {
       char* hb = smem + ho + (c & 1) * FF_H_BYTES;
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    FF_TSM(2 * c + 1)
   }
 
   FF_TS(4)

@@ -4,6 +4,6 @@
 cd "$(dirname "$0")/.."
 touch aliparaformerasr_amd/csrc/k_ffn.hip
 make -C aliparaformerasr_amd/csrc EXTRA="-DFF_TIMING $FF_EXTRA" > /dev/null 2>&1 || { echo "build failed"; exit 1; }
-python tools/ffn_timing.py
+python ${FF_PY:-tools/ffn_timing.py}
 touch aliparaformerasr_amd/csrc/k_ffn.hip
 make -C aliparaformerasr_amd/csrc > /dev/null 2>&1

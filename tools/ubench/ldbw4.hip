@@ -21,7 +21,7 @@ __device__ __forceinline__ void wait_use(f4& r) { asm volatile("s_waitcnt vmcnt(
 // A workgroup walks segments (seg + rot) % NSEG, fragment by fragment; `reps` passes over the image.
 template <int DEPTH>
 __global__ __launch_bounds__(512) void stream_kernel(const char* __restrict__ img, int nseg, int frags, size_t wstride, size_t seg_stride,
-                                                     int rot_groups, int reps, float* sink) {
+                                                     int rot_groups, int reps, float* sink, size_t fstride = 1024, size_t wg_private = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rot = rot_groups > 1 ? (int)((blockIdx.x >> 3) % (unsigned)rot_groups) * (nseg / rot_groups) : 0;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) void stream_kernel(const char* __restrict__ im
   auto next = [&]() -> const char* {
     int seg = nseg_i + rot;
     seg = seg >= nseg ? seg - nseg : seg;
-    const char* p = img + (size_t)seg * seg_stride + (size_t)wave * wstride + (size_t)nf * 1024 + lane * 16;
+    const char* p = img + (size_t)blockIdx.x * wg_private + (size_t)seg * seg_stride + (size_t)wave * wstride + (size_t)nf * fstride + lane * 16;
     if (++nf == frags) { nf = 0; if (++nseg_i == nseg) nseg_i = 0; }
     return p;
   };
@@ -55,14 +55,15 @@ __global__ __launch_bounds__(512) void stream_kernel(const char* __restrict__ im
 }
 
 template <int DEPTH>
-int run(const char* name, const char* img, int nseg, int frags, size_t wstride, size_t seg_stride, int rot_groups, float* sink, int grid) {
+int run(const char* name, const char* img, int nseg, int frags, size_t wstride, size_t seg_stride, int rot_groups, float* sink, int grid,
+        size_t fstride = 1024, size_t wg_private = 0) {
   const int reps = 24;
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  hipLaunchKernelGGL(stream_kernel<DEPTH>, dim3(grid), dim3(512), 0, 0, img, nseg, frags, wstride, seg_stride, rot_groups, 2, sink);
+  hipLaunchKernelGGL(stream_kernel<DEPTH>, dim3(grid), dim3(512), 0, 0, img, nseg, frags, wstride, seg_stride, rot_groups, 2, sink, fstride, wg_private);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
-  hipLaunchKernelGGL(stream_kernel<DEPTH>, dim3(grid), dim3(512), 0, 0, img, nseg, frags, wstride, seg_stride, rot_groups, reps, sink);
+  hipLaunchKernelGGL(stream_kernel<DEPTH>, dim3(grid), dim3(512), 0, 0, img, nseg, frags, wstride, seg_stride, rot_groups, reps, sink, fstride, wg_private);
   CK(hipEventRecord(b));
   CK(hipDeviceSynchronize());
   float ms = 0;
@@ -81,22 +82,16 @@ int main() {
   CK(hipMalloc(&img, bytes));
   CK(hipMemset(img, 1, bytes));
   for (int grid : {250, 32}) {
-    // W1 / W2 of the main loop: 8 chunks (segments) x 8 waves x 32 KiB (U) ... modelled as 16 segments of 8 x 32 KiB = 4 MiB per pass
-    if (run<8>("main loop: 16 seg, wave stride 32 KiB", img, 16, 32, 32 << 10, 256 << 10, 1, sink, grid)) return 1;
-    if (run<8>("main loop: 16 seg, wave stride 32 KiB", img, 16, 32, 32 << 10, 256 << 10, 8, sink, grid)) return 1;
-    if (run<8>("main loop: 16 seg, wave stride 32 + 4 KiB", img, 16, 32, 36 << 10, 288 << 10, 1, sink, grid)) return 1;
-    if (run<8>("main loop: 16 seg, wave stride 32 + 4 KiB", img, 16, 32, 36 << 10, 288 << 10, 8, sink, grid)) return 1;
-    if (run<8>("main loop: 16 seg, wave stride 32 + 1 KiB", img, 16, 32, 33 << 10, 264 << 10, 8, sink, grid)) return 1;
-    if (run<16>("main loop: 16 seg, wave stride 32 KiB", img, 16, 32, 32 << 10, 256 << 10, 8, sink, grid)) return 1;
-    if (run<16>("main loop: 16 seg, wave stride 32 + 4 KiB", img, 16, 32, 36 << 10, 288 << 10, 8, sink, grid)) return 1;
-    // Wq of the tail: 3 passes (segments) x 8 waves x 64 KiB = 1.5 MiB per pass
-    if (run<8>("tail: 3 seg, wave stride 64 KiB", img, 3, 64, 64 << 10, 512 << 10, 1, sink, grid)) return 1;
-    if (run<8>("tail: 3 seg, wave stride 64 KiB", img, 3, 64, 64 << 10, 512 << 10, 3, sink, grid)) return 1;
-    if (run<8>("tail: 3 seg, wave stride 64 + 4 KiB", img, 3, 64, 68 << 10, 544 << 10, 1, sink, grid)) return 1;
-    if (run<8>("tail: 3 seg, wave stride 64 + 4 KiB", img, 3, 64, 68 << 10, 544 << 10, 3, sink, grid)) return 1;
-    if (run<8>("tail: 3 seg, wave stride 64 + 1 KiB", img, 3, 64, 65 << 10, 520 << 10, 3, sink, grid)) return 1;
-    if (run<16>("tail: 3 seg, wave stride 64 KiB", img, 3, 64, 64 << 10, 512 << 10, 1, sink, grid)) return 1;
-    if (run<16>("tail: 3 seg, wave stride 64 + 4 KiB", img, 3, 64, 68 << 10, 544 << 10, 3, sink, grid)) return 1;
+    // the kernel's pattern: 16 segments of 8 wave slices x 32 KiB (4 MiB per pass), every workgroup the same image in the same order
+    if (run<8>("kernel pattern: wave stride 32 KiB, shared image", img, 16, 32, 32 << 10, 256 << 10, 1, sink, grid)) return 1;
+    if (run<4>("kernel pattern: wave stride 32 KiB, shared image", img, 16, 32, 32 << 10, 256 << 10, 1, sink, grid)) return 1;
+    // waves ADJACENT: wave w reads fragment 8 f + w of a contiguous 256 KiB segment (a workgroup step = 8 KiB contiguous)
+    if (run<8>("adjacent waves (8 KiB contiguous per step), shared image", img, 16, 32, 1 << 10, 256 << 10, 1, sink, grid, 8 << 10)) return 1;
+    // every workgroup its OWN 128 KiB image (32 MB in all: L2-resident per XCD), kernel pattern inside it
+    if (run<8>("private 128 KiB image per workgroup, wave stride 16 KiB", img, 1, 16, 16 << 10, 0, 1, sink, grid, 1024, 128 << 10)) return 1;
+    if (run<8>("private 128 KiB image per workgroup, adjacent waves", img, 1, 16, 1 << 10, 0, 1, sink, grid, 8 << 10, 128 << 10)) return 1;
+    // a SMALL shared image (512 KiB: one chunk) — does the footprint matter?
+    if (run<8>("kernel pattern, shared 512 KiB image", img, 2, 32, 32 << 10, 256 << 10, 1, sink, grid)) return 1;
   }
   return 0;
 }
