@@ -70,6 +70,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   { const char* e = getenv("PF_FFN_MIN"); if (e && e[0]) ffn_fused_min_rows_ = atoi(e); }
   { const char* e = getenv("PF_DEC_FFN"); if (e && e[0]) dec_ffn_fused_ = e[0] != '0'; }
   { const char* e = getenv("PF_DEC_OUT_CHAIN"); if (e && e[0]) dec_out_chain_ = e[0] != '0'; }
+  { const char* e = getenv("PF_DEC_MID"); if (e && e[0]) dec_mid_ = e[0] != '0'; }     // A/B: finishing pass + norm2 + FSMN + norm3 + q in one launch (k_decmid.hip)
   { const char* e = getenv("PF_ATTN_FFN"); if (e && e[0]) attn_ffn_ = e[0] != '0'; }
   { const char* e = getenv("PF_QKV_TAIL"); if (e && e[0]) qkv_tail_ = e[0] != '0'; }
 
@@ -502,6 +503,10 @@ void Engine::load_weights(const pf_engine_config& cfg) {
       if (L.ffn_img && dec_out_chain_ && L.out.w && L.out.bias && L.out.Kpad == D) {
         L.out_wt = (half_t*)dalloc(ffn_outproj_weight_bytes());
         launch_ffn_retile_out(stream_, L.out.w, L.out.Kpad, L.out_wt);
+      }
+      if (L.ffn_img && dec_mid_ && L.q.w && L.q.bias && L.q.Kpad == D && L.q.N == D) {
+        L.q_wt = (half_t*)dalloc(ffn_outproj_weight_bytes());
+        launch_ffn_retile_out(stream_, L.q.w, L.q.Kpad, L.q_wt);
       }
       dec_.push_back(L);
     }
@@ -1236,6 +1241,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   const DecLayer* pend = nullptr;
   // ffn_dec: norm1 -> w_1 + ReLU -> LayerNorm(2048) -> w_2 (no bias) [-> LayerNorm `post`]; leaves t32 (unfused) or
   // post(t) in n32 / n16
+  bool mid_next = false;                                // the coming ffn_dec call leaves its shares to launch_dec_mid
   auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2, const half_t* img, const LNp& post, float* n32, half_t* n16) {
     if (img && !dsmall) {
       // norm1 | the whole block in the split form of the fused FFN kernel + its finishing pass (LayerNorm over the hidden
@@ -1250,6 +1256,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
       FfnDecArgs f{};
       f.A = xdn16; f.lda = D; f.img = img; f.ws = ws_decffn_.p; f.M = Md; f.eps_hidden = 1e-12f;
       f.ln_g = post.g; f.ln_b = post.b; f.eps = 1e-12f; f.n32 = n32; f.ldn32 = D; f.n16 = n16; f.ldn16 = D;
+      f.no_finish = mid_next;
       if (pend) {
         f.A = nullptr; f.ctx = ctxd16; f.lda_c = D; f.Wot = pend->out_wt; f.bo = pend->out.bias;
         f.resid = xd; f.ldr = D; f.out_x = xd_alt; f.ldx = D; f.ln1_g = n1.g; f.ln1_b = n1.b; f.eps1 = 1e-12f;
@@ -1298,9 +1305,27 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
 
   for (int i = 0; i < nd; ++i) {
     const DecLayer& Lr = dec_[i];
+    // round 6: the finishing pass of the split FFN form, norm2, the FSMN memory, the residual, norm3 and the q-projection in ONE
+    // launch (k_decmid.hip): a decoder layer = split FFN | middle | cross-attention
+    const bool mid = dec_mid_ && Lr.ffn_img && Lr.q_wt && !dsmall && D == 512 && mc_.kernel == 11;
+    mid_next = mid;
     ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2, Lr.ffn_img, Lr.norm2, tn32, nullptr);
-    bool fused = false;
-    if (f_fsmn) {
+    mid_next = false;
+    bool mid_done = false;
+    if (mid) {
+      DecMidArgs m{};
+      m.ws = ws_decffn_.p; m.img = Lr.ffn_img; m.splits = 0; m.eps_hidden = 1e-12f;
+      m.n2_g = Lr.norm2.g; m.n2_b = Lr.norm2.b; m.eps2 = 1e-12f;
+      m.fsmn_wT = Lr.fsmn_wT; m.k = mc_.kernel; m.token_num = plan_.token_num; m.B = B; m.L = L;
+      m.x = xd; m.n3_g = Lr.norm3.g; m.n3_b = Lr.norm3.b;
+      m.Wqt = Lr.q_wt; m.bq = Lr.q.bias; m.qscale = qscale; m.q16 = qd16; m.ldq = D;
+      prof_begin("dec_mid", 2.0 * Md * (double)D * D);
+      mid_done = launch_dec_mid(stream_, m);
+      prof_end("dec_mid");
+      PF_CHECK(mid_done, PF_ERR_UNSUPPORTED, "decoder: the fused middle launch does not cover this geometry");
+    }
+    bool fused = mid_done;
+    if (f_fsmn && !mid_done) {
       prof_begin("fsmn", 0);
       fused = launch_fsmn_dec_ln(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd, Lr.norm3.g, Lr.norm3.b, xdn16);
       prof_end("fsmn");
@@ -1313,7 +1338,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
       launch_layernorm(stream_, xd, Md, D, Lr.norm3.g, Lr.norm3.b, xdn16, D, nullptr, 0);
       prof_end("layernorm");
     }
-    gemm("gemm_dec_q", Lr.q, xdn16, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
+    if (!mid_done) gemm("gemm_dec_q", Lr.q, xdn16, D, Md, nullptr, 0, qd16, D, nullptr, 0, nullptr, 0, false, D, qscale);
     AttnArgs a{};
     a.q = qd16; a.q_bstride = (int64_t)L * D; a.q_rstride = D;
     a.k = kv16 + (size_t)i * 2 * D; a.v = kv16 + (size_t)i * 2 * D + D;

@@ -67,6 +67,7 @@ struct DecLayer {
   LNp norm1, ffn_norm, norm2, norm3; Lin w1, w2, q, out, kv32; float* fsmn_wT = nullptr;   // kv32: fp32 pointers only
   half_t* ffn_img = nullptr;   // (W1, gamma_F (.) W2, b1, colsum, W2 beta_F) in the fragment order of the split FFN form (k_ffn.hip; null: not built)
   half_t* out_wt = nullptr;    // the cross-attention out-projection weight in that kernel's fragment order: the NEXT block's launch runs it
+  half_t* q_wt = nullptr;      // the cross-attention query projection in the same fragment order (k_decmid.hip; null: not built)
 };
 
 struct DevBuf {       // grow-only device allocation
@@ -254,6 +255,7 @@ class Engine {
   bool qkv_tail_ = true;             // PF_QKV_TAIL: the next layer's Q | K | V projection behind the fused block, same launch
   bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
+  bool dec_mid_ = true;              // PF_DEC_MID: finishing pass + norm2 + FSMN + residual + norm3 + q-projection in one launch (k_decmid.hip)
   bool dec_out_chain_ = true;        // PF_DEC_OUT_CHAIN: a decoder layer's out-projection + the next norm1 in front of the next FFN launch
   bool dec_ffn_fused_ = true;        // PF_DEC_FFN: the decoder's FFN block (with its LayerNorm over the hidden) as the split form of the same kernel
   int ffn_fused_min_rows_ = 1200;    // PF_FFN_MIN: below, 64-row tiles leave most CUs idle and the persistent kernels tie or win (tools/mid_rows.py)

@@ -1006,7 +1006,7 @@ void launch_ffn_dec(hipStream_t s, const FfnDecArgs& a) {
   PF_CHECK(a.M > 0 && a.img && a.ws, PF_ERR_INVALID_ARG, "ffn_dec: missing operand");
   PF_CHECK(a.lda % 8 == 0 && (!a.t32 || a.ldt % 4 == 0) && (!a.n32 || a.ldn32 % 4 == 0) && (!a.n16 || a.ldn16 % 4 == 0), PF_ERR_INVALID_ARG,
            "ffn_dec: leading dimensions must keep 16-byte (8-byte for f16) row alignment");
-  PF_CHECK(!a.ln_g == !a.ln_b && (a.ln_g || (!a.n16 && !a.n32)) && (a.t32 || a.n16 || a.n32), PF_ERR_INVALID_ARG, "ffn_dec: outputs");
+  PF_CHECK(a.no_finish || (!a.ln_g == !a.ln_b && (a.ln_g || (!a.n16 && !a.n32)) && (a.t32 || a.n16 || a.n32)), PF_ERR_INVALID_ARG, "ffn_dec: outputs");
   const int S = a.splits > 0 ? a.splits : ffn_dec_splits(a.M);
   PF_CHECK(S == 1 || S == 2 || S == 3 || S == 4 || S == 8, PF_ERR_INVALID_ARG, "ffn_dec: splits must be 1 | 2 | 3 | 4 | 8");
   const int Mp = (int)round_up(a.M, 64);
@@ -1087,11 +1087,14 @@ void launch_ffn_dec(hipStream_t s, const FfnDecArgs& a) {
   }
 #undef PF_DEC_GO
   PF_HIP(hipGetLastError());
+  if (a.no_finish) return;
   hipLaunchKernelGGL(ffn_dec_finish_kernel, dim3((unsigned)cdiv(a.M, 4)), dim3(256), 0, s, d.part, d.stats, S, Mp, a.M,
                      reinterpret_cast<const float*>(a.img + 2 * FFD_W) + 2304, a.eps_hidden, a.ln_g, a.ln_b, a.eps, a.t32, a.ldt, a.n32, a.ldn32,
                      a.n16, a.ldn16);
   PF_HIP(hipGetLastError());
 }
+
+const float* ffn_dec_image_cd(const half_t* img) { return reinterpret_cast<const float*>(img + 2 * FFD_W) + 2304; }
 
 size_t ffn_fused_weight_bytes() { return (size_t)2 * 131072 * 16; }      // W1t | W2t: 2 MiB each
 size_t ffn_outproj_weight_bytes() { return (size_t)32768 * 16; }          // Wot: 512 KiB

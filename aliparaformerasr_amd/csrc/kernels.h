@@ -186,7 +186,21 @@ struct FfnDecArgs {
   float* t32; int ldt;                           // t, fp32 [M,512] or null
   const float* ln_g; const float* ln_b; float eps;
   float* n32; int ldn32; half_t* n16; int ldn16; // LayerNorm(t) or null
+  bool no_finish = false;                        // the shares stay in ws: launch_dec_mid (k_decmid.hip) finishes them
 };
+const float* ffn_dec_image_cd(const half_t* img);  // the (c | d) vectors of the finishing pass inside the image
+
+// the middle of a decoder layer in one launch (k_decmid.hip, round 6): finishing pass of the split FFN + norm2 + FSMN memory +
+// residual + norm3 + q-projection, on the workspace a launch_ffn_dec(no_finish) left behind
+struct DecMidArgs {
+  const void* ws; const half_t* img; int splits; float eps_hidden;   // as the FfnDecArgs of the split launch in front
+  const float* n2_g; const float* n2_b; float eps2;                   // norm2
+  const float* fsmn_wT; int k; const int32_t* token_num; int B, L;    // taps [k][512], token_num [B]
+  float* x;                                                           // residual stream [B L, 512] fp32, updated in place
+  const float* n3_g; const float* n3_b;                               // norm3
+  const half_t* Wqt; const float* bq; float qscale; half_t* q16; int ldq;   // launch_ffn_retile_out image of Wq; q out f16 [B L, ldq]
+};
+bool launch_dec_mid(hipStream_t s, const DecMidArgs& a);              // false: geometry not covered (caller runs the three launches)
 size_t ffn_dec_image_bytes();
 size_t ffn_dec_workspace_bytes(int M, int splits = 0);
 int ffn_dec_splits(int M);

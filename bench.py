@@ -58,7 +58,7 @@ ALPHA_NEAR = 0.1              # an oracle sum(alpha) this close to an integer is
 # takes the most time in a step (found by an untimed profiling step before the timed region)
 CLASSES = ("fbank", "lfr_cmvn_pad", "layernorm", "gemm_qkv", "fsmn", "attn_self", "gemm_out", "gemm_outffn", "gemm_ffn", "gemm_ffn1",
            "gemm_ffn2", "gemm_cif", "cif_misc", "gemm_dec_kv", "gemm_dec_ffn", "gemm_dec_ffn1", "gemm_dec_ffn2",
-           "gemm_dec_q", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc",
+           "gemm_dec_q", "dec_mid", "attn_cross", "gemm_dec_out", "gemm_vocab", "argmax", "gemm_ts", "lstm", "ts_misc",
            "seaco_embed", "gemm_seaco", "attn_seaco", "seaco_merge", "quantize")
 # (N, K, what) of the encoder GEMM classes: [rows x K] x [K x N]
 GEMM_SHAPES = {"gemm_qkv": (1536, 512, "QKV projection + bias, q scaled"),

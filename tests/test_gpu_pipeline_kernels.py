@@ -615,3 +615,42 @@ def test_gemm_small_fsmn_epilogue_and_layernorm_in_the_reduction(eng, M, T, K):
         np.testing.assert_allclose(n32, m32, rtol=1e-3, atol=1e-3)
     again = eng.op_gemm_rc(A, Wm, bias=bias, resid=resid, ln=(g, b), short_input=True, **kw)
     assert np.array_equal(again[0], x) and np.array_equal(again[2], n32)
+
+
+def test_decoder_middle_in_one_launch(monkeypatch):
+    """Round 6: finishing pass of the split FFN + norm2 + FSMN memory + residual + norm3 + q-projection as ONE launch
+    (k_decmid.hip, `PF_DEC_MID`) against the three launches it replaces, on the same engine inputs: ragged utterances (token_num
+    below L, L not a multiple of the kernel's 32-row blocks, an utterance shorter than the FSMN half-window), log-probs equal up to
+    the f16 rounding of q (both forms accumulate the q product over K in the same order), token_num / L / ids identical; and against
+    the oracle with the engine's rounding points."""
+    from aliparaformerasr_amd.engine import Engine
+    from oracle import frontend as fe, model as om
+    cfg = W.paraformer_large_config(enc_layers=2, dec_layers=3, vocab=300)
+    w = W.synth_weights(cfg, seed=19)
+    w["predictor.out.bias"] = np.asarray([-0.2], np.float32)          # ~0.45 per frame: L well above 32 for the long utterances
+    cmvn = W.synth_cmvn()
+    lens = [16000 * 24, 16000 * 9, 16000 * 17, 4000, 16000 * 30, 16000 * 13] * 3
+    audio = [W.synth_audio(n, 300 + u) for u, n in enumerate(lens)]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PF_DEC_MID", flag)
+        eng = Engine(weights=W.pack_pfw(cfg, w), cmvn=cmvn, device=0)
+        out[flag] = eng.recognize(audio, want_logits=True)
+        ids_only = eng.recognize(audio)
+        np.testing.assert_array_equal(ids_only.token_ids, out[flag].token_ids)
+        eng.close()
+    a, b = out["0"], out["1"]
+    assert a.L == b.L and a.L > 64 and a.L % 32 != 0 and int(a.token_num.min()) < a.L - 32   # (every row is padded to Tmax, quirk Q2: no short rows)
+    np.testing.assert_array_equal(a.token_num, b.token_num)
+    d = float(np.abs(a.logits - b.logits).max())
+    print("decoder middle fused vs three launches: L = %d, token_num %d .. %d, max |d log-prob| %.3e" % (a.L, a.token_num.min(), a.token_num.max(), d))
+    assert d < 5e-3, d
+    srt = np.sort(a.logits, axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2e-2
+    np.testing.assert_array_equal(a.token_ids[safe], b.token_ids[safe])
+    conf = fe.FrontendConf(dither=0.0)
+    feats = [fe.wav_frontend(x, conf, cmvn[0], cmvn[1]) for x in audio]
+    speech = fe.pad_sequence(feats).reshape(len(audio), -1, 560)
+    ref = om.Oracle(om.ModelConfig(**cfg), w, quant="fp16").paraformer(speech)
+    np.testing.assert_array_equal(b.token_num, ref["token_num"])
+    assert float(np.abs(b.logits - ref["logits"]).max()) < 5e-2
