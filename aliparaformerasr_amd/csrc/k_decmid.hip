@@ -38,6 +38,13 @@ constexpr int DM_R = 32, DM_D = 512, DM_F = 2048;
 constexpr int DM_ROWB = DM_D * 4;                         // an fp32 row in LDS
 constexpr int DM_TILE = DM_R * DM_D * 2;                  // 32 KiB: 8 k-blocks of [32 rows][128 B]
 
+#ifdef DM_TIMING
+__device__ unsigned dm_tm[256 * 8 * 8];
+#define DM_TS(i) { tm_[i] = (unsigned)(__builtin_readcyclecounter() - t_begin_); }
+#else
+#define DM_TS(i)
+#endif
+
 struct DecMidDev {
   const float* part; const float* stats; const float* cd; int S, Mp;
   float eps_f;
@@ -62,13 +69,17 @@ __device__ __forceinline__ float dm_wave_sum(float v) {
 
 template <int K>
 __global__ __launch_bounds__(512, 1) void dec_mid_kernel(DecMidDev p) {
-  constexpr int left = (K - 1) / 2, NROWS = DM_R + K - 1, PF = 8;
+  constexpr int left = (K - 1) / 2, NROWS = DM_R + K - 1, PF = 8;     // (16 fragments in flight: no difference, profiles/round6_small_ab.txt)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* zrows = smem;                                     // [NROWS][512] fp32: norm2(t) of the window rows
   char* tile = smem + NROWS * DM_ROWB;                    // f16 operand tile of phase C
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lh = lane >> 5, l31 = lane & 31;
+#ifdef DM_TIMING
+  unsigned tm_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin_ = __builtin_readcyclecounter();
+#endif
   const int nblk = (p.L + DM_R - 1) / DM_R;
   const int b = (int)blockIdx.x / nblk, l0 = ((int)blockIdx.x - b * nblk) * DM_R;
   const int nvalid = p.token_num[b];
@@ -162,7 +173,9 @@ __global__ __launch_bounds__(512, 1) void dec_mid_kernel(DecMidDev p) {
       *reinterpret_cast<float4a*>(zrows + (size_t)r * DM_ROWB + c1 * 4) = z1;
     }
   }
+  DM_TS(0)
   __syncthreads();
+  DM_TS(1)
 
   // ---- B: FSMN + residual + norm3 -> x (HBM) and the f16 operand tile (LDS)
   {
@@ -224,7 +237,9 @@ __global__ __launch_bounds__(512, 1) void dec_mid_kernel(DecMidDev p) {
       *reinterpret_cast<h4*>(tile + (c1 >> 6) * (DM_R * 128) + row * 128 + ((((c1 & 63) >> 3) ^ swz(row)) << 4) + (c1 & 7) * 2) = y1;
     }
   }
+  DM_TS(2)
   __syncthreads();
+  DM_TS(3)
 
   // ---- C: Q^T[64 x 32] of this wave; accumulators start as the bias of its 64 columns
   f16x yacc[2];
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(512, 1) void dec_mid_kernel(DecMidDev p) {
       *reinterpret_cast<float4*>(r + c1) = xr[q][1];
     }
   }
+  DM_TS(4)
   // rows l0 + l31: lanes l / l + 32 hold columns 8 g + 0..3 / 8 g + 4..7; after v_permlane32_swap lane l holds the 8 columns of
   // group 2 gp, lane l + 32 those of group 2 gp + 1: 16-byte row-major stores
   typedef float f2v __attribute__((ext_vector_type(2)));
@@ -292,7 +308,21 @@ __global__ __launch_bounds__(512, 1) void dec_mid_kernel(DecMidDev p) {
       const h8 hv = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);
       if (lrow < p.L) *reinterpret_cast<h8*>(qrow + j * 32 + 16 * gp + 8 * lh) = hv;
     }
+#ifdef DM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DM_TS(5)
+  if (lane == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) dm_tm[(blockIdx.x * 8 + wave) * 8 + i] = tm_[i];
+#endif
 }
+
+#ifdef DM_TIMING
+}  // namespace pf
+extern "C" int pf_debug_decmid_timing(unsigned* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::dm_tm), (size_t)n * 4, 0, hipMemcpyDeviceToHost);
+}
+namespace pf {
+#endif
 
 size_t dec_mid_lds_bytes(int k) { return (size_t)(DM_R + k - 1) * DM_ROWB + DM_TILE; }
 
