@@ -415,7 +415,43 @@ __global__ __launch_bounds__(64 * NW, (NS > 2 || NW == 8) ? NW / 4 : 2) void att
   const int qrow = q0 + lc;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   float r_lo = 0.f, r_hi = 0.f;
-  if (qrow < p.Lq) {
+  // 16-byte stores (round 6): lanes l / l + 32 hold columns 8 g + 0..3 / 8 g + 4..7 of query row l; after v_permlane32_swap lane l
+  // holds the 8 columns of group 2 gp, lane l + 32 those of group 2 gp + 1 (k_ffn.hip's V pass): 8 dwordx4 instead of 16 dwordx2
+  // per lane — the store tail of an attention epilogue is issue-bound, not bandwidth-bound (MI355X guide, T21)
+  const bool wide = (p.o_rs & 7) == 0 && ((reinterpret_cast<uintptr_t>(ob) & 15) == 0);
+  if (wide) {
+    const float inv = qrow < p.Lq ? 1.0f / l_tot : 0.f;
+    half_t* op = ob + (int64_t)qrow * p.o_rs + 8 * lh;
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        unsigned x[2], y[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          f2v xa = {o_acc[db][8 * gp + 2 * e + 0], o_acc[db][8 * gp + 2 * e + 1]};
+          f2v ya = {o_acc[db][8 * gp + 4 + 2 * e + 0], o_acc[db][8 * gp + 4 + 2 * e + 1]};
+          xa *= inv; ya *= inv;
+          const h2v xh = __builtin_convertvector(xa, h2v), yh = __builtin_convertvector(ya, h2v);
+          if (p.range && qrow < p.Lq) {                 // of the values as stored (f16)
+            const float a0 = (float)xh[0], a1 = (float)xh[1], a2 = (float)yh[0], a3 = (float)yh[1];
+            r_lo = fminf(fminf(r_lo, a0), fminf(fminf(a1, a2), a3));
+            r_hi = fmaxf(fmaxf(r_hi, a0), fmaxf(fmaxf(a1, a2), a3));
+          }
+          x[e] = __builtin_bit_cast(unsigned, xh);
+          y[e] = __builtin_bit_cast(unsigned, yh);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[e]), "+v"(y[e]));
+        const h4 lo_ = __builtin_bit_cast(h4, (unsigned long long)x[0] | ((unsigned long long)x[1] << 32));
+        const h4 hi_ = __builtin_bit_cast(h4, (unsigned long long)y[0] | ((unsigned long long)y[1] << 32));
+        typedef _Float16 h8o __attribute__((ext_vector_type(8)));
+        const h8o hv = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (qrow < p.Lq) *reinterpret_cast<h8o*>(op + db * 32 + 16 * gp) = hv;
+      }
+  } else if (qrow < p.Lq) {
     const float inv = 1.0f / l_tot;
     half_t* op = ob + (int64_t)qrow * p.o_rs + 4 * lh;
 #pragma unroll
