@@ -745,24 +745,36 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_kernel(FfnDev p) {
       }
       FF_TS(8 + 2 * pass)
       if (pr < 2) {
-        // Q (scaled) | K: 32 x 8 blocks of the blocked [M, 1024] matrix, 8-byte stores straight from the accumulators
+        // Q (scaled) | K: 32 x 8 blocks of the blocked [M, 1024] matrix.  Lanes l / l + 32 hold columns 0..3 / 4..7 of row l of block g;
+        // after v_permlane32_swap lane l holds the whole 16-byte row of block 2 gp, lane l + 32 that of block 2 gp + 1: 8 dwordx4 per
+        // pass and lane instead of 16 dwordx2 (store tails are issue-bound, MI355X guide T21).  Plain stores: on gfx950 stores count in
+        // vmcnt IN ORDER with the loads, so a write-through (sc1) store's long acknowledgement holds up the next pass's counted waits
+        // for its weight fragments (round 6 timeline).
         const int qk0 = pr * 512 + wave * 64;
-        char* ob = reinterpret_cast<char*>(p.out_qk) + ((size_t)(m0 >> 5) * 128 + (size_t)(qk0 >> 3)) * 512 + l31_e * 16 + lh_e * 8;
+        char* ob = reinterpret_cast<char*>(p.out_qk) + ((size_t)(m0 >> 5) * 128 + (size_t)(qk0 >> 3)) * 512 + l31_e * 16;
         constexpr size_t rb_stride = (size_t)128 * 512;
         const float sc = pr == 0 ? p.qscale : 1.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+          for (int gp = 0; gp < 2; ++gp)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              f2v lo2 = {yacc[i][j][4 * g + 0], yacc[i][j][4 * g + 1]}, hi2 = {yacc[i][j][4 * g + 2], yacc[i][j][4 * g + 3]};
-              lo2 *= sc; hi2 *= sc;
-              const h2v l = __builtin_convertvector(lo2, h2v), hh = __builtin_convertvector(hi2, h2v);
-              const h4 hv = {l[0], l[1], hh[0], hh[1]};
-              // (plain stores: on gfx950 stores count in vmcnt IN ORDER with the loads, so a write-through (sc1) store's long
-              //  acknowledgement holds up the next pass's counted waits for its weight fragments — round 6 timeline, −0.8 %)
-              asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(ob + i * rb_stride + (size_t)(j * 4 + g) * 512), "v"(hv) : "memory");
+              unsigned x[2], y[2];
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                f2v xa = {yacc[i][j][8 * gp + 2 * e + 0], yacc[i][j][8 * gp + 2 * e + 1]};
+                f2v ya = {yacc[i][j][8 * gp + 4 + 2 * e + 0], yacc[i][j][8 * gp + 4 + 2 * e + 1]};
+                xa *= sc; ya *= sc;
+                x[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(xa, h2v));
+                y[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(ya, h2v));
+              }
+#pragma unroll
+              for (int e = 0; e < 2; ++e) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[e]), "+v"(y[e]));
+              const h4 lo_ = __builtin_bit_cast(h4, (unsigned long long)x[0] | ((unsigned long long)x[1] << 32));
+              const h4 hi_ = __builtin_bit_cast(h4, (unsigned long long)y[0] | ((unsigned long long)y[1] << 32));
+              const h8 hv = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);
+              asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ob + i * rb_stride + (size_t)(j * 4 + 2 * gp + lh_e) * 512), "v"(hv) : "memory");
             }
       } else {
         // V: row-major [M, ldvo]; lanes l / l + 32 hold columns 8g + 0..3 / 8g + 4..7 of row l: after v_permlane32_swap lane l
