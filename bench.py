@@ -50,7 +50,7 @@ SAMPLES = SECONDS * 16000
 LCAP = 512
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense f16/bf16 MFMA (MI355X_MICROARCH.md)
 SUSTAINED_F16_TFLOPS = 1700.0  # measured: 256 CUs issuing v_mfma_f32_32x32x16_f16 back to back (profiles/round3_ubench_kstep.txt)
-PMC_FILE = os.path.join(ROOT, "profiles", "round5_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round6_pmc.json")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_MARGIN = 0.05          # = MARGIN of tests/test_gpu_full_depth.py (the two oracles never disagree above 0.02)
 ALPHA_NEAR = 0.1              # an oracle sum(alpha) this close to an integer is a near-tie of token_num = floor(sum alpha)

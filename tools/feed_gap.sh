@@ -2,7 +2,7 @@
 # Counters behind the "operand feed gap" question: SQ wait / issue / LDS / MFMA-busy cycles and TA / TCP
 # stall counters of the encoder GEMM kernels, one rocprofv3 --pmc pass per counter group (never combined with tracing
 # domains).  Output: gpurun_out/$TAG/pmc_<group>.json (tools/pmc_counters.py)
-TAG=${1:-round4}
+TAG=${1:-round6}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ run_pass() {
   for c in "$@"; do if have $c; then list="$list $c"; else echo "counter $c not available" >> $OUT/pmc_skipped.txt; fi; done
   [ -z "$list" ] && return
   rm -rf /tmp/prof_$name
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $list --output-format csv -d /tmp/prof_$name -- python $ROOT/bench.py --no-cpu-baseline --no-via-recognizer --steps 1 --warmup 1 --in-flight 1 ) > $OUT/rocprof_$name.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $list --output-format csv -d /tmp/prof_$name -- python $ROOT/bench.py --no-cpu-baseline --no-via-recognizer --no-exact --steps 1 --warmup 1 --in-flight 1 ) > $OUT/rocprof_$name.log 2>&1
   find /tmp/prof_$name -name "*counter_collection.csv" -exec cp {} /tmp/pmc_$name.csv \;
   python tools/pmc_counters.py /tmp/pmc_$name.csv > $OUT/pmc_$name.json 2>> $OUT/pmc_err.txt
 }

@@ -13,9 +13,8 @@ ROWS = [
     ("ffn_fused_kernel<8, 0, 2, 1, 1, 0>", "encoder layer tail, ONE launch: out-projection + FSMN + norm2 + FFN + next norm1 + next Q|K|V (k_ffn.hip)"),
     ("attn_kernel<8, 2>", "self-attention (k_attn.hip, 8 waves x 32 queries, Q|K blocked)"),
     ("ffn_fused_kernel<8, 0, 2, 2, 0, 3>", "decoder: previous layer's out-projection + norm1 + FFN block, split form, 3 shares per 64-row tile (k_ffn.hip)"),
-    ("ffn_dec_finish_kernel", "decoder: shares summed, hidden LayerNorm applied from row statistics, norm2"),
-    ("fsmn_dec_ln_kernel", "decoder: FSMN memory + residual + norm3"),
-    ("gemm_f16_pp3<1, 1>", "decoder q-projection (128-row tiles, f16 result)"),
+    ("dec_mid_kernel", "decoder (round 6): finishing pass of the split FFN + norm2 + FSMN memory + residual + norm3 + q-projection, one launch (k_decmid.hip)"),
+    ("ffn_dec_finish_kernel", "decoder: shares summed, hidden LayerNorm applied from row statistics, norm2 (final block only since round 6)"),
     ("attn_kernel<4, 2>", "cross-attention (decoder, 4 waves x 32 queries)"),
     ("gemm_f16_pp3<1, 2>", "K / V projection of all 16 decoder layers (one GEMM, N = 16384)"),
 ]

@@ -33,11 +33,12 @@ def main():
         ("CIF im2col", "cif_im2col_kernel", None, (M * D * 2 + M * 3 * D * 2) / 1e6),
         ("CIF weighted gather", "cif_gather_kernel", None, (M * D * 4 + Md * D * 4) / 1e6),
     ]
-    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (round 5)\n")
+    tag = next((a for a in sys.argv[3:] if not a.isdigit()), "round6")
+    print("# Per-kernel roofline, paraformer-large 32 x 30 s on one MI355X (%s)\n" % tag)
     print("Source: `%s` (rocprofv3 --kernel-trace, average kernel duration) and the HIP-event class times of "
           "`bench.py` (`class_ms_per_step`).  L = %d.  Peaks: HBM 8 TB/s spec (6.3 TB/s achievable), dense f16 MFMA 2.5 PFLOP/s.\n" % (trace.split("/")[-1], L))
     print("## HBM-bound kernels\n\n| kernel | avg µs | launches/step | algorithmic MB | achieved TB/s | of 8 TB/s | of 6.3 TB/s |\n|---|---|---|---|---|---|---|")
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 11     # forward passes in the traced command: warmup 2 + 1 profiling + 5 timed + 3 host-audio calls
+    steps = next((int(a) for a in sys.argv[3:] if a.isdigit()), 11)     # forward passes in the traced command: warmup 2 + 1 profiling + 5 timed + 3 host-audio calls
     for label, sub, grid, mb in mem:
         us, n = find(sub, grid)
         if us is None:
