@@ -1758,500 +1758,6 @@ void Engine::forward_device(const float* speech_dev, int B, int T, bool want_log
   last_flops_ = fl * B;
 }
 
-// ------------------------------------------------------------------ fp32 parity mode -------
-// math_mode = 1: the same graph with fp32 activations and fp32 weights on the fp32 matrix path (k_fp32.hip).  Supported
-// for the paraformer and SenseVoice graphs (no BiCIF head, no SeACo branch); one launch per graph node, no fusion.
-enum { F_X = 0, F_XN, F_Q, F_K, F_V, F_CTX, F_FS, F_H, F_T, F_COUNT };
-
-// One Linear of the fp32 graph.  math_mode 1: exact fp32 products on v_mfma_f32_32x32x2_f32 (k_fp32.hip).  math_mode 3
-// ("exact", round 5): operands as hi + 2^-11 lo' pairs of f16 numbers (22 mantissa bits, launch_split_x3) and
-//   x W^T = hi_x hi_W^T + 2^-11 (hi_x lo'_W^T + lo'_x hi_W^T)            (the lo lo term is 2^-22 relative: dropped)
-// as TWO launches of the pipeline's own f16 MFMA kernels with fp32 results: [hi_x] x [hi_W] (depth K) -> t, then
-// [hi_x | lo'_x] x [lo'_W | hi_W] (depth 2 K) scaled by 2^-11 in the epilogue, + t, + residual, ReLU — three times the f16
-// MFMA work at 16x the fp32 matrix rate.  The weight pairs are built on first use and kept (same bytes as the fp32 matrix).
-// flags: kX3OutPair — the result is only the A operand of the NEXT gemm32 (FFN hidden): in mode 3 it is written as its
-// (hi | lo') pair by the product's epilogue and `out` is not touched; kX3InPair — A is that pair (the `A` pointer is ignored in
-// mode 3).  Mode 1 ignores both flags.  resid2: a second fp32 addend with the row stride of resid (the FSMN memory beside the
-// residual stream).
-// attention of the fp32 graph: math_mode 1 on the fp32 matrix path; math_mode 3: PF_X3_ATTN = 0 the same, 1 = x3 operands
-// throughout, 2 = fp32 scores (what is exponentiated stays exact) + x3 operands for P V
-void Engine::attention32(const float* q, int64_t q_bs, int q_rs, const float* k, int64_t k_bs, int k_rs, const float* v, int64_t v_bs,
-                         int v_rs, float* o, int64_t o_bs, int o_rs, int B, int H, int Lq, int Lk, bool only_operand) {
-  const char* acls = (q_rs == k_rs && Lq == Lk) ? "attn32_self" : "attn32_cross";
-  prof_begin(acls, 4.0 * B * H * (double)Lq * Lk * 128);
-  struct End { Engine* e; const char* c; ~End() { e->prof_end(c); } } end_{this, acls};
-  // only_operand: o [B * Lq, H * 128] (dense rows) is nothing but the A operand of the gemm32 that follows — in math_mode 3 the
-  // fp32-MFMA kernel's epilogue writes it as that product's (hi | lo') pair (no fp32 context, no split pass)
-  const int Dm = H * 128, M = B * Lq;
-  if (only_operand && x3_mode_ && x3_fuse_ && x3_attn_ == 0 && o_rs == Dm && o_bs == (int64_t)Lq * Dm && Dm % 64 == 0 && M > gemm_small_max_rows()) {
-    const int64_t Mp = round_up(M, 256) + 128;
-    ensure(ws_x3a_, (size_t)Mp * 2 * Dm * 2);
-    half_t* a2 = (half_t*)ws_x3a_.p;
-    if (launch_attention_f32_pair(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, a2, (int64_t)Lq * 2 * Dm, 2 * Dm, Dm, B, H, Lq, Lk)) {
-      x3a_src_ = o; x3a_M_ = M; x3a_K_ = Dm; x3a_ld_ = Dm; x3a_buf_ = a2; x3a_pair_only_ = true;
-      return;
-    }
-  }
-  if (x3_mode_ && x3_attn_ == 1) launch_attention_x3(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, false);
-  else if (x3_mode_ && x3_attn_ == 2) launch_attention_x3(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, true);
-  else launch_attention_f32(stream_, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk);
-}
-
-void Engine::layernorm32(const float* x, int M, int D, const LNp& ln, float* xn) {
-  prof_begin("layernorm", 0);
-  struct End { Engine* e; ~End() { e->prof_end("layernorm"); } } end_{this};
-  if (x3_mode_ && x3_fuse_ && D == 512 && M > gemm_small_max_rows()) {
-    const int64_t Mp = round_up(M, 256) + 128;
-    ensure(ws_x3a_, (size_t)Mp * 2 * D * 2);
-    half_t* a2 = (half_t*)ws_x3a_.p;
-    launch_layernorm_pair(stream_, x, M, ln.g, ln.b, a2, 2 * D, D);
-    x3a_src_ = xn; x3a_M_ = M; x3a_K_ = D; x3a_ld_ = D; x3a_buf_ = a2; x3a_pair_only_ = true;
-    return;
-  }
-  launch_layernorm(stream_, x, M, D, ln.g, ln.b, nullptr, 0, xn, D);
-}
-
-void Engine::gemm32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
-                    const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
-  // the class's FLOPs are the fp32 graph's 2 M N K; math_mode 3 executes three times that on the f16 matrix cores
-  const char* cls = cls32_;
-  prof_begin(cls, 2.0 * M * (double)N * K);
-  gemm32_impl(A, lda, W, ldw, bias, M, N, K, out, ldc, resid, ldr, relu, scale_cols, scale, flags, resid2);
-  prof_end(cls);
-}
-
-void Engine::gemm32_impl(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K, float* out, int ldc,
-                         const float* resid, int ldr, bool relu, int scale_cols, float scale, int flags, const float* resid2) {
-  // (a q-scale on the leading columns only — the fused Q | K | V product — is an option of the one-launch form's epilogue)
-  const bool part_scale = scale_cols > 0 && scale_cols < N;
-  const bool x3 = x3_mode_ && M >= 64 && ldw == K && (!part_scale || (x3_one_ && scale_cols % 64 == 0 && M > gemm_small_max_rows())) &&
-                  (ldc % 4) == 0 && (!resid || ldr % 4 == 0);
-  const bool pair_ok = x3 && M > gemm_small_max_rows();
-  if (!x3) {
-    PF_CHECK(!(flags & kX3InPair) || !x3_pair_live_, PF_ERR_UNSUPPORTED, "gemm32: operand pair without its consumer");
-    PF_CHECK(!(x3a_pair_only_ && x3a_src_ == A), PF_ERR_UNSUPPORTED, "gemm32: the operand exists only as an x3 pair, but this product does not take the x3 form");
-    launch_gemm_f32(stream_, A, lda, W, ldw, bias, M, N, K, out, ldc, resid, ldr, relu, scale_cols, scale);
-    if (resid2) {
-      PF_CHECK(ldc == N && ldr == N, PF_ERR_UNSUPPORTED, "gemm32: a second addend needs contiguous rows");
-      launch_add_f32(stream_, out, resid2, (int64_t)M * N);
-    }
-    return;
-  }
-  const int Kp = (int)round_up(K, 64);
-  const int64_t Np = round_up(N, 256), Mp = round_up(M, 256) + 128;
-  auto it = x3w_.find(std::make_pair(W, N));
-  if (it == x3w_.end()) {
-    half_t* wc = (half_t*)dalloc((size_t)Np * 2 * Kp * 2);
-    PF_HIP(hipMemsetAsync(wc, 0, (size_t)Np * 2 * Kp * 2, stream_));
-    launch_split_x3(stream_, W, N, K, ldw, wc, 2 * Kp, Kp, 1);        // rows = [lo'_W | hi_W]
-    it = x3w_.emplace(std::make_pair(W, N), wc).first;
-  }
-  const half_t* wcat = it->second;
-  const int ldt = (int)round_up(N, 4);
-  ensure(ws_x3t_, (size_t)Mp * ldt * 4);
-  float* t = (float*)ws_x3t_.p;
-  half_t* a2;
-  if ((flags & kX3InPair) && x3_pair_live_) {
-    PF_CHECK(x3_pair_M_ == M && x3_pair_K_ == K, PF_ERR_INVALID_ARG, "gemm32: operand pair of another shape");
-    a2 = (half_t*)ws_x3h_.p;                                          // written by the producing product's epilogue
-    x3_pair_live_ = false; x3a_src_ = nullptr; x3a_pair_only_ = false;
-  } else {
-    ensure(ws_x3a_, (size_t)Mp * 2 * Kp * 2);
-    a2 = (half_t*)ws_x3a_.p;
-    // kX3SameInput: the caller states that A is the (unchanged) operand of its previous gemm32 call — Q, K and V share one
-    // (or the producer wrote the pair itself: layernorm32 / attention32 — then there is no fp32 form to split)
-    const bool same = ((flags & kX3SameInput) || x3a_pair_only_) && x3a_src_ == A && x3a_M_ == M && x3a_K_ == K && x3a_ld_ == lda && x3a_buf_ == a2;
-    PF_CHECK(same || !(x3a_pair_only_ && x3a_src_ == A), PF_ERR_UNSUPPORTED, "gemm32: the operand pair in the arena is not the one this product names");
-    if (!same) { launch_split_x3(stream_, A, M, K, lda, a2, 2 * Kp, Kp, 0); x3a_pair_only_ = false; }   // rows = [hi_x | lo'_x]
-    x3a_src_ = A; x3a_M_ = M; x3a_K_ = K; x3a_ld_ = lda; x3a_buf_ = a2;
-  }
-  const bool out_pair = (flags & kX3OutPair) && pair_ok && N % 64 == 0;
-  const int Np64 = (int)round_up(N, 64);
-  if (out_pair) {
-    ensure(ws_x3h_, (size_t)Mp * 2 * Np64 * 2);
-    PF_CHECK((void*)ws_x3h_.p != (void*)a2, PF_ERR_UNSUPPORTED, "gemm32: chained operand pairs");
-  }
-  if (x3_one_ && pair_ok) {
-    // ONE launch: the K loop walks the cross terms first ([hi_x | lo'_x] x [lo'_W | hi_W], depth 2 Kp), scales the accumulators
-    // by 2^-11, steps the cursors back (A to hi_x, W to hi_W) and adds hi_x hi_W^T (depth Kp) on top — small terms first, one
-    // fp32 accumulator, no [M, N] intermediate written and read back (FFN-up: 2 x 131 MB per layer), half the launches
-    GemmArgs c{};
-    c.A = a2; c.lda = 2 * Kp; c.W = wcat; c.ldw = 2 * Kp; c.bias = bias; c.M = M; c.N = N; c.K = 3 * Kp;
-    c.k_wrap = 2 * Kp / 64; c.a_wrap = 2 * Kp; c.w_wrap = Kp; c.wrap_scale = 1.0f / 2048.0f;
-    if (out_pair) {
-      c.out_f16 = (half_t*)ws_x3h_.p; c.ldc16 = 2 * Np64; c.f16_lo_off = Np64;
-      x3_pair_live_ = true; x3_pair_M_ = M; x3_pair_K_ = N;
-    } else {
-      c.out_f32 = out; c.ldc32 = ldc;
-    }
-    c.scale_cols = part_scale ? scale_cols : (scale_cols ? (int)round_up(N, 64) : 0); c.scale = scale;
-    c.add2 = resid2; c.ld2 = ldr; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
-    c.out_padded = 1; c.small_ws = small_ws_;
-    launch_gemm(stream_, c);                                          // out = (x W^T + bias) [* scale] [+ resid2] [+ resid]; ReLU
-    return;
-  }
-  GemmArgs g{};
-  g.A = a2; g.lda = 2 * Kp; g.W = wcat + Kp; g.ldw = 2 * Kp; g.bias = bias; g.M = M; g.N = N; g.K = Kp;
-  g.out_f32 = t; g.ldc32 = ldt; g.scale_cols = scale_cols ? (int)round_up(N, 64) : 0; g.scale = scale;
-  g.add2 = resid2; g.ld2 = ldr;
-  g.out_padded = 1; g.small_ws = small_ws_;
-  launch_gemm(stream_, g);                                            // t = (hi_x hi_W^T + bias) [* scale] [+ resid2]
-  GemmArgs c{};
-  c.A = a2; c.lda = 2 * Kp; c.W = wcat; c.ldw = 2 * Kp; c.M = M; c.N = N; c.K = 2 * Kp;
-  if (out_pair) {
-    c.out_f16 = (half_t*)ws_x3h_.p; c.ldc16 = 2 * Np64; c.f16_lo_off = Np64;
-    x3_pair_live_ = true; x3_pair_M_ = M; x3_pair_K_ = N;
-  } else {
-    c.out_f32 = out; c.ldc32 = ldc;
-  }
-  c.add2 = t; c.ld2 = ldt; c.resid = resid; c.ldr = ldr; c.relu = relu ? 1 : 0;
-  c.scale_cols = (int)round_up(N, 64); c.scale = (scale_cols ? scale : 1.f) * (1.0f / 2048.0f);
-  c.out_padded = 1; c.small_ws = small_ws_;
-  launch_gemm(stream_, c);                                            // out = cross * 2^-11 [* scale] + t + resid; ReLU
-}
-
-void Engine::enc_layer_fp32(const EncLayer& L, bool first, const float* speech_dev, int B, int T, float** f) {
-  const int D = mc_.d_model, M = B * T, F = mc_.ffn, Fd = mc_.feat_dim;
-  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
-  const int din = first ? Fd : D;
-  if (first) {
-    launch_posenc_f32(stream_, speech_dev, (const float*)ws_pe_.p, B, T, Fd, std::sqrt((float)D), f[F_T]);
-    launch_layernorm(stream_, f[F_T], M, Fd, L.norm1.g, L.norm1.b, nullptr, 0, f[F_XN], Fd);
-  } else {
-    layernorm32(f[F_X], M, D, L.norm1, f[F_XN]);
-  }
-  const float* Wq = L.qkv.w32;
-  // math_mode 3 above the short-input threshold: Q | K | V as ONE x3 product of N = 3 D (the weight is stored [Q | K | V] rows;
-  // q-scale on the first D columns) into the three consecutive buffers read as one [M, 3 D] matrix
-  const bool qkv_one = x3_mode_ && x3_one_ && x3_fuse_ && M > gemm_small_max_rows() && mc_.kernel == 11 && D % 64 == 0 &&
-                       f[F_K] == f[F_Q] + (size_t)M * D && f[F_V] == f[F_K] + (size_t)M * D;
-  cls32_ = "gemm32_qkv";
-  if (qkv_one) {
-    float* qkv = f[F_Q];
-    gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, 3 * D, din, qkv, 3 * D, nullptr, 0, false, D, qscale);
-    prof_begin("fsmn", 0);
-    launch_fsmn_f32_ld(stream_, qkv + 2 * D, 3 * D, L.fsmn_wT, B, T, D, mc_.kernel, f[F_FS]);
-    prof_end("fsmn");
-    attention32(qkv, (int64_t)T * 3 * D, 3 * D, qkv + D, (int64_t)T * 3 * D, 3 * D, qkv + 2 * D, (int64_t)T * 3 * D, 3 * D, f[F_CTX],
-                (int64_t)T * D, D, B, mc_.heads, T, T, true);
-  } else {
-  gemm32(f[F_XN], din, Wq, din, L.qkv.bias, M, D, din, f[F_Q], D, nullptr, 0, false, D, qscale);
-  gemm32(f[F_XN], din, Wq + (size_t)D * din, din, L.qkv.bias + D, M, D, din, f[F_K], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
-  gemm32(f[F_XN], din, Wq + (size_t)2 * D * din, din, L.qkv.bias + 2 * D, M, D, din, f[F_V], D, nullptr, 0, false, 0, 1.f, kX3SameInput);
-  launch_fsmn_f32(stream_, f[F_V], L.fsmn_wT, nullptr, B, T, D, mc_.kernel, f[F_FS]);
-  attention32(f[F_Q], (int64_t)T * D, D, f[F_K], (int64_t)T * D, D, f[F_V], (int64_t)T * D, D, f[F_CTX],
-                       (int64_t)T * D, D, B, mc_.heads, T, T, true);
-  }
-  cls32_ = "gemm32_out";
-  if (first) {
-    gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_FS], D, false, 0, 1.f);
-  } else {
-    // x = x + (lin + fsmn): the fp32 graph adds the attention block's two terms first; here the sum of three is formed in the
-    // product's epilogue as (lin + fsmn) + x up to one rounding of the association
-    gemm32(f[F_CTX], D, L.out.w32, D, L.out.bias, M, D, D, f[F_X], D, f[F_X], D, false, 0, 1.f, 0, f[F_FS]);
-  }
-  layernorm32(f[F_X], M, D, L.norm2, f[F_XN]);
-  cls32_ = "gemm32_ffn1";
-  gemm32(f[F_XN], D, L.w1.w32, D, L.w1.bias, M, F, D, f[F_H], F, nullptr, 0, true, 0, 1.f, kX3OutPair);
-  cls32_ = "gemm32_ffn2";
-  gemm32(f[F_H], F, L.w2.w32, F, L.w2.bias, M, D, F, f[F_X], D, f[F_X], D, false, 0, 1.f, kX3InPair);
-  cls32_ = "gemm32_misc";
-}
-
-void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logits) {
-  const int D = mc_.d_model, F = mc_.ffn, V = mc_.vocab, Fd = mc_.feat_dim, M = B * T, T1 = T + 1;
-  const int taps = mc_.cif_l_order + mc_.cif_r_order + 1;
-  build_pe(T);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t W = (size_t)std::max(std::max(Fd, D), taps * D);
-  size_t o_f[F_COUNT];
-  o_f[F_X] = carve((size_t)M * D * 4); o_f[F_XN] = carve((size_t)M * W * 4); o_f[F_Q] = carve((size_t)M * D * 4);
-  o_f[F_K] = carve((size_t)M * D * 4); o_f[F_V] = carve((size_t)M * D * 4); o_f[F_CTX] = carve((size_t)M * D * 4);
-  o_f[F_FS] = carve((size_t)M * D * 4); o_f[F_H] = carve((size_t)M * F * 4); o_f[F_T] = carve((size_t)M * W * 4);
-  const size_t o_H = carve((size_t)M * D * 4), o_al = carve((size_t)B * T1 * 4), o_fc = carve((size_t)B * 4), o_tn = carve((size_t)B * 4);
-  const size_t o_ff = carve((size_t)B * T1 * 4), o_wc = carve((size_t)B * T1 * 4), o_wr = carve((size_t)B * T1 * 4), o_mx = carve(256);
-  ensure(ws_f32_, off);
-  char* base = (char*)ws_f32_.p;
-  float* f[F_COUNT];
-  for (int i = 0; i < F_COUNT; ++i) f[i] = (float*)(base + o_f[i]);
-  H32_ = (float*)(base + o_H); alphas_ = (float*)(base + o_al);
-  plan_.fire_count = (int32_t*)(base + o_fc); plan_.token_num = (int32_t*)(base + o_tn);
-  plan_.fire_frame = (int32_t*)(base + o_ff); plan_.w_cur = (float*)(base + o_wc);
-  plan_.w_rem = (float*)(base + o_wr); plan_.max_count = (int32_t*)(base + o_mx);
-
-  x3_pair_live_ = false; x3a_src_ = nullptr; x3a_pair_only_ = false;      // (a forward that threw may have left an operand pair announced)
-  for (size_t i = 0; i < enc_.size(); ++i) enc_layer_fp32(enc_[i], i == 0, speech_dev, B, T, f);
-  if (tp_.empty()) {
-    launch_layernorm(stream_, f[F_X], M, D, enc_after_.g, enc_after_.b, nullptr, 0, H32_, D);
-  } else {
-    launch_layernorm(stream_, f[F_X], M, D, enc_after_.g, enc_after_.b, nullptr, 0, f[F_X], D);
-    for (size_t i = 0; i < tp_.size(); ++i) enc_layer_fp32(tp_[i], false, nullptr, B, T, f);
-    launch_layernorm(stream_, f[F_X], M, D, tp_norm_.g, tp_norm_.b, nullptr, 0, H32_, D);
-  }
-  const int ldV = (int)round_up(V, 4);
-  last_.peak_len = 0;
-  last_.cif_peak.clear();
-  if (mc_.kind == "sensevoicesmall") {
-    size_t o2 = 0;
-    auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-    const size_t o_lg = c2((size_t)M * ldV * 4), o_ids = c2((size_t)M * 8);
-    ensure(ws_dec_, o2);
-    logits_ = (float*)((char*)ws_dec_.p + o_lg); ids_dev_ = (int64_t*)((char*)ws_dec_.p + o_ids); logits_ld_ = ldV;
-    gemm32(H32_, D, ctc_.w32, D, ctc_.bias, M, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
-    launch_argmax(stream_, logits_, M, V, ldV, want_logits ? 2 : 1, ids_dev_);
-    last_.B = B; last_.L = T; last_.V = V; last_.T = T;
-    last_.ids.assign((size_t)M, 0);
-    last_.token_num.assign(B, T);
-    last_.fire_count.assign(B, T);
-    PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)M * 8, hipMemcpyDeviceToHost, stream_));
-    last_flops_ = 0;
-    return;
-  }
-  // ---- CIF predictor
-  launch_im2col_f32(stream_, H32_, B, T, D, mc_.cif_l_order, mc_.cif_r_order, f[F_T]);
-  cls32_ = "gemm32_cif";
-  gemm32(f[F_T], taps * D, cif_conv_w32_, taps * D, cif_conv_.bias, M, D, taps * D, f[F_FS], D, nullptr, 0, true, 0, 1.f);
-  launch_cif_alpha(stream_, f[F_FS], B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
-  if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
-  else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
-  if (mc_.timestamp_head) timestamp_head_fp32(B, T);
-  int32_t L = 0;
-  last_.fire_count.resize(B);
-  last_.token_num.resize(B);
-  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  if (l_hook_) L = l_hook_(L);
-  last_.B = B; last_.L = L; last_.V = V; last_.T = T;
-  last_.ids.assign((size_t)B * L, 0);
-  last_flops_ = 0;
-  if (L == 0) return;
-  // ---- decoder
-  const int Md = B * L;
-  size_t o2 = 0;
-  auto c2 = [&](size_t bytes) { size_t o = o2; o2 += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o_x = c2((size_t)Md * D * 4), o_xn = c2((size_t)Md * D * 4), o_h = c2((size_t)Md * F * 4), o_hn = c2((size_t)Md * F * 4);
-  const size_t o_t = c2((size_t)Md * D * 4), o_tn2 = c2((size_t)Md * D * 4), o_q = c2((size_t)Md * D * 4), o_ctx = c2((size_t)Md * D * 4);
-  const size_t o_kv = c2((size_t)M * 2 * D * 4), o_lg = c2((size_t)Md * ldV * 4), o_ids = c2((size_t)Md * 8);
-  ensure(ws_dec_, o2);
-  char* b2 = (char*)ws_dec_.p;
-  float* xd = (float*)(b2 + o_x); float* xn = (float*)(b2 + o_xn); float* hd = (float*)(b2 + o_h); float* hn = (float*)(b2 + o_hn);
-  float* t32 = (float*)(b2 + o_t); float* tn32 = (float*)(b2 + o_tn2); float* qd = (float*)(b2 + o_q); float* cx = (float*)(b2 + o_ctx);
-  float* kv = (float*)(b2 + o_kv);
-  logits_ = (float*)(b2 + o_lg); ids_dev_ = (int64_t*)(b2 + o_ids); logits_ld_ = ldV;
-  if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, H32_, alphas_, B, T, D, T1, plan_, L, xd);
-  else launch_cif_gather(stream_, H32_, B, T, D, T1, plan_, L, xd);
-  const bool bias_branch = mc_.seaco && n_hotwords_ > 0;
-  float* e0 = nullptr;                                 // SeACo: the bias decoder also starts from the CIF embeds
-  if (bias_branch) {
-    ensure(ws_seaco_in_, (size_t)Md * D * 4);
-    e0 = (float*)ws_seaco_in_.p;
-    PF_HIP(hipMemcpyAsync(e0, xd, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
-  }
-  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
-  cls32_ = "gemm32_dec";
-  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
-    layernorm32(xd, Md, D, n1, xn);
-    gemm32(xn, D, w1.w32, D, w1.bias, Md, F, D, hd, F, nullptr, 0, true, 0, 1.f);
-    launch_layernorm(stream_, hd, Md, F, fn.g, fn.b, nullptr, 0, hn, F);
-    gemm32(hn, F, w2.w32, F, nullptr, Md, D, F, t32, D, nullptr, 0, false, 0, 1.f);
-  };
-  for (size_t i = 0; i < dec_.size(); ++i) {
-    const DecLayer& Lr = dec_[i];
-    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
-    launch_layernorm(stream_, t32, Md, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
-    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, plan_.token_num, B, L, D, mc_.kernel, xd);
-    layernorm32(xd, Md, D, Lr.norm3, xn);
-    gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, Md, D, D, qd, D, nullptr, 0, false, D, qscale);
-    gemm32(H32_, D, Lr.kv32.w32, D, Lr.kv32.bias, M, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
-    attention32(qd, (int64_t)L * D, D, kv, (int64_t)T * 2 * D, 2 * D, kv + D, (int64_t)T * 2 * D, 2 * D, cx,
-                         (int64_t)L * D, D, B, mc_.heads, L, T, true);
-    gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, Md, D, D, xd, D, xd, D, false, 0, 1.f);
-  }
-  ffn_dec(dec_final_norm1_, dec_final_w1_, dec_final_ffn_norm_, dec_final_w2_);
-  launch_layernorm(stream_, t32, Md, D, dec_after_.g, dec_after_.b, nullptr, 0, xn, D);
-  cls32_ = "gemm32_vocab";
-  gemm32(xn, D, dec_out_.w32, D, dec_out_.bias, Md, V, D, logits_, ldV, nullptr, 0, false, 0, 1.f);
-  launch_argmax(stream_, logits_, Md, V, ldV, want_logits ? 2 : 1, ids_dev_);
-  cls32_ = "gemm32_misc";
-  if (bias_branch) seaco_head_fp32(B, L, e0, xn, want_logits);      // xn = the ASR decoder's after_norm hidden
-  PF_HIP(hipMemcpyAsync(last_.ids.data(), ids_dev_, (size_t)Md * 8, hipMemcpyDeviceToHost, stream_));
-}
-
-// ---- fp32 forms of the two heads (math_mode 1): the same graphs as timestamp_head / seaco_head with fp32 weights and
-// activations, one launch per graph node; the recurrences run as one fp32 GEMM + one cell kernel per time step.
-void Engine::lstm_fp32(const float* x, int Bn, int Tn, const float* w_ih, const float* w_hh, const float* bias, bool reverse,
-                       float* xg, float* gates, float* hbuf, float* cbuf, float* hout, int ldh, int col0) {
-  const int D = mc_.d_model;
-  // input half of the gates for every row at once: xg[b * Tn + t, 0:4D] = x W_ih^T + (b_ih + b_hh)
-  gemm32(x, D, w_ih, D, bias, Bn * Tn, 4 * D, D, xg, 4 * D, nullptr, 0, false, 0, 1.f);
-  PF_HIP(hipMemsetAsync(hbuf, 0, (size_t)Bn * D * 4, stream_));
-  PF_HIP(hipMemsetAsync(cbuf, 0, (size_t)Bn * D * 4, stream_));
-  for (int st = 0; st < Tn; ++st) {
-    const int t = reverse ? Tn - 1 - st : st;
-    // gates[b] = xg[b * Tn + t] + h[b] W_hh^T   (rows of the residual operand are Tn * 4D apart)
-    launch_gemm_f32(stream_, hbuf, D, w_hh, D, nullptr, Bn, 4 * D, D, gates, 4 * D, xg + (size_t)t * 4 * D, Tn * 4 * D, false, 0, 1.f);
-    launch_lstm_cell_f32(stream_, gates, 4 * D, cbuf, hbuf, hout + (size_t)t * ldh + col0, (int64_t)Tn * ldh, Bn, D);
-  }
-}
-
-void Engine::timestamp_head_fp32(int B, int T) {
-  const int D = mc_.d_model, up = mc_.upsample;
-  const int M = B * T, T3 = up * T;
-  const int64_t M3 = (int64_t)B * T3;
-  PF_CHECK(ts_up_w32_, PF_ERR_UNSUPPORTED, "fp32 timestamp head: operands were not prepared (engine not created in math_mode 1)");
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o_up = carve((size_t)M3 * D * 4), o_xg = carve((size_t)M3 * 4 * D * 4), o_ho = carve((size_t)M3 * 2 * D * 4);
-  const size_t o_g = carve((size_t)B * 4 * D * 4), o_h = carve((size_t)B * D * 4), o_c = carve((size_t)B * D * 4);
-  const size_t o_al = carve((size_t)M3 * 4), o_pk = carve((size_t)M3 * 4);
-  // math_mode 3: the recurrence as ONE persistent launch with (hi, lo') pair operands (k_bicif.hip, lstm_ring_kernel<true>): room for
-  // both directions' input gates, the four pair slots of h and the sync words
-  const bool x3_rec = x3_mode_ && x3_fuse_ && !lstm_steps_ && D == 512 && (D / 8) * 2 * ((B + 31) / 32) <= cus_;
-  const size_t o_xg2 = x3_rec ? carve((size_t)(M3 + 256) * 8 * D * 4) : 0, o_hs = x3_rec ? carve((size_t)2 * 4 * B * 2 * D * 2) : 0, o_sw = x3_rec ? carve(256) : 0;
-  ensure(ws_ts_, off);
-  char* base = (char*)ws_ts_.p;
-  float* up32 = (float*)(base + o_up); float* xg = (float*)(base + o_xg); float* hout = (float*)(base + o_ho);
-  float* gates = (float*)(base + o_g); float* hb = (float*)(base + o_h); float* cb = (float*)(base + o_c);
-  float* al = (float*)(base + o_al);
-  us_peak_ = (float*)(base + o_pk);
-  // [M, 3D] row-major IS [3M, D]
-  gemm32(H32_, D, ts_up_w32_, D, ts_up_.bias, M, up * D, D, up32, up * D, nullptr, 0, false, 0, 1.f);
-  const char* sfx[2] = {"", "_reverse"};
-  bool done = false;
-  if (x3_rec) {
-    if (!ts_whh_x3_) {                                   // [2 dir][4D][hi (D) | lo' (D)], built once from the fp32 tensors
-      ts_whh_x3_ = (half_t*)dalloc((size_t)2 * 4 * D * 2 * D * 2);
-      for (int d = 0; d < 2; ++d)
-        launch_split_x3(stream_, tensor(std::string("predictor.blstm.weight_hh") + sfx[d]).dev, 4 * D, D, D, ts_whh_x3_ + (size_t)d * 4 * D * 2 * D, 2 * D, D, 0);
-    }
-    float* xg2 = (float*)(base + o_xg2);
-    for (int d = 0; d < 2; ++d)                          // input half of the gates, both directions side by side: [M3, 8D]
-      gemm32(up32, D, tensor(std::string("predictor.blstm.weight_ih") + sfx[d]).dev, D, ts_ih_.bias + (size_t)d * 4 * D, (int)M3, 4 * D, D,
-             xg2 + (size_t)d * 4 * D, 8 * D, nullptr, 0, false, 0, 1.f, d == 1 ? kX3SameInput : 0);
-    LstmArgs a{};
-    a.whh = ts_whh_x3_; a.xg = xg2; a.hstate = (half_t*)(base + o_hs); a.cstate = nullptr; a.hout = hout; a.B = B; a.T3 = T3; a.D = D; a.ndir = 2;
-    unsigned* sw = (unsigned*)(base + o_sw);
-    done = launch_lstm_persistent_x3(stream_, a, sw);
-    if (done) lstm_err_ = sw + 63;
-  }
-  if (!done)
-  for (int d = 0; d < 2; ++d)
-    lstm_fp32(up32, B, T3, tensor(std::string("predictor.blstm.weight_ih") + sfx[d]).dev,
-              tensor(std::string("predictor.blstm.weight_hh") + sfx[d]).dev, ts_ih_.bias + (size_t)d * 4 * D, d == 1, xg, gates, hb,
-              cb, hout, 2 * D, d * D);
-  launch_us_alpha(stream_, hout, M3, 2 * D, ts_out_w_, ts_out_b_, mc_.cif_smooth2, mc_.cif_noise2, al);
-  launch_us_peak(stream_, al, plan_.token_num, B, T3, mc_.cif_threshold - 1e-4f, us_peak_);
-  last_.peak_len = T3;
-  last_.cif_peak.resize((size_t)M3);
-  PF_HIP(hipMemcpyAsync(last_.cif_peak.data(), us_peak_, (size_t)M3 * 4, hipMemcpyDeviceToHost, stream_));
-}
-
-void Engine::seaco_head_fp32(int B, int L, const float* e0, const float* hid_asr, bool want_logits) {
-  const int D = mc_.d_model, V = mc_.vocab, Fs = mc_.seaco_ffn, ns = (int)sdec_.size();
-  const int N = n_hotwords_, J = 10, NJ = N * J;
-  const int Md = B * L, R = 2 * Md;
-  const int ldV = (int)round_up(V, 4);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o_ids = carve((size_t)NJ * 4), o_e = carve((size_t)NJ * D * 4), o_e2 = carve((size_t)NJ * D * 4), o_xg = carve((size_t)NJ * 4 * D * 4);
-  const size_t o_g = carve((size_t)N * 4 * D * 4), o_hb = carve((size_t)N * D * 4), o_cb = carve((size_t)N * D * 4);
-  const size_t o_kv = carve((size_t)NJ * 2 * D * 4), o_x = carve((size_t)R * D * 4), o_xn = carve((size_t)R * D * 4);
-  const size_t o_h = carve((size_t)R * Fs * 4), o_hn = carve((size_t)R * Fs * 4), o_t = carve((size_t)R * D * 4), o_tn = carve((size_t)R * D * 4);
-  const size_t o_q = carve((size_t)R * D * 4), o_cx = carve((size_t)R * D * 4), o_hid = carve((size_t)R * D * 4);
-  const size_t o_dha = carve((size_t)Md * ldV * 4), o_did = carve((size_t)Md * 8), o_tn2 = carve((size_t)2 * B * 4);
-  ensure(ws_seaco_, off);
-  char* base = (char*)ws_seaco_.p;
-  int32_t* ids = (int32_t*)(base + o_ids);
-  float* ea = (float*)(base + o_e); float* eb = (float*)(base + o_e2); float* xg = (float*)(base + o_xg);
-  float* gates = (float*)(base + o_g); float* hb = (float*)(base + o_hb); float* cb = (float*)(base + o_cb);
-  float* kv = (float*)(base + o_kv); float* xs = (float*)(base + o_x); float* xn = (float*)(base + o_xn);
-  float* hd = (float*)(base + o_h); float* hn = (float*)(base + o_hn); float* t32 = (float*)(base + o_t); float* tn32 = (float*)(base + o_tn);
-  float* qd = (float*)(base + o_q); float* cx = (float*)(base + o_cx); float* hid = (float*)(base + o_hid);
-  float* dha = (float*)(base + o_dha); int64_t* dha_ids = (int64_t*)(base + o_did); int32_t* tn2 = (int32_t*)(base + o_tn2);
-  // ---- hotword embedder: Embedding -> LSTM stack (all J outputs kept), rows n * J + j
-  PF_HIP(hipMemcpyAsync(ids, hotwords_.data(), (size_t)NJ * 4, hipMemcpyHostToDevice, stream_));
-  launch_embed_gather(stream_, seaco_embed_w_, ids, NJ, D, (int)tensor("seaco.embed.weight").shape[0], ea, nullptr);
-  float* cur = ea;
-  float* nxt = eb;
-  for (size_t l = 0; l < seaco_lstm_.size(); ++l) {
-    const std::string p = "seaco.lstm.l" + std::to_string(l);
-    lstm_fp32(cur, N, J, tensor(p + ".weight_ih").dev, tensor(p + ".weight_hh").dev, seaco_lstm_[l].ih.bias, false, xg, gates, hb, cb,
-              nxt, D, 0);
-    std::swap(cur, nxt);
-  }
-  const float* bias_embed = cur;                       // [NJ, D]
-  // ---- bias decoder on [CIF embeds ; decoder hidden]
-  PF_HIP(hipMemcpyAsync(xs, e0, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(xs + (size_t)Md * D, hid_asr, (size_t)Md * D * 4, hipMemcpyDeviceToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(tn2, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(tn2 + B, plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToDevice, stream_));
-  const float qscale = 1.0f / std::sqrt((float)(D / mc_.heads));
-  auto ffn_dec = [&](const LNp& n1, const Lin& w1, const LNp& fn, const Lin& w2) {
-    launch_layernorm(stream_, xs, R, D, n1.g, n1.b, nullptr, 0, xn, D);
-    gemm32(xn, D, w1.w32, D, w1.bias, R, Fs, D, hd, Fs, nullptr, 0, true, 0, 1.f);
-    launch_layernorm(stream_, hd, R, Fs, fn.g, fn.b, nullptr, 0, hn, Fs);
-    gemm32(hn, Fs, w2.w32, Fs, nullptr, R, D, Fs, t32, D, nullptr, 0, false, 0, 1.f);
-  };
-  for (int i = 0; i < ns; ++i) {
-    const DecLayer& Lr = sdec_[i];
-    ffn_dec(Lr.norm1, Lr.w1, Lr.ffn_norm, Lr.w2);
-    launch_layernorm(stream_, t32, R, D, Lr.norm2.g, Lr.norm2.b, nullptr, 0, tn32, D);
-    launch_fsmn_dec(stream_, tn32, Lr.fsmn_wT, tn2, 2 * B, L, D, mc_.seaco_kernel, xs);
-    launch_layernorm(stream_, xs, R, D, Lr.norm3.g, Lr.norm3.b, nullptr, 0, xn, D);
-    gemm32(xn, D, Lr.q.w32, D, Lr.q.bias, R, D, D, qd, D, nullptr, 0, false, D, qscale);
-    gemm32(bias_embed, D, Lr.kv32.w32, D, Lr.kv32.bias, NJ, 2 * D, D, kv, 2 * D, nullptr, 0, false, 0, 1.f);
-    attention32(qd, (int64_t)L * D, D, kv, 0, 2 * D, kv + D, 0, 2 * D, cx, (int64_t)L * D, D, 2 * B, mc_.heads, L, NJ);
-    gemm32(cx, D, Lr.out.w32, D, Lr.out.bias, R, D, D, xs, D, xs, D, false, 0, 1.f);
-  }
-  ffn_dec(seaco_final_norm1_, seaco_final_w1_, seaco_final_ffn_norm_, seaco_final_w2_);
-  launch_layernorm(stream_, t32, R, D, seaco_after_.g, seaco_after_.b, nullptr, 0, hid, D);
-  // ---- merged = cif_attended + dec_attended -> hotword_output_layer -> NO-BIAS merge with the ASR rows
-  launch_add_f32(stream_, hid, hid + (size_t)Md * D, (int64_t)Md * D);
-  gemm32(hid, D, seaco_out_.w32, D, seaco_out_.bias, Md, V, D, dha, ldV, nullptr, 0, false, 0, 1.f);
-  launch_argmax(stream_, dha, Md, V, ldV, 2, dha_ids);
-  launch_seaco_merge(stream_, dha, ldV, dha_ids, Md, V, mc_.seaco_nobias, want_logits ? 1 : 0, logits_, logits_ld_, ids_dev_);
-}
-
-void Engine::forward_feats_host(const float* speech, int B, int T, bool want_logits) {
-  PF_CHECK(speech && B > 0 && T > 0, PF_ERR_INVALID_ARG, "forward_feats: bad arguments");
-  PF_HIP(hipSetDevice(device_));
-  const size_t n = (size_t)B * T * mc_.feat_dim;
-  ensure(ws_speech_, n * 4);
-  PF_HIP(hipMemcpyAsync(ws_speech_.p, speech, n * 4, hipMemcpyHostToDevice, stream_));
-  forward_device((const float*)ws_speech_.p, B, T, want_logits);
-}
-
-void Engine::model_proj_host(const float* const* speech, const int32_t* n_floats, int B, bool want_logits) {
-  PF_CHECK(B > 0, PF_ERR_INVALID_ARG, "model_proj: empty batch");
-  PF_HIP(hipSetDevice(device_));
-  const int W = mc_.feat_dim;
-  int maxf = 0;
-  std::vector<int64_t> offs(B);
-  int64_t tot = 0;
-  for (int b = 0; b < B; ++b) {
-    PF_CHECK(speech[b] || n_floats[b] == 0, PF_ERR_INVALID_ARG, "model_proj: null speech");
-    offs[b] = tot;
-    tot += round_up(n_floats[b], 4);
-    maxf = std::max(maxf, n_floats[b]);
-  }
-  PF_CHECK(maxf > 0 && maxf % W == 0, PF_ERR_INVALID_ARG, "model_proj: feature length not a multiple of 560");
-  const int T = maxf / W;
-  ensure(ws_tmp_, (size_t)tot * 4 + (size_t)B * 12 + 64);
-  float* rag = (float*)ws_tmp_.p;
-  int64_t* offd = (int64_t*)((char*)ws_tmp_.p + round_up(tot * 4, 8));
-  int32_t* nd = (int32_t*)(offd + B);
-  for (int b = 0; b < B; ++b)
-    if (n_floats[b] > 0)
-      PF_HIP(hipMemcpyAsync(rag + offs[b], speech[b], (size_t)n_floats[b] * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(offd, offs.data(), (size_t)B * 8, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(nd, n_floats, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-  ensure(ws_speech_, (size_t)B * maxf * 4);
-  launch_pad_sentinel(stream_, rag, offd, nd, B, maxf, (float*)ws_speech_.p);
-  forward_device((const float*)ws_speech_.p, B, T, want_logits);
-}
 
 // Per-thread result slots live in thread-local storage keyed by the engine's uid: a slot dies with its thread
 // (no growth under thread-pool churn; a new thread that happens to re-use an OS thread id starts empty), is
@@ -2351,783 +1857,6 @@ void Engine::fetch(pf_batch_out* out) {
   // the call that receives the ids completes the learn-L-then-fetch protocol: release the slot (a B*L*V host
   // copy of the log-probs may hang off it)
   if (slot && out->token_ids) t_slots.erase(it);
-}
-
-// ------------------------------------------------------------------ stand-alone ops -------
-void Engine::op_lfr_cmvn_pad(const float* const* fbank, const int32_t* t80, int B, int sentinel, float* out,
-                             int64_t cap, int32_t* tmax_out) {
-  PF_HIP(hipSetDevice(device_));
-  const int nm = fc_.n_mels, W = fc_.lfr_m * nm;
-  std::vector<int64_t> foff(B + 1, 0);
-  int tmax = 0;
-  for (int b = 0; b < B; ++b) { foff[b + 1] = foff[b] + t80[b]; tmax = std::max(tmax, t80[b] / fc_.lfr_n); }
-  if (tmax_out) *tmax_out = tmax;
-  const int64_t need = (int64_t)B * tmax * W;
-  PF_CHECK(cap >= need, PF_ERR_CAPACITY, "lfr_cmvn_pad: out capacity < " + std::to_string(need));
-  if (need == 0) return;
-  ensure(ws_fbank_, (size_t)std::max<int64_t>(foff[B], 1) * nm * 4);
-  ensure(ws_meta_, (size_t)(B + 1) * 8 + (size_t)B * 4 + 64);
-  ensure(ws_speech_, (size_t)need * 4);
-  for (int b = 0; b < B; ++b)
-    if (t80[b] > 0)
-      PF_HIP(hipMemcpyAsync((float*)ws_fbank_.p + foff[b] * nm, fbank[b], (size_t)t80[b] * nm * 4,
-                            hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(ws_meta_.p, foff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, stream_));
-  int32_t* t80d = (int32_t*)((char*)ws_meta_.p + (size_t)(B + 1) * 8);
-  PF_HIP(hipMemcpyAsync(t80d, t80, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-  launch_lfr_cmvn_pad(stream_, (const float*)ws_fbank_.p, (const int64_t*)ws_meta_.p, t80d, B, tmax, fc_.lfr_m,
-                      fc_.lfr_n, nm, cmvn_shift_, cmvn_scale_, cmvn_shift_ ? 1 : 0, sentinel, (float*)ws_speech_.p);
-  PF_HIP(hipMemcpyAsync(out, ws_speech_.p, (size_t)need * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_argmax(const float* x, int64_t rows, int V, int64_t* ids) {
-  PF_HIP(hipSetDevice(device_));
-  if (rows == 0) return;
-  ensure(ws_tmp_, (size_t)rows * V * 4 + (size_t)rows * 8 + 256);
-  float* xd = (float*)ws_tmp_.p;
-  int64_t* idd = (int64_t*)((char*)ws_tmp_.p + round_up((int64_t)rows * V * 4, 256));
-  PF_HIP(hipMemcpyAsync(xd, x, (size_t)rows * V * 4, hipMemcpyHostToDevice, stream_));
-  launch_argmax(stream_, xd, rows, V, V, 0, idd);
-  PF_HIP(hipMemcpyAsync(ids, idd, (size_t)rows * 8, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_gemm(const float* A, const float* W, const float* bias, int M, int N, int K, int epi, float* C) {
-  PF_HIP(hipSetDevice(device_));
-  if (M == 0 || N == 0) return;
-  const int Kp = (int)round_up(K, 64);
-  const int64_t Mp = round_up(M, 256), Np = round_up(N, 256);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t oA = carve((size_t)M * K * 4), oW = carve((size_t)N * K * 4), ob = carve((size_t)N * 4);
-  const size_t oA16 = carve((size_t)Mp * Kp * 2), oW16 = carve((size_t)Np * Kp * 2), oC = carve((size_t)Mp * N * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemcpyAsync(base + oA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
-  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemsetAsync(base + oA16, 0, (size_t)Mp * Kp * 2, stream_));
-  PF_HIP(hipMemsetAsync(base + oW16, 0, (size_t)Np * Kp * 2, stream_));
-  launch_f32_to_f16(stream_, (const float*)(base + oA), M, K, K, (half_t*)(base + oA16), Kp);
-  launch_f32_to_f16(stream_, (const float*)(base + oW), N, K, K, (half_t*)(base + oW16), Kp);
-  GemmArgs g{};
-  g.A = (half_t*)(base + oA16); g.lda = Kp; g.W = (half_t*)(base + oW16); g.ldw = Kp;
-  g.bias = bias ? (const float*)(base + ob) : nullptr;
-  g.M = M; g.N = N; g.K = Kp; g.relu = epi == 1;
-  g.out_padded = 1;
-  const bool f16out = epi == 2;
-  if (f16out) { g.out_f16 = (half_t*)(base + oC); g.ldc16 = N; }
-  else { g.out_f32 = (float*)(base + oC); g.ldc32 = N; }
-  prof_begin("gemm_op", 2.0 * M * (double)N * K);
-  launch_gemm(stream_, g);
-  prof_end("gemm_op");
-  if (f16out) {
-    std::vector<uint16_t> tmp((size_t)M * N);
-    PF_HIP(hipMemcpyAsync(tmp.data(), base + oC, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
-    PF_HIP(hipStreamSynchronize(stream_));
-    for (size_t i = 0; i < tmp.size(); ++i) {
-      half_t hv;
-      std::memcpy(&hv, &tmp[i], 2);
-      C[i] = (float)hv;
-    }
-  } else {
-    PF_HIP(hipMemcpyAsync(C, base + oC, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
-    PF_HIP(hipStreamSynchronize(stream_));
-  }
-}
-
-void Engine::x3_forget(const float* W) {
-  for (auto it = x3w_.begin(); it != x3w_.end();) {
-    if (it->first.first != W) { ++it; continue; }
-    for (size_t i = 0; i < owned_.size(); ++i)
-      if (owned_[i] == (void*)it->second) { owned_.erase(owned_.begin() + i); break; }
-    hipFree(it->second);
-    it = x3w_.erase(it);
-  }
-}
-
-// A Linear / the FFN block of the fp32 graph exactly as enc_layer_fp32() launches them (gemm32: math_mode 1 on the fp32
-// matrix path, math_mode 3 as x3 products with the K-loop wrap and, in the block, the operand-pair epilogue).
-void Engine::op_linear32(const float* x, const float* W, const float* bias, const float* resid, int M, int N, int K, bool relu, float* y) {
-  PF_CHECK(fp32_mode_, PF_ERR_UNSUPPORTED, "linear32: the engine was not created with math_mode 1 or 3");
-  PF_HIP(hipSetDevice(device_));
-  const int ldc = (int)round_up(N, 4);
-  const int64_t Mp = round_up(M, 256) + 128, Np = round_up(N, 256);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t ox = carve((size_t)Mp * K * 4), oW = carve((size_t)Np * K * 4), ob = carve((size_t)Np * 4), orr = carve((size_t)Mp * ldc * 4),
-               oy = carve((size_t)Mp * ldc * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base, 0, off, stream_));
-  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
-  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-  if (resid) PF_HIP(hipMemcpy2DAsync(base + orr, (size_t)ldc * 4, resid, (size_t)N * 4, (size_t)N * 4, M, hipMemcpyHostToDevice, stream_));
-  gemm32((const float*)(base + ox), K, (const float*)(base + oW), K, bias ? (const float*)(base + ob) : nullptr, M, N, K, (float*)(base + oy), ldc,
-         resid ? (const float*)(base + orr) : nullptr, ldc, relu, 0, 1.f);
-  PF_HIP(hipMemcpy2DAsync(y, (size_t)N * 4, base + oy, (size_t)ldc * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  x3_forget((const float*)(base + oW));
-  x3a_src_ = nullptr;
-}
-
-void Engine::op_ffn32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, int M, int D, int F, float* y) {
-  PF_CHECK(fp32_mode_, PF_ERR_UNSUPPORTED, "ffn32: the engine was not created with math_mode 1 or 3");
-  PF_CHECK(D % 4 == 0 && F % 4 == 0, PF_ERR_INVALID_ARG, "ffn32: D and F must be multiples of 4");
-  PF_HIP(hipSetDevice(device_));
-  const int64_t Mp = round_up(M, 256) + 128, Dp = round_up(D, 256), Fp = round_up(F, 256);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t ox = carve((size_t)Mp * D * 4), o1 = carve((size_t)Fp * D * 4), ob1 = carve((size_t)Fp * 4), o2 = carve((size_t)Dp * F * 4),
-               ob2 = carve((size_t)Dp * 4), oh = carve((size_t)Mp * F * 4), oy = carve((size_t)Mp * D * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base, 0, off, stream_));
-  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + o1, W1, (size_t)F * D * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + o2, W2, (size_t)D * F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-  const float* xd = (const float*)(base + ox);
-  gemm32(xd, D, (const float*)(base + o1), D, (const float*)(base + ob1), M, F, D, (float*)(base + oh), F, nullptr, 0, true, 0, 1.f, kX3OutPair);
-  gemm32((const float*)(base + oh), F, (const float*)(base + o2), F, (const float*)(base + ob2), M, D, F, (float*)(base + oy), D, xd, D, false, 0, 1.f,
-         kX3InPair);
-  PF_HIP(hipMemcpyAsync(y, base + oy, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  x3_forget((const float*)(base + o1));
-  x3_forget((const float*)(base + o2));
-  x3a_src_ = nullptr;
-}
-
-// GEMM exactly as the pipeline launches it: kernel kind (fp32 / f16 row-major / f16 blocked result), tile height,
-// blocked A operand, residual / second addend, column scaling — the stand-alone counterpart of Engine::gemm().
-void Engine::op_gemm_ex(const pf_gemm_desc& ds, const float* A, const float* W, float* C) {
-  PF_HIP(hipSetDevice(device_));
-  const int M = ds.M, N = ds.N, K = ds.K;
-  PF_CHECK(M > 0 && N > 0 && K > 0, PF_ERR_INVALID_ARG, "gemm_ex: empty problem");
-  PF_CHECK(ds.out_kind >= 0 && ds.out_kind <= 2, PF_ERR_INVALID_ARG, "gemm_ex: out_kind must be 0, 1 or 2");
-  PF_CHECK(ds.tile_rows == 0 || ds.tile_rows == 32 || ds.tile_rows == 128 || ds.tile_rows == 256 || ds.tile_rows == 512 || ds.tile_rows == 1024 ||
-               ds.tile_rows == 2048,
-           PF_ERR_INVALID_ARG, "gemm_ex: tile_rows must be 0, 32 (= the short-input kernel), 128, 256, 512 (= the 256 x {192,256} tile kernel), "
-           "1024 (= its persistent form for the blocked result) or 2048 (= the k-step-32 fp32-result kernel)");
-  PF_CHECK(ds.out_kind == 0 || (!ds.resid && !ds.add2), PF_ERR_INVALID_ARG, "gemm_ex: residual / addend need the fp32 result kind");
-  PF_CHECK(ds.out_kind != 2 || N % 64 == 0, PF_ERR_INVALID_ARG, "gemm_ex: blocked result needs N % 64 == 0");
-  const int Kp = (int)round_up(K, 64);
-  const int64_t Mp = round_up(M, 256) + 128, Np = round_up(N, 256);
-  const int ld32 = (int)round_up(N, 4), ld16 = (int)round_up(N, 8);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t oA = carve((size_t)M * K * 4), oW = carve((size_t)N * K * 4), ob = carve((size_t)N * 4);
-  const size_t oA16 = carve((size_t)Mp * Kp * 2), oW16 = carve((size_t)Np * Kp * 2);
-  const size_t oR = carve((size_t)Mp * ld32 * 4), oD = carve((size_t)Mp * ld32 * 4), oC = carve((size_t)Mp * std::max(ld32, ld16) * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + oA16, 0, (size_t)Mp * Kp * 2, stream_));
-  PF_HIP(hipMemsetAsync(base + oW16, 0, (size_t)Np * Kp * 2, stream_));
-  std::vector<half_t> ablk;
-  if (ds.a_blocked) {
-    // host-side re-layout (independent of the kernel's own index arithmetic): element (m, k) at
-    // ((m/32 * Kp/8 + k/8) * 32 + m%32) * 8 + k%8
-    ablk.assign((size_t)Mp * Kp, (half_t)0.f);
-    for (int m = 0; m < M; ++m)
-      for (int k = 0; k < K; ++k)
-        ablk[(((size_t)(m >> 5) * (Kp >> 3) + (k >> 3)) * 32 + (m & 31)) * 8 + (k & 7)] = (half_t)A[(size_t)m * K + k];
-    PF_HIP(hipMemcpyAsync(base + oA16, ablk.data(), ablk.size() * 2, hipMemcpyHostToDevice, stream_));
-  } else {
-    PF_HIP(hipMemcpyAsync(base + oA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + oA), M, K, K, (half_t*)(base + oA16), Kp);
-  }
-  PF_HIP(hipMemcpyAsync(base + oW, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
-  launch_f32_to_f16(stream_, (const float*)(base + oW), N, K, K, (half_t*)(base + oW16), Kp);
-  if (ds.bias) PF_HIP(hipMemcpyAsync(base + ob, ds.bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-  if (ds.resid)
-    PF_HIP(hipMemcpy2DAsync(base + oR, (size_t)ld32 * 4, ds.resid, (size_t)N * 4, (size_t)N * 4, M, hipMemcpyHostToDevice, stream_));
-  if (ds.add2)
-    PF_HIP(hipMemcpy2DAsync(base + oD, (size_t)ld32 * 4, ds.add2, (size_t)N * 4, (size_t)N * 4, M, hipMemcpyHostToDevice, stream_));
-  GemmArgs g{};
-  g.A = (half_t*)(base + oA16); g.lda = Kp; g.W = (half_t*)(base + oW16); g.ldw = Kp;
-  g.bias = ds.bias ? (const float*)(base + ob) : nullptr;
-  g.M = M; g.N = N; g.K = Kp; g.relu = ds.relu ? 1 : 0;
-  g.scale_cols = ds.scale_cols; g.scale = ds.scale;
-  g.out_padded = 1;
-  g.a_blocked = ds.a_blocked ? 1 : 0;
-  g.force_mi = ds.tile_rows == 128 ? 1 : (ds.tile_rows == 256 ? 2 : (ds.tile_rows == 32 ? 4 : (ds.tile_rows == 1024 ? 5 : (ds.tile_rows == 2048 ? 6 : 0))));
-  g.small_ws = small_ws_;
-  if (ds.out_kind == 0) {
-    g.out_f32 = (float*)(base + oC); g.ldc32 = ld32;
-    if (ds.resid) { g.resid = (const float*)(base + oR); g.ldr = ld32; }
-    if (ds.add2) { g.add2 = (const float*)(base + oD); g.ld2 = ld32; }
-  } else {
-    g.out_f16 = (half_t*)(base + oC); g.ldc16 = ds.out_kind == 2 ? N : ld16;
-    g.out_blocked = ds.out_kind == 2;
-  }
-  static const int reps = [] { const char* e = getenv("PF_OP_REPEAT"); return e ? std::max(1, atoi(e)) : 1; }();   // tools/: warm-cache timing
-  for (int r = 0; r < reps; ++r) {
-    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 2.0 * M * (double)N * K);
-    launch_gemm(stream_, g);
-    prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
-  }
-  if (ds.out_kind == 0) {
-    PF_HIP(hipMemcpy2DAsync(C, (size_t)N * 4, base + oC, (size_t)ld32 * 4, (size_t)N * 4, M, hipMemcpyDeviceToHost, stream_));
-    PF_HIP(hipStreamSynchronize(stream_));
-  } else {
-    const size_t rows = ds.out_kind == 2 ? (size_t)round_up(M, 32) : (size_t)M;
-    const size_t ld = ds.out_kind == 2 ? (size_t)N : (size_t)ld16;
-    std::vector<half_t> tmp(rows * ld);
-    PF_HIP(hipMemcpyAsync(tmp.data(), base + oC, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
-    PF_HIP(hipStreamSynchronize(stream_));
-    for (int m = 0; m < M; ++m)
-      for (int n = 0; n < N; ++n) {
-        const size_t idx = ds.out_kind == 2 ? (((size_t)(m >> 5) * (N >> 3) + (n >> 3)) * 32 + (m & 31)) * 8 + (n & 7)
-                                            : (size_t)m * ld + n;
-        C[(size_t)m * N + n] = (float)tmp[idx];
-      }
-  }
-}
-
-void Engine::op_gemm_rc(const pf_gemm_rc_desc& ds, const float* A, const float* W, float* x_out, float* n16_out,
-                        float* n32_out) {
-  PF_HIP(hipSetDevice(device_));
-  const int M = ds.M, K = ds.K, N = 512;
-  PF_CHECK(M > 0 && K > 0 && K % 64 == 0, PF_ERR_INVALID_ARG, "gemm_rc: K must be a positive multiple of 64");
-  PF_CHECK(!ds.fsmn_v || (ds.fsmn_w && ds.fsmn_k > 0), PF_ERR_INVALID_ARG, "gemm_rc: FSMN needs weights");
-  PF_CHECK((ds.ln_gamma != nullptr) == (ds.ln_beta != nullptr), PF_ERR_INVALID_ARG, "gemm_rc: gamma and beta go together");
-  const int64_t Mp = round_up(M, 256) + 128;
-  const int k = ds.fsmn_k;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * std::max(K, N), (int64_t)N * K) * 4);
-  const size_t oA16 = carve((size_t)Mp * K * 2), oW16 = carve((size_t)N * K * 2), ob = carve((size_t)N * 4);
-  const size_t oR = carve((size_t)Mp * N * 4), oV = carve((size_t)(Mp + 128) * 3 * N * 2), owT = carve((size_t)std::max(k, 1) * N * 4);
-  const size_t og = carve((size_t)N * 4), obe = carve((size_t)N * 4), oX = carve((size_t)Mp * N * 4), oN16 = carve((size_t)Mp * N * 2);
-  const size_t oN32 = carve((size_t)Mp * N * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + oA16, 0, (size_t)Mp * K * 2, stream_));
-  std::vector<half_t> ablk;
-  if (ds.a_blocked) {
-    ablk.assign((size_t)Mp * K, (half_t)0.f);
-    for (int m = 0; m < M; ++m)
-      for (int kk = 0; kk < K; ++kk)
-        ablk[(((size_t)(m >> 5) * (K >> 3) + (kk >> 3)) * 32 + (m & 31)) * 8 + (kk & 7)] = (half_t)A[(size_t)m * K + kk];
-    PF_HIP(hipMemcpyAsync(base + oA16, ablk.data(), ablk.size() * 2, hipMemcpyHostToDevice, stream_));
-  } else {
-    PF_HIP(hipMemcpyAsync(base + o32, A, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), M, K, K, (half_t*)(base + oA16), K);
-    PF_HIP(hipStreamSynchronize(stream_));
-  }
-  PF_HIP(hipMemcpyAsync(base + o32, W, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
-  launch_f32_to_f16(stream_, (const float*)(base + o32), N, K, K, (half_t*)(base + oW16), K);
-  PF_HIP(hipStreamSynchronize(stream_));
-  GemmRcArgs g{};
-  g.A = (half_t*)(base + oA16); g.lda = K; g.a_blocked = ds.a_blocked ? 1 : 0;
-  g.W = (half_t*)(base + oW16); g.ldw = K; g.M = M; g.K = K;
-  if (ds.bias) { PF_HIP(hipMemcpyAsync(base + ob, ds.bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_)); g.bias = (const float*)(base + ob); }
-  if (ds.resid) { PF_HIP(hipMemcpyAsync(base + oR, ds.resid, (size_t)M * N * 4, hipMemcpyHostToDevice, stream_)); g.resid = (const float*)(base + oR); g.ldr = N; }
-  std::vector<float> wT;
-  if (ds.fsmn_v) {
-    // the V slice of a [M, 3*512] QKV buffer, as in the pipeline (row stride 1536 halves)
-    PF_HIP(hipMemsetAsync(base + oV, 0, (size_t)(Mp + 128) * 3 * N * 2, stream_));
-    PF_HIP(hipMemcpyAsync(base + o32, ds.fsmn_v, (size_t)M * N * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), M, N, N, (half_t*)(base + oV) + 2 * N, 3 * N);
-    wT.resize((size_t)k * N);
-    for (int c = 0; c < N; ++c)
-      for (int j = 0; j < k; ++j) wT[(size_t)j * N + c] = ds.fsmn_w[(size_t)c * k + j];
-    PF_HIP(hipMemcpyAsync(base + owT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
-    g.fsmn_v = (half_t*)(base + oV) + 2 * N; g.ldv = 3 * N; g.fsmn_wT = (const float*)(base + owT); g.fsmn_k = k;
-  }
-  g.T = ds.T > 0 ? ds.T : M;
-  if (ds.ln_gamma) {
-    PF_HIP(hipMemcpyAsync(base + og, ds.ln_gamma, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-    PF_HIP(hipMemcpyAsync(base + obe, ds.ln_beta, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-    g.ln_g = (const float*)(base + og); g.ln_b = (const float*)(base + obe); g.eps = 1e-12f;
-    if (n16_out) { g.out_n16 = (half_t*)(base + oN16); g.ldn16 = N; }
-    if (n32_out) { g.out_n32 = (float*)(base + oN32); g.ldn32 = N; }
-  }
-  if (x_out) { g.out_x = (float*)(base + oX); g.ldx = N; }
-  PF_CHECK(!ds.split_k, PF_ERR_UNSUPPORTED, "gemm_rc: the split-K forms (k_gemm_sk.hip) were removed in round 5 — the fused FFN block replaced them (numbers: profiles/round4_splitk_pairs.txt)");
-  if (ds.short_input) {
-    // the short-input forms of the same nodes, as enc_layer / the decoder run them for M <= 512 rows
-    PF_CHECK(!ds.a_blocked, PF_ERR_INVALID_ARG, "gemm_rc: the short-input kernels take a row-major A");
-    GemmSmallArgs q{};
-    q.A = g.A; q.lda = K; q.W = g.W; q.ldw = K; q.bias = g.bias; q.M = M; q.N = N; q.K = K; q.ws = small_ws_;
-    q.resid = g.resid; q.ldr = N;
-    const bool need_x = g.out_x || (g.ln_g && K <= 576);
-    if (need_x) { q.out_f32 = (float*)(base + oX); q.ldc32 = N; }
-    if (K <= 576) {
-      q.fsmn_v = g.fsmn_v; q.ldv = g.ldv; q.fsmn_wT = g.fsmn_wT; q.fsmn_k = g.fsmn_k; q.T = g.T;
-      launch_gemm_small(stream_, q);
-      if (g.ln_g) launch_layernorm(stream_, q.out_f32, M, N, g.ln_g, g.ln_b, g.out_n16, N, g.out_n32, N);
-    } else {
-      PF_CHECK(!g.fsmn_v, PF_ERR_INVALID_ARG, "gemm_rc: the split short-input form has no FSMN term");
-      q.post_ln_g = g.ln_g; q.post_ln_b = g.ln_b; q.post_n16 = g.out_n16; q.ldn16 = N; q.post_n32 = g.out_n32; q.ldn32 = N;
-      launch_gemm_small(stream_, q);
-    }
-  } else {
-    prof_begin("gemm_op", 2.0 * M * (double)N * K);
-    launch_gemm_rc(stream_, g);
-    prof_end("gemm_op");
-  }
-  if (x_out) PF_HIP(hipMemcpyAsync(x_out, base + oX, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
-  if (g.out_n32) PF_HIP(hipMemcpyAsync(n32_out, base + oN32, (size_t)M * N * 4, hipMemcpyDeviceToHost, stream_));
-  std::vector<half_t> tmp;
-  if (g.out_n16) {
-    tmp.resize((size_t)M * N);
-    PF_HIP(hipMemcpyAsync(tmp.data(), base + oN16, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
-  }
-  PF_HIP(hipStreamSynchronize(stream_));
-  for (size_t i = 0; i < tmp.size(); ++i) n16_out[i] = (float)tmp[i];
-}
-
-// Encoder FFN as enc_layer() runs it: FFN-up writes the hidden in the blocked activation layout (kind 3),
-// FFN-down reads it as a blocked A operand and adds bias + residual (kind 2).  y = resid + W2 relu(W1 x + b1) + b2.
-void Engine::op_ffn(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
-                    const float* resid, int M, int D, int F, float* y) {
-  PF_HIP(hipSetDevice(device_));
-  PF_CHECK(M > 0 && D % 64 == 0 && F % 64 == 0, PF_ERR_INVALID_ARG, "ffn: D and F must be multiples of 64");
-  const int64_t Mp = round_up(M, 256) + 128, Fp = round_up(F, 256), Dp = round_up(D, 256);
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * D, (int64_t)F * D) * 4);
-  const size_t ox16 = carve((size_t)Mp * D * 2), ow1 = carve((size_t)Fp * D * 2), ow2 = carve((size_t)Dp * F * 2);
-  const size_t ob1 = carve((size_t)F * 4), ob2 = carve((size_t)D * 4), oh = carve((size_t)Mp * F * 2);
-  const size_t oxr = carve((size_t)Mp * D * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + ox16, 0, oxr - ox16, stream_));
-  auto up16 = [&](const float* src, int rows, int cols, size_t dst) {
-    PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), cols);
-    PF_HIP(hipStreamSynchronize(stream_));
-  };
-  up16(x, M, D, ox16); up16(w1, F, D, ow1); up16(w2, D, F, ow2);
-  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + oxr, resid, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
-  Lin L1, L2;
-  L1.w = (half_t*)(base + ow1); L1.bias = (const float*)(base + ob1); L1.N = F; L1.K = D; L1.Kpad = D;
-  L2.w = (half_t*)(base + ow2); L2.bias = (const float*)(base + ob2); L2.N = D; L2.K = F; L2.Kpad = F;
-  float* xr = (float*)(base + oxr);
-  gemm("gemm_ffn1", L1, (half_t*)(base + ox16), D, M, nullptr, 0, (half_t*)(base + oh), F, nullptr, 0, nullptr, 0, true, 0, 1.f, true, 1);
-  gemm("gemm_ffn2", L2, (half_t*)(base + oh), F, M, xr, D, nullptr, 0, xr, D, nullptr, 0, false, 0, 1.f, true, 2);
-  PF_HIP(hipMemcpyAsync(y, xr, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-// The encoder FFN block as enc_layer() launches it for long inputs: retile W1 / W2, then ONE launch of ffn_fused_kernel.
-// The decoder's FFN block in the split form of the fused kernel (k_ffn.hip), standalone: t = LN_F(relu(f16(x) W1^T + b1)) W2^T,
-// n = LayerNorm(t); x = the block's normalised input, or (ds.ctx) LayerNorm norm1 of x_out = resid + ctx Wo^T + bo computed by
-// the same launch.
-void Engine::op_dec_ffn_fused(const pf_dec_ffn_desc& ds, float* t_out, float* n_out, float* x_out) {
-  PF_HIP(hipSetDevice(device_));
-  const int D = 512, F = 2048, M = ds.M, splits = ds.splits;
-  PF_CHECK(M > 0, PF_ERR_INVALID_ARG, "dec_ffn_fused: M must be positive");
-  PF_CHECK(splits == 0 || splits == 1 || splits == 2 || splits == 3 || splits == 4 || splits == 8, PF_ERR_INVALID_ARG,
-           "dec_ffn_fused: splits must be 0 (automatic) | 1 | 2 | 3 | 4 | 8");
-  const bool op = ds.ctx != nullptr;
-  const int64_t Mp = round_up(M, 256) + 128;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * D, (int64_t)F * D) * 4);
-  const size_t ox16 = carve((size_t)Mp * D * 2), ow1 = carve((size_t)F * D * 2), ow2 = carve((size_t)D * F * 4);
-  const size_t oimg = carve(ffn_dec_image_bytes()), ows = carve(ffn_dec_workspace_bytes(M, splits));
-  const size_t ob1 = carve((size_t)F * 4), ogf = carve((size_t)F * 4), obf = carve((size_t)F * 4), og = carve((size_t)D * 4), obe = carve((size_t)D * 4);
-  const size_t ot = carve((size_t)M * D * 4), on = carve((size_t)M * D * 4);
-  const size_t owo = carve((size_t)D * D * 2), owot = carve(ffn_outproj_weight_bytes()), obo = carve((size_t)D * 4);
-  const size_t og1 = carve((size_t)D * 4), obe1 = carve((size_t)D * 4), oxr = carve((size_t)Mp * D * 4), oxo = carve((size_t)Mp * D * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));
-  auto up16 = [&](const float* src, int rows, int cols, size_t dst, int ldo) {
-    PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), ldo);
-    PF_HIP(hipStreamSynchronize(stream_));
-  };
-  auto up = [&](const float* src, size_t n, size_t dst) { PF_HIP(hipMemcpyAsync(base + dst, src, n * 4, hipMemcpyHostToDevice, stream_)); };
-  up16(op ? ds.ctx : ds.x, M, D, ox16, D); up16(ds.w1, F, D, ow1, D);
-  up(ds.w2, (size_t)D * F, ow2); up(ds.b1, F, ob1); up(ds.gamma_f, F, ogf); up(ds.beta_f, F, obf);
-  if (ds.ln_gamma) { up(ds.ln_gamma, D, og); up(ds.ln_beta, D, obe); }
-  launch_ffn_dec_retile(stream_, (const half_t*)(base + ow1), D, (const float*)(base + ow2), (const float*)(base + ogf),
-                        (const float*)(base + obf), (const float*)(base + ob1), (half_t*)(base + oimg));
-  FfnDecArgs f{};
-  f.A = (const half_t*)(base + ox16); f.lda = D; f.img = (const half_t*)(base + oimg); f.ws = base + ows; f.M = M; f.splits = splits;
-  f.eps_hidden = 1e-12f; f.eps = 1e-12f;
-  if (op) {
-    up16(ds.wo, D, D, owo, D);
-    launch_ffn_retile_out(stream_, (const half_t*)(base + owo), D, (half_t*)(base + owot));
-    up(ds.bo, D, obo); up(ds.ln1_gamma, D, og1); up(ds.ln1_beta, D, obe1);
-    PF_HIP(hipMemsetAsync(base + oxr, 0, (size_t)Mp * D * 4, stream_));
-    up(ds.resid, (size_t)M * D, oxr);
-    f.A = nullptr; f.ctx = (const half_t*)(base + ox16); f.lda_c = D; f.Wot = (const half_t*)(base + owot); f.bo = (const float*)(base + obo);
-    f.resid = (const float*)(base + oxr); f.ldr = D; f.out_x = (float*)(base + oxo); f.ldx = D;
-    f.ln1_g = (const float*)(base + og1); f.ln1_b = (const float*)(base + obe1); f.eps1 = 1e-12f;
-  }
-  if (t_out) { f.t32 = (float*)(base + ot); f.ldt = D; }
-  if (ds.ln_gamma) { f.ln_g = (const float*)(base + og); f.ln_b = (const float*)(base + obe); }
-  if (n_out) { f.n32 = (float*)(base + on); f.ldn32 = D; }
-  const char* rep = getenv("PF_OP_REPEAT");                        // tools/: repeated launches, timed as class "gemm_op_warm"
-  const int reps = rep ? std::max(1, atoi(rep)) : 1;
-  for (int r = 0; r < reps; ++r) {
-    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F + (op ? 2.0 * M * (double)D * D : 0.0));
-    launch_ffn_dec(stream_, f);
-    prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
-  }
-  if (t_out) PF_HIP(hipMemcpyAsync(t_out, base + ot, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
-  if (n_out) PF_HIP(hipMemcpyAsync(n_out, base + on, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
-  if (x_out && op) PF_HIP(hipMemcpyAsync(x_out, base + oxo, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_ffn_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* resid,
-                          const float* g, const float* be, int M, float* x_out, float* n16_out, const pf_attn_ffn_desc* op) {
-  PF_HIP(hipSetDevice(device_));
-  const int D = 512, F = 2048;
-  PF_CHECK(M > 0, PF_ERR_INVALID_ARG, "ffn_fused: M must be positive");
-  PF_CHECK(op || x, PF_ERR_INVALID_ARG, "ffn_fused: missing operand");
-  const int64_t Mp = round_up(M, 256) + 128;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * D, (int64_t)F * D) * 4);
-  const size_t ox16 = carve((size_t)Mp * D * 2), ow1 = carve((size_t)F * D * 2), ow2 = carve((size_t)D * F * 2);
-  const size_t owt = carve(ffn_fused_weight_bytes());
-  const size_t ob1 = carve((size_t)F * 4), ob2 = carve((size_t)D * 4), og = carve((size_t)D * 4), obe = carve((size_t)D * 4);
-  const size_t oxr = carve((size_t)Mp * D * 4), oxo = carve((size_t)Mp * D * 4), on16 = carve((size_t)Mp * D * 2);
-  // out-projection form: Wo (f16 + its image), bias, the V slice inside a [M, 3 D] QKV-shaped buffer, taps, norm2, x_mid scratch
-  const size_t owo = carve((size_t)D * D * 2), owot = carve(ffn_outproj_weight_bytes()), obo = carve((size_t)D * 4);
-  const size_t ov = carve((size_t)(Mp + 128) * 3 * D * 2), owT = carve((size_t)11 * D * 4), og2 = carve((size_t)D * 4), obe2 = carve((size_t)D * 4);
-  const bool tail = op && op->wqkv;
-  const size_t owq = carve((size_t)3 * D * D * 2), owqt = carve(3 * ffn_outproj_weight_bytes()), obq = carve((size_t)3 * D * 4);
-  const size_t oqk = carve((size_t)Mp * 2 * D * 2), ovo = carve((size_t)Mp * D * 2);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + ox16, 0, (size_t)Mp * D * 2, stream_));
-  PF_HIP(hipMemsetAsync(base + oxr, 0, (size_t)Mp * D * 4, stream_));
-  auto up16 = [&](const float* src, int rows, int cols, size_t dst, int ldo) {
-    PF_HIP(hipMemcpyAsync(base + o32, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), rows, cols, cols, (half_t*)(base + dst), ldo);
-    PF_HIP(hipStreamSynchronize(stream_));
-  };
-  up16(op ? op->ctx : x, M, D, ox16, D); up16(w1, F, D, ow1, D); up16(w2, D, F, ow2, F);
-  PF_HIP(hipMemcpyAsync(base + ob1, b1, (size_t)F * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ob2, b2, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-  if (resid) PF_HIP(hipMemcpyAsync(base + oxr, resid, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
-  launch_ffn_retile(stream_, (half_t*)(base + ow1), D, (half_t*)(base + ow2), F, (half_t*)(base + owt));
-  FfnFusedArgs f{};
-  f.A = (half_t*)(base + ox16); f.lda = D; f.Wt = (half_t*)(base + owt); f.b1 = (const float*)(base + ob1); f.b2 = (const float*)(base + ob2);
-  f.M = M; f.resid = resid || !op ? (const float*)(base + oxr) : nullptr; f.ldr = D; f.eps = 1e-12f;
-  std::vector<float> wT;
-  if (op) {
-    up16(op->wo, D, D, owo, D);
-    launch_ffn_retile_out(stream_, (half_t*)(base + owo), D, (half_t*)(base + owot));
-    PF_HIP(hipMemsetAsync(base + ov, 0, (size_t)(Mp + 128) * 3 * D * 2, stream_));
-    PF_HIP(hipMemcpyAsync(base + o32, op->v, (size_t)M * D * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + o32), M, D, D, (half_t*)(base + ov) + 2 * D, 3 * D);
-    PF_HIP(hipStreamSynchronize(stream_));
-    wT.resize((size_t)11 * D);
-    for (int c = 0; c < D; ++c)
-      for (int j = 0; j < 11; ++j) wT[(size_t)j * D + c] = op->fsmn_w[(size_t)c * 11 + j];
-    PF_HIP(hipMemcpyAsync(base + owT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
-    PF_HIP(hipMemcpyAsync(base + obo, op->bo, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-    PF_HIP(hipMemcpyAsync(base + og2, op->ln2_gamma, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-    PF_HIP(hipMemcpyAsync(base + obe2, op->ln2_beta, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-    f.ctx = (half_t*)(base + ox16); f.lda_c = D; f.Wot = (half_t*)(base + owot); f.bo = (const float*)(base + obo);
-    f.fsmn_v = (half_t*)(base + ov) + 2 * D; f.ldv = 3 * D; f.fsmn_wT = (const float*)(base + owT); f.T = op->T > 0 ? op->T : M;
-    f.ln2_g = (const float*)(base + og2); f.ln2_b = (const float*)(base + obe2);
-    f.A = nullptr;
-  }
-  if (tail) {
-    PF_CHECK(op->bqkv && g, PF_ERR_INVALID_ARG, "attn_ffn_fused: the Q | K | V tail needs its bias and the LayerNorm in front of it");
-    up16(op->wqkv, 3 * D, D, owq, D);
-    for (int part = 0; part < 3; ++part)
-      launch_ffn_retile_out(stream_, (half_t*)(base + owq) + (size_t)part * D * D, D,
-                            (half_t*)(base + owqt) + (size_t)part * (ffn_outproj_weight_bytes() / 2));
-    PF_HIP(hipMemcpyAsync(base + obq, op->bqkv, (size_t)3 * D * 4, hipMemcpyHostToDevice, stream_));
-    f.Wqt = (half_t*)(base + owqt); f.bq = (const float*)(base + obq); f.out_qk = (half_t*)(base + oqk); f.out_v = (half_t*)(base + ovo);
-    f.ldvo = D; f.qscale = 1.0f / std::sqrt(128.0f);
-  }
-  if (x_out) { f.out_x = (float*)(base + oxo); f.ldx = D; }
-  if (g) {
-    PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-    PF_HIP(hipMemcpyAsync(base + obe, be, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-    f.ln_g = (const float*)(base + og); f.ln_b = (const float*)(base + obe);
-    if (n16_out) { f.out_n16 = (half_t*)(base + on16); f.ldn16 = D; }
-  }
-  const char* rep = getenv("PF_OP_REPEAT");                        // tools/: repeated launches, timed as class "gemm_op_warm"
-  const int reps = rep ? std::max(1, atoi(rep)) : 1;
-  for (int r = 0; r < reps; ++r) {                                 // (resid is a separate buffer: repeats compute the same result)
-    prof_begin(r == 0 ? "gemm_op" : "gemm_op_warm", 4.0 * M * (double)D * F + (op ? 2.0 * M * (double)D * D : 0.0));
-    launch_ffn_fused(stream_, f);
-    prof_end(r == 0 ? "gemm_op" : "gemm_op_warm");
-  }
-  if (x_out) PF_HIP(hipMemcpyAsync(x_out, base + oxo, (size_t)M * D * 4, hipMemcpyDeviceToHost, stream_));
-  std::vector<half_t> n16;
-  if (f.out_n16) {
-    n16.resize((size_t)M * D);
-    PF_HIP(hipMemcpyAsync(n16.data(), base + on16, n16.size() * 2, hipMemcpyDeviceToHost, stream_));
-  }
-  PF_HIP(hipStreamSynchronize(stream_));
-  if (f.out_n16)
-    for (size_t i = 0; i < n16.size(); ++i) n16_out[i] = (float)n16[i];
-  if (tail) {
-    std::vector<half_t> qk((size_t)Mp * 2 * D), vv((size_t)M * D);
-    PF_HIP(hipMemcpy(qk.data(), base + oqk, qk.size() * 2, hipMemcpyDeviceToHost));
-    PF_HIP(hipMemcpy(vv.data(), base + ovo, vv.size() * 2, hipMemcpyDeviceToHost));
-    for (int m = 0; m < M; ++m)
-      for (int n = 0; n < 2 * D; ++n) {                       // blocked [Mpad, 1024]: ((m / 32 * 128 + n / 8) * 32 + m % 32) * 8 + n % 8
-        const float val = (float)qk[(((size_t)(m >> 5) * 128 + (n >> 3)) * 32 + (m & 31)) * 8 + (n & 7)];
-        float* dst = n < D ? op->q_out : op->k_out;
-        if (dst) dst[(size_t)m * D + (n & (D - 1))] = val;
-      }
-    if (op->v_out)
-      for (size_t i = 0; i < vv.size(); ++i) op->v_out[i] = (float)vv[i];
-  }
-}
-
-// Encoder FSMN exactly as enc_layer() launches it: the f16 V slice of a [M, 3D] QKV buffer (row stride 3D).
-void Engine::op_fsmn_enc(const float* v, const float* w, int B, int T, int D, int k, float* y) {
-  PF_HIP(hipSetDevice(device_));
-  PF_CHECK(D % 8 == 0 && B > 0 && T > 0, PF_ERR_INVALID_ARG, "fsmn_enc: bad shape");
-  const size_t n = (size_t)B * T * D;
-  std::vector<float> wT((size_t)D * k);
-  for (int c = 0; c < D; ++c)
-    for (int j = 0; j < k; ++j) wT[(size_t)j * D + c] = w[(size_t)c * k + j];
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
-  const size_t ov = carve(n * 4), oq = carve(((size_t)B * T + 128) * 3 * D * 2), ow = carve(wT.size() * 4), oy = carve(n * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + oq, 0, ((size_t)B * T + 128) * 3 * D * 2, stream_));
-  PF_HIP(hipMemcpyAsync(base + ov, v, n * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ow, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
-  half_t* vs = (half_t*)(base + oq) + 2 * D;
-  launch_f32_to_f16(stream_, (const float*)(base + ov), (int64_t)B * T, D, D, vs, 3 * D);
-  launch_fsmn_enc(stream_, vs, 3 * D, (const float*)(base + ow), B, T, D, k, (float*)(base + oy));
-  PF_HIP(hipMemcpyAsync(y, base + oy, n * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-// Decoder FSMN exactly as the decoder launches it: x += (dwconv(tn*m) + tn*m)*m, m = (l < token_num[b]).
-void Engine::op_fsmn_dec(const float* tn, const float* w, const int32_t* token_num, int B, int L, int D, int k, float* x) {
-  PF_HIP(hipSetDevice(device_));
-  PF_CHECK(D % 4 == 0 && B > 0 && L > 0, PF_ERR_INVALID_ARG, "fsmn_dec: bad shape");
-  const size_t n = (size_t)B * L * D;
-  std::vector<float> wT((size_t)D * k);
-  for (int c = 0; c < D; ++c)
-    for (int j = 0; j < k; ++j) wT[(size_t)j * D + c] = w[(size_t)c * k + j];
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
-  const size_t ot = carve(n * 4), ox = carve(n * 4), ow = carve(wT.size() * 4), on = carve((size_t)B * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemcpyAsync(base + ot, tn, n * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ox, x, n * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ow, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + on, token_num, (size_t)B * 4, hipMemcpyHostToDevice, stream_));
-  launch_fsmn_dec(stream_, (const float*)(base + ot), (const float*)(base + ow), (const int32_t*)(base + on), B, L, D, k,
-                  (float*)(base + ox));
-  PF_HIP(hipMemcpyAsync(x, base + ox, n * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-// The pipeline's vocabulary tail: log-probs y = (x - max) - log(sum exp(x - max)) and the reference's last-index
-// arg-max over y (OfflineRecognizer.cs:139-152 scans the graph OUTPUT).  y == nullptr: ids only (mode 1).
-void Engine::op_logsoftmax_argmax(const float* x, int64_t rows, int V, float* y, int64_t* ids) {
-  PF_HIP(hipSetDevice(device_));
-  if (rows == 0) return;
-  const int ld = (int)round_up(V, 4);
-  ensure(ws_tmp_, (size_t)rows * ld * 4 + (size_t)rows * 8 + 256);
-  float* xd = (float*)ws_tmp_.p;
-  int64_t* idd = (int64_t*)((char*)ws_tmp_.p + round_up((int64_t)rows * ld * 4, 256));
-  PF_HIP(hipMemcpy2DAsync(xd, (size_t)ld * 4, x, (size_t)V * 4, (size_t)V * 4, rows, hipMemcpyHostToDevice, stream_));
-  launch_argmax(stream_, xd, rows, V, ld, y ? 2 : 1, idd);
-  if (y) PF_HIP(hipMemcpy2DAsync(y, (size_t)V * 4, xd, (size_t)ld * 4, (size_t)V * 4, rows, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(ids, idd, (size_t)rows * 8, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int D, float* y) {
-  PF_HIP(hipSetDevice(device_));
-  if (rows == 0) return;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o; };
-  const size_t ox = carve((size_t)rows * D * 4), og = carve((size_t)D * 4), obb = carve((size_t)D * 4), oy = carve((size_t)rows * D * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemcpyAsync(base + ox, x, (size_t)rows * D * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + og, g, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + obb, b, (size_t)D * 4, hipMemcpyHostToDevice, stream_));
-  launch_layernorm(stream_, (const float*)(base + ox), rows, D, (const float*)(base + og), (const float*)(base + obb),
-                   nullptr, 0, (float*)(base + oy), D);
-  PF_HIP(hipMemcpyAsync(y, base + oy, (size_t)rows * D * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_attention(const float* q, const float* k, const float* v, int B, int Lq, int Lk, int H, float* o) {
-  PF_HIP(hipSetDevice(device_));
-  const int Dm = H * 128;
-  const int64_t nq = (int64_t)B * Lq, nk = (int64_t)B * Lk;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
-  const size_t oin = carve((size_t)std::max(nq, nk) * Dm * 4);
-  const size_t oq = carve((size_t)(nq + 128) * Dm * 2), ok = carve((size_t)(nk + 128) * Dm * 2);
-  const size_t ov = carve((size_t)(nk + 128) * Dm * 2), oo = carve((size_t)(nq + 128) * Dm * 2), oo32 = carve((size_t)nq * Dm * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + oq, 0, off - oq, stream_));
-  auto up = [&](const float* src, int64_t rows, size_t dst) {
-    PF_HIP(hipMemcpyAsync(base + oin, src, (size_t)rows * Dm * 4, hipMemcpyHostToDevice, stream_));
-    launch_f32_to_f16(stream_, (const float*)(base + oin), rows, Dm, Dm, (half_t*)(base + dst), Dm);
-    PF_HIP(hipStreamSynchronize(stream_));
-  };
-  up(q, nq, oq); up(k, nk, ok); up(v, nk, ov);
-  AttnArgs a{};
-  a.q = (half_t*)(base + oq); a.k = (half_t*)(base + ok); a.v = (half_t*)(base + ov); a.o = (half_t*)(base + oo);
-  a.q_bstride = (int64_t)Lq * Dm; a.k_bstride = a.v_bstride = (int64_t)Lk * Dm; a.o_bstride = (int64_t)Lq * Dm;
-  a.q_rstride = a.k_rstride = a.v_rstride = a.o_rstride = Dm;
-  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
-  prof_begin("attn_op", 4.0 * B * (double)Lq * Lk * Dm);
-  launch_attention(stream_, a);
-  prof_end("attn_op");
-  // f16 -> f32 on the host side of the copy
-  std::vector<uint16_t> tmp((size_t)nq * Dm);
-  PF_HIP(hipMemcpyAsync(tmp.data(), base + oo, tmp.size() * 2, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  for (size_t i = 0; i < tmp.size(); ++i) {
-    half_t hv;
-    std::memcpy(&hv, &tmp[i], 2);
-    o[i] = (float)hv;
-  }
-  (void)oo32;
-}
-
-// The encoder's fused Q | K | V projection and its self-attention as enc_layer() launches them for long inputs: the persistent
-// 256 x 192 kernel (Q scaled and K blocked, V row-major: k_gemm_qkv.hip) followed by the attention kernel reading that layout.
-// x [B*T, K], w [1536, K] ([Q | K | V] rows), bias [1536] or null; outputs (each may be null) q / k / v / ctx [B*T, 512] as
-// fp32 copies of the stored f16 values (q / k de-blocked on the host).
-void Engine::op_qkv_attention(const float* x, const float* w, const float* bias, int B, int T, int K, float* q_out, float* k_out,
-                              float* v_out, float* ctx_out) {
-  PF_HIP(hipSetDevice(device_));
-  const int D = 512, H = 4, N = 3 * D;
-  const int M = B * T;
-  PF_CHECK(M > 0 && K > 0, PF_ERR_INVALID_ARG, "qkv_attention: empty input");
-  const int Kpad = (int)round_up(K, 64);
-  PF_CHECK(gemm_qkvp_applicable(M, Kpad, Kpad, Kpad, D), PF_ERR_INVALID_ARG, "qkv_attention: shape not covered by the 256 x 192 kernel");
-  const int64_t Mp = round_up(M, 256) + 128;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
-  const size_t o32 = carve((size_t)std::max<int64_t>((int64_t)M * K, (int64_t)N * K) * 4), oA = carve((size_t)Mp * Kpad * 2);
-  const size_t oW = carve((size_t)N * Kpad * 2), oWp = carve((size_t)N * Kpad * 2), ob = carve((size_t)N * 4), obp = carve((size_t)N * 4);
-  const size_t oqk = carve((size_t)Mp * 2 * D * 2), ov = carve((size_t)Mp * D * 2), oc = carve((size_t)Mp * D * 2);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemsetAsync(base + oA, 0, (size_t)Mp * Kpad * 2, stream_));
-  PF_HIP(hipMemsetAsync(base + oW, 0, (size_t)N * Kpad * 2, stream_));
-  PF_HIP(hipMemcpyAsync(base + o32, x, (size_t)M * K * 4, hipMemcpyHostToDevice, stream_));
-  launch_f32_to_f16(stream_, (const float*)(base + o32), M, K, K, (half_t*)(base + oA), Kpad);
-  PF_HIP(hipStreamSynchronize(stream_));
-  PF_HIP(hipMemcpyAsync(base + o32, w, (size_t)N * K * 4, hipMemcpyHostToDevice, stream_));
-  launch_f32_to_f16(stream_, (const float*)(base + o32), N, K, K, (half_t*)(base + oW), Kpad);
-  if (bias) PF_HIP(hipMemcpyAsync(base + ob, bias, (size_t)N * 4, hipMemcpyHostToDevice, stream_));
-  launch_qkv_permute(stream_, (half_t*)(base + oW), Kpad, bias ? (const float*)(base + ob) : nullptr, (half_t*)(base + oWp), (float*)(base + obp));
-  const float qscale = 1.0f / std::sqrt((float)(D / H));
-  half_t* qk = (half_t*)(base + oqk);
-  half_t* vb = (half_t*)(base + ov);
-  prof_begin("gemm_op", 2.0 * M * (double)N * K);
-  launch_gemm_qkvp(stream_, (half_t*)(base + oA), Kpad, (half_t*)(base + oWp), Kpad, (const float*)(base + obp), M, Kpad, qscale, qk, vb, D);
-  prof_end("gemm_op");
-  AttnArgs a{};
-  a.q = qk; a.k = qk; a.qk_blocked = 1; a.blk_groups = 2 * D / 8; a.blk_brows = T; a.blk_kgrp = D / 8;
-  a.v = vb; a.v_bstride = (int64_t)T * D; a.v_rstride = D;
-  a.o = (half_t*)(base + oc); a.o_bstride = (int64_t)T * D; a.o_rstride = D;
-  a.q_rstride = a.k_rstride = 8;                          // ignored (alignment checks only)
-  a.B = B; a.H = H; a.Lq = T; a.Lk = T;
-  prof_begin("attn_op", 4.0 * B * (double)T * T * D);
-  launch_attention(stream_, a);
-  prof_end("attn_op");
-  std::vector<half_t> hqk((size_t)Mp * 2 * D), hv((size_t)M * D), hc((size_t)M * D);
-  PF_HIP(hipMemcpyAsync(hqk.data(), qk, hqk.size() * 2, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(hv.data(), vb, hv.size() * 2, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(hc.data(), base + oc, hc.size() * 2, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  const int G = 2 * D / 8;
-  for (int m = 0; m < M; ++m)
-    for (int c = 0; c < 2 * D; ++c) {
-      const float val = (float)hqk[(((size_t)(m >> 5) * G + (c >> 3)) * 32 + (m & 31)) * 8 + (c & 7)];
-      if (c < D) { if (q_out) q_out[(size_t)m * D + c] = val; }
-      else if (k_out) k_out[(size_t)m * D + c - D] = val;
-    }
-  for (size_t i = 0; i < hv.size(); ++i) {
-    if (v_out) v_out[i] = (float)hv[i];
-    if (ctx_out) ctx_out[i] = (float)hc[i];
-  }
-}
-
-void Engine::op_fsmn(const float* v, const float* w, const float* mask, int B, int T, int D, int k, float* y) {
-  PF_HIP(hipSetDevice(device_));
-  PF_CHECK(D % 4 == 0, PF_ERR_INVALID_ARG, "fsmn: D must be a multiple of 4");
-  const size_t n = (size_t)B * T * D;
-  if (n == 0) return;
-  std::vector<float> wT((size_t)D * k);
-  for (int c = 0; c < D; ++c)
-    for (int j = 0; j < k; ++j) wT[(size_t)j * D + c] = w[(size_t)c * k + j];
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
-  const size_t ov = carve(n * 4), ow = carve(wT.size() * 4), om = carve((size_t)B * T * 4), oy = carve(n * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  PF_HIP(hipMemcpyAsync(base + ov, v, n * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + ow, wT.data(), wT.size() * 4, hipMemcpyHostToDevice, stream_));
-  if (mask) PF_HIP(hipMemcpyAsync(base + om, mask, (size_t)B * T * 4, hipMemcpyHostToDevice, stream_));
-  launch_fsmn_f32(stream_, (const float*)(base + ov), (const float*)(base + ow), mask ? (const float*)(base + om) : nullptr,
-                  B, T, D, k, (float*)(base + oy));
-  PF_HIP(hipMemcpyAsync(y, base + oy, n * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_cif(const float* H, const float* alphas, int B, int T, int D, float thr, int Lcap, float* E,
-                    int32_t* fire_count, int32_t* token_num, int32_t* L_out) {
-  PF_HIP(hipSetDevice(device_));
-  PF_CHECK(D % 4 == 0 && B > 0 && T > 0, PF_ERR_INVALID_ARG, "cif: bad shape");
-  const int T1 = T + 1;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) { size_t o2 = off; off += round_up((int64_t)bytes, (int64_t)kAlign); return o2; };
-  const size_t oH = carve((size_t)B * T * D * 4), oa = carve((size_t)B * T1 * 4), ofc = carve((size_t)B * 4), otn = carve((size_t)B * 4);
-  const size_t off_ = carve((size_t)B * T1 * 4), owc = carve((size_t)B * T1 * 4), owr = carve((size_t)B * T1 * 4), omx = carve(256);
-  const size_t oE = carve((size_t)B * std::max(Lcap, 1) * D * 4);
-  ensure(ws_tmp_, off);
-  char* base = (char*)ws_tmp_.p;
-  CifPlan p;
-  p.fire_count = (int32_t*)(base + ofc); p.token_num = (int32_t*)(base + otn); p.fire_frame = (int32_t*)(base + off_);
-  p.w_cur = (float*)(base + owc); p.w_rem = (float*)(base + owr); p.max_count = (int32_t*)(base + omx);
-  PF_HIP(hipMemcpyAsync(base + oH, H, (size_t)B * T * D * 4, hipMemcpyHostToDevice, stream_));
-  PF_HIP(hipMemcpyAsync(base + oa, alphas, (size_t)B * T1 * 4, hipMemcpyHostToDevice, stream_));
-  if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, (const float*)(base + oa), B, T1, p);
-  else launch_cif_scan(stream_, (const float*)(base + oa), B, T1, thr, p);
-  int32_t L = 0;
-  PF_HIP(hipMemcpyAsync(&L, p.max_count, 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(fire_count, p.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(token_num, p.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-  if (L_out) *L_out = L;
-  PF_CHECK(L <= Lcap, PF_ERR_CAPACITY, "cif: Lcap " + std::to_string(Lcap) + " < L = " + std::to_string(L));
-  if (Lcap == 0) return;
-  if (mc_.cif_cumsum) launch_cif_gather_cumsum(stream_, (const float*)(base + oH), (const float*)(base + oa), B, T, D, T1, p, Lcap, (float*)(base + oE));
-  else launch_cif_gather(stream_, (const float*)(base + oH), B, T, D, T1, p, Lcap, (float*)(base + oE));
-  PF_HIP(hipMemcpyAsync(E, base + oE, (size_t)B * Lcap * D * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
-}
-
-void Engine::op_encoder(const float* speech, int B, int T, float* H) {
-  PF_HIP(hipSetDevice(device_));
-  PF_CHECK(speech && H && B > 0 && T > 0, PF_ERR_INVALID_ARG, "encoder: bad arguments");
-  const size_t n = (size_t)B * T * mc_.feat_dim;
-  ensure(ws_speech_, n * 4);
-  PF_HIP(hipMemcpyAsync(ws_speech_.p, speech, n * 4, hipMemcpyHostToDevice, stream_));
-  encoder((const float*)ws_speech_.p, B, T);
-  PF_HIP(hipMemcpyAsync(H, H32_, (size_t)B * T * mc_.d_model * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
 }
 
 }  // namespace pf
