@@ -17,6 +17,11 @@ namespace pf {
 
 static const size_t kAlign = 256;
 
+// live engines' main streams and the streams parked by the hardware-queue probe (Engine::own_hardware_queue below)
+static std::mutex g_main_mu;
+static std::vector<std::pair<int, hipStream_t>> g_main_streams;      // (device, main stream) of the live engines
+static std::vector<hipStream_t> g_parked;
+
 // ------------------------------------------------------------------ construction ----------
 Engine::Engine(const pf_engine_config& cfg) {
   device_ = cfg.device;
@@ -90,6 +95,7 @@ Engine::Engine(const pf_engine_config& cfg) {
   uid_ = register_uid();
   try {
     PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    own_hardware_queue();
     PF_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     PF_HIP(hipEventCreateWithFlags(&ev_scan_, hipEventDisableTiming));
     PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
@@ -139,7 +145,64 @@ void Engine::release() {
     if (b->p) { hipFree(b->p); b->p = nullptr; b->bytes = 0; }
   if (blob_owned_ && blob_dev_) hipFree(blob_dev_);
   blob_dev_ = nullptr;
-  if (stream_) { hipStreamDestroy(stream_); stream_ = nullptr; }
+  if (stream_) {
+    {
+      std::lock_guard<std::mutex> lk(g_main_mu);
+      for (size_t i = 0; i < g_main_streams.size(); ++i)
+        if (g_main_streams[i].second == stream_) { g_main_streams.erase(g_main_streams.begin() + (long)i); break; }
+      if (g_main_streams.empty()) {                           // the last engine of the process: the parked streams go too
+        for (hipStream_t s : g_parked) hipStreamDestroy(s);
+        g_parked.clear();
+      }
+    }
+    hipStreamDestroy(stream_); stream_ = nullptr;
+  }
+}
+
+// Engines on one device overlap (the recognizer's pool, bench.py's steps in flight) only if their main streams sit on DIFFERENT
+// hardware queues: HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (4) queues, and two streams on one queue run their kernels in
+// submission order.  Which queue a new stream gets depends on every stream the process has created and destroyed before — measured
+// in round 6: the second pair of engines of a process (bench.py's `exact` twin behind the f16 engines) did not overlap at all (38.6 ms
+// per step with two in flight against 35.1 in a fresh process; GPU_MAX_HW_QUEUES=8 brought 34.9 back).  So the constructor PROBES: a
+// single wave spins ~150 us on a live engine's main stream while an empty kernel goes to the new stream; if the empty kernel does not
+// finish well before the spinning one, the two streams share a queue: the new stream is parked (kept alive, so that the runtime's
+// allocator moves on) and another one is tried, up to 8 times.  PF_QUEUE_PROBE=0 switches the probe off.
+
+void Engine::own_hardware_queue() {
+  static const int on = env_int("PF_QUEUE_PROBE", 1);
+  std::lock_guard<std::mutex> lk(g_main_mu);
+  if (on) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    PF_HIP(hipEventCreate(&ea));
+    PF_HIP(hipEventCreate(&eb));
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      bool clash = false;
+      int seen = 0;
+      for (auto it = g_main_streams.rbegin(); it != g_main_streams.rend() && seen < 3 && !clash; ++it) {
+        if (it->first != device_) continue;
+        ++seen;
+        launch_spin(it->second, 300000ull);                  // ~150 us at ~2 GHz, one wave: every other CU stays free
+        launch_nop(stream_);
+        PF_HIP(hipEventRecord(eb, stream_));
+        PF_HIP(hipEventRecord(ea, it->second));
+        PF_HIP(hipEventSynchronize(ea));
+        PF_HIP(hipEventSynchronize(eb));
+        float ms = 0.f;
+        PF_HIP(hipEventElapsedTime(&ms, eb, ea));            // how long before the spinning kernel's end the empty one was done
+        clash = ms < 0.05f;
+      }
+      if (!clash) {
+        if (attempt && getenv("PF_QUEUE_PROBE_VERBOSE")) fprintf(stderr, "pf: engine main stream moved to another hardware queue after %d attempt(s)\n", attempt);
+        break;
+      }
+      g_parked.push_back(stream_);                           // stays alive: the next stream gets another queue
+      stream_ = nullptr;
+      PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    }
+    hipEventDestroy(ea);
+    hipEventDestroy(eb);
+  }
+  g_main_streams.emplace_back(device_, stream_);
 }
 
 void* Engine::dalloc(size_t bytes) {

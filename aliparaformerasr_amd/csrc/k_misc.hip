@@ -918,4 +918,16 @@ void launch_argmax(hipStream_t s, float* x, int64_t rows, int V, int ldx, int mo
   PF_HIP(hipGetLastError());
 }
 
+// ---- hardware-queue probe (round 6, Engine::own_hardware_queue): a single wave that spins for ~`cycles` shader clocks, and an empty kernel
+__global__ void spin_kernel(unsigned long long cycles) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < (1 << 22); ++i) {
+    if (__builtin_readcyclecounter() - t0 >= cycles) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+__global__ void nop_kernel() {}
+void launch_spin(hipStream_t s, unsigned long long cycles) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, cycles); }
+void launch_nop(hipStream_t s) { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace pf

@@ -98,7 +98,7 @@ def exact_object(Engine, StepPipeline, wdev_ptr, nbytes, cmvn, device, audio, ho
             if hotwords is not None:
                 e_.set_hotwords(hotwords)
         pipe = StepPipeline(E, lambda e_i, par: engs[e_i].run_staged(), None)
-        pipe.run(0, E)                                       # warm-up: also builds the (lo | hi) weight images
+        pipe.run(0, E * int(os.environ.get("PF_EXACT_WARMUP", "1")))   # warm-up: also builds the (lo | hi) weight images
         for e_ in engs:
             e_.sync()
         eng = engs[0]
