@@ -99,6 +99,7 @@ Engine::Engine(const pf_engine_config& cfg) {
     PF_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));
     PF_HIP(hipEventCreateWithFlags(&ev_scan_, hipEventDisableTiming));
     PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
+    own_hardware_queue_ts();
     PF_HIP(hipEventCreateWithFlags(&ev_ts_, hipEventDisableTiming));
     PF_HIP(hipEventCreateWithFlags(&ev_enc_, hipEventDisableTiming));
     load_weights(cfg);
@@ -203,6 +204,35 @@ void Engine::own_hardware_queue() {
     hipEventDestroy(eb);
   }
   g_main_streams.emplace_back(device_, stream_);
+}
+
+// the timestamp head runs BESIDE the decoder on ts_stream_: the same requirement against the engine's own main stream
+void Engine::own_hardware_queue_ts() {
+  static const int on = env_int("PF_QUEUE_PROBE", 1);
+  if (!on || !ts_stream_) return;
+  std::lock_guard<std::mutex> lk(g_main_mu);
+  hipEvent_t ea = nullptr, eb = nullptr;
+  PF_HIP(hipEventCreate(&ea));
+  PF_HIP(hipEventCreate(&eb));
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    launch_spin(stream_, 300000ull);
+    launch_nop(ts_stream_);
+    PF_HIP(hipEventRecord(eb, ts_stream_));
+    PF_HIP(hipEventRecord(ea, stream_));
+    PF_HIP(hipEventSynchronize(ea));
+    PF_HIP(hipEventSynchronize(eb));
+    float ms = 0.f;
+    PF_HIP(hipEventElapsedTime(&ms, eb, ea));
+    if (ms >= 0.05f) {
+      if (attempt && getenv("PF_QUEUE_PROBE_VERBOSE")) fprintf(stderr, "pf: timestamp stream moved to another hardware queue after %d attempt(s)\n", attempt);
+      break;
+    }
+    g_parked.push_back(ts_stream_);
+    ts_stream_ = nullptr;
+    PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
+  }
+  hipEventDestroy(ea);
+  hipEventDestroy(eb);
 }
 
 void* Engine::dalloc(size_t bytes) {

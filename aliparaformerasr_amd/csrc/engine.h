@@ -255,6 +255,7 @@ class Engine {
   bool qkv_tail_ = true;             // PF_QKV_TAIL: the next layer's Q | K | V projection behind the fused block, same launch
   bool attn_ffn_ = true;             // PF_ATTN_FFN: out-projection + FSMN + norm2 in front of the fused FFN block, one launch
   bool ffn_fused_ = true;            // PF_FFN_FUSED: the encoder FFN block as one launch (k_ffn.hip)
+  void own_hardware_queue_ts();
   void own_hardware_queue();         // round 6: the main stream must not share a hardware queue with another live engine's (see engine.cpp)
   bool dec_mid_ = true;              // PF_DEC_MID: finishing pass + norm2 + FSMN + residual + norm3 + q-projection in one launch (k_decmid.hip)
   bool dec_out_chain_ = true;        // PF_DEC_OUT_CHAIN: a decoder layer's out-projection + the next norm1 in front of the next FFN launch
