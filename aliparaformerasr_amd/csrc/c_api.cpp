@@ -947,7 +947,7 @@ int pf_stream_set_timestamps(pf_stream* h, const int32_t* ints, const int32_t* l
   PF_TRY
   Stream* s = S(h);
   PF_CHECK(n >= 0, PF_ERR_INVALID_ARG, "negative timestamp count");
-  std::vector<std::vector<int32_t>> ts;
+  TsList ts;
   size_t off = 0;
   for (int i = 0; i < n; ++i) {
     NEED(lens);
@@ -1233,7 +1233,7 @@ int pf_host_decode(const char* const* tokens, int32_t n_tokens, const int64_t* i
   std::vector<std::string> tk;
   for (int i = 0; i < n_tokens; ++i) tk.emplace_back(tokens[i]);
   std::vector<int64_t> idv(ids, ids + n_ids);
-  std::vector<std::vector<int32_t>> ts;
+  TsList ts;
   size_t off = 0;
   for (int i = 0; i < n_ts; ++i) {
     ts.emplace_back(ts_ints + off, ts_ints + off + ts_lens[i]);

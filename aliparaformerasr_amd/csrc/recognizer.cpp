@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstring>
 #include <set>
 
@@ -31,10 +32,22 @@ static int count_sub(const std::string& s, const std::string& sub) {
 }
 // IsChinese(str, allMatch: true): ^[一-龥]+$  (OfflineRecognizer.cs:428-439)
 static bool is_chinese_all(const std::string& s) {
-  const std::vector<uint32_t> cps = utf8_decode(s);
-  if (cps.empty()) return false;
-  for (uint32_t c : cps)
-    if (c < 0x4e00 || c > 0x9fa5) return false;
+  // (the decoding of utf8_decode, hostutil.cpp, without the vector: this runs once per token of every result)
+  const size_t n = s.size();
+  if (n == 0) return false;
+  for (size_t i = 0; i < n;) {
+    const unsigned char c = (unsigned char)s[i];
+    uint32_t cp;
+    int extra;
+    if (c < 0x80) { cp = c; extra = 0; }
+    else if ((c >> 5) == 0x6) { cp = c & 0x1F; extra = 1; }
+    else if ((c >> 4) == 0xE) { cp = c & 0x0F; extra = 2; }
+    else if ((c >> 3) == 0x1E) { cp = c & 0x07; extra = 3; }
+    else { cp = 0xFFFD; extra = 0; }
+    ++i;
+    for (int k = 0; k < extra && i < n; ++k, ++i) cp = (cp << 6) | ((unsigned char)s[i] & 0x3F);
+    if (cp < 0x4e00 || cp > 0x9fa5) return false;
+  }
   return true;
 }
 // C# IndexOf(x) > 0 : found and not at position 0
@@ -54,15 +67,18 @@ static void remove_first_equal_to_last(std::vector<T>& v) {
 }
 
 ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std::vector<int64_t>& ids,
-                              const std::vector<std::vector<int32_t>>& timestamps) {
+                              const TsList& timestamps) {
   ResultEntity r;
+  r.Tokens.reserve(ids.size());
+  r.Timestamps.reserve(ids.size());
   std::string text, lastToken;
+  text.reserve(ids.size() * 4);
   bool haveLastTs = false;
-  std::vector<int32_t> lastTs;
+  TsVec lastTs;
   const size_t n = std::min(ids.size(), timestamps.size());    // Zip
   for (size_t i = 0; i < n; ++i) {
     const int64_t token = ids[i];
-    const std::vector<int32_t>& ts = timestamps[i];
+    const TsVec& ts = timestamps[i];
     if (token == 2) break;
     if (token < 0 || token >= (int64_t)tokens.size()) throw Error(PF_ERR_RECOGNITION, "token id out of range");
     std::string cur = tokens[(size_t)token];
@@ -79,13 +95,13 @@ ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std:
     const std::string comb = lastToken + kBar + cur + kBar;
     auto merged_ts = [&]() {
       if (!haveLastTs) return ts;
-      std::vector<int32_t> t = lastTs;
-      t.insert(t.end(), ts.begin(), ts.end());
+      TsVec t = lastTs;
+      t.append(ts.begin(), ts.end());
       return t;
     };
     if (index_gt0(comb, "@@" + kBar + kBar)) {
       const std::string curToken = replaced(comb, "@@" + kBar + kBar, "");
-      const std::vector<int32_t> curTs = merged_ts();
+      const TsVec curTs = merged_ts();
       remove_first_equal_to_last(r.Tokens);
       r.Tokens.push_back(replaced(curToken, kBar, ""));
       if (r.Timestamps.empty()) throw Error(PF_ERR_RECOGNITION, "Sequence contains no elements");
@@ -94,7 +110,7 @@ ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std:
       lastToken = curToken; lastTs = curTs; haveLastTs = true;
     } else if ((count_sub(comb, kBar) == 3 || count_sub(comb, kBar) == 5) && index_lt0(comb, kBar + kBar + kBar)) {
       const std::string curToken = replaced(comb, kBar + kBar, "");
-      const std::vector<int32_t> curTs = merged_ts();
+      const TsVec curTs = merged_ts();
       if (!r.Tokens.empty()) remove_first_equal_to_last(r.Tokens);
       r.Tokens.push_back(replaced(curToken, kBar, ""));
       if (!r.Timestamps.empty()) r.Timestamps.pop_back();
@@ -121,7 +137,7 @@ ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std:
   return r;
 }
 
-std::vector<std::vector<int32_t>> time_stamp_lfr6(const float* us_cif_peak, int n, std::vector<int64_t> tokens) {
+TsList time_stamp_lfr6(const float* us_cif_peak, int n, const std::vector<int64_t>& tokens_in) {
   // float32 arithmetic throughout, (int)(t*1000) truncation (quirk Q10)
   const int START_END_THRESHOLD = 5, MAX_TOKEN_DURATION = 30;
   volatile float tr0 = 10.0f * 6;
@@ -129,7 +145,8 @@ std::vector<std::vector<int32_t>> time_stamp_lfr6(const float* us_cif_peak, int 
   const float TIME_RATE = tr1 / 3;
   const float total_offset = -1.5f;
   const int num_frames = n;
-  if (tokens.empty()) throw Error(PF_ERR_RECOGNITION, "Sequence contains no elements");   // tokens.Last()
+  if (tokens_in.empty()) throw Error(PF_ERR_RECOGNITION, "Sequence contains no elements");   // tokens.Last()
+  std::vector<int64_t> tokens(tokens_in);
   if (tokens.back() == 2) tokens.pop_back();
   std::vector<float> fire;
   for (int i = 0; i < n; ++i)
@@ -165,7 +182,7 @@ std::vector<std::vector<int32_t>> time_stamp_lfr6(const float* us_cif_peak, int 
     tl.back()[1] = (float)num_frames * TIME_RATE;
   }
   nc.push_back(true);
-  std::vector<std::vector<int32_t>> out;
+  TsList out;
   const size_t m = std::min(nc.size(), tl.size());
   for (size_t i = 0; i < m; ++i) {
     if (!nc[i]) continue;
@@ -214,7 +231,10 @@ Stream::Stream(std::shared_ptr<Recognizer> r) : owner(std::move(r)) {}
 Stream::Stream(const std::string& mvn_path, const ConfEntity& conf) : uconf(conf) {
   if (!mvn_path.empty()) parse_mvn_text(read_text_file(mvn_path.c_str()), ushift, uscale);   // WavFrontend.cs:19 LoadCmvn
 }
-Stream::~Stream() { drop_device_audio(); }
+Stream::~Stream() {
+  drop_device_audio();
+  if (dev_ev) hipEventDestroy(dev_ev);
+}
 
 // frames GetFbank + LfrCmvn return for one AddSamples call of n samples (WavFrontend.cs:31-111; kaldi frame count)
 static int conf_lfr_frames(const ConfEntity& c, int64_t n) {
@@ -222,7 +242,12 @@ static int conf_lfr_frames(const ConfEntity& c, int64_t n) {
   return (c.lfr_m == 1 && c.lfr_n == 1) ? t80 : t80 / c.lfr_n;
 }
 
+void Stream::wait_device_audio() {
+  if (dev_ev_pending) { hipEventSynchronize(dev_ev); dev_ev_pending = false; }
+}
+
 void Stream::drop_device_audio() {
+  wait_device_audio();                                  // the buffer goes back to the cache: no DMA may still be writing it
   if (dev_audio && owner) owner->audio_free(dev_audio, dev_bytes);
   dev_audio = nullptr; dev_bytes = 0; dev_n = 0;
   device_form = false;
@@ -234,6 +259,7 @@ void Stream::materialize() {
   Recognizer::Lease e = owner->acquire();
   std::vector<float> feats;
   int t = 0;
+  wait_device_audio();
   if (dev_n > 0) e->frontend_from_device(dev_audio, dev_n, feats, t);
   e.release();
   drop_device_audio();
@@ -263,11 +289,11 @@ void Stream::AddSamples(const float* samples, int64_t n) {
     float* d = nullptr;
     bool on_device = true;
     try {
-      if (n > 0) { d = owner->audio_alloc((size_t)n * 4, &got); owner->upload(d, samples, (size_t)n * 4); }
+      if (n > 0) { d = owner->audio_alloc((size_t)n * 4, &got); owner->upload(d, samples, (size_t)n * 4, &dev_ev, &dev_ev_pending); }
     } catch (const Error& ex) {
-      if (d) owner->audio_free(d, got);
-      if (ex.code == PF_ERR_DISPOSED) throw;
       (void)hipGetLastError();                                      // clear the sticky out-of-memory status
+      if (d) { (void)hipDeviceSynchronize(); owner->audio_free(d, got); }   // (pieces of a staged upload may be in flight)
+      if (ex.code == PF_ERR_DISPOSED) throw;
       on_device = false;
     }
     if (on_device) {
@@ -294,7 +320,7 @@ void Stream::Dispose() {
   drop_device_audio();
   std::vector<float>().swap(Speech);
   std::vector<int64_t>().swap(Tokens);
-  std::vector<std::vector<int32_t>>().swap(Timestamps);
+  TsList().swap(Timestamps);
   std::vector<std::vector<int32_t>>().swap(Hotwords);
   has_speech = false;
   SpeechLength = 0;
@@ -377,6 +403,11 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   ec.weights_device = image_.get();
   ec.weights_bytes = image_bytes_;
   { const char* e = getenv("PF_RECOGNIZER_AUDIO_CACHE_MB"); if (e && e[0]) audio_cache_cap_ = (size_t)std::max(0, atoi(e)) << 20; }
+  { const char* e = getenv("PF_RECOGNIZER_STAGING_MB"); if (e && e[0]) staging_bytes_ = (size_t)std::min(1024, std::max(0, atoi(e))) << 20; }
+  { const char* e = getenv("PF_RECOGNIZER_STAGING_POLICY"); staging_always_ = e && std::string(e) == "always"; }
+  { const char* e = getenv("PF_RECOGNIZER_COPY_THREADS"); if (e && e[0]) crew_threads_ = std::min(15, std::max(0, atoi(e))); }
+  crew_threads_ = std::min<int>(crew_threads_, std::max(0, (int)std::thread::hardware_concurrency() - 1));
+  { const char* e = getenv("PF_RECOGNIZER_STAGING_PIECE_KB"); if (e && e[0]) staging_piece_ = (size_t)std::max(64, atoi(e)) << 10; }
   engines_.push_back(make_engine());
   busy_.push_back(0);
   engine_kind_ = engines_[0]->model().kind;
@@ -470,6 +501,81 @@ Recognizer::Lease Recognizer::acquire() {
   }
 }
 
+// ------------------------------------------------------------------ CopyCrew ------------
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
+CopyCrew::CopyCrew(int helpers) {
+  try {
+    for (int i = 0; i < helpers; ++i) th_.emplace_back([this] { run(); });
+  } catch (...) {                                       // no more threads: work with those we have (copy() never needs one)
+  }
+}
+
+CopyCrew::~CopyCrew() {
+  { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+  cv_.notify_all();
+  for (auto& t : th_) t.join();
+}
+
+bool CopyCrew::take(Job& j) {
+  if (queued_.load(std::memory_order_acquire) <= 0) return false;
+  std::lock_guard<std::mutex> lk(mu_);
+  if (q_.empty()) return false;
+  j = q_.front();
+  q_.pop_front();
+  queued_.fetch_sub(1, std::memory_order_release);
+  return true;
+}
+
+void CopyCrew::run() {
+  using clk = std::chrono::steady_clock;
+  for (;;) {
+    Job j;
+    bool got = false;
+    const auto t0 = clk::now();
+    for (int spins = 0; !got && !stop_.load(std::memory_order_relaxed); ++spins) {
+      got = take(j);
+      if (got) break;
+      cpu_relax();
+      if ((spins & 255) == 255 && clk::now() - t0 > std::chrono::microseconds(400)) break;
+    }
+    if (!got) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return stop_.load() || !q_.empty(); });
+      if (q_.empty()) return;                             // stop
+      j = q_.front();
+      q_.pop_front();
+      queued_.fetch_sub(1, std::memory_order_release);
+    }
+    std::memcpy(j.d, j.s, j.n);
+    j.left->fetch_sub(1, std::memory_order_release);
+  }
+}
+
+void CopyCrew::copy(char* dst, const char* src, size_t bytes) {
+  const size_t kMinShare = (size_t)128 << 10;
+  const int parts = (int)std::min<size_t>(th_.size() + 1, bytes / kMinShare);
+  if (parts <= 1) { std::memcpy(dst, src, bytes); return; }
+  const size_t share = ((bytes / parts) + 4095) & ~(size_t)4095;
+  std::atomic<int> left(0);
+  size_t mine = std::min(share, bytes);
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (size_t off = mine; off < bytes; off += share) {
+      left.fetch_add(1, std::memory_order_relaxed);
+      q_.push_back({dst + off, src + off, std::min(share, bytes - off), &left});
+      queued_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  cv_.notify_all();
+  std::memcpy(dst, src, mine);
+  while (left.load(std::memory_order_acquire) > 0) {      // shares nobody has taken yet are ours as well
+    Job j;
+    if (take(j)) { std::memcpy(j.d, j.s, j.n); j.left->fetch_sub(1, std::memory_order_release); }
+    else cpu_relax();
+  }
+}
+
 float* Recognizer::audio_alloc(size_t bytes, size_t* got) {
   const size_t cls = (size_t)round_up((int64_t)std::max<size_t>(bytes, 4), (int64_t)(256 << 10));   // 256 KiB classes
   *got = cls;
@@ -504,14 +610,90 @@ void Recognizer::audio_free(float* p, size_t bytes) {
   hipFree(p);
 }
 
-void Recognizer::upload(float* dst, const float* src, size_t bytes) {
-  CopyLane& ln = lanes_[next_lane_.fetch_add(1) % lanes_.size()];
-  std::lock_guard<std::mutex> lk(ln.mu);
+static std::atomic<long long> g_up_ns{0}, g_up_copy_ns{0}, g_up_wait_ns{0}, g_up_calls{0};
+static const int kUpTiming = env_int("PF_UPLOAD_TIMING", 0);
+struct UpTimer {                                         // PF_UPLOAD_TIMING=1: where an upload's host time goes (tools/r6_staging_ab.sh)
+  std::atomic<long long>& acc; std::chrono::steady_clock::time_point t0;
+  explicit UpTimer(std::atomic<long long>& a) : acc(a) { if (kUpTiming) t0 = std::chrono::steady_clock::now(); }
+  ~UpTimer() { if (kUpTiming) acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+bool Recognizer::seen_before(const void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(seen_mu_);
+  if (seen_.size() >= 16384) seen_.clear();
+  auto it = seen_.find(p);
+  if (it != seen_.end() && it->second == bytes) return true;
+  seen_[p] = bytes;
+  return false;
+}
+
+void Recognizer::upload(float* dst, const float* src, size_t bytes, hipEvent_t* ev, bool* pending) {
+  UpTimer whole(g_up_ns);
+  if (kUpTiming && (++g_up_calls % 256) == 0)
+    fprintf(stderr, "[upload] %lld calls: %.1f us per call, host copy %.1f, ring waits %.1f\n", (long long)g_up_calls, g_up_ns / 1e3 / g_up_calls,
+            g_up_copy_ns / 1e3 / g_up_calls, g_up_wait_ns / 1e3 / g_up_calls);
+  // a lane nobody is copying through right now, else the next in turn
+  const unsigned first = next_lane_.fetch_add(1);
+  std::unique_lock<std::mutex> lk;
+  CopyLane* lnp = nullptr;
+  for (unsigned i = 0; i < lanes_.size() && !lnp; ++i) {
+    CopyLane& c = lanes_[(first + i) % lanes_.size()];
+    std::unique_lock<std::mutex> t(c.mu, std::try_to_lock);
+    if (t.owns_lock()) { lk = std::move(t); lnp = &c; }
+  }
+  if (!lnp) { lnp = &lanes_[first % lanes_.size()]; lk = std::unique_lock<std::mutex>(lnp->mu); }
+  CopyLane& ln = *lnp;
   if (disposed_) throw Error(PF_ERR_DISPOSED, "OfflineRecognizer");     // (Dispose destroys the lanes under this lock)
   PF_HIP(hipSetDevice(device_));
   if (!ln.s) PF_HIP(hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking));
-  PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ln.s));
-  PF_HIP(hipStreamSynchronize(ln.s));                  // the samples are on the device when AddSamples returns
+  const bool staged = ev && staging_bytes_ > 0 && (staging_always_ || !seen_before(src, bytes));
+  if (staged && !ln.tried) {
+    ln.tried = true;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, staging_bytes_, hipHostMallocDefault) == hipSuccess) { ln.pin = (char*)p; ln.cap = staging_bytes_; }
+    else (void)hipGetLastError();                                       // no pinned memory: the runtime's pageable copy below
+  }
+  if (!staged || !ln.pin) {
+    PF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ln.s));
+    PF_HIP(hipStreamSynchronize(ln.s));                // the samples are on the device when AddSamples returns
+    return;
+  }
+  if (crew_threads_ > 0) std::call_once(crew_once_, [&] { crew_.reset(new CopyCrew(crew_threads_)); });
+  // staged: piece by piece through the pinned ring; the DMA of piece i runs under the host copy of piece i + 1
+  const size_t piece = std::min(staging_piece_, ln.cap);
+  for (size_t done = 0; done < bytes;) {
+    const size_t nb = std::min(piece, bytes - done);
+    if (ln.head + nb > ln.cap) ln.head = 0;
+    const size_t off = ln.head;
+    // pieces still in flight over [off, off + nb): the ring is FIFO on one stream, so everything up to the last overlap is done
+    // once that one is
+    int last = -1;
+    for (int i = 0; i < (int)ln.inflight.size(); ++i) {
+      const CopyLane::Piece& q = ln.inflight[i];
+      if (q.off < off + nb && off < q.off + q.bytes) last = i;
+    }
+    if (last >= 0) {
+      UpTimer w(g_up_wait_ns);
+      PF_HIP(hipEventSynchronize(ln.inflight[last].ev));
+      for (int i = 0; i <= last; ++i) { ln.spare.push_back(ln.inflight.front().ev); ln.inflight.pop_front(); }
+    }
+    {
+      UpTimer c(g_up_copy_ns);
+      if (crew_) crew_->copy(ln.pin + off, (const char*)src + done, nb);
+      else std::memcpy(ln.pin + off, (const char*)src + done, nb);
+    }
+    PF_HIP(hipMemcpyAsync((char*)dst + done, ln.pin + off, nb, hipMemcpyHostToDevice, ln.s));
+    hipEvent_t pe = nullptr;
+    if (!ln.spare.empty()) { pe = ln.spare.back(); ln.spare.pop_back(); }
+    else PF_HIP(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
+    if (hipEventRecord(pe, ln.s) != hipSuccess) { ln.spare.push_back(pe); PF_HIP(hipStreamSynchronize(ln.s)); }
+    else ln.inflight.push_back({off, nb, pe});
+    ln.head = off + nb;
+    done += nb;
+  }
+  if (!*ev) PF_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  PF_HIP(hipEventRecord(*ev, ln.s));
+  *pending = true;
 }
 
 std::shared_ptr<Stream> Recognizer::CreateOfflineStream() {
@@ -573,9 +755,37 @@ void Recognizer::free_device_side() {
   audio_cached_bytes_ = 0;
   for (CopyLane& ln : lanes_) {
     std::lock_guard<std::mutex> lk(ln.mu);
-    if (ln.s) { hipStreamDestroy(ln.s); ln.s = nullptr; }
+    if (ln.s) { hipStreamSynchronize(ln.s); hipStreamDestroy(ln.s); ln.s = nullptr; }
+    for (auto& q : ln.inflight) hipEventDestroy(q.ev);
+    for (hipEvent_t e : ln.spare) hipEventDestroy(e);
+    ln.inflight.clear(); ln.spare.clear();
+    if (ln.pin) { hipHostFree(ln.pin); ln.pin = nullptr; ln.cap = 0; }
   }
+  crew_.reset();                                   // (every lane has been through its lock above: no upload is using the helpers)
   image_.reset();                                  // freed when the last engine that adopted it is gone
+}
+
+// PF_RECOGNIZER_TIMING=1: where a GetResults call spends its time on the host (printed every 32 calls)
+static const int kFwdTiming = env_int("PF_RECOGNIZER_TIMING", 0);
+static std::atomic<long long> g_fwd_ns[8];
+static std::atomic<long long> g_fwd_calls{0};
+struct FwdClock {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(int i) {
+    if (!kFwdTiming) return;
+    const auto n = std::chrono::steady_clock::now();
+    g_fwd_ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count();
+    t = n;
+  }
+};
+static void fwd_report() {
+  if (!kFwdTiming) return;
+  const long long c = ++g_fwd_calls;
+  if (c % 32) return;
+  static const char* names[8] = {"acquire", "hotwords+waits", "stage_audio", "enqueue", "first fetch (sync)", "second fetch", "tokens+timestamps+RemoveChunk", "text"};
+  fprintf(stderr, "[GetResults] %lld calls:", c);
+  for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f us |", names[i], g_fwd_ns[i] / 1e3 / c);
+  fprintf(stderr, "\n");
 }
 
 void Recognizer::Forward(const std::vector<Stream*>& streams) {
@@ -590,11 +800,13 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     if (all_dev && sv && !sv_device_prompt_) all_dev = false;
     if (!all_dev)
       for (Stream* s : streams) s->materialize();
+    FwdClock fc;
     Lease lease = acquire();
     Engine* e = lease.get();
     const ModelCfg& mc = e->model();
     const int W = mc.feat_dim;
     const int B = (int)streams.size();
+    fc.lap(0);
     if (!all_dev && sv) {
       // SenseVoice split-embed variant: prepend [emb(lang), emb(1), emb(2), emb(textnorm)] to Speech
       // IN PLACE (OfflineProjOfSenseVoiceSmall.cs:78-106, quirk Q8); effective ids per quirk Q7.
@@ -635,9 +847,16 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
       // rows]) and the model, one stream of launches: WavFrontend.cs:31-111 + Utils/PadHelper.cs:25 + ModelProj
       std::vector<const float*> ptrs;
       std::vector<int64_t> ns;
-      for (Stream* s : streams) { ptrs.push_back(s->dev_audio); ns.push_back(s->dev_n); }
+      for (Stream* s : streams) {
+        ptrs.push_back(s->dev_audio); ns.push_back(s->dev_n);
+        // staged uploads may still be landing: the engine's stream waits for them, the host does not
+        if (s->dev_ev_pending) PF_HIP(hipStreamWaitEvent(e->stream(), s->dev_ev, 0));
+      }
+      fc.lap(1);
       e->stage_device_audio(ptrs.data(), ns.data(), B);
+      fc.lap(2);
       e->run_staged(false);
+      fc.lap(3);
     } else {
       std::vector<const float*> ptrs;
       std::vector<int32_t> lens;
@@ -648,6 +867,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     std::memset(&out, 0, sizeof(out));
     out.struct_size = sizeof(out);
     e->fetch(&out);                       // sync; learn L
+    fc.lap(4);
     const int L = out.L;
     std::vector<int64_t> ids((size_t)B * std::max(L, 1));
     out.token_ids = ids.data();
@@ -656,13 +876,15 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     std::vector<float> peak((size_t)B * std::max(P, 1));
     if (P > 0) { out.cif_peak = peak.data(); out.cif_peak_cap = (int64_t)peak.size(); }
     e->fetch(&out);
+    fc.lap(5);
     lease.release();                      // the device work of this call is over: the text stage below needs no engine
     for (int b = 0; b < B; ++b) {
       Stream* s = streams[b];
       s->Tokens.assign(ids.begin() + (size_t)b * out.l_cap, ids.begin() + (size_t)b * out.l_cap + L);   // :187
+      s->Timestamps.reserve(s->Timestamps.size() + (size_t)L);
       if (P > 0) {
         // :172-183: the peak row and ALL L arg-max ids go to time_stamp_lfr6_onnx
-        std::vector<std::vector<int32_t>> ts = time_stamp_lfr6(peak.data() + (size_t)b * P, P, s->Tokens);
+        TsList ts = time_stamp_lfr6(peak.data() + (size_t)b * P, P, s->Tokens);
         for (auto& t2 : ts) s->Timestamps.push_back(t2);
       } else {
         for (int l = 0; l < L; ++l) s->Timestamps.push_back({0, 0});                                    // :151,:188
@@ -681,6 +903,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
       }
       s->RemoveChunk();                                                                                  // :189
     }
+    fc.lap(6);
   } catch (const Error& ex) {
     if (ex.code == PF_ERR_RECOGNITION) throw;
     throw Error(PF_ERR_RECOGNITION, std::string("Offline recognition failed: ") + ex.what());           // :194-197
@@ -697,8 +920,11 @@ Recognizer::~Recognizer() {
 
 void Recognizer::GetResults(const std::vector<Stream*>& streams) {
   Forward(streams);
+  FwdClock fc;
   std::vector<ResultEntity> out;
   for (Stream* s : streams) out.push_back(decode_multi_one(tokens_, s->Tokens, s->Timestamps));
+  fc.lap(7);
+  fwd_report();
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
     for (auto it = t_results.begin(); it != t_results.end();)

@@ -2,14 +2,18 @@
 // (AliParaformerAsr/OfflineRecognizer.cs:13-477) and OfflineStream
 // (AliParaformerAsr/OfflineStream.cs:7-121) above the device engine.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <initializer_list>
 #include <map>
 #include <array>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "engine.h"
@@ -17,25 +21,73 @@
 
 namespace pf {
 
+// One timestamp, the reference's int[]: {begin_ms, end_ms} — or several pairs in a row where DecodeMulti merges word pieces
+// (OfflineRecognizer.cs:350-395).  Up to six ints live inside the object: a std::vector per token cost one heap allocation when
+// Forward pushes it, one when DecodeMulti copies it and a free each — 0.4 ms of host time per 32 x 30 s GetResults (round 6).
+class TsVec {
+ public:
+  TsVec() = default;
+  TsVec(std::initializer_list<int32_t> l) { append(l.begin(), l.end()); }
+  TsVec(const int32_t* a, const int32_t* b) { append(a, b); }
+  const int32_t* data() const { return n_ <= kInline ? inl_ : big_.data(); }
+  size_t size() const { return n_; }
+  const int32_t* begin() const { return data(); }
+  const int32_t* end() const { return data() + n_; }
+  int32_t operator[](size_t i) const { return data()[i]; }
+  void append(const int32_t* a, const int32_t* b) {
+    const size_t k = (size_t)(b - a);
+    if (n_ > kInline) big_.insert(big_.end(), a, b);
+    else if (n_ + k <= kInline) std::copy(a, b, inl_ + n_);
+    else { big_.assign(inl_, inl_ + n_); big_.insert(big_.end(), a, b); }
+    n_ += (uint32_t)k;
+  }
+  bool operator==(const TsVec& o) const { return n_ == o.n_ && std::equal(begin(), end(), o.begin()); }
+ private:
+  static constexpr uint32_t kInline = 6;
+  uint32_t n_ = 0;
+  int32_t inl_[kInline] = {0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> big_;
+};
+using TsList = std::vector<TsVec>;
+
 // OfflineRecognizerResultEntity (Model/OfflineRecognizerResultEntity.cs:9-29)
 struct ResultEntity {
   std::string Text;
   int TextLen = 0;                              // UTF-16 length, as C# string.Length
   std::vector<std::string> Tokens;
-  std::vector<std::vector<int32_t>> Timestamps;
+  TsList Timestamps;
 };
 
 // DecodeMulti for one stream (OfflineRecognizer.cs:304-418)
 ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std::vector<int64_t>& ids,
-                              const std::vector<std::vector<int32_t>>& timestamps);
+                              const TsList& timestamps);
 // time_stamp_lfr6_onnx (OfflineRecognizer.cs:200-302); throws PF_ERR_RECOGNITION where the C#
 // would throw inside Forward's try block.
-std::vector<std::vector<int32_t>> time_stamp_lfr6(const float* us_cif_peak, int n, std::vector<int64_t> tokens);
+TsList time_stamp_lfr6(const float* us_cif_peak, int n, const std::vector<int64_t>& tokens);
 // GetHotwords (OfflineRecognizer.cs:72-90) over in-memory lines; appends [sos_eos_id]
 std::vector<std::vector<int32_t>> hotword_ids(const std::vector<std::string>& tokens,
                                               const std::vector<std::string>& lines, int sos_eos_id);
 
 class Recognizer;
+
+// Helper threads that share the HOST side of a staged upload (caller's array -> pinned ring): one core copies 1.9 MB (30 s of
+// samples) in ~130 us, four in a third of that.  Helpers spin for a short while after a job (a batch arrives as a burst of
+// AddSamples calls) and sleep on a condition variable otherwise; the calling thread copies a share itself and, while it waits,
+// takes queued shares too — a call never depends on a helper being awake.
+class CopyCrew {
+ public:
+  explicit CopyCrew(int helpers);
+  ~CopyCrew();
+  void copy(char* dst, const char* src, size_t bytes);
+ private:
+  struct Job { char* d; const char* s; size_t n; std::atomic<int>* left; };
+  bool take(Job& j);
+  void run();
+  std::mutex mu_; std::condition_variable cv_; std::deque<Job> q_;
+  std::atomic<int> queued_{0}; std::atomic<bool> stop_{false};
+  std::vector<std::thread> th_;
+};
+
 
 // Ownership: a stream shares ownership of its recognizer OBJECT (so a stream handle that outlives
 // pf_recognizer_free still reaches valid memory and answers PF_ERR_DISPOSED), the recognizer does not track
@@ -70,12 +122,14 @@ class Stream {
   // device form: the samples of the single AddSamples call (dev_audio may be null when dev_n == 0)
   bool device_form = false;
   float* dev_audio = nullptr; size_t dev_bytes = 0; int64_t dev_n = 0;
+  hipEvent_t dev_ev = nullptr; bool dev_ev_pending = false;   // recorded behind the last DMA piece of dev_audio (staged uploads)
+  void wait_device_audio();                                   // host-side wait for that event
   void materialize();                                         // device form -> host form (features computed and read back)
   void drop_device_audio();
   bool hotwords_null = false;
   std::vector<std::vector<int32_t>> Hotwords;
   std::vector<int64_t> Tokens{0, 0};                          // OfflineStream.cs:26
-  std::vector<std::vector<int32_t>> Timestamps;
+  TsList Timestamps;
   void RemoveChunk();                                         // OfflineStream.cs:69-79
   bool disposed = false;
   std::shared_ptr<Recognizer> owner;
@@ -122,7 +176,9 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   // device buffers for the streams' audio (size-class cache: a server creating one stream per utterance re-uses them)
   float* audio_alloc(size_t bytes, size_t* got);
   void audio_free(float* p, size_t bytes);
-  void upload(float* dst, const float* src, size_t bytes);    // host -> device on a copy stream of its own, synchronous
+  // host -> device on a copy lane.  Returns when `src` may be reused; with `ev` (staged form) the bytes are on the device when
+  // *ev has completed and *pending is set — without staging the call is synchronous and *pending stays false
+  void upload(float* dst, const float* src, size_t bytes, hipEvent_t* ev = nullptr, bool* pending = nullptr);
   int device() const { return device_; }
   bool device_streams() const { return device_streams_; }     // new streams keep their first AddSamples call's audio on the device
   int feature_floats(int64_t n_samples);                      // what GetFbank + LfrCmvn return for n samples (float count)
@@ -151,7 +207,25 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   std::vector<float> sv_embed_; bool sv_use_itn_ = false;     // SenseVoice prompt table, cached so quirk Q8 needs no engine lease
   size_t audio_cache_cap_ = (size_t)1 << 30;                  // PF_RECOGNIZER_AUDIO_CACHE_MB
   std::map<size_t, std::vector<float*>> audio_cache_; size_t audio_cached_bytes_ = 0;
-  struct CopyLane { std::mutex mu; hipStream_t s = nullptr; };
+  // A copy lane = a stream + a ring of PINNED host memory.  AddSamples copies the caller's (pageable) samples into the ring piece by
+  // piece and queues one DMA per piece: the call returns when the last piece has been COPIED OUT of the caller's array — the
+  // reference's contract (the array belongs to the caller again) — not when the DMA has landed; the stream's `dev_ev` says when
+  // it has, and whoever reads dev_audio waits for it (on the engine's stream in Forward).  The runtime's own pageable path
+  // stages and copies one after the other and returns after both (2.9 ms per 32 x 30 s of one caller, round 5).
+  struct CopyLane {
+    std::mutex mu; hipStream_t s = nullptr;
+    char* pin = nullptr; size_t cap = 0, head = 0; bool tried = false;
+    struct Piece { size_t off, bytes; hipEvent_t ev; };
+    std::deque<Piece> inflight; std::vector<hipEvent_t> spare;
+  };
+  std::unique_ptr<CopyCrew> crew_; std::once_flag crew_once_; int crew_threads_ = 3;   // PF_RECOGNIZER_COPY_THREADS (helpers)
+  // Which way an upload goes.  A (pointer, size) seen before is a buffer the caller re-uses: the runtime keeps such pages pinned
+  // after their first copy and DMAs straight out of them (50 us per 1.9 MB) — no staged copy beats that.  An array not seen
+  // before would be pinned first (120 - 390 us, tools/ubench/h2d.cpp): it goes through the ring (45 - 60 us).
+  std::mutex seen_mu_; std::unordered_map<const void*, size_t> seen_; bool staging_always_ = false;   // PF_RECOGNIZER_STAGING_POLICY=always
+  bool seen_before(const void* p, size_t bytes);
+  size_t staging_bytes_ = (size_t)16 << 20;                   // PF_RECOGNIZER_STAGING_MB per lane (0: the runtime's pageable copy)
+  size_t staging_piece_ = (size_t)2 << 20;                    // PF_RECOGNIZER_STAGING_PIECE_KB
   std::array<CopyLane, 4> lanes_;
   std::atomic<unsigned> next_lane_{0};
   std::vector<std::string> tokens_;

@@ -281,6 +281,47 @@ def test_device_form_equals_host_form(model_dir, monkeypatch):
     assert txt_d == txt_h
 
 
+def test_staged_upload_equals_the_synchronous_one(model_dir, monkeypatch):
+    """AddSamples copies the caller's array into a ring of pinned memory piece by piece and returns when the array is the caller's
+    again; the DMA lands later and GetResults' stream waits for it (recognizer.h, CopyLane).  Same ids and texts as the
+    synchronous pageable copy (PF_RECOGNIZER_STAGING_MB=0) — with a ring SMALLER than one upload (1 MB, 256 KB pieces: every
+    upload wraps and waits for its own earlier pieces), with the caller's array overwritten right after the call, and with
+    streams dropped while their pieces are still in flight (their buffers go back to the cache and are handed out again)."""
+    audio = [W.synth_audio(n, 160 + u) for u, n in enumerate((480000, 1000, 300000, 480000, 16000, 420000))]
+    monkeypatch.setenv("PF_RECOGNIZER_STAGING_MB", "0")
+    r0 = _make(model_dir)
+    ids0, txt0, _ = _batch_ids(r0, audio)
+    # policy "always": every upload through the ring ("auto", the default, sends a (pointer, size) it has seen before down the
+    # runtime's own path, whose pinning of re-used buffers no staged copy beats — the third case mixes both)
+    for mb, piece, policy in (("16", "2048", "always"), ("1", "256", "always"), ("16", "1024", "auto")):
+        monkeypatch.setenv("PF_RECOGNIZER_STAGING_MB", mb)
+        monkeypatch.setenv("PF_RECOGNIZER_STAGING_PIECE_KB", piece)
+        monkeypatch.setenv("PF_RECOGNIZER_STAGING_POLICY", policy)
+        r = _make(model_dir)
+        for rep in range(3):
+            for a in audio:                                  # dropped with the DMA behind them still running
+                r.CreateOfflineStream().AddSamples(a)
+            streams = []
+            for a in audio:
+                buf = a.copy()
+                st = r.CreateOfflineStream()
+                st.AddSamples(buf)
+                buf[:] = 7.0                                 # the array is the caller's again
+                streams.append(st)
+            res = r.GetResults(streams)
+            np.testing.assert_array_equal(np.asarray([st.Tokens for st in streams]), ids0)
+            assert [x.Text for x in res] == txt0
+        # the host form of a staged stream (second AddSamples call) reads the device samples too: it must wait for them
+        st = r.CreateOfflineStream()
+        st.AddSamples(audio[0][:240000])
+        st.AddSamples(audio[0][240000:])
+        s0 = r0.CreateOfflineStream()
+        s0.AddSamples(audio[0][:240000])
+        s0.AddSamples(audio[0][240000:])
+        assert r.GetResult(st).Text == r0.GetResult(s0).Text
+        r.Dispose()
+
+
 def test_second_add_samples_appends_features_like_the_reference(model_dir):
     """OfflineStream.cs:40-54: every AddSamples call runs GetFbank + LfrCmvn on ITS samples and appends the features — two
     calls are not one call on the concatenation (each call has its own frame grid and its own LFR left context).  The
