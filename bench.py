@@ -838,6 +838,20 @@ def main():
             engs[last_e].run_staged()
         engs[last_e].sync()
         serial_ms = (time.perf_counter() - t1) / n1 * 1e3
+    # the same serial step when the GPU has IDLED before it (the one-caller window of the recognizer: 1.5 ms of uploads and 0.5 ms
+    # of host work sit between two steps) — the sleep is outside the clock
+    after_idle = {}
+    if rank == 0:
+        for idle_ms in (0.0, 2.5):
+            acc = 0.0
+            for _ in range(4):
+                engs[last_e].sync()
+                time.sleep(idle_ms * 1e-3)
+                t1 = time.perf_counter()
+                engs[last_e].run_staged()
+                engs[last_e].sync()
+                acc += time.perf_counter() - t1
+            after_idle["%.1f" % idle_ms] = acc / 4 * 1e3
     res = engs[last_e].fetch()
     ms_dom, n_dom, fpl_dom = eng.profile_get(dominant)
     for e_ in engs:                                          # every engine computed the same batch: concurrency must not change a single id
@@ -945,6 +959,7 @@ def main():
             "ms_first_step_alone": solo_ms,          # the first timed step, run with nothing else in flight (and 50 event pairs)
             # first-class twin of `value`: the same job strictly one step at a time — the figure rounds 1-3 reported
             "ms_per_step_one_in_flight": serial_ms if E > 1 else dt / args.steps * 1e3,
+            "serial_step_ms_after_idle_ms": after_idle,
             "value_one_in_flight": (world * B * seconds / (serial_ms * 1e-3)) if (E > 1 and serial_ms) else value,
             "rtf": dt / audio_s, "utt_per_s": world * B * args.steps / dt,
             "rccl_ranks": world if use_dist else 0,
