@@ -847,6 +847,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
       // rows]) and the model, one stream of launches: WavFrontend.cs:31-111 + Utils/PadHelper.cs:25 + ModelProj
       std::vector<const float*> ptrs;
       std::vector<int64_t> ns;
+      PF_HIP(hipSetDevice(device_));
       for (Stream* s : streams) {
         ptrs.push_back(s->dev_audio); ns.push_back(s->dev_n);
         // staged uploads may still be landing: the engine's stream waits for them, the host does not
