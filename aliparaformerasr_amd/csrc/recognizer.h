@@ -16,6 +16,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "copycrew.h"
 #include "engine.h"
 #include "hostutil.h"
 
@@ -69,25 +70,6 @@ std::vector<std::vector<int32_t>> hotword_ids(const std::vector<std::string>& to
                                               const std::vector<std::string>& lines, int sos_eos_id);
 
 class Recognizer;
-
-// Helper threads that share the HOST side of a staged upload (caller's array -> pinned ring): one core copies 1.9 MB (30 s of
-// samples) in ~130 us, four in a third of that.  Helpers spin for a short while after a job (a batch arrives as a burst of
-// AddSamples calls) and sleep on a condition variable otherwise; the calling thread copies a share itself and, while it waits,
-// takes queued shares too — a call never depends on a helper being awake.
-class CopyCrew {
- public:
-  explicit CopyCrew(int helpers);
-  ~CopyCrew();
-  void copy(char* dst, const char* src, size_t bytes);
- private:
-  struct Job { char* d; const char* s; size_t n; std::atomic<int>* left; };
-  bool take(Job& j);
-  void run();
-  std::mutex mu_; std::condition_variable cv_; std::deque<Job> q_;
-  std::atomic<int> queued_{0}; std::atomic<bool> stop_{false};
-  std::vector<std::thread> th_;
-};
-
 
 // Ownership: a stream shares ownership of its recognizer OBJECT (so a stream handle that outlives
 // pf_recognizer_free still reaches valid memory and answers PF_ERR_DISPOSED), the recognizer does not track

@@ -187,6 +187,32 @@ def test_host_parsers_under_sanitizers(tmp_path):
     assert r.stdout.startswith("ok ")
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_copy_helpers_under_sanitizers(san, tmp_path):
+    """csrc/copycrew.cpp (the helper threads that share the host side of a staged AddSamples upload: spinning and sleeping helpers,
+    shares taken by helpers and callers alike, several callers on one crew) under -fsanitize=thread / address: every copy exact,
+    nothing written outside the destination, no report."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / ("copycrew_" + san))
+    cs = os.path.join(root, "aliparaformerasr_amd", "csrc")
+    b = subprocess.run([hipcc, "-x", "hip", "--offload-arch=gfx950", "-g", "-O1", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-std=c++17",
+                        "-I" + cs, os.path.join(root, "tests", "native", "copycrew_sanitize.cpp"), os.path.join(cs, "copycrew.cpp"),
+                        "-o", exe, "-lpthread"], capture_output=True, text=True)
+    if b.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + b.stderr[-300:])
+    r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert "Sanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.startswith("ok ")
+
+
 @pytest.mark.skipif(not os.environ.get("PF_SANITIZE_FULL"), reason="set PF_SANITIZE_FULL=1: rebuilds the whole library with ASan + UBSan (minutes)")
 @pytest.mark.timeout(3000)
 def test_every_host_entry_point_under_sanitizers(tmp_path):
