@@ -13,6 +13,7 @@ python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-via-recognizer --acc
 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-via-recognizer --accuracy exact > $OUT/bench_exact.json 2>> $OUT/bench.err
 python bench.py --via recognizer --steps 32 --callers 4 > $OUT/bench_via_recognizer_4callers.json 2>> $OUT/bench.err
 python bench.py --via recognizer --steps 24 --callers 2 --in-flight 2 > $OUT/bench_via_recognizer_2callers.json 2>> $OUT/bench.err
+python bench.py --via recognizer --steps 32 --callers 4 --fresh-host-audio > $OUT/bench_via_recognizer_4callers_fresh.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --model sensevoice > $OUT/bench_sensevoice.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --model seaco > $OUT/bench_seaco.json 2>> $OUT/bench.err
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-via-recognizer --batch 128 > $OUT/bench_batch128.json 2>> $OUT/bench.err
@@ -38,7 +39,7 @@ ls -la $OUT
 tail -3 $OUT/bench.err
 python -c "
 import json
-for f in ('bench','bench_one_in_flight','bench_sensevoice','bench_seaco','bench_batch128','bench_int8','bench_seaco_int8','bench_fp32','bench_exact','bench_via_recognizer_4callers','bench_via_recognizer_2callers'):
+for f in ('bench','bench_one_in_flight','bench_sensevoice','bench_seaco','bench_batch128','bench_int8','bench_seaco_int8','bench_fp32','bench_exact','bench_via_recognizer_4callers','bench_via_recognizer_2callers','bench_via_recognizer_4callers_fresh'):
     try:
         d=json.load(open('$OUT/'+f+'.json')); print(f, round(d['ms_per_step'],3), round(d['value']), d['roofline']['frac'], d.get('cpu_baseline',{}).get('value'))
     except Exception as e: print(f, 'FAILED', e)
