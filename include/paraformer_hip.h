@@ -431,7 +431,11 @@ pf_engine* pf_recognizer_engine(pf_recognizer* r);
 int pf_recognizer_num_engines(pf_recognizer* r);
 
 int pf_recognizer_create_stream(pf_recognizer* r, pf_stream** out);     /* CreateOfflineStream :92 */
-int pf_stream_add_samples(pf_stream* s, const float* samples, int64_t n); /* AddSamples, OfflineStream.cs:36 */
+/* AddSamples, OfflineStream.cs:36.  `samples` belongs to the caller again when the call returns (the reference's contract): an
+   array the recognizer has not seen before has been copied into pinned staging memory by then and its DMA may still be in
+   flight — whatever reads the samples later (pf_recognizer_get_results, a second pf_stream_add_samples, pf_stream_free) waits
+   for it by itself. */
+int pf_stream_add_samples(pf_stream* s, const float* samples, int64_t n);
 /* stream.Hotwords = List<int[]> (flattened ids + per-hotword lengths); n_hotwords < 0 sets null. */
 int pf_stream_set_hotwords(pf_stream* s, const int32_t* ids, const int32_t* lens, int32_t n_hotwords);
 int pf_stream_get_hotwords(pf_stream* s, int32_t* ids, int32_t ids_cap, int32_t* lens,
