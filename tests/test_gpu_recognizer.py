@@ -322,6 +322,43 @@ def test_staged_upload_equals_the_synchronous_one(model_dir, monkeypatch):
         r.Dispose()
 
 
+def test_staged_uploads_from_concurrent_callers(model_dir, monkeypatch):
+    """Four caller threads on one recognizer, every batch out of arrays made for it, every upload through a ring that holds
+    fewer bytes than one caller's batch (2 MB per lane, 256 KB pieces: lanes are contended, rings wrap and wait for their own
+    DMAs while other callers' kernels run): every caller gets the ids and texts of the synchronous path, every time."""
+    import threading
+    audio = [W.synth_audio(n, 260 + u) for u, n in enumerate((320000, 160000, 480000, 8000, 240000, 400000))]
+    monkeypatch.setenv("PF_RECOGNIZER_STAGING_MB", "0")
+    r0 = _make(model_dir)
+    ids0, txt0, _ = _batch_ids(r0, audio)
+    r0.Dispose()
+    monkeypatch.setenv("PF_RECOGNIZER_STAGING_MB", "2")
+    monkeypatch.setenv("PF_RECOGNIZER_STAGING_PIECE_KB", "256")
+    monkeypatch.setenv("PF_RECOGNIZER_STAGING_POLICY", "always")
+    monkeypatch.setenv("PF_RECOGNIZER_ENGINES", "3")
+    r = _make(model_dir)
+    errs = []
+
+    def caller(t):
+        try:
+            for rep in range(6):
+                fresh = [np.array(a) for a in audio]
+                ids, txt, _ = _batch_ids(r, fresh)
+                for f in fresh:
+                    f[:] = -3.0
+                np.testing.assert_array_equal(ids, ids0)
+                assert txt == txt0
+        except BaseException as ex:                        # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs[0]
+    r.Dispose()
+
+
 def test_second_add_samples_appends_features_like_the_reference(model_dir):
     """OfflineStream.cs:40-54: every AddSamples call runs GetFbank + LfrCmvn on ITS samples and appends the features — two
     calls are not one call on the concatenation (each call has its own frame grid and its own LFR left context).  The
