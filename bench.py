@@ -612,8 +612,8 @@ def group_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)      # (even: with two steps in flight an odd K leaves one engine a step more)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0,
                     help="utterances per GPU (default: 32 = BASELINE.json configs[1] for EVERY --gpus N, so the points of a "
                          "1/2/4/8 scaling curve are comparable and N = 1 is the headline; 64 for --model sensevoice = configs[2])")
