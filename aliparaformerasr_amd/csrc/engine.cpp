@@ -169,13 +169,29 @@ void Engine::release() {
 // finish well before the spinning one, the two streams share a queue: the new stream is parked (kept alive, so that the runtime's
 // allocator moves on) and another one is tried, up to 8 times.  PF_QUEUE_PROBE=0 switches the probe off.
 
+namespace {
+struct ProbeEvents {                                          // (the probe's calls may throw: the events go with the scope)
+  hipEvent_t a = nullptr, b = nullptr;
+  ProbeEvents() { PF_HIP(hipEventCreate(&a)); if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); throw Error(PF_ERR_DEVICE, "hipEventCreate"); } }
+  ~ProbeEvents() { hipEventDestroy(a); hipEventDestroy(b); }
+};
+// a stream parked by the probe has done its work once the next stream exists: keep the last few, destroy the oldest (a process that
+// creates and destroys recognizers beside a long-lived one would otherwise collect them for ever)
+void park_stream(hipStream_t s) {
+  g_parked.push_back(s);
+  if (g_parked.size() > 24) {
+    for (int i = 0; i < 8; ++i) hipStreamDestroy(g_parked[(size_t)i]);
+    g_parked.erase(g_parked.begin(), g_parked.begin() + 8);
+  }
+}
+}  // namespace
+
 void Engine::own_hardware_queue() {
   static const int on = env_int("PF_QUEUE_PROBE", 1);
   std::lock_guard<std::mutex> lk(g_main_mu);
   if (on) {
-    hipEvent_t ea = nullptr, eb = nullptr;
-    PF_HIP(hipEventCreate(&ea));
-    PF_HIP(hipEventCreate(&eb));
+    ProbeEvents ev;
+    hipEvent_t ea = ev.a, eb = ev.b;
     for (int attempt = 0; attempt < 8; ++attempt) {
       bool clash = false;
       int seen = 0;
@@ -196,12 +212,10 @@ void Engine::own_hardware_queue() {
         if (attempt && getenv("PF_QUEUE_PROBE_VERBOSE")) fprintf(stderr, "pf: engine main stream moved to another hardware queue after %d attempt(s)\n", attempt);
         break;
       }
-      g_parked.push_back(stream_);                           // stays alive: the next stream gets another queue
+      park_stream(stream_);                                  // stays alive: the next stream gets another queue
       stream_ = nullptr;
       PF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     }
-    hipEventDestroy(ea);
-    hipEventDestroy(eb);
   }
   g_main_streams.emplace_back(device_, stream_);
 }
@@ -211,9 +225,8 @@ void Engine::own_hardware_queue_ts() {
   static const int on = env_int("PF_QUEUE_PROBE", 1);
   if (!on || !ts_stream_) return;
   std::lock_guard<std::mutex> lk(g_main_mu);
-  hipEvent_t ea = nullptr, eb = nullptr;
-  PF_HIP(hipEventCreate(&ea));
-  PF_HIP(hipEventCreate(&eb));
+  ProbeEvents ev;
+  hipEvent_t ea = ev.a, eb = ev.b;
   for (int attempt = 0; attempt < 8; ++attempt) {
     launch_spin(stream_, 300000ull);
     launch_nop(ts_stream_);
@@ -227,12 +240,10 @@ void Engine::own_hardware_queue_ts() {
       if (attempt && getenv("PF_QUEUE_PROBE_VERBOSE")) fprintf(stderr, "pf: timestamp stream moved to another hardware queue after %d attempt(s)\n", attempt);
       break;
     }
-    g_parked.push_back(ts_stream_);
+    park_stream(ts_stream_);
     ts_stream_ = nullptr;
     PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
   }
-  hipEventDestroy(ea);
-  hipEventDestroy(eb);
 }
 
 void* Engine::dalloc(size_t bytes) {
