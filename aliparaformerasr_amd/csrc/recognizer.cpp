@@ -66,8 +66,29 @@ static void remove_first_equal_to_last(std::vector<T>& v) {
   v.erase(it);
 }
 
-ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std::vector<int64_t>& ids,
-                              const TsList& timestamps) {
+// kind of a vocabulary entry for DecodeMulti: 2 = one of the four markers it skips, 1 = all-Chinese, 0 = anything else
+static int token_kind(const std::string& cur) {
+  if (cur == "</s>" || cur == "<s>" || cur == "<blank>" || cur == "<unk>") return 2;
+  return is_chinese_all(cur) ? 1 : 0;
+}
+static std::string token_text(const std::string& line) {       // tokens.txt lines may carry "\t<id>": the text is what precedes the tab
+  const size_t tab = line.find('\t');
+  return tab == std::string::npos ? line : line.substr(0, tab);
+}
+
+TokenTable::TokenTable(const std::vector<std::string>& tokens) {
+  cur.reserve(tokens.size());
+  kind.reserve(tokens.size());
+  for (const std::string& t : tokens) {
+    cur.push_back(token_text(t));
+    kind.push_back((uint8_t)token_kind(cur.back()));
+  }
+}
+
+// DecodeMulti for one stream; `lookup(token, kind)` returns the entry's text and its kind (computed per token by the plain form,
+// read from the recognizer's table by the other: 32 x 167 tokens per GetResults)
+template <class Lookup>
+static ResultEntity decode_multi_core(size_t vocab, const std::vector<int64_t>& ids, const TsList& timestamps, Lookup&& lookup) {
   ResultEntity r;
   r.Tokens.reserve(ids.size());
   r.Timestamps.reserve(ids.size());
@@ -80,12 +101,11 @@ ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std:
     const int64_t token = ids[i];
     const TsVec& ts = timestamps[i];
     if (token == 2) break;
-    if (token < 0 || token >= (int64_t)tokens.size()) throw Error(PF_ERR_RECOGNITION, "token id out of range");
-    std::string cur = tokens[(size_t)token];
-    const size_t tab = cur.find('\t');
-    if (tab != std::string::npos) cur = cur.substr(0, tab);
-    if (cur == "</s>" || cur == "<s>" || cur == "<blank>" || cur == "<unk>") continue;
-    if (is_chinese_all(cur)) {
+    if (token < 0 || token >= (int64_t)vocab) throw Error(PF_ERR_RECOGNITION, "token id out of range");
+    int kind = 0;
+    const std::string& cur = lookup((size_t)token, kind);
+    if (kind == 2) continue;
+    if (kind == 1) {
       text += cur;
       r.Tokens.push_back(cur);
       r.Timestamps.push_back(ts);
@@ -135,6 +155,23 @@ ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std:
   r.Text = text;
   r.TextLen = utf16_length(text);
   return r;
+}
+
+ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std::vector<int64_t>& ids,
+                              const TsList& timestamps) {
+  std::string scratch;
+  return decode_multi_core(tokens.size(), ids, timestamps, [&](size_t t, int& kind) -> const std::string& {
+    scratch = token_text(tokens[t]);
+    kind = token_kind(scratch);
+    return scratch;
+  });
+}
+
+ResultEntity decode_multi_one(const TokenTable& table, const std::vector<int64_t>& ids, const TsList& timestamps) {
+  return decode_multi_core(table.cur.size(), ids, timestamps, [&](size_t t, int& kind) -> const std::string& {
+    kind = table.kind[t];
+    return table.cur[t];
+  });
 }
 
 TsList time_stamp_lfr6(const float* us_cif_peak, int n, const std::vector<int64_t>& tokens_in) {
@@ -346,6 +383,7 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   if (!tokens.empty()) {
     if (!file_exists(tokens)) throw Error(PF_ERR_IO, "tokens file not found: " + tokens);
     tokens_ = read_lines(tokens);
+    token_table_ = TokenTable(tokens_);
   }
   if (tokens_.empty()) throw Error(PF_ERR_TOKENS, "tokens invalid");
   if (!hotword.empty() && file_exists(hotword))                    // :34-38, :75
@@ -848,7 +886,7 @@ void Recognizer::GetResults(const std::vector<Stream*>& streams) {
   Forward(streams);
   FwdClock fc;
   std::vector<ResultEntity> out;
-  for (Stream* s : streams) out.push_back(decode_multi_one(tokens_, s->Tokens, s->Timestamps));
+  for (Stream* s : streams) out.push_back(decode_multi_one(token_table_, s->Tokens, s->Timestamps));
   fc.lap(7);
   fwd_report();
   {

@@ -62,6 +62,15 @@ struct ResultEntity {
 // DecodeMulti for one stream (OfflineRecognizer.cs:304-418)
 ResultEntity decode_multi_one(const std::vector<std::string>& tokens, const std::vector<int64_t>& ids,
                               const TsList& timestamps);
+// What DecodeMulti derives from a vocabulary entry every time it meets it (the text in front of a tab, whether it is one of the four
+// markers, whether it is all Chinese), computed once per recognizer
+struct TokenTable {
+  TokenTable() = default;
+  explicit TokenTable(const std::vector<std::string>& tokens);
+  std::vector<std::string> cur;
+  std::vector<uint8_t> kind;
+};
+ResultEntity decode_multi_one(const TokenTable& table, const std::vector<int64_t>& ids, const TsList& timestamps);
 // time_stamp_lfr6_onnx (OfflineRecognizer.cs:200-302); throws PF_ERR_RECOGNITION where the C#
 // would throw inside Forward's try block.
 TsList time_stamp_lfr6(const float* us_cif_peak, int n, const std::vector<int64_t>& tokens);
@@ -211,6 +220,7 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   std::array<CopyLane, 4> lanes_;
   std::atomic<unsigned> next_lane_{0};
   std::vector<std::string> tokens_;
+  TokenTable token_table_;
   ConfEntity conf_;
   std::vector<std::vector<int32_t>> hotwords_;
   uint64_t uid_ = 0;                                          // key of this recognizer in the per-thread result store
