@@ -479,7 +479,7 @@ def recognizer_bench(cfg, weights, cmvn, audio, seconds, batches, callers, engin
             p = C.POINTER(C.c_int64)()
             n = C.c_int32()
             N.check(lib.pf_stream_tokens(C.c_void_p(hs[b]), C.byref(p), n))
-            ids.append(np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64))
+            ids.append(np.frombuffer(C.string_at(p, n.value * 8), dtype=np.int64) if n.value else np.zeros(0, np.int64))   # (a copy)
             lib.pf_stream_free(C.c_void_p(hs[b]))
         return np.stack(ids), texts
 
