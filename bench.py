@@ -428,6 +428,12 @@ def cpu_baseline(cfg, weights, cmvn):
             "reference_published": "rtf 0.0371 (RTFx 27) on an i7-10750H, settings unstated (README.EN.md:134-136)"}
 
 
+# the recognizer's engine pool in the via_recognizer lines = the library's default (PF_RECOGNIZER_ENGINES unset): callers beyond the
+# pool queue on a busy engine and do their uploads and text stages meanwhile.  Measured with 4 callers (round 6): 2 engines 8.61 ms per
+# batch, 3: 8.89, 4: 8.79 - 9.13 — rounds 4 - 5 ran this line with max(3, callers) engines
+POOL_ENGINES = 2
+
+
 def recognizer_bench(cfg, weights, cmvn, audio, seconds, batches, callers, engines, tag, fresh=False):
     """The reference's own timing window through the drop-in API (VERDICT r4 "missing" #1): host float32 audio in, ids and
     text out — `CreateOfflineStream` + `AddSamples` per utterance, ONE `GetResults` per batch, the result texts read back
@@ -545,7 +551,7 @@ def via_recognizer_main(args):
     cfg = W.sensevoice_small_config(use_itn=True) if sv else W.paraformer_large_config()
     weights = W.synth_weights(cfg, 42)
     audio = [W.synth_audio(seconds * 16000, u) for u in range(B)]
-    E = args.in_flight if args.in_flight > 0 else max(3, args.callers)
+    E = args.in_flight if args.in_flight > 0 else POOL_ENGINES
     r = recognizer_bench(cfg, weights, W.synth_cmvn(), audio, seconds, args.steps, args.callers, E,
                          args.model if seconds == (10 if sv else SECONDS) and B == (64 if sv else BATCH_PER_GPU) else None,
                          fresh=args.fresh_host_audio)
@@ -994,12 +1000,12 @@ def main():
             for e_ in engs:
                 e_.close()
             engs = []
-            out["via_recognizer"] = recognizer_bench(cfg, weights, cmvn, audio, seconds, 4 * args.callers, args.callers, max(3, args.callers), args.model)
+            out["via_recognizer"] = recognizer_bench(cfg, weights, cmvn, audio, seconds, 4 * args.callers, args.callers, POOL_ENGINES, args.model)
             assert out["via_recognizer"]["ids_vs_fp32_oracle"] is None or out["via_recognizer"]["ids_vs_fp32_oracle"]["ok"]
             # the same window when every batch comes out of host arrays made for it (a server's request buffers) instead of the
             # same 32 arrays every time, whose pages the runtime keeps pinned after their first copy: the recognizer stages arrays
             # it has not seen before through pinned memory (recognizer.h, CopyLane)
-            fr = recognizer_bench(cfg, weights, cmvn, audio, seconds, 4 * args.callers, args.callers, max(3, args.callers), args.model, fresh=True)
+            fr = recognizer_bench(cfg, weights, cmvn, audio, seconds, 4 * args.callers, args.callers, POOL_ENGINES, args.model, fresh=True)
             assert fr["ids_sha1"] == out["via_recognizer"]["ids_sha1"]
             out["via_recognizer"]["fresh_host_arrays"] = {k: fr[k] for k in ("ms_per_batch", "rtfx", "ms_per_batch_one_caller", "one_caller_split")}
         if world == 1 and not args.no_cpu_baseline and not sv and seconds == SECONDS:
