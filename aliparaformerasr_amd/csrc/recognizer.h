@@ -202,7 +202,8 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   // piece and queues one DMA per piece: the call returns when the last piece has been COPIED OUT of the caller's array — the
   // reference's contract (the array belongs to the caller again) — not when the DMA has landed; the stream's `dev_ev` says when
   // it has, and whoever reads dev_audio waits for it (on the engine's stream in Forward).  The runtime's own pageable path
-  // stages and copies one after the other and returns after both (2.9 ms per 32 x 30 s of one caller, round 5).
+  // pins the caller's pages, copies and returns after both: 120 - 390 us per 1.9 MB for pages it has not seen, 50 us for pages it
+  // still holds pinned from an earlier copy (tools/ubench/h2d.cpp, profiles/round6_staging_ab.txt) — hence the policy below.
   struct CopyLane {
     std::mutex mu; hipStream_t s = nullptr;
     char* pin = nullptr; size_t cap = 0, head = 0; bool tried = false;
