@@ -1241,7 +1241,12 @@ int pf_host_decode(const char* const* tokens, int32_t n_tokens, const int64_t* i
   }
   pf_decoded* d = new pf_decoded();
   try {
+    // both forms of DecodeMulti — per-token derivations on the fly, and out of the table a recognizer builds once — must agree:
+    // this entry is what the golden vectors and the fuzz harness drive, the recognizer itself uses the table
     d->r = decode_multi_one(tk, idv, ts);
+    const ResultEntity t = decode_multi_one(TokenTable(tk), idv, ts);
+    PF_CHECK(t.Text == d->r.Text && t.TextLen == d->r.TextLen && t.Tokens == d->r.Tokens && t.Timestamps == d->r.Timestamps,
+             PF_ERR_RECOGNITION, "DecodeMulti: the table form disagrees with the plain form");
   } catch (...) {
     delete d;
     throw;
