@@ -621,6 +621,18 @@ void Recognizer::upload(float* dst, const float* src, size_t bytes, hipEvent_t* 
     PF_HIP(hipStreamSynchronize(ln.s));                // the samples are on the device when AddSamples returns
     return;
   }
+  if (!ln.sp) {
+    // The DMAs of a staged upload are copy KERNELS on this part: on a plain stream they queue behind the other callers' compute
+    // kernels and land 0.3 ms late each (the ring fills, AddSamples waits: 10.6 - 11.0 ms per batch with 4 callers against 9.3 - 9.6).
+    // The staged path therefore has a stream of its own at the device's highest priority; the runtime's own path keeps the plain
+    // one (its synchronous copies were 3 us slower there).  PF_RECOGNIZER_LANE_PRIORITY=0: a plain stream for both.
+    static const int prio = env_int("PF_RECOGNIZER_LANE_PRIORITY", 1);
+    int lo = 0, hi = 0;
+    if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+      if (hipStreamCreateWithPriority(&ln.sp, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ln.sp = nullptr; }
+    }
+    if (!ln.sp) PF_HIP(hipStreamCreateWithFlags(&ln.sp, hipStreamNonBlocking));
+  }
   if (crew_threads_ > 0) std::call_once(crew_once_, [&] { crew_.reset(new CopyCrew(crew_threads_)); });
   // staged: piece by piece through the pinned ring; the DMA of piece i runs under the host copy of piece i + 1
   const size_t piece = std::min(staging_piece_, ln.cap);
@@ -645,17 +657,17 @@ void Recognizer::upload(float* dst, const float* src, size_t bytes, hipEvent_t* 
       if (crew_) crew_->copy(ln.pin + off, (const char*)src + done, nb);
       else std::memcpy(ln.pin + off, (const char*)src + done, nb);
     }
-    PF_HIP(hipMemcpyAsync((char*)dst + done, ln.pin + off, nb, hipMemcpyHostToDevice, ln.s));
+    PF_HIP(hipMemcpyAsync((char*)dst + done, ln.pin + off, nb, hipMemcpyHostToDevice, ln.sp));
     hipEvent_t pe = nullptr;
     if (!ln.spare.empty()) { pe = ln.spare.back(); ln.spare.pop_back(); }
     else PF_HIP(hipEventCreateWithFlags(&pe, hipEventDisableTiming));
-    if (hipEventRecord(pe, ln.s) != hipSuccess) { ln.spare.push_back(pe); PF_HIP(hipStreamSynchronize(ln.s)); }
+    if (hipEventRecord(pe, ln.sp) != hipSuccess) { ln.spare.push_back(pe); PF_HIP(hipStreamSynchronize(ln.sp)); }
     else ln.inflight.push_back({off, nb, pe});
     ln.head = off + nb;
     done += nb;
   }
   if (!*ev) PF_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-  PF_HIP(hipEventRecord(*ev, ln.s));
+  PF_HIP(hipEventRecord(*ev, ln.sp));
   *pending = true;
 }
 
@@ -719,6 +731,7 @@ void Recognizer::free_device_side() {
   for (CopyLane& ln : lanes_) {
     std::lock_guard<std::mutex> lk(ln.mu);
     if (ln.s) { hipStreamSynchronize(ln.s); hipStreamDestroy(ln.s); ln.s = nullptr; }
+    if (ln.sp) { hipStreamSynchronize(ln.sp); hipStreamDestroy(ln.sp); ln.sp = nullptr; }
     for (auto& q : ln.inflight) hipEventDestroy(q.ev);
     for (hipEvent_t e : ln.spare) hipEventDestroy(e);
     ln.inflight.clear(); ln.spare.clear();

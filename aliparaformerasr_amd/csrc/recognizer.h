@@ -205,7 +205,8 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   // pins the caller's pages, copies and returns after both: 120 - 390 us per 1.9 MB for pages it has not seen, 50 us for pages it
   // still holds pinned from an earlier copy (tools/ubench/h2d.cpp, profiles/round6_staging_ab.txt) — hence the policy below.
   struct CopyLane {
-    std::mutex mu; hipStream_t s = nullptr;
+    std::mutex mu; hipStream_t s = nullptr;          // the runtime's pageable path (synchronous)
+    hipStream_t sp = nullptr;                        // the staged path: highest stream priority (its DMAs are copy kernels)
     char* pin = nullptr; size_t cap = 0, head = 0; bool tried = false;
     struct Piece { size_t off, bytes; hipEvent_t ev; };
     std::deque<Piece> inflight; std::vector<hipEvent_t> spare;
