@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <set>
 
@@ -127,6 +128,7 @@ void Engine::release() {
   hipSetDevice(device_);
   if (stream_) hipStreamSynchronize(stream_);
   if (aux_stream_) { hipStreamSynchronize(aux_stream_); hipStreamDestroy(aux_stream_); aux_stream_ = nullptr; }
+  if (plan_host_) { hipHostFree(plan_host_); plan_host_ = nullptr; plan_host_dev_ = nullptr; plan_host_cap_ = 0; }
   if (ev_scan_) { hipEventDestroy(ev_scan_); ev_scan_ = nullptr; }
   if (ts_stream_) { hipStreamSynchronize(ts_stream_); hipStreamDestroy(ts_stream_); ts_stream_ = nullptr; }
   if (ev_ts_) { hipEventDestroy(ev_ts_); ev_ts_ = nullptr; }
@@ -244,6 +246,19 @@ void Engine::own_hardware_queue_ts() {
     ts_stream_ = nullptr;
     PF_HIP(hipStreamCreateWithFlags(&ts_stream_, hipStreamNonBlocking));
   }
+}
+
+// pinned host memory the CIF plan's counts are exported into (PF_PLAN_ZERO_COPY=0: the three device-to-host copies of rounds 1-5)
+void Engine::ensure_plan_host(int B) {
+  static const int on = env_int("PF_PLAN_ZERO_COPY", 1);
+  if (!on || plan_host_cap_ >= B) return;
+  if (plan_host_) { hipHostFree(plan_host_); plan_host_ = nullptr; plan_host_dev_ = nullptr; plan_host_cap_ = 0; }
+  const int cap = std::max(64, (int)round_up(B, 64));
+  void* p = nullptr;
+  if (hipHostMalloc(&p, (size_t)(1 + 2 * cap) * 4, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); hipHostFree(p); return; }
+  plan_host_ = (int32_t*)p; plan_host_dev_ = (int32_t*)d; plan_host_cap_ = cap;
 }
 
 void* Engine::dalloc(size_t bytes) {
@@ -1263,6 +1278,8 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
   else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
   prof_end("cif_misc");
+  ensure_plan_host(B);
+  if (plan_host_) launch_export_plan(stream_, plan_.max_count, plan_.fire_count, plan_.token_num, B, plan_host_dev_);
   PF_HIP(hipEventRecord(ev_scan_, stream_));
   last_.peak_len = 0;
   last_.cif_peak.clear();
@@ -1282,11 +1299,20 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   int32_t L = 0;
   last_.fire_count.resize(B);
   last_.token_num.resize(B);
-  PF_HIP(hipStreamWaitEvent(aux_stream_, ev_scan_, 0));
-  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, aux_stream_));
-  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
-  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
-  PF_HIP(hipStreamSynchronize(aux_stream_));
+  if (plan_host_) {
+    // the counts were written into pinned host memory by export_plan_kernel right behind the scan (above): the event in front of the
+    // K / V GEMM says they are there — no copy is queued, nothing waits for the GEMM
+    PF_HIP(hipEventSynchronize(ev_scan_));
+    L = plan_host_[0];
+    std::memcpy(last_.fire_count.data(), plan_host_ + 1, (size_t)B * 4);
+    std::memcpy(last_.token_num.data(), plan_host_ + 1 + B, (size_t)B * 4);
+  } else {
+    PF_HIP(hipStreamWaitEvent(aux_stream_, ev_scan_, 0));
+    PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, aux_stream_));
+    PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
+    PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
+    PF_HIP(hipStreamSynchronize(aux_stream_));
+  }
   if (l_hook_) L = l_hook_(L);                       // shard of a multi-device batch: the batch-wide maximum
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);

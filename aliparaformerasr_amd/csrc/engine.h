@@ -241,6 +241,8 @@ class Engine {
   uint32_t next_dither_seed() { return fc_.dither_seed * 2654435761u + (dither_calls_++) * 40503u; }
   int device_ = 0;
   hipStream_t stream_ = nullptr;
+  int32_t* plan_host_ = nullptr; int32_t* plan_host_dev_ = nullptr; int plan_host_cap_ = 0;   // CIF counts exported into pinned host memory
+  void ensure_plan_host(int B);
   hipStream_t aux_stream_ = nullptr;   // carries the decoder-length read-back, so stream_ keeps running (K/V projections) meanwhile
   hipEvent_t ev_scan_ = nullptr;       // CIF scan finished
   // the BiCIF timestamp head depends on the encoder output and token_num only: it runs on its own stream beside the

@@ -930,4 +930,21 @@ __global__ void nop_kernel() {}
 void launch_spin(hipStream_t s, unsigned long long cycles) { hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, cycles); }
 void launch_nop(hipStream_t s) { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, s); }
 
+// The decoder length and the per-utterance counts of the CIF plan, written straight into PINNED HOST memory (dst is the device alias
+// of a hipHostMalloc'ed buffer: [0] = max_count, [1 .. B] = fire_count, [1 + B .. 2 B] = token_num).  The engine waits for an event
+// behind this kernel instead of queueing three device-to-host copies — copies are kernels of their own on this part and could not
+// start while the K / V projection GEMM that follows the scan held the device (round 6: the read-back was serialised behind it).
+__global__ void export_plan_kernel(const int32_t* __restrict__ max_count, const int32_t* __restrict__ fire_count,
+                                   const int32_t* __restrict__ token_num, int B, volatile int32_t* dst) {
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    dst[1 + i] = fire_count[i];
+    dst[1 + B + i] = token_num[i];
+  }
+  if (threadIdx.x == 0) dst[0] = max_count[0];
+  __threadfence_system();
+}
+void launch_export_plan(hipStream_t s, const int32_t* max_count, const int32_t* fire_count, const int32_t* token_num, int B, int32_t* dst_dev) {
+  hipLaunchKernelGGL(export_plan_kernel, dim3(1), dim3(256), 0, s, max_count, fire_count, token_num, B, dst_dev);
+}
+
 }  // namespace pf

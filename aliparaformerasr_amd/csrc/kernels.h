@@ -224,6 +224,7 @@ void launch_im2col_f32(hipStream_t s, const float* H, int B, int T, int D, int l
 void launch_add_f32(hipStream_t s, float* x, const float* y, int64_t n);     // x += y
 void launch_spin(hipStream_t s, unsigned long long cycles);                  // one wave spinning ~cycles shader clocks (queue probe)
 void launch_nop(hipStream_t s);
+void launch_export_plan(hipStream_t s, const int32_t* max_count, const int32_t* fire_count, const int32_t* token_num, int B, int32_t* dst_dev);
 void launch_posenc_f32(hipStream_t s, const float* x, const float* pe, int B, int T, int F, float xscale, float* out);
 // one LSTM time step on fp32 gate pre-activations [B, 4D] (i, f, g, o): c / h [B, D] updated in place, h also to hout
 void launch_lstm_cell_f32(hipStream_t s, const float* gates, int ldg, float* c, float* h, float* hout, int64_t hout_bs, int B, int D);
