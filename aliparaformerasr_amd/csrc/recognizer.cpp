@@ -442,6 +442,7 @@ Recognizer::Recognizer(const std::string& model, const std::string& config, cons
   ec.weights_bytes = image_bytes_;
   { const char* e = getenv("PF_RECOGNIZER_AUDIO_CACHE_MB"); if (e && e[0]) audio_cache_cap_ = (size_t)std::max(0, atoi(e)) << 20; }
   { const char* e = getenv("PF_RECOGNIZER_STAGING_MB"); if (e && e[0]) staging_bytes_ = (size_t)std::min(1024, std::max(0, atoi(e))) << 20; }
+  { const char* e = getenv("PF_RECOGNIZER_STAGGER"); if (e && e[0]) stagger_frac_ = std::max(0.f, std::min(0.9f, (float)atof(e))); }
   { const char* e = getenv("PF_RECOGNIZER_STAGING_POLICY"); staging_always_ = e && std::string(e) == "always"; }
   { const char* e = getenv("PF_RECOGNIZER_COPY_THREADS"); if (e && e[0]) crew_threads_ = std::min(15, std::max(0, atoi(e))); }
   crew_threads_ = std::min<int>(crew_threads_, std::max(0, (int)std::thread::hardware_concurrency() - 1));
@@ -764,6 +765,34 @@ static void fwd_report() {
   fprintf(stderr, "\n");
 }
 
+// Two steps that start together on two engines finish together, and their callers then upload together — with the GPU idle — and
+// start together again: a convoy that cost two callers on two engines 1.5 - 2 ms per cycle (10.0 - 10.4 ms per batch where four callers
+// reached 8.6).  Any offset between the engines persists once it exists, and the best one is about half a step (the other caller's
+// uploads and text stage then sit in the middle of this caller's kernels): a step does not start within stagger_frac_ x (the recent
+// duration of a step) of the previous start on another engine of the pool — the caller sleeps the difference, once.  Same box,
+// 32 x 30 s: 2 callers 10.0 -> 8.6 ms per batch, 3 callers 8.56 -> 8.39, 4 callers 8.56 -> 8.50 (PF_RECOGNIZER_STAGGER, default
+// 0.35; 0 = off; profiles/round6_staging_ab.txt, run 8).
+void Recognizer::stagger_start() {
+  if (stagger_frac_ <= 0.f) return;
+  using clk = std::chrono::steady_clock;
+  long long wait_us = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    const long long gap_us = std::min<long long>(10000, (long long)(stagger_frac_ * step_ema_us_));
+    const auto now = clk::now();
+    const long long since = std::chrono::duration_cast<std::chrono::microseconds>(now - last_start_).count();
+    if (gap_us > 0 && since >= 0 && since < gap_us) wait_us = gap_us - since;
+    last_start_ = now + std::chrono::microseconds(wait_us);
+  }
+  if (wait_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(wait_us));
+}
+
+void Recognizer::note_step(std::chrono::steady_clock::time_point t0) {
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  std::lock_guard<std::mutex> lk(mu_);
+  step_ema_us_ = step_ema_us_ <= 0.0 ? us : 0.75 * step_ema_us_ + 0.25 * us;
+}
+
 void Recognizer::Forward(const std::vector<Stream*>& streams) {
   if (streams.empty()) return;                                      // :120-123
   try {
@@ -777,6 +806,8 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     if (!all_dev)
       for (Stream* s : streams) s->materialize();
     FwdClock fc;
+    std::chrono::steady_clock::time_point t_step;
+    bool timed_step = false;
     Lease lease = acquire();
     Engine* e = lease.get();
     const ModelCfg& mc = e->model();
@@ -830,6 +861,9 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
         if (s->dev_ev_pending) PF_HIP(hipStreamWaitEvent(e->stream(), s->dev_ev, 0));
       }
       fc.lap(1);
+      stagger_start();
+      t_step = std::chrono::steady_clock::now();
+      timed_step = true;
       e->stage_device_audio(ptrs.data(), ns.data(), B);
       fc.lap(2);
       e->run_staged(false);
@@ -844,6 +878,7 @@ void Recognizer::Forward(const std::vector<Stream*>& streams) {
     std::memset(&out, 0, sizeof(out));
     out.struct_size = sizeof(out);
     e->fetch(&out);                       // sync; learn L
+    if (timed_step) note_step(t_step);
     fc.lap(4);
     const int L = out.L;
     std::vector<int64_t> ids((size_t)B * std::max(L, 1));

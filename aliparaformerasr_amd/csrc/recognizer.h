@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <initializer_list>
@@ -181,6 +182,10 @@ class Recognizer : public std::enable_shared_from_this<Recognizer> {
   std::condition_variable cv_;
   std::vector<std::shared_ptr<Engine>> engines_;
   std::vector<char> busy_;
+  float stagger_frac_ = 0.35f; double step_ema_us_ = 0.0;      // PF_RECOGNIZER_STAGGER (Recognizer::stagger_start)
+  std::chrono::steady_clock::time_point last_start_{};
+  void stagger_start();
+  void note_step(std::chrono::steady_clock::time_point t0);
   int max_engines_ = 2;                                       // PF_RECOGNIZER_ENGINES (1..8)
   bool device_streams_ = true;                                // PF_RECOGNIZER_DEVICE_STREAMS=0: always the host form
   int feat_m_ = 1;

@@ -468,7 +468,7 @@ def test_two_callers_on_one_recognizer_overlap(mid_model_dir, monkeypatch):
     for t in range(2):
         np.testing.assert_array_equal(out[t][0], ids0)
         assert out[t][1] == txt0
-    # measured 1.56 - 1.88 over the pool's boxes (host thread scheduling); 2.0 = no overlap.  (Round 6 took 0.5 ms of host work out
+    # measured 1.25 with the pool's start stagger (Recognizer::stagger_start; 1.56 - 1.88 before it, over the pool's boxes); 2.0 = no overlap.  (Round 6 took 0.5 ms of host work out
     # of every call — work that two callers had been hiding under each other's kernels anyway: `one` gained, `two` did not.)
     assert two < 1.93 * one, (one, two)
     r.Dispose()
