@@ -778,7 +778,9 @@ void Recognizer::stagger_start() {
   long long wait_us = 0;
   {
     std::lock_guard<std::mutex> lk(mu_);
-    const long long gap_us = std::min<long long>(10000, (long long)(stagger_frac_ * step_ema_us_));
+    // (N engines evenly apart are a step / N apart: the fraction is quoted for a pool of two)
+    const double n = (double)std::max<size_t>(2, engines_.size());
+    const long long gap_us = std::min<long long>(10000, (long long)(stagger_frac_ * 2.0 / n * step_ema_us_));
     const auto now = clk::now();
     const long long since = std::chrono::duration_cast<std::chrono::microseconds>(now - last_start_).count();
     if (gap_us > 0 && since >= 0 && since < gap_us) wait_us = gap_us - since;
