@@ -16,6 +16,12 @@
 using clk = std::chrono::steady_clock;
 static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 
+__global__ void export_kernel(const int* __restrict__ src, volatile int* dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+  __threadfence_system();
+}
+
 int main() {
   const size_t n = 480000 * 4, N = 32;
   std::vector<std::vector<float>> src(N, std::vector<float>(n / 4, 0.25f));
@@ -104,6 +110,33 @@ int main() {
       printf("l  staged, 2 pieces + records : %7.1f us per upload; 32 waits on the consumer stream %.1f us; consumer free %.1f us later\n",
              us(t0, t1) / N, us(t1, t2), us(t2, t3));
       CK(hipStreamDestroy(s2));
+    }
+    {
+      // device -> host, small: what the engine's read-backs cost (decoder length: 3 x ~132 B; the ids: 43 KB)
+      std::vector<char> pageable(65536);
+      for (size_t bytes : {(size_t)4, (size_t)132, (size_t)43008}) {
+        t0 = clk::now();
+        for (size_t i = 0; i < N; ++i) { CK(hipMemcpyAsync(pageable.data(), dev, bytes, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
+        t1 = clk::now();
+        for (size_t i = 0; i < N; ++i) { CK(hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); }
+        t2 = clk::now();
+        printf("m  D2H %6zu B + sync         : pageable %6.1f us   pinned %6.1f us\n", bytes, us(t0, t1) / N, us(t1, t2) / N);
+      }
+      t0 = clk::now();
+      for (size_t i = 0; i < N; ++i) {
+        hipLaunchKernelGGL(export_kernel, dim3(1), dim3(256), 0, s, (const int*)dev, (volatile int*)pin, 33);
+        CK(hipEventRecord(ev[0], s));
+        CK(hipEventSynchronize(ev[0]));
+      }
+      t1 = clk::now();
+      printf("n  kernel -> mapped pinned + event sync (132 B) : %6.1f us\n", us(t0, t1) / N);
+      t0 = clk::now();
+      for (size_t i = 0; i < N; ++i) {
+        hipLaunchKernelGGL(export_kernel, dim3(42), dim3(256), 0, s, (const int*)dev, (volatile int*)pin, 10752);
+        CK(hipStreamSynchronize(s));
+      }
+      t1 = clk::now();
+      printf("o  kernel -> mapped pinned + stream sync (43 KB): %6.1f us\n", us(t0, t1) / N);
     }
     t0 = clk::now();
     CK(hipMemcpy(dev, pin, n * N, hipMemcpyHostToDevice));
