@@ -261,6 +261,34 @@ void Engine::ensure_plan_host(int B) {
   plan_host_ = (int32_t*)p; plan_host_dev_ = (int32_t*)d; plan_host_cap_ = cap;
 }
 
+// The CIF plan's counts on their way to the host (all three arithmetic modes).  export_plan goes right behind the scan: the counts
+// are written into pinned host memory by a kernel and ev_scan_ is recorded; read_back_plan waits for that event alone and fills
+// last_.fire_count / last_.token_num.  Without pinned memory (or with PF_PLAN_ZERO_COPY=0): three copies on the side stream.
+void Engine::export_plan(int B) {
+  ensure_plan_host(B);
+  if (plan_host_) launch_export_plan(stream_, plan_.max_count, plan_.fire_count, plan_.token_num, B, plan_host_dev_);
+  PF_HIP(hipEventRecord(ev_scan_, stream_));
+}
+
+int32_t Engine::read_back_plan(int B) {
+  int32_t L = 0;
+  last_.fire_count.resize(B);
+  last_.token_num.resize(B);
+  if (plan_host_) {
+    PF_HIP(hipEventSynchronize(ev_scan_));
+    L = plan_host_[0];
+    std::memcpy(last_.fire_count.data(), plan_host_ + 1, (size_t)B * 4);
+    std::memcpy(last_.token_num.data(), plan_host_ + 1 + B, (size_t)B * 4);
+  } else {
+    PF_HIP(hipStreamWaitEvent(aux_stream_, ev_scan_, 0));
+    PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, aux_stream_));
+    PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
+    PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
+    PF_HIP(hipStreamSynchronize(aux_stream_));
+  }
+  return L;
+}
+
 void* Engine::dalloc(size_t bytes) {
   void* p = nullptr;
   PF_HIP(hipMalloc(&p, std::max<size_t>(bytes, 256)));
@@ -1278,9 +1306,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
   else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
   prof_end("cif_misc");
-  ensure_plan_host(B);
-  if (plan_host_) launch_export_plan(stream_, plan_.max_count, plan_.fire_count, plan_.token_num, B, plan_host_dev_);
-  PF_HIP(hipEventRecord(ev_scan_, stream_));
+  export_plan(B);
   last_.peak_len = 0;
   last_.cif_peak.clear();
   if (mc_.timestamp_head) start_timestamp_head(B, T);
@@ -1296,23 +1322,7 @@ void Engine::predictor_and_decoder(int B, int T, bool want_logits) {
     gemm("gemm_dec_kv", dec_kv_all_, H16_, D, M, nullptr, 0, kv16, ldkv, nullptr, 0, nullptr, 0, false, 0, 1.f);
   // the path's only host sync: the decoder length L is data dependent.  The read-back rides a side stream that waits
   // for the CIF scan alone.
-  int32_t L = 0;
-  last_.fire_count.resize(B);
-  last_.token_num.resize(B);
-  if (plan_host_) {
-    // the counts were written into pinned host memory by export_plan_kernel right behind the scan (above): the event in front of the
-    // K / V GEMM says they are there — no copy is queued, nothing waits for the GEMM
-    PF_HIP(hipEventSynchronize(ev_scan_));
-    L = plan_host_[0];
-    std::memcpy(last_.fire_count.data(), plan_host_ + 1, (size_t)B * 4);
-    std::memcpy(last_.token_num.data(), plan_host_ + 1 + B, (size_t)B * 4);
-  } else {
-    PF_HIP(hipStreamWaitEvent(aux_stream_, ev_scan_, 0));
-    PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, aux_stream_));
-    PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
-    PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, aux_stream_));
-    PF_HIP(hipStreamSynchronize(aux_stream_));
-  }
+  int32_t L = read_back_plan(B);       // (the K / V GEMM above is queued BEHIND the event this waits for: nothing waits for the GEMM)
   if (l_hook_) L = l_hook_(L);                       // shard of a multi-device batch: the batch-wide maximum
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);

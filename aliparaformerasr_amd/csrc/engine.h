@@ -243,6 +243,8 @@ class Engine {
   hipStream_t stream_ = nullptr;
   int32_t* plan_host_ = nullptr; int32_t* plan_host_dev_ = nullptr; int plan_host_cap_ = 0;   // CIF counts exported into pinned host memory
   void ensure_plan_host(int B);
+  void export_plan(int B);
+  int32_t read_back_plan(int B);
   hipStream_t aux_stream_ = nullptr;   // carries the decoder-length read-back, so stream_ keeps running (K/V projections) meanwhile
   hipEvent_t ev_scan_ = nullptr;       // CIF scan finished
   // the BiCIF timestamp head depends on the encoder output and token_num only: it runs on its own stream beside the

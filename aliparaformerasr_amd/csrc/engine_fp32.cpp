@@ -273,14 +273,10 @@ void Engine::forward_fp32(const float* speech_dev, int B, int T, bool want_logit
   launch_cif_alpha(stream_, f[F_FS], B, T, D, cif_out_w_, cif_out_b_, mc_.cif_smooth, mc_.cif_noise, mc_.cif_tail, alphas_);
   if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
   else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
+  export_plan(B);
   if (mc_.timestamp_head) timestamp_head_fp32(B, T);
-  int32_t L = 0;
-  last_.fire_count.resize(B);
-  last_.token_num.resize(B);
-  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
+  int32_t L = read_back_plan(B);
+  if (mc_.timestamp_head) PF_HIP(hipStreamSynchronize(stream_));       // (the in-line head's results are read below as before)
   if (l_hook_) L = l_hook_(L);
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);

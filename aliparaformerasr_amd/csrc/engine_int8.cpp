@@ -271,18 +271,12 @@ void Engine::forward_int8(const float* speech_dev, int B, int T, bool want_logit
     if (mc_.cif_cumsum) launch_cif_scan_cumsum(stream_, alphas_, B, T1, plan_);
     else launch_cif_scan(stream_, alphas_, B, T1, mc_.cif_threshold, plan_);
     prof_end("cif_misc");
-    PF_HIP(hipEventRecord(ev_scan_, stream_));
+    export_plan(B);
   }
   // BiCIF timestamp head: ConvTranspose1d, LSTM and the excluded cif_output2 MatMul are float nodes of the int8 export too
   // (quantize_dynamic is run with op_types_to_quantize = ["MatMul"]): the f16 path's head, beside the decoder
   if (mc_.timestamp_head) start_timestamp_head(B, T);
-  int32_t L = 0;
-  last_.fire_count.resize(B);
-  last_.token_num.resize(B);
-  PF_HIP(hipMemcpyAsync(&L, plan_.max_count, 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.fire_count.data(), plan_.fire_count, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipMemcpyAsync(last_.token_num.data(), plan_.token_num, (size_t)B * 4, hipMemcpyDeviceToHost, stream_));
-  PF_HIP(hipStreamSynchronize(stream_));
+  int32_t L = read_back_plan(B);
   if (l_hook_) L = l_hook_(L);
   last_.B = B; last_.L = L; last_.V = V; last_.T = T;
   last_.ids.assign((size_t)B * L, 0);
