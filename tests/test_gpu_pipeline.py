@@ -167,7 +167,7 @@ def test_full_depth_seaco_with_timestamps():
 def test_zero_copy_length_read_back_equals_the_copies():
     """The decoder length and the per-utterance counts reach the host through pinned memory + an event (Engine::ensure_plan_host,
     export_plan_kernel) instead of through three device-to-host copies on a side stream; PF_PLAN_ZERO_COPY=0 is the old form.  The knob
-    is read once per process, so each form runs in a process of its own: same L, token_num, fire counts and ids on a ragged batch
+    is read once per process, so each form runs in a process of its own: same L, token_num and ids in the f16, int8 and exact modes on a ragged batch
     (incl. an utterance too short for a token) and on a second call with another batch size (the host buffer grows)."""
     import json
     import os
@@ -179,11 +179,14 @@ def test_zero_copy_length_read_back_equals_the_copies():
         "from aliparaformerasr_amd import weights as W\n"
         "from aliparaformerasr_amd.engine import Engine\n"
         "cfg = W.paraformer_large_config(enc_layers=2, dec_layers=2, vocab=300)\n"
-        "e = Engine(weights=W.pack_pfw(cfg, W.synth_weights(cfg, seed=31)), cmvn=W.synth_cmvn(), device=0)\n"
+        "blob = W.pack_pfw(cfg, W.synth_weights(cfg, seed=31))\n"
         "out = []\n"
-        "for lens in ((48000, 1200, 80000, 16000, 33000), tuple(16000 + 977 * u for u in range(70))):\n"
-        "    r = e.recognize([W.synth_audio(n, 400 + u) for u, n in enumerate(lens)])\n"
-        "    out.append({'L': int(r.L), 'token_num': np.asarray(r.token_num).tolist(), 'ids': np.asarray(r.token_ids).tolist()})\n"
+        "for mode in (0, 2, 3):\n"                      # f16, int8, exact: each has its own read-back site
+        "    e = Engine(weights=blob, cmvn=W.synth_cmvn(), device=0, math_mode=mode)\n"
+        "    for lens in ((48000, 1200, 80000, 16000, 33000), tuple(16000 + 977 * u for u in range(70))):\n"
+        "        r = e.recognize([W.synth_audio(n, 400 + u) for u, n in enumerate(lens)])\n"
+        "        out.append({'L': int(r.L), 'token_num': np.asarray(r.token_num).tolist(), 'ids': np.asarray(r.token_ids).tolist()})\n"
+        "    e.close()\n"
         "print(json.dumps(out))\n")
     res = {}
     for v in ("0", "1"):
@@ -192,5 +195,5 @@ def test_zero_copy_length_read_back_equals_the_copies():
         assert p.returncode == 0, p.stderr[-3000:]
         res[v] = json.loads([l for l in p.stdout.splitlines() if l.startswith("[")][-1])
     assert res["0"] == res["1"]
-    assert res["1"][0]["L"] > 0 and len(res["1"][1]["token_num"]) == 70
+    assert len(res["1"]) == 6 and res["1"][0]["L"] > 0 and len(res["1"][1]["token_num"]) == 70
 
